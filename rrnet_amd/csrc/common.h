@@ -1,0 +1,50 @@
+// Shared helpers for the gfx950 (MI355X / CDNA4) kernels.  wave = 64 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#define RR_OK 0
+#define RR_ERR_ARG (-1)
+#define RR_ERR_LAUNCH (-2)
+#define RR_ERR_UNSUPPORTED (-3)
+
+void rr_set_error(const char *fmt, ...);
+
+#define RR_CHECK_ARG(cond, ...)            \
+    do {                                   \
+        if (!(cond)) {                     \
+            rr_set_error(__VA_ARGS__);     \
+            return RR_ERR_ARG;             \
+        }                                  \
+    } while (0)
+
+#define RR_CHECK_LAUNCH(name)                                              \
+    do {                                                                   \
+        hipError_t e_ = hipGetLastError();                                 \
+        if (e_ != hipSuccess) {                                            \
+            rr_set_error("%s: launch failed: %s", name, hipGetErrorString(e_)); \
+            return RR_ERR_LAUNCH;                                          \
+        }                                                                  \
+    } while (0)
+
+static inline int rr_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}

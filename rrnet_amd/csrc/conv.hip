@@ -1,0 +1,577 @@
+// im2col-free NHWC fp32 convolutions on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+// Replaces, for the hourglass / head / stage-2 stack of the reference, what it delegates to
+// cuDNN through nn.Conv2d: /root/reference/backbones/hourglass.py:17,21,25,48,143,167,173,
+// /root/reference/detectors/centernet_detector.py:62,73,85,
+// /root/reference/detectors/fasterrcnn_detector.py:11 + backbones/resnet.py:22-28.
+//
+// One implicit-GEMM kernel family, no column matrix is ever materialised:
+//   fprop : Y[m,ko]  = sum_{tap,c}  X[pix(m,tap), c]   * W[ko,tap,c]      M = N*P*Q, N = K,  Kg = R*S*C
+//   dgrad : dX[m,c]  = sum_{tap,ko} dY[pix'(m,tap),ko] * W[ko,tap,c]      M = N*H*W, N = C,  Kg = R*S*K
+//   wgrad : dW[ko,tap,c] += sum_m   dY[m,ko] * X[pix(m,tap), c]           M = K, N = C, Kg = N*P*Q (split)
+// Activations NHWC, weights OHWI ([K][R][S][C], torch channels_last of the reference's
+// parameter).  Workgroup = 256 threads = 4 waves; block tile 128 x BN (BN = 128: 2x2 waves of
+// 64x64; BN = 32: 4x1 waves of 32x32) x 32 deep; operands are staged global -> registers ->
+// LDS (double buffered, one barrier per K-step) with the pixel gather / zero padding done on
+// the way in; every wave runs TM*TN accumulators of 32x32 (16 VGPRs each).  The [m][k] LDS
+// images are padded to 36 floats per row so that one ds_read_b128 per lane feeds four
+// MFMA K-steps conflict-free; [k][n] images are read with ds_read_b32.
+// K-chunks run channel-chunk outer / filter-tap inner so the 9 taps of a 3x3 re-read the same
+// 128-B lines from L2, and block ids are remapped so that an XCD owns a contiguous tile range.
+//
+// Roofline: MFMA-bound (fp32 matrix peak 157.3 TFLOP/s); algorithmic FLOPs = 2*M*N*Kg.
+#include "common.h"
+#include "rrnet_hip.h"
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128;
+constexpr int BK = 32;
+constexpr int LDA = 36;  // [m][k] image row stride (floats): conflict-free ds_read_b128
+
+struct ConvArgs {
+    const float *src;  // fprop: X [N,H,W,C]      dgrad: dY [N,P,Q,K]
+    const float *w;    // [K][R][S][C]
+    float *dst;        // fprop: Y [N,P,Q,K]      dgrad: dX [N,H,W,C]
+    const float *bias; // fprop only, [K] or null
+    double *stat_slab; // fprop only: [mtiles][2][K] per-block column sums / sums of squares, or null
+    int N;
+    int SH, SW, SC;    // source spatial / channels
+    int DH, DW, DC;    // destination spatial / channels (DC = GEMM N)
+    int R, S, stride, pad_h, pad_w;
+    int relu, accumulate;
+    int M;             // N*DH*DW
+    int Kg;            // R*S*SC
+    int wK, wC;        // weight dims K, C
+};
+
+__device__ __forceinline__ int xcd_remap(int bid, int nb)
+{
+    const int q = nb >> 3, r = nb & 7, xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// MODE 0 = fprop, 1 = dgrad.  SCALAR: source/weight channel counts not multiples of 4.
+template <int BN, int MODE, bool SCALAR>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
+{
+    constexpr int WN = BN / 64 ? BN / 64 : 1;   // waves along N
+    constexpr int WM = 4 / WN;                  // waves along M
+    constexpr int TM = BM / (WM * 32);
+    constexpr int TN = BN / (WN * 32);
+    constexpr bool B_KN = (MODE == 1);          // dgrad reads W as [k][n]
+    constexpr int LDB = B_KN ? BN : LDA;
+    constexpr int A_ELEMS = BM * LDA;
+    constexpr int B_ELEMS = B_KN ? BK * BN : BN * LDA;
+    constexpr int AJ = BM / 32;                 // float4 per thread for the A image
+    constexpr int BJ = BN / 32;                 // float4 per thread for the B image
+
+    extern __shared__ __align__(16) float lds[];
+    float *As = lds;                    // [2][A_ELEMS]
+    float *Bs = lds + 2 * A_ELEMS;      // [2][B_ELEMS]
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int ntiles = (a.DC + BN - 1) / BN;
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int n_tile = logical % ntiles, m_tile = logical / ntiles;
+    const int m0 = m_tile * BM, n0 = n_tile * BN;
+
+    const int RS = a.R * a.S;
+    const int cpt = (a.SC + BK - 1) / BK;                  // channel chunks per tap (vector mode)
+    const int nk = SCALAR ? (a.Kg + BK - 1) / BK : cpt * RS;
+
+    // ---- per-thread A rows: destination pixel coordinates
+    const int a_col = (t & 7) * 4;
+    int a_n[AJ], a_h[AJ], a_w[AJ];
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+        const int m = m0 + (t >> 3) + 32 * j;
+        if (m < a.M) {
+            const int hw = a.DH * a.DW;
+            const int n = m / hw, rem = m - n * hw;
+            const int h = rem / a.DW;
+            a_n[j] = n; a_h[j] = h; a_w[j] = rem - h * a.DW;
+        } else {
+            a_n[j] = -1; a_h[j] = 0; a_w[j] = 0;
+        }
+    }
+
+    f32x4 ra[AJ], rb[BJ];
+
+    auto src_offset = [&](int j, int r, int s, long &off) -> bool {
+        if (a_n[j] < 0) return false;
+        int ih, iw;
+        if (MODE == 0) {
+            ih = a_h[j] * a.stride - a.pad_h + r;
+            iw = a_w[j] * a.stride - a.pad_w + s;
+            if (ih < 0 || iw < 0 || ih >= a.SH || iw >= a.SW) return false;
+        } else {
+            const int th = a_h[j] + a.pad_h - r, tw = a_w[j] + a.pad_w - s;
+            if (th < 0 || tw < 0) return false;
+            if (a.stride == 1) { ih = th; iw = tw; }
+            else {
+                ih = th / a.stride; iw = tw / a.stride;
+                if (ih * a.stride != th || iw * a.stride != tw) return false;
+            }
+            if (ih >= a.SH || iw >= a.SW) return false;
+        }
+        off = (((long)a_n[j] * a.SH + ih) * a.SW + iw) * a.SC;
+        return true;
+    };
+
+    auto load_tiles = [&](int kc) {
+        if (!SCALAR) {
+            const int cch = kc / RS, tap = kc - cch * RS;
+            const int r = tap / a.S, s = tap - r * a.S;
+            const int c0 = cch * BK;
+            // A: BM rows x 32 channels of one tap
+#pragma unroll
+            for (int j = 0; j < AJ; ++j) {
+                long off;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if ((c0 + a_col < a.SC) && src_offset(j, r, s, off))
+                    v = *reinterpret_cast<const f32x4 *>(a.src + off + c0 + a_col);
+                ra[j] = v;
+            }
+            if (!B_KN) {  // fprop: B[n = ko][k = (tap, c)] = w[ko][tap][c]
+#pragma unroll
+                for (int j = 0; j < BJ; ++j) {
+                    const int ko = n0 + (t >> 3) + 32 * j;
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (ko < a.wK && c0 + a_col < a.wC)
+                        v = *reinterpret_cast<const f32x4 *>(a.w + ((long)ko * RS + tap) * a.wC + c0 + a_col);
+                    rb[j] = v;
+                }
+            } else {      // dgrad: B[k = (tap, ko)][n = c] = w[ko][tap][c]
+                constexpr int TPR = BN / 4;          // threads per k-row
+                constexpr int RPP = 256 / TPR;       // k-rows per pass
+#pragma unroll
+                for (int j = 0; j < BJ; ++j) {
+                    const int kk = t / TPR + RPP * j;
+                    const int ko = c0 + kk;          // c0 indexes the source channels = K here
+                    const int c = n0 + (t % TPR) * 4;
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (ko < a.wK && c < a.wC)
+                        v = *reinterpret_cast<const f32x4 *>(a.w + ((long)ko * RS + tap) * a.wC + c);
+                    rb[j] = v;
+                }
+            }
+        } else {
+            // linear k = tap * SC + c over R*S*SC; the 4 columns of this thread decode once per chunk
+            int e_tap[4], e_c[4];
+            bool e_ok[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = kc * BK + a_col + e;
+                e_ok[e] = k < a.Kg;
+                e_tap[e] = k / a.SC;
+                e_c[e] = k - e_tap[e] * a.SC;
+            }
+#pragma unroll
+            for (int j = 0; j < AJ; ++j) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    long off;
+                    const int r = e_tap[e] / a.S, s = e_tap[e] - r * a.S;
+                    if (e_ok[e] && src_offset(j, r, s, off)) v[e] = a.src[off + e_c[e]];
+                }
+                ra[j] = v;
+            }
+            if (!B_KN) {  // w[ko][k] with k linear — OHWI is already [K][R*S*C]
+#pragma unroll
+                for (int j = 0; j < BJ; ++j) {
+                    const int ko = n0 + (t >> 3) + 32 * j;
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int k = kc * BK + a_col + e;
+                        if (ko < a.wK && k < a.Kg) v[e] = a.w[(long)ko * a.Kg + k];
+                    }
+                    rb[j] = v;
+                }
+            } else {
+                constexpr int TPR = BN / 4;
+                constexpr int RPP = 256 / TPR;
+#pragma unroll
+                for (int j = 0; j < BJ; ++j) {
+                    const int k = kc * BK + t / TPR + RPP * j;   // k = tap * K + ko
+                    const int tap = k / a.SC, ko = k - tap * a.SC;
+                    const int c = n0 + (t % TPR) * 4;
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (k < a.Kg && c + e < a.wC) v[e] = a.w[((long)ko * RS + tap) * a.wC + c + e];
+                    rb[j] = v;
+                }
+            }
+        }
+    };
+
+    auto store_tiles = [&](int buf) {
+        float *A = As + buf * A_ELEMS;
+        float *B = Bs + buf * B_ELEMS;
+#pragma unroll
+        for (int j = 0; j < AJ; ++j)
+            *reinterpret_cast<f32x4 *>(A + ((t >> 3) + 32 * j) * LDA + a_col) = ra[j];
+        if (!B_KN) {
+#pragma unroll
+            for (int j = 0; j < BJ; ++j)
+                *reinterpret_cast<f32x4 *>(B + ((t >> 3) + 32 * j) * LDA + a_col) = rb[j];
+        } else {
+            constexpr int TPR = BN / 4;
+            constexpr int RPP = 256 / TPR;
+#pragma unroll
+            for (int j = 0; j < BJ; ++j)
+                *reinterpret_cast<f32x4 *>(B + (t / TPR + RPP * j) * LDB + (t % TPR) * 4) = rb[j];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int lr = lane & 31, lh = lane >> 5;
+
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    for (int kc = 0; kc < nk; ++kc) {
+        const int buf = kc & 1;
+        if (kc + 1 < nk) load_tiles(kc + 1);
+        const float *A = As + buf * A_ELEMS;
+        const float *B = Bs + buf * B_ELEMS;
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; ++kk) {
+            f32x4 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                fa[i] = *reinterpret_cast<const f32x4 *>(A + ((wm * TM + i) * 32 + lr) * LDA + kk * 8 + lh * 4);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if (!B_KN) {
+                    fb[j] = *reinterpret_cast<const f32x4 *>(B + ((wn * TN + j) * 32 + lr) * LDA + kk * 8 + lh * 4);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) fb[j][e] = B[(kk * 8 + lh * 4 + e) * LDB + (wn * TN + j) * 32 + lr];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+        }
+        if (kc + 1 < nk) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue.  D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    double *sred = reinterpret_cast<double *>(lds);   // [WM][BN][2], reuses the staging LDS
+    const bool do_stats = (MODE == 0) && a.stat_slab != nullptr;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int ncol = n0 + (wn * TN + j) * 32 + lr;
+        const bool n_ok = ncol < a.DC;
+        const float bv = (MODE == 0 && a.bias != nullptr && n_ok) ? a.bias[ncol] : 0.f;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = (e & 3) + 8 * (e >> 2) + 4 * lh;
+                const int m = m0 + (wm * TM + i) * 32 + row;
+                float v = acc[i][j][e] + bv;
+                if (MODE == 0 && a.relu) v = v > 0.f ? v : 0.f;
+                if (m < a.M && n_ok) {
+                    float *p = a.dst + (long)m * a.DC + ncol;
+                    if (a.accumulate) v += *p;
+                    *p = v;
+                    s1 += v;
+                    s2 += v * v;
+                }
+            }
+        }
+        if (do_stats) {
+            double d1 = (double)s1, d2 = (double)s2;
+            d1 += __shfl_xor(d1, 32, 64);
+            d2 += __shfl_xor(d2, 32, 64);
+            if (lh == 0) {
+                const int cl = (wn * TN + j) * 32 + lr;
+                sred[(wm * BN + cl) * 2 + 0] = d1;
+                sred[(wm * BN + cl) * 2 + 1] = d2;
+            }
+        }
+    }
+    if (do_stats) {
+        __syncthreads();
+        if (t < BN && n0 + t < a.DC) {
+            double d1 = 0.0, d2 = 0.0;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) {
+                d1 += sred[(w * BN + t) * 2 + 0];
+                d2 += sred[(w * BN + t) * 2 + 1];
+            }
+            double *slab = a.stat_slab + (long)m_tile * 2 * a.DC;
+            slab[n0 + t] = d1;
+            slab[a.DC + n0 + t] = d2;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// wgrad: dW[ko][tap][c] += sum over a slice of the N*P*Q pixels.  GEMM M = K (ko), N = C.
+struct WgradArgs {
+    const float *x;   // [N,H,W,C]
+    const float *dy;  // [N,P,Q,K]
+    float *dw;        // [K][R][S][C], accumulated with float atomics
+    int N, H, W, C, K, R, S, P, Q, stride, pad_h, pad_w;
+    int M;            // N*P*Q
+    int chunks_per_split;
+    int mt, nt;       // tiles along K and C
+};
+
+template <int BN, bool A_SCALAR, bool B_SCALAR>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a)
+{
+    constexpr int WN = BN / 64 ? BN / 64 : 1;
+    constexpr int WM = 4 / WN;
+    constexpr int TM = BM / (WM * 32);
+    constexpr int TN = BN / (WN * 32);
+    constexpr int A_ELEMS = BK * BM, B_ELEMS = BK * BN;
+    constexpr int AJ = BM / 32, BJ = BN / 32;
+    constexpr int TPR_B = BN / 4, RPP_B = 256 / TPR_B;
+
+    extern __shared__ __align__(16) float lds[];
+    float *As = lds, *Bs = lds + 2 * A_ELEMS;
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int RS = a.R * a.S;
+    int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int tap = logical % RS; logical /= RS;
+    const int n_tile = logical % a.nt; logical /= a.nt;
+    const int m_tile = logical % a.mt;
+    const int split = logical / a.mt;
+    const int r = tap / a.S, s = tap - r * a.S;
+    const int ko0 = m_tile * BM, c0 = n_tile * BN;
+    const int total_chunks = (a.M + BK - 1) / BK;
+    const int kc_begin = split * a.chunks_per_split;
+    int kc_end = kc_begin + a.chunks_per_split;
+    if (kc_end > total_chunks) kc_end = total_chunks;
+    if (kc_begin >= kc_end) return;
+
+    f32x4 ra[AJ], rb[BJ];
+    const int a_row = t >> 5, a_col = (t & 31) * 4;            // A: 32 threads per pixel row, 8 rows per pass
+    const int b_row = t / TPR_B, b_col = (t % TPR_B) * 4;
+
+    auto load_tiles = [&](int kc) {
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) {
+            const int m = kc * BK + a_row + 8 * j;
+            const int ko = ko0 + a_col;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (m < a.M) {
+                if (!A_SCALAR) {
+                    if (ko < a.K) v = *reinterpret_cast<const f32x4 *>(a.dy + (long)m * a.K + ko);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (ko + e < a.K) v[e] = a.dy[(long)m * a.K + ko + e];
+                }
+            }
+            ra[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) {
+            const int m = kc * BK + b_row + RPP_B * j;
+            const int c = c0 + b_col;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (m < a.M) {
+                const int pq = a.P * a.Q;
+                const int n = m / pq, rem = m - n * pq;
+                const int p = rem / a.Q, q = rem - p * a.Q;
+                const int ih = p * a.stride - a.pad_h + r, iw = q * a.stride - a.pad_w + s;
+                if (ih >= 0 && iw >= 0 && ih < a.H && iw < a.W) {
+                    const long off = (((long)n * a.H + ih) * a.W + iw) * a.C + c;
+                    if (!B_SCALAR) {
+                        if (c < a.C) v = *reinterpret_cast<const f32x4 *>(a.x + off);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (c + e < a.C) v[e] = a.x[off + e];
+                    }
+                }
+            }
+            rb[j] = v;
+        }
+    };
+    auto store_tiles = [&](int buf) {
+        float *A = As + buf * A_ELEMS, *B = Bs + buf * B_ELEMS;
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) *reinterpret_cast<f32x4 *>(A + (a_row + 8 * j) * BM + a_col) = ra[j];
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) *reinterpret_cast<f32x4 *>(B + (b_row + RPP_B * j) * BN + b_col) = rb[j];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int lr = lane & 31, lh = lane >> 5;
+    load_tiles(kc_begin);
+    store_tiles(0);
+    __syncthreads();
+    for (int kc = kc_begin; kc < kc_end; ++kc) {
+        const int buf = (kc - kc_begin) & 1;
+        if (kc + 1 < kc_end) load_tiles(kc + 1);
+        const float *A = As + buf * A_ELEMS, *B = Bs + buf * B_ELEMS;
+#pragma unroll
+        for (int k2 = 0; k2 < BK / 2; ++k2) {
+            float fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = A[(2 * k2 + lh) * BM + (wm * TM + i) * 32 + lr];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = B[(2 * k2 + lh) * BN + (wn * TN + j) * 32 + lr];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        if (kc + 1 < kc_end) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int c = c0 + (wn * TN + j) * 32 + lr;
+        if (c >= a.C) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int ko = ko0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (ko < a.K) unsafeAtomicAdd(a.dw + ((long)ko * RS + tap) * a.C + c, acc[i][j][e]);
+            }
+    }
+}
+
+template <typename K, typename A>
+int launch(K kern, int blocks, size_t lds, hipStream_t stream, const A &args, const char *name)
+{
+    if (lds > 48 * 1024)
+        hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, stream, args);
+    RR_CHECK_LAUNCH(name);
+    return RR_OK;
+}
+
+size_t igemm_lds(int bn, bool b_kn) { return sizeof(float) * 2 * (BM * LDA + (b_kn ? BK * bn : bn * LDA)); }
+
+}  // namespace
+
+extern "C" size_t rr_conv_stat_slab_bytes(int n, int p, int q, int k)
+{
+    const long M = (long)n * p * q;
+    return (size_t)((M + BM - 1) / BM) * 2 * k * sizeof(double);
+}
+
+extern "C" int rr_conv_fprop(const float *x, const float *w, const float *bias, float *y, double *stat_slab,
+                             int n, int h, int wd, int c, int k, int r, int s, int stride, int pad_h,
+                             int pad_w, int relu, hipStream_t stream)
+{
+    RR_CHECK_ARG(n > 0 && h > 0 && wd > 0 && c > 0 && k > 0 && r > 0 && s > 0 && stride > 0, "rr_conv_fprop: bad dims");
+    ConvArgs a{};
+    a.src = x; a.w = w; a.dst = y; a.bias = bias; a.stat_slab = stat_slab;
+    a.N = n; a.SH = h; a.SW = wd; a.SC = c;
+    a.DH = (h + 2 * pad_h - r) / stride + 1; a.DW = (wd + 2 * pad_w - s) / stride + 1; a.DC = k;
+    RR_CHECK_ARG(a.DH > 0 && a.DW > 0, "rr_conv_fprop: empty output");
+    a.R = r; a.S = s; a.stride = stride; a.pad_h = pad_h; a.pad_w = pad_w;
+    a.relu = relu; a.accumulate = 0;
+    const long M = (long)n * a.DH * a.DW;
+    RR_CHECK_ARG(M < (1l << 31) && (long)n * h * wd * c < (1l << 40), "rr_conv_fprop: tensor too large");
+    a.M = (int)M; a.Kg = r * s * c; a.wK = k; a.wC = c;
+    const bool scalar = (c % 4) != 0;
+    const int bn = k > 32 ? 128 : 32;
+    const int blocks = rr_cdiv(M, BM) * rr_cdiv(k, bn);
+    const size_t lds = igemm_lds(bn, false);
+    if (bn == 128) return scalar ? launch(conv_igemm_kernel<128, 0, true>, blocks, lds, stream, a, "rr_conv_fprop")
+                                 : launch(conv_igemm_kernel<128, 0, false>, blocks, lds, stream, a, "rr_conv_fprop");
+    return scalar ? launch(conv_igemm_kernel<32, 0, true>, blocks, lds, stream, a, "rr_conv_fprop")
+                  : launch(conv_igemm_kernel<32, 0, false>, blocks, lds, stream, a, "rr_conv_fprop");
+}
+
+extern "C" int rr_conv_dgrad(const float *dy, const float *w, float *dx, int n, int h, int wd, int c, int k,
+                             int r, int s, int stride, int pad_h, int pad_w, int accumulate,
+                             hipStream_t stream)
+{
+    RR_CHECK_ARG(n > 0 && h > 0 && wd > 0 && c > 0 && k > 0 && r > 0 && s > 0 && stride > 0, "rr_conv_dgrad: bad dims");
+    ConvArgs a{};
+    a.src = dy; a.w = w; a.dst = dx; a.bias = nullptr; a.stat_slab = nullptr;
+    a.N = n;
+    a.SH = (h + 2 * pad_h - r) / stride + 1; a.SW = (wd + 2 * pad_w - s) / stride + 1; a.SC = k;
+    a.DH = h; a.DW = wd; a.DC = c;
+    a.R = r; a.S = s; a.stride = stride; a.pad_h = pad_h; a.pad_w = pad_w;
+    a.relu = 0; a.accumulate = accumulate;
+    const long M = (long)n * h * wd;
+    RR_CHECK_ARG(M < (1l << 31), "rr_conv_dgrad: tensor too large");
+    a.M = (int)M; a.Kg = r * s * k; a.wK = k; a.wC = c;
+    const bool scalar = (k % 4) != 0 || (c % 4) != 0;
+    const int bn = c > 32 ? 128 : 32;
+    const int blocks = rr_cdiv(M, BM) * rr_cdiv(c, bn);
+    const size_t lds = igemm_lds(bn, true);
+    if (bn == 128) return scalar ? launch(conv_igemm_kernel<128, 1, true>, blocks, lds, stream, a, "rr_conv_dgrad")
+                                 : launch(conv_igemm_kernel<128, 1, false>, blocks, lds, stream, a, "rr_conv_dgrad");
+    return scalar ? launch(conv_igemm_kernel<32, 1, true>, blocks, lds, stream, a, "rr_conv_dgrad")
+                  : launch(conv_igemm_kernel<32, 1, false>, blocks, lds, stream, a, "rr_conv_dgrad");
+}
+
+extern "C" int rr_conv_wgrad(const float *x, const float *dy, float *dw, int n, int h, int wd, int c, int k,
+                             int r, int s, int stride, int pad_h, int pad_w, hipStream_t stream)
+{
+    RR_CHECK_ARG(n > 0 && h > 0 && wd > 0 && c > 0 && k > 0 && r > 0 && s > 0 && stride > 0, "rr_conv_wgrad: bad dims");
+    WgradArgs a{};
+    a.x = x; a.dy = dy; a.dw = dw;
+    a.N = n; a.H = h; a.W = wd; a.C = c; a.K = k; a.R = r; a.S = s;
+    a.P = (h + 2 * pad_h - r) / stride + 1; a.Q = (wd + 2 * pad_w - s) / stride + 1;
+    a.stride = stride; a.pad_h = pad_h; a.pad_w = pad_w;
+    const long M = (long)n * a.P * a.Q;
+    RR_CHECK_ARG(M > 0 && M < (1l << 31), "rr_conv_wgrad: bad pixel count");
+    a.M = (int)M;
+    const int bn = c > 32 ? 128 : 32;
+    a.mt = rr_cdiv(k, BM); a.nt = rr_cdiv(c, bn);
+    const int tiles = a.mt * a.nt * r * s;
+    const int total_chunks = rr_cdiv(M, BK);
+    // enough splits to put ~6 workgroups on each of the 256 CUs, but never fewer than 8 K-steps per split
+    int splits = rr_cdiv(256 * 6, tiles);
+    if (splits > rr_cdiv(total_chunks, 8)) splits = rr_cdiv(total_chunks, 8);
+    if (splits < 1) splits = 1;
+    a.chunks_per_split = rr_cdiv(total_chunks, splits);
+    splits = rr_cdiv(total_chunks, a.chunks_per_split);
+    const int blocks = tiles * splits;
+    const size_t lds = sizeof(float) * 2 * (BK * BM + BK * bn);
+    const bool as = (k % 4) != 0, bs = (c % 4) != 0;
+#define WG(BNv)                                                                                                   \
+    (as ? (bs ? launch(conv_wgrad_kernel<BNv, true, true>, blocks, lds, stream, a, "rr_conv_wgrad")              \
+              : launch(conv_wgrad_kernel<BNv, true, false>, blocks, lds, stream, a, "rr_conv_wgrad"))            \
+        : (bs ? launch(conv_wgrad_kernel<BNv, false, true>, blocks, lds, stream, a, "rr_conv_wgrad")             \
+              : launch(conv_wgrad_kernel<BNv, false, false>, blocks, lds, stream, a, "rr_conv_wgrad")))
+    return bn == 128 ? WG(128) : WG(32);
+#undef WG
+}

@@ -1,0 +1,60 @@
+"""Drop-in for the reference's ext/nms/nms_wrapper.py (soft_nms :13-19, nms :23-33), backed by
+the wavefront-parallel HIP kernels in librrnet_hip.so instead of the Cython/CUDA extensions
+ext/nms/nms/{cpu_nms.pyx,gpu_nms.pyx,nms_kernel.cu}.
+
+`soft_nms` keeps the reference's host contract (numpy in, numpy out, in-place mutation of a
+C-contiguous float32 `dets`, unmodified rows otherwise).  The batched device entry points
+(`soft_nms_segments`, `hard_nms_segments`) are what the model / operator code uses so that the
+per-image x per-class Python loops of the reference become one launch."""
+import numpy as np
+import torch
+
+from rrnet_amd import _C
+
+_P = _C.c_void_p
+
+
+def soft_nms_segments(boxes, seg_off, max_seg, sigma=0.5, Nt=0.3, threshold=0.001, method=1):
+    """boxes: cuda float32 [total, stride>=5] (modified in place); seg_off: cuda int32 [nseg+1].
+    Returns n_out cuda int32 [nseg]; rows [seg_off[s], seg_off[s]+n_out[s]) are the kept boxes in
+    the reference's order.  Raises ZeroDivisionError where the reference would."""
+    _C.require_cuda(boxes, seg_off)
+    assert boxes.dtype == torch.float32 and boxes.is_contiguous() and boxes.dim() == 2
+    assert seg_off.dtype == torch.int32
+    nseg = seg_off.numel() - 1
+    n_out = torch.zeros(max(nseg, 0), dtype=torch.int32, device=boxes.device)
+    if nseg <= 0:
+        return n_out
+    if int(method) == 2 and float(np.float32(sigma)) == 0.0:
+        raise ZeroDivisionError("float division")
+    err = torch.zeros(1, dtype=torch.int32, device=boxes.device)
+    f_ws = _C.fn("rr_soft_nms_workspace_bytes", [_C.c_int, _C.c_int], _C.c_size_t)
+    nbytes = f_ws(boxes.size(0), int(max_seg))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=boxes.device) if nbytes else None
+    f = _C.fn("rr_soft_nms_segments", [_P, _P, _C.c_int, _C.c_int, _C.c_int, _C.c_float, _C.c_float,
+                                       _C.c_float, _C.c_int, _P, _P, _P, _P])
+    _C.check(f(_C.ptr(boxes), _C.ptr(seg_off), nseg, int(max_seg), boxes.size(1), float(np.float32(sigma)),
+               float(np.float32(Nt)), float(np.float32(threshold)), int(method), _C.ptr(n_out), _C.ptr(err),
+               _C.ptr(ws), _C.stream()), "rr_soft_nms_segments")
+    if int(err.item()) != 0:
+        raise ZeroDivisionError("float division")
+    return n_out
+
+
+def soft_nms(dets, sigma=0.5, Nt=0.3, threshold=0.001, method=1):
+    """Reference signature (nms_wrapper.py:13-19).  `dets`: array-like [N, >=5]."""
+    work = np.ascontiguousarray(dets, dtype=np.float32)
+    n = work.shape[0]
+    if n == 0:
+        return np.asarray(dets)[[]] if not isinstance(dets, np.ndarray) else dets[[]]
+    dev = torch.device("cuda", torch.cuda.current_device())
+    d = torch.from_numpy(work).to(dev)
+    seg = torch.tensor([0, n], dtype=torch.int32, device=dev)
+    n_out = soft_nms_segments(d, seg, n, sigma, Nt, threshold, np.uint8(method))
+    k = int(n_out.item())
+    # in-place mutation, as the Cython routine does on the buffer it was handed: when `dets`
+    # already was C-contiguous float32, `work` IS `dets` and the caller sees the permuted rows.
+    work[:k] = d[:k].cpu().numpy()
+    if not isinstance(dets, np.ndarray):
+        dets = np.asarray(dets)
+    return dets[list(range(k))]
