@@ -49,13 +49,50 @@ def stream():
     return c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def fn(name, argtypes, restype=c_int):
+_CTYPE = {"int": c_int, "float": c_float, "double": c_double, "size_t": c_size_t, "long": c_long,
+          "hipStream_t": c_void_p, "void": None}
+_SIGS = None
+
+
+def header_signatures():
+    """Parses include/rrnet_hip.h (shipped next to the library as rrnet_amd/rrnet_hip.h when
+    installed, otherwise <repo>/include) -> {name: (restype, [argtypes])}.  The header is the
+    single source of truth for the ABI; pointers map to void*."""
+    import re
+    global _SIGS
+    if _SIGS is not None:
+        return _SIGS
+    cands = [os.path.join(_HERE, "rrnet_hip.h"), os.path.join(os.path.dirname(_HERE), "include", "rrnet_hip.h")]
+    path = next(p for p in cands if os.path.exists(p))
+    text = re.sub(r"/\*.*?\*/", "", open(path).read(), flags=re.S)
+    sigs = {}
+    for m in re.finditer(r"(?m)^\s*(const\s+char\s*\*|int\s|size_t\s|void\s|double\s)\s*(rr_\w+)\s*\(([^;{]*?)\)\s*;", text):
+        ret, name, args = m.group(1), m.group(2), m.group(3).strip()
+        restype = ctypes.c_char_p if "char" in ret else _CTYPE[ret.strip()]
+        argtypes = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                if "*" in a:
+                    argtypes.append(c_void_p)
+                else:
+                    toks = a.replace("const", "").split()
+                    argtypes.append(_CTYPE[toks[0]])
+        sigs[name] = (restype, argtypes)
+    _SIGS = sigs
+    return sigs
+
+
+def fn(name, argtypes=None, restype=None):
+    """Entry point `name` with the prototype declared in include/rrnet_hip.h."""
     f = getattr(lib(), name, None)
     if f is None:
         raise RRNetHipError("librrnet_hip.so does not export %s (stale build?)" % name)
     if f.argtypes is None:
-        f.argtypes = argtypes
-        f.restype = restype
+        sig = header_signatures().get(name)
+        if sig is None:
+            raise RRNetHipError("%s is not declared in include/rrnet_hip.h" % name)
+        f.restype, f.argtypes = sig[0], sig[1]
     return f
 
 

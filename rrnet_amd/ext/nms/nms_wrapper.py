@@ -28,11 +28,10 @@ def soft_nms_segments(boxes, seg_off, max_seg, sigma=0.5, Nt=0.3, threshold=0.00
     if int(method) == 2 and float(np.float32(sigma)) == 0.0:
         raise ZeroDivisionError("float division")
     err = torch.zeros(1, dtype=torch.int32, device=boxes.device)
-    f_ws = _C.fn("rr_soft_nms_workspace_bytes", [_C.c_int, _C.c_int], _C.c_size_t)
+    f_ws = _C.fn("rr_soft_nms_workspace_bytes")
     nbytes = f_ws(boxes.size(0), int(max_seg))
     ws = torch.empty(nbytes, dtype=torch.uint8, device=boxes.device) if nbytes else None
-    f = _C.fn("rr_soft_nms_segments", [_P, _P, _C.c_int, _C.c_int, _C.c_int, _C.c_float, _C.c_float,
-                                       _C.c_float, _C.c_int, _P, _P, _P, _P])
+    f = _C.fn("rr_soft_nms_segments")
     _C.check(f(_C.ptr(boxes), _C.ptr(seg_off), nseg, int(max_seg), boxes.size(1), float(np.float32(sigma)),
                float(np.float32(Nt)), float(np.float32(threshold)), int(method), _C.ptr(n_out), _C.ptr(err),
                _C.ptr(ws), _C.stream()), "rr_soft_nms_segments")

@@ -1,0 +1,68 @@
+"""CPU-side boundary checks (no GPU, no compute calls): the C-ABI library builds for gfx950,
+loads, and exports every symbol include/rrnet_hip.h declares; the Python bindings take their
+prototypes from that header; the product package never imports the oracle."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built_lib():
+    from rrnet_amd.csrc import build
+    return build.build(verbose=False)
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    from rrnet_amd import _C
+    sigs = _C.header_signatures()
+    assert "rr_soft_nms_segments" in sigs and "rr_conv_fprop" in sigs and "rr_last_error" in sigs
+    out = subprocess.check_output(["nm", "-D", "--defined-only", built_lib], text=True)
+    exported = {l.split()[-1] for l in out.splitlines() if l.strip()}
+    missing = [n for n in sigs if n not in exported]
+    assert not missing, "declared in include/rrnet_hip.h but not exported: %s" % missing
+    L = _C.lib()
+    for n in sigs:
+        assert getattr(L, n) is not None
+    assert L.rr_abi_version() == 1
+
+
+def test_bindings_only_call_declared_entry_points():
+    from rrnet_amd import _C
+    sigs = _C.header_signatures()
+    used = set()
+    for dp, _, files in os.walk(os.path.join(ROOT, "rrnet_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                used |= set(re.findall(r'_C\.fn\("(\w+)"', open(os.path.join(dp, f)).read()))
+    assert used, "no bindings found"
+    assert not (used - set(sigs)), "bindings call undeclared entry points: %s" % (used - set(sigs))
+
+
+def test_product_never_touches_the_oracle():
+    bad = []
+    for dp, _, files in os.walk(os.path.join(ROOT, "rrnet_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                txt = open(os.path.join(dp, f)).read()
+                if re.search(r"^\s*(from|import)\s+oracle\b", txt, re.M) or "liboracle" in txt:
+                    bad.append(os.path.join(dp, f))
+    assert not bad, bad
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from rrnet_amd import _C
+    monkeypatch.setattr(_C, "_lib", None)
+    monkeypatch.setattr(_C, "LIB_PATH", "/nonexistent/librrnet_hip.so")
+    with pytest.raises(_C.RRNetHipError):
+        _C.lib()
+
+
+def test_cpu_tensors_are_refused():
+    import torch
+    from rrnet_amd import _C
+    with pytest.raises(_C.RRNetHipError):
+        _C.require_cuda(torch.zeros(3))

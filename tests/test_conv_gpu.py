@@ -1,0 +1,103 @@
+"""GPU parity: NHWC fp32 MFMA convolutions (fprop / dgrad / wgrad, through the C ABI) against
+torch-CPU conv2d and its autograd — torch is the de-facto spec of these layers.
+Tolerance: fp32 accumulation in a different order, |err| <= 1e-4 + 1e-4*|ref| scaled by sqrt(Kg)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+# (N, C, H, W, K, R, S, stride, pad_h, pad_w, bias, relu)
+SHAPES = [
+    (2, 32, 16, 16, 32, 3, 3, 1, 1, 1, False, False),
+    (2, 256, 16, 16, 256, 3, 3, 1, 1, 1, False, False),     # the dominant shape, small spatial
+    (1, 64, 9, 13, 128, 3, 3, 1, 1, 1, False, False),       # ragged M / N tiles
+    (2, 128, 16, 16, 256, 3, 3, 2, 1, 1, False, False),     # stride-2 3x3
+    (2, 128, 15, 17, 256, 1, 1, 2, 0, 0, False, False),     # stride-2 1x1 skip, odd size
+    (2, 256, 8, 8, 384, 1, 1, 1, 0, 0, False, False),
+    (2, 3, 32, 32, 16, 7, 7, 2, 3, 3, False, False),        # stem (scalar gather path)
+    (2, 3, 30, 34, 128, 7, 7, 2, 3, 3, False, False),
+    (1, 256, 12, 12, 10, 1, 1, 1, 0, 0, True, False),       # hm head 1x1 (BN=32 tile, N masked)
+    (1, 256, 12, 12, 2, 1, 1, 1, 0, 0, True, False),
+    (1, 256, 20, 12, 1, 17, 1, 1, 8, 0, True, False),       # HCov
+    (1, 256, 12, 20, 1, 1, 17, 1, 0, 8, True, False),       # WCov
+    (1, 256, 10, 10, 256, 3, 3, 1, 1, 1, True, True),       # head 3x3 + bias + ReLU
+    (7, 256, 3, 3, 64, 1, 1, 1, 0, 0, False, False),        # stage-2 bottleneck on RoIs
+    (7, 64, 3, 3, 64, 3, 3, 1, 1, 1, False, False),
+    (7, 256, 1, 1, 4, 1, 1, 1, 0, 0, True, False),          # regressor
+    (2, 48, 8, 8, 24, 3, 3, 1, 1, 1, False, False),         # channels not a multiple of 32
+    (2, 12, 6, 6, 8, 3, 3, 2, 1, 1, False, False),
+    (1, 512, 4, 4, 512, 3, 3, 1, 1, 1, False, False),
+]
+
+
+def _mk(shape, seed):
+    rng = np.random.default_rng(seed)
+    return torch.from_numpy(rng.standard_normal(shape).astype(np.float32))
+
+
+@pytest.mark.parametrize("cfg", SHAPES, ids=lambda c: "n%dc%dh%dw%dk%dr%ds%d_s%d" % c[:8])
+def test_conv_fprop_dgrad_wgrad(cfg):
+    from rrnet_amd import ops
+    n, c, h, w, k, r, s, stride, ph, pw, use_bias, relu = cfg
+    x = _mk((n, c, h, w), 1)
+    wt = _mk((k, c, r, s), 2) * (1.0 / np.sqrt(c * r * s))
+    b = _mk((k,), 3) if use_bias else None
+    xr = x.clone().requires_grad_()
+    wr = wt.clone().requires_grad_()
+    y_ref = F.conv2d(xr, wr, b, stride=stride, padding=(ph, pw))
+    if relu:
+        y_ref = F.relu(y_ref)
+    gy = _mk(tuple(y_ref.shape), 4)
+    y_ref.backward(gy)
+
+    xd = ops.to_nhwc(x.cuda())
+    wd = ops.to_nhwc(wt.cuda())
+    bd = b.cuda() if use_bias else None
+    y, slab = ops.conv_fprop(xd, wd, bd, stride, (ph, pw), relu, want_stats=True)
+    tol = 2e-5 * np.sqrt(c * r * s)
+    np.testing.assert_allclose(y.cpu().numpy(), y_ref.detach().numpy(), atol=tol, rtol=1e-4)
+    # fused BatchNorm partial sums: column sums / sums of squares of y
+    p, q = y.shape[2], y.shape[3]
+    st = slab.view(-1, 2, k).sum(0).cpu().numpy()
+    yr = y_ref.detach().double().permute(0, 2, 3, 1).reshape(-1, k).numpy()
+    np.testing.assert_allclose(st[0], yr.sum(0), atol=1e-3 * np.sqrt(n * p * q), rtol=1e-4)
+    np.testing.assert_allclose(st[1], (yr * yr).sum(0), atol=1e-3 * np.sqrt(n * p * q), rtol=1e-4)
+
+    gy_eff = gy.clone()
+    if relu:
+        gy_eff = gy_eff * (y_ref.detach() > 0).float()
+    gyd = ops.to_nhwc(gy_eff.cuda())
+    dx = ops.conv_dgrad(gyd, wd, (n, c, h, w), stride, (ph, pw))
+    tol = 2e-5 * np.sqrt(k * r * s)
+    np.testing.assert_allclose(dx.cpu().numpy(), xr.grad.numpy(), atol=tol, rtol=1e-4)
+    # accumulate form
+    base = _mk((n, c, h, w), 5)
+    acc = ops.to_nhwc(base.cuda()).clone(memory_format=torch.channels_last)
+    ops.conv_dgrad(gyd, wd, (n, c, h, w), stride, (ph, pw), out=acc, accumulate=True)
+    np.testing.assert_allclose(acc.cpu().numpy(), (xr.grad + base).numpy(), atol=tol, rtol=1e-4)
+
+    dw = torch.zeros((k, r, s, c), device="cuda").permute(0, 3, 1, 2)
+    ops.conv_wgrad(xd, gyd, dw, stride, (ph, pw))
+    tol = 3e-5 * np.sqrt(n * p * q)
+    np.testing.assert_allclose(dw.cpu().numpy(), wr.grad.numpy(), atol=tol, rtol=2e-4)
+
+
+def test_conv_linearity_large():
+    """Size-independent property at a BASELINE-sized layer (256->256 3x3 on 256x256, B=1):
+    conv(a*x1 + x2) == a*conv(x1) + conv(x2) within fp32 rounding, and a spot check of one
+    output row against torch-CPU."""
+    from rrnet_amd import ops
+    torch.manual_seed(0)
+    x1 = ops.to_nhwc(torch.randn(1, 256, 256, 256, device="cuda"))
+    x2 = ops.to_nhwc(torch.randn(1, 256, 256, 256, device="cuda"))
+    w = ops.to_nhwc(torch.randn(256, 256, 3, 3, device="cuda") / 48.0)
+    y1 = ops.conv_fprop(x1, w, None, 1, (1, 1))
+    y2 = ops.conv_fprop(x2, w, None, 1, (1, 1))
+    y12 = ops.conv_fprop(ops.to_nhwc(0.5 * x1 + x2), w, None, 1, (1, 1))
+    err = (y12 - (0.5 * y1 + y2)).abs().max().item()
+    assert err < 5e-4, err
+    rows = slice(100, 104)
+    ref = F.conv2d(x1[:, :, 99:105, :].cpu(), w.cpu(), None, 1, (0, 1))
+    np.testing.assert_allclose(y1[:, :, rows, :].cpu().numpy(), ref.numpy(), atol=1e-3, rtol=1e-3)
