@@ -69,6 +69,113 @@ int rr_conv_dgrad(const float *dy, const float *w, float *dx, int n, int h, int 
 int rr_conv_wgrad(const float *x, const float *dy, float *dw, int n, int h, int wd, int c, int k,
                   int r, int s, int stride, int pad_h, int pad_w, hipStream_t stream);
 
+/* ---- BatchNorm / ReLU / residual / up-path / Adam (HBM-bound NHWC elementwise) -------- *
+ * Replace nn.BatchNorm2d (SyncBatchNorm via operators/rrnet_operator.py:27) + ReLU + residual
+ * add of backbones/hourglass.py:18-19,22,26,34-40,51,59-60 and backbones/resnet.py:23-50;
+ * nn.Upsample x2 + bilinear(align_corners) resize + add of backbones/hourglass.py:113,121-124;
+ * F.adaptive_avg_pool2d of detectors/fasterrcnn_detector.py:15; optim.Adam of
+ * operators/rrnet_operator.py:29,138.  `total` = element count, `c` = channels (NHWC inner).
+ * Training statistics: rr_conv_fprop's slab -> rr_bn_reduce_slab -> sums[2][c] (the SyncBN
+ * exchange all-reduces exactly this buffer plus the sample count) -> rr_bn_finalize ->
+ * mean/invstd (saved for backward), scale/shift (for rr_bn_apply), running stats updated with
+ * `momentum` and the unbiased variance.
+ * rr_bn_apply: out = relu?(y*scale+shift [+ res | + res*res_scale+res_shift]).
+ * rr_bn_bwd_reduce: sums[2][c] = per-channel sum(dy), sum(dy*xhat), dy = dz*(z>0) if z.
+ * rr_bn_bwd_apply: dx = gamma*invstd*(dy - sums0/count - xhat*sums1/count); g_out (optional)
+ *   receives dy for the residual branch; dgamma/dbeta (optional) are accumulated from sums.
+ *   `count_dev` (optional, both finalize and bwd_apply): sample count read from device memory
+ *   instead of `count` — the SyncBN exchange all-reduces it next to the sums.
+ * rr_sum_n: out = (sum of n<=8 tensors) * (z>0 if z): gradient fan-in of a multiply-used tensor.
+ * rr_bias_relu_bwd: dy_masked = dy*(z>0) (if z), dbias += column sums (conv+bias+ReLU heads,
+ *   detectors/centernet_detector.py:85-93).
+ * rr_upsample_add: out[n,h,w] = up1[n,h,w] + bilinear_ac(nearest2x(low))[h,w]; the exact 2x
+ *   case never builds the intermediate image. */
+int rr_bn_reduce_slab(const double *slab, int mtiles, int c, double *sums, hipStream_t stream);
+int rr_bn_finalize(const double *sums, double count, const double *count_dev, const float *gamma, const float *beta,
+                   float *running_mean, float *running_var, float momentum, float eps, float *mean,
+                   float *invstd, float *scale, float *shift, int c, hipStream_t stream);
+int rr_bn_eval_coeffs(const float *gamma, const float *beta, const float *running_mean,
+                      const float *running_var, float eps, float *scale, float *shift, int c,
+                      hipStream_t stream);
+int rr_bn_apply(const float *y, const float *scale, const float *shift, const float *res,
+                const float *res_scale, const float *res_shift, float *out, long total, int c, int relu,
+                hipStream_t stream);
+int rr_bn_bwd_reduce(const float *dz, const float *z, const float *y, const float *mean,
+                     const float *invstd, double *sums, long npix, int c, hipStream_t stream);
+int rr_bn_bwd_apply(const float *dz, const float *z, const float *y, const float *mean,
+                    const float *invstd, const float *gamma, const double *sums, double count,
+                    const double *count_dev, float *dx, float *g_out, float *dgamma, float *dbeta, long total,
+                    int c, hipStream_t stream);
+int rr_relu_fwd(const float *x, float *out, long total, hipStream_t stream);
+int rr_sum_n(const float *const *grads, int n, const float *z, float *out, long total, hipStream_t stream);
+int rr_bias_relu_bwd(const float *dy, const float *z, float *dy_masked, float *dbias, long npix, int c,
+                     hipStream_t stream);
+int rr_upsample_add_fwd(const float *up1, const float *low, float *out, int n, int h, int w, int lh, int lw,
+                        int c, hipStream_t stream);
+int rr_upsample_add_bwd(const float *dout, float *dlow, int n, int h, int w, int lh, int lw, int c,
+                        hipStream_t stream);
+int rr_avgpool_fwd(const float *x, float *out, long r, int hw, int c, hipStream_t stream);
+int rr_avgpool_bwd(const float *dout, float *dx, long r, int hw, int c, hipStream_t stream);
+int rr_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, long n, float lr,
+                 float beta1, float beta2, float eps, int step, float grad_scale, hipStream_t stream);
+
+/* ---- losses --------------------------------------------------------------------------- *
+ * rr_focal_loss_fwd/bwd: clamp(sigmoid(x),1e-4,1-1e-4) + focal_loss_for_hm of
+ *   operators/rrnet_operator.py:55-57 + modules/loss/functional.py:25-51.  logits and gt share
+ *   one layout; sums[3] (double, device) = { sum log(p)(1-p)^2 [g==1], sum log(1-p)p^2(1-g)^4
+ *   [g<1], #(g==1) }; loss = -(s0+s1)/s2, or -s1 when s2 == 0.  bwd: dlogits = *gout * gscale *
+ *   dloss/dlogits (gout: device scalar).
+ * rr_regl1_fwd/bwd: modules/loss/regl1loss.py:9-17.  pred NHWC [b,hw,c]; mask, ind [b,m] float;
+ *   target [b,m,c]; sums = { sum|pred*m - t*m|, sum of the expanded mask }; loss = s0/(s1+1e-4).
+ *   bwd zeroes dpred [b,hw,c] and scatters with float atomics.
+ * rr_stage2_loss: operators/rrnet_operator.py:63-102 — per RoI max IoU (torchvision box_iou
+ *   definition) against gt [b,g,gstride>=4] xyxy, positives IoU > 0.5, Faster-RCNN targets with
+ *   the +1 width convention, smooth-L1 mean per image / b; images without positives add 0.
+ *   rois [r,5] = (image, x1,y1,x2,y2) in feature coords, scaled by `scale`.  Outputs: tgt [r,4],
+ *   pos [r], npos [b], loss[0] (double), dreg_unit [r,4] = dloss/dreg. */
+int rr_focal_loss_fwd(const float *logits, const float *gt, long n, double *sums, hipStream_t stream);
+int rr_focal_loss_bwd(const float *logits, const float *gt, long n, const double *sums, const float *gout,
+                      float gscale, float *dlogits, hipStream_t stream);
+int rr_regl1_fwd(const float *pred, const float *mask, const float *ind, const float *target, int b, int m,
+                 int c, long hw, double *sums, hipStream_t stream);
+int rr_regl1_bwd(const float *pred, const float *mask, const float *ind, const float *target, int b, int m,
+                 int c, long hw, const double *sums, const float *gout, float gscale, float *dpred,
+                 hipStream_t stream);
+int rr_stage2_loss(const float *rois, const float *reg, int r, const float *gt, int b, int g, int gstride,
+                   float scale, float *tgt, int *pos, int *npos, double *loss, float *dreg_unit,
+                   hipStream_t stream);
+
+/* ---- decode / NMS plumbing ------------------------------------------------------------ *
+ * rr_decode_topk: models/rrnet.py:93-138 (_topk + gathers + transform_bbox).  hm NHWC
+ *   [b,h,w,c] logits (is_logits=1: sigmoid applied) or ready scores (0); wh, off NHWC [b,h,w,2];
+ *   out [b,k,6] = x1,y1,x2,y2,score,cls in feature coordinates, score-descending, ties by the
+ *   reference's flat index.  k <= min(4096, c*h*w).  No 3x3 peak filter (the reference never
+ *   applies one); rr_peak3x3 provides operators/centernet_operator.py:204-210 as an option.
+ * rr_group_by_class: stable regrouping of each image's k rows by class (classes ascending =
+ *   torch.unique order of models/rrnet.py:59); seg_off [b*num_classes+1] row offsets.
+ * rr_hard_nms_segments: torchvision.ops.nms as called at models/rrnet.py:69,78; rows of a
+ *   segment score-descending, 6 floats per row; kept rows are compacted to the segment front.
+ * rr_pack_segments: phase 0 -> out_off [nseg+1] exclusive prefix of n_out (out_off[nseg] = R);
+ *   phase 1 -> rois [R,5], scores [R], clses [R] (models/rrnet.py:37-49) and/or rows6 [R,6]. */
+int rr_decode_topk(const float *hm, int is_logits, const float *wh, const float *off, int b, int h, int w,
+                   int c, int k, float *out, hipStream_t stream);
+int rr_peak3x3(const float *hm, float *scores, int b, int h, int w, int c, hipStream_t stream);
+int rr_group_by_class(const float *boxes, int b, int k, int num_classes, int cls_base, float *grouped,
+                      int *seg_off, hipStream_t stream);
+int rr_hard_nms_segments(float *boxes, const int *seg_off, int nseg, int max_seg_boxes, float thresh,
+                         int *n_out, hipStream_t stream);
+int rr_pack_segments(const float *grouped, const int *seg_off, const int *n_out, int nseg, int segs_per_image,
+                     int *out_off, float *rois, float *scores, float *clses, float *rows6, int phase,
+                     hipStream_t stream);
+
+/* ---- RoIAlign --------------------------------------------------------------------------- *
+ * torchvision.ops.roi_align(feat, rois, (ph,pw)) at models/rrnet.py:51 (spatial_scale 1,
+ * sampling_ratio -1, legacy coordinates).  feat NHWC [b,h,w,c]; out NHWC [r,ph,pw,c]. */
+int rr_roi_align_fwd(const float *feat, const float *rois, int r, int h, int w, int c, int ph, int pw,
+                     float spatial_scale, int sampling_ratio, float *out, hipStream_t stream);
+int rr_roi_align_bwd(const float *dout, const float *rois, int r, int b, int h, int w, int c, int ph, int pw,
+                     float spatial_scale, int sampling_ratio, float *dfeat, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,340 @@
+// Heat-map decode for gfx950: sigmoid -> top-K -> gather -> box assembly, one workgroup per image.
+//
+// Replaces models/rrnet.py:93-138 (RRNet._topk + _gather_feat + _transpose_and_gather_feat +
+// transform_bbox): torch.topk over [B,C,H*W], a second torch.topk over [B,C*K], five gathers and
+// two NHWC permute copies in the reference.  The two-level top-k equals one global top-K over the
+// C*H*W scores of an image (every member of the global top-K is inside its class's top-K), which is
+// what this kernel computes with a 3-pass radix select (11+11+10 bits, LDS histograms), an
+// LDS-resident bitonic sort of the K winners and a fused gather of offset / wh.
+// Ordering: score descending; equal scores ordered by the reference's flat index c*H*W + y*W + x
+// ascending (torch.topk leaves the order of ties unspecified).
+// HBM-bound: algorithmic bytes = C*H*W*4 per image (the map is read once from HBM, the later
+// passes hit L2) + K*(2+2)*4 gathered + K*6*4 written.
+//
+// Also here: the optional 3x3 peak filter (operators/centernet_operator.py:204-210 `_ctnet_nms`,
+// dead code in the reference, named by north_star) and the per-class grouping / packing helpers
+// that turn the reference's per-image x per-class Python loops (models/rrnet.py:37-46,56-80,
+// operators/rrnet_operator.py:211-232) into batched launches.
+#include "common.h"
+#include "rrnet_hip.h"
+
+namespace {
+
+constexpr int DT = 1024;  // threads per image
+
+__device__ __forceinline__ unsigned int f2ord(float f)
+{
+    const unsigned int u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(unsigned int o)
+{
+    return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
+}
+__device__ __forceinline__ float score_of(float v, int is_logits) { return is_logits ? 1.0f / (1.0f + expf(-v)) : v; }
+
+// wave 0: find the bin (scanning from the top) where the running count reaches `need`.
+// result[0] = bin, result[1] = count strictly above that bin.
+__device__ void find_bin(const int *hist, int nbins, int need, int *result)
+{
+    if (threadIdx.x >= 64) return;
+    const int lane = threadIdx.x;
+    const int per = nbins / 64;
+    const int hi = nbins - 1 - lane * per;  // this lane owns bins hi, hi-1, ..., hi-per+1
+    int mine = 0;
+    for (int k = 0; k < per; ++k) mine += hist[hi - k];
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += v;
+    }
+    const int excl = incl - mine;
+    if (excl < need && incl >= need) {
+        int run = excl;
+        for (int k = 0; k < per; ++k) {
+            const int h = hist[hi - k];
+            if (run + h >= need) {
+                result[0] = hi - k;
+                result[1] = run;
+                break;
+            }
+            run += h;
+        }
+    }
+}
+
+__global__ __launch_bounds__(DT) void decode_topk_kernel(const float *hm, int is_logits, const float *wh, const float *off,
+                                                         int H, int W, int C, int K, int KP, float *out)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    unsigned long long *keys = reinterpret_cast<unsigned long long *>(smem);  // [KP]
+    int *hist = reinterpret_cast<int *>(keys + KP);                           // [2048]
+    int *scan = hist + 2048;                                                  // [DT/64 + 1]
+    __shared__ int res[2];
+    __shared__ int cnt_gt;
+
+    const int tid = threadIdx.x;
+    const long HW = (long)H * W;
+    const long n = HW * C;
+    const float *x = hm + (long)blockIdx.x * n;
+
+    // ---- radix select of the K-th largest ordered key
+    unsigned int prefix = 0;   // bits fixed so far (top-aligned)
+    int need = K;
+    for (int pass = 0; pass < 3; ++pass) {
+        const int shift = pass == 0 ? 21 : (pass == 1 ? 10 : 0);
+        const int nb = pass == 2 ? 1024 : 2048;
+        for (int i = tid; i < 2048; i += DT) hist[i] = 0;
+        __syncthreads();
+        for (long i = tid; i < n; i += DT) {
+            const unsigned int o = f2ord(score_of(x[i], is_logits));
+            const bool in = pass == 0 ? true : (pass == 1 ? (o >> 21) == (prefix >> 21) : (o >> 10) == (prefix >> 10));
+            if (in) atomicAdd(&hist[(o >> shift) & (nb - 1)], 1);
+        }
+        __syncthreads();
+        find_bin(hist, nb, need, res);
+        __syncthreads();
+        prefix |= (unsigned int)res[0] << shift;
+        need -= res[1];
+        __syncthreads();
+    }
+    const unsigned int thr = prefix;   // ordered key of the K-th largest score
+    const int need_eq = need;          // how many elements equal to thr are taken
+    const int n_gt = K - need_eq;
+
+    // ---- collect: strictly greater (any order) + the first need_eq equal ones in (thread, round) order
+    int my_eq = 0;
+    for (long i = tid; i < n; i += DT) my_eq += (f2ord(score_of(x[i], is_logits)) == thr) ? 1 : 0;
+    // block exclusive scan of my_eq
+    int incl = my_eq;
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) scan[wave] = incl;
+    if (tid == 0) cnt_gt = 0;
+    __syncthreads();
+    int base_eq = incl - my_eq;
+    for (int w = 0; w < wave; ++w) base_eq += scan[w];
+    for (int i = K + tid; i < KP; i += DT) keys[i] = 0ull;
+    __syncthreads();
+    int eq_i = 0;
+    for (long i = tid; i < n; i += DT) {
+        const unsigned int o = f2ord(score_of(x[i], is_logits));
+        if (o < thr) continue;
+        const int c = (int)(i % C);
+        const long pix = i / C;
+        const unsigned int ref = (unsigned int)(c * HW + pix);
+        const unsigned long long key = ((unsigned long long)o << 32) | (unsigned long long)(0xffffffffu - ref);
+        if (o > thr) {
+            const int p = atomicAdd(&cnt_gt, 1);
+            keys[p] = key;
+        } else {
+            const int r = base_eq + eq_i++;
+            if (r < need_eq) keys[n_gt + r] = key;
+        }
+    }
+    __syncthreads();
+
+    // ---- bitonic sort, descending
+    for (int k2 = 2; k2 <= KP; k2 <<= 1) {
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < KP / 2; t += DT) {
+                const int lo = ((t / j) * 2 * j) + (t % j);
+                const int hi2 = lo + j;
+                const bool desc = ((lo & k2) == 0);
+                const unsigned long long a = keys[lo], b = keys[hi2];
+                if ((a < b) == desc) { keys[lo] = b; keys[hi2] = a; }
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- gather + box assembly (models/rrnet.py:122-137)
+    for (int k = tid; k < K; k += DT) {
+        const unsigned long long key = keys[k];
+        const float score = ord2f((unsigned int)(key >> 32));
+        const unsigned int ref = 0xffffffffu - (unsigned int)(key & 0xffffffffu);
+        const int cls = (int)(ref / HW);
+        const long pix = ref % HW;
+        const float xs0 = (float)(pix % W), ys0 = (float)(pix / W);
+        const float *po = off + ((long)blockIdx.x * HW + pix) * 2;
+        const float *pw = wh + ((long)blockIdx.x * HW + pix) * 2;
+        const float xs = xs0 + po[0], ys = ys0 + po[1];
+        const float w_ = fmaxf(pw[0], 0.f), h_ = fmaxf(pw[1], 0.f);
+        const float px = xs - w_ / 2.f, py = ys - h_ / 2.f;
+        float *o = out + ((long)blockIdx.x * K + k) * 6;
+        o[0] = px; o[1] = py; o[2] = w_ + px; o[3] = h_ + py; o[4] = score; o[5] = (float)cls;
+    }
+}
+
+// scores[b,y,x,c] = sigmoid(hm) if it is the maximum of its 3x3 window (same class) else 0
+__global__ void peak3x3_kernel(const float *hm, float *scores, int B, int H, int W, int C)
+{
+    const long total = (long)B * H * W * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        long p = i / C;
+        const int xw = (int)(p % W); p /= W;
+        const int y = (int)(p % H);
+        const long b = p / H;
+        const float v = 1.0f / (1.0f + expf(-hm[i]));
+        float m = v;
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int yy = y + dy, xx = xw + dx;
+                if (yy < 0 || xx < 0 || yy >= H || xx >= W) continue;
+                const float u = 1.0f / (1.0f + expf(-hm[((b * H + yy) * W + xx) * C + c]));
+                m = fmaxf(m, u);
+            }
+        scores[i] = (m == v) ? v : 0.f;
+    }
+}
+
+// ---- stable grouping of each image's rows by class (rows arrive score-descending) ------------
+// boxes [B,K,6] -> grouped [B,K,6] with classes ascending, order inside a class preserved;
+// seg_off [B*NC+1] row offsets of every (image, class) segment in the flattened [B*K] row space.
+__global__ __launch_bounds__(256) void group_by_class_kernel(const float *boxes, int K, int NC, int cls_base,
+                                                             float *grouped, int *seg_off)
+{
+    extern __shared__ int sm[];   // count[NC], start[NC]
+    int *count = sm, *start = sm + NC;
+    const int b = blockIdx.x;
+    const int n = K;
+    const float *src = boxes + (long)b * K * 6;
+    for (int c = threadIdx.x; c < NC; c += 256) count[c] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int c = (int)src[i * 6 + 5] - cls_base;
+        if (c >= 0 && c < NC) atomicAdd(&count[c], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int c = 0; c < NC; ++c) {
+            start[c] = run;
+            seg_off[b * NC + c] = b * K + run;
+            run += count[c];
+        }
+        if (b == gridDim.x - 1) seg_off[(b + 1) * NC] = b * K + run;
+    }
+    __syncthreads();
+    // one thread per class keeps the order stable
+    for (int c = threadIdx.x; c < NC; c += 256) {
+        int w = start[c];
+        float *dst = grouped + (long)b * K * 6;
+        for (int i = 0; i < n; ++i) {
+            if ((int)src[i * 6 + 5] - cls_base == c) {
+#pragma unroll
+                for (int e = 0; e < 6; ++e) dst[w * 6 + e] = src[i * 6 + e];
+                ++w;
+            }
+        }
+    }
+}
+
+// exclusive prefix of n_out over segments -> row offsets of the packed output (single block)
+__global__ void seg_prefix_kernel(const int *n_out, int nseg, int *out_off /*[nseg+1]*/)
+{
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nseg; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = i < nseg ? n_out[i] : 0;
+        // simple Hillis-Steele in LDS
+        __shared__ int buf[1024];
+        buf[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            const int t = threadIdx.x >= o ? buf[threadIdx.x - o] : 0;
+            __syncthreads();
+            buf[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < nseg) out_off[i] = carry + buf[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += buf[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out_off[nseg] = carry;
+}
+
+// kept rows of every segment -> packed rois [R,5] = (image, x1,y1,x2,y2), scores [R], classes [R]
+__global__ void pack_segments_kernel(const float *grouped, const int *seg_off, const int *n_out, const int *out_off,
+                                     int segs_per_image, float *rois, float *scores, float *clses, float *rows6)
+{
+    const int s = blockIdx.x;
+    const int n = n_out[s];
+    const float *src = grouped + (long)seg_off[s] * 6;
+    const int o0 = out_off[s];
+    const float img = (float)(s / segs_per_image);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const float *r = src + i * 6;
+        if (rois) {
+            float *q = rois + (long)(o0 + i) * 5;
+            q[0] = img; q[1] = r[0]; q[2] = r[1]; q[3] = r[2]; q[4] = r[3];
+            scores[o0 + i] = r[4];
+            clses[o0 + i] = r[5];
+        }
+        if (rows6) {
+            float *q = rows6 + (long)(o0 + i) * 6;
+#pragma unroll
+            for (int e = 0; e < 6; ++e) q[e] = r[e];
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int rr_decode_topk(const float *hm, int is_logits, const float *wh, const float *off, int b, int h, int w,
+                              int c, int k, float *out, hipStream_t stream)
+{
+    RR_CHECK_ARG(b > 0 && h > 0 && w > 0 && c > 0, "rr_decode_topk: bad dims");
+    RR_CHECK_ARG(k > 0 && k <= 4096 && (long)k <= (long)h * w * c, "rr_decode_topk: k=%d out of range (1..min(4096, C*H*W))", k);
+    RR_CHECK_ARG((long)h * w * c < (1l << 31), "rr_decode_topk: map too large");
+    int kp = 2;
+    while (kp < k) kp <<= 1;
+    const size_t lds = (size_t)kp * 8 + 2048 * 4 + (DT / 64 + 1) * 4;
+    hipLaunchKernelGGL(decode_topk_kernel, dim3(b), dim3(DT), lds, stream, hm, is_logits, wh, off, h, w, c, k, kp, out);
+    RR_CHECK_LAUNCH("rr_decode_topk");
+    return RR_OK;
+}
+
+extern "C" int rr_peak3x3(const float *hm, float *scores, int b, int h, int w, int c, hipStream_t stream)
+{
+    const long total = (long)b * h * w * c;
+    long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(peak3x3_kernel, dim3((int)blocks), dim3(256), 0, stream, hm, scores, b, h, w, c);
+    RR_CHECK_LAUNCH("rr_peak3x3");
+    return RR_OK;
+}
+
+extern "C" int rr_group_by_class(const float *boxes, int b, int k, int num_classes, int cls_base,
+                                 float *grouped, int *seg_off, hipStream_t stream)
+{
+    RR_CHECK_ARG(b > 0 && k > 0 && num_classes > 0 && num_classes <= 1024, "rr_group_by_class: bad dims");
+    hipLaunchKernelGGL(group_by_class_kernel, dim3(b), dim3(256), 2 * num_classes * sizeof(int), stream, boxes, k,
+                       num_classes, cls_base, grouped, seg_off);
+    RR_CHECK_LAUNCH("rr_group_by_class");
+    return RR_OK;
+}
+
+extern "C" int rr_pack_segments(const float *grouped, const int *seg_off, const int *n_out, int nseg, int segs_per_image,
+                                int *out_off, float *rois, float *scores, float *clses, float *rows6, int phase,
+                                hipStream_t stream)
+{
+    RR_CHECK_ARG(nseg > 0 && segs_per_image > 0, "rr_pack_segments: bad dims");
+    if (phase == 0) {   // offsets only: the caller reads out_off[nseg] to size the outputs
+        hipLaunchKernelGGL(seg_prefix_kernel, dim3(1), dim3(1024), 0, stream, n_out, nseg, out_off);
+    } else {
+        hipLaunchKernelGGL(pack_segments_kernel, dim3(nseg), dim3(128), 0, stream, grouped, seg_off, n_out, out_off,
+                           segs_per_image, rois, scores, clses, rows6);
+    }
+    RR_CHECK_LAUNCH("rr_pack_segments");
+    return RR_OK;
+}

@@ -1,0 +1,535 @@
+// HBM-bound NHWC elementwise / per-channel-reduction kernels around the convolutions:
+// BatchNorm (training statistics, apply, backward), ReLU, residual add, fan-out gradient sums,
+// nearest-2x upsample + add, bilinear (align_corners) resize, bias gradients, fused Adam.
+//
+// Replaces what the reference runs as separate ATen kernels:
+//   nn.BatchNorm2d / SyncBatchNorm + ReLU + residual add   backbones/hourglass.py:18-19,22,26,34-40,51,59-60
+//   nn.Upsample(scale_factor=2) + bilinear resize + add     backbones/hourglass.py:113,121-124
+//   optim.Adam                                              operators/rrnet_operator.py:29,138
+// All kernels move 16 B per lane (float4 along the channel axis, C % 4 == 0) and are bound by
+// HBM bandwidth; algorithmic bytes = 4 B x (tensors read + tensors written) x elements.
+#include "common.h"
+#include "rrnet_hip.h"
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int EW_THREADS = 256;
+inline int ew_blocks(long n4) { long b = (n4 + EW_THREADS - 1) / EW_THREADS; return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b)); }
+
+// ---- BatchNorm statistics ------------------------------------------------------------------
+// slab [mtiles][2][C] (doubles, written by rr_conv_fprop) -> sums [2][C]
+__global__ void bn_reduce_slab_kernel(const double *slab, int mtiles, int C, double *sums)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // over 2*C
+    if (i >= 2 * C) return;
+    double s = 0.0;
+    for (int m = 0; m < mtiles; ++m) s += slab[(long)m * 2 * C + i];
+    sums[i] = s;
+}
+
+// sums [2][C] over `count` samples -> mean / invstd / scale / shift (+ running stats, momentum update
+// with the unbiased variance, as nn.BatchNorm2d does in training mode).
+__global__ void bn_finalize_kernel(const double *sums, double count_h, const double *count_d, const float *gamma, const float *beta,
+                                   float *running_mean, float *running_var, float momentum, float eps,
+                                   float *mean, float *invstd, float *scale, float *shift, int C)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double count = count_d ? *count_d : count_h;   // device count: SyncBN with ragged per-rank sample counts
+    const double m = sums[c] / count;
+    double var = sums[C + c] / count - m * m;
+    if (var < 0.0) var = 0.0;
+    const float istd = (float)(1.0 / sqrt(var + (double)eps));
+    mean[c] = (float)m;
+    invstd[c] = istd;
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    const float sc = g * istd;
+    scale[c] = sc;
+    shift[c] = b - (float)m * sc;
+    if (running_mean) {
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+}
+
+// eval mode: scale/shift from the running statistics
+__global__ void bn_eval_coeffs_kernel(const float *gamma, const float *beta, const float *running_mean,
+                                      const float *running_var, float eps, float *scale, float *shift, int C)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float sc = gamma[c] / sqrtf(running_var[c] + eps);
+    scale[c] = sc;
+    shift[c] = beta[c] - running_mean[c] * sc;
+}
+
+// out = relu?( y*scale+shift  [+ res | + res*res_scale+res_shift] )
+__global__ __launch_bounds__(EW_THREADS) void bn_apply_kernel(const f32x4 *y, const float *scale, const float *shift,
+                                                              const f32x4 *res, const float *res_scale,
+                                                              const float *res_shift, f32x4 *out, long n4, int C4,
+                                                              int relu)
+{
+    for (long i = (long)blockIdx.x * EW_THREADS + threadIdx.x; i < n4; i += (long)gridDim.x * EW_THREADS) {
+        const int c = (int)(i % C4) * 4;
+        f32x4 v = y[i];
+        const f32x4 sc = *reinterpret_cast<const f32x4 *>(scale + c), sh = *reinterpret_cast<const f32x4 *>(shift + c);
+        v = v * sc + sh;
+        if (res) {
+            f32x4 r = res[i];
+            if (res_scale) {
+                const f32x4 rs = *reinterpret_cast<const f32x4 *>(res_scale + c);
+                const f32x4 rh = *reinterpret_cast<const f32x4 *>(res_shift + c);
+                r = r * rs + rh;
+            }
+            v = v + r;
+        }
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+        }
+        out[i] = v;
+    }
+}
+
+// per-channel sums of dy and dy*xhat, dy = dz * (z > 0 if z given).  Each workgroup walks a slice of
+// the pixels with a fixed channel quad per thread, reduces over its pixel lanes in LDS and adds one
+// double per channel per workgroup to sums[2][C].
+__global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_kernel(const float *dz, const float *z, const float *y,
+                                                                   const float *mean, const float *invstd,
+                                                                   double *sums, long npix, int C)
+{
+    __shared__ float red[2][EW_THREADS * 4];
+    const int C4 = C / 4;                      // <= EW_THREADS (checked by the launcher)
+    const int lanes = EW_THREADS / C4;         // pixel lanes per pass
+    const int t = threadIdx.x;
+    const int cq = t % C4, pl = t / C4;
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+    if (pl < lanes) {
+        const f32x4 mu = *reinterpret_cast<const f32x4 *>(mean + cq * 4);
+        const f32x4 is = *reinterpret_cast<const f32x4 *>(invstd + cq * 4);
+        for (long p = (long)blockIdx.x * lanes + pl; p < npix; p += (long)gridDim.x * lanes) {
+            const long off = p * C + cq * 4;
+            f32x4 g = *reinterpret_cast<const f32x4 *>(dz + off);
+            if (z) {
+                const f32x4 zz = *reinterpret_cast<const f32x4 *>(z + off);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g[e] = zz[e] > 0.f ? g[e] : 0.f;
+            }
+            const f32x4 xh = (*reinterpret_cast<const f32x4 *>(y + off) - mu) * is;
+            s1 += g;
+            s2 += g * xh;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[0][t * 4 + e] = s1[e]; red[1][t * 4 + e] = s2[e]; }
+    __syncthreads();
+    for (int c = t; c < C; c += EW_THREADS) {
+        double a = 0.0, b = 0.0;
+        for (int l = 0; l < lanes; ++l) {
+            a += (double)red[0][(l * C4 + c / 4) * 4 + (c & 3)];
+            b += (double)red[1][(l * C4 + c / 4) * 4 + (c & 3)];
+        }
+        unsafeAtomicAdd(sums + c, a);
+        unsafeAtomicAdd(sums + C + c, b);
+    }
+}
+
+// dx = gamma*invstd*(dy - sum_dy/count - xhat*sum_dy_xhat/count); optional g_out = dy (the masked
+// gradient, for the residual branch); workgroup 0 also accumulates dgamma / dbeta.
+__global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(const f32x4 *dz, const f32x4 *z, const f32x4 *y,
+                                                                  const float *mean, const float *invstd,
+                                                                  const float *gamma, const double *sums, double count_h,
+                                                                  const double *count_d, f32x4 *dx, f32x4 *g_out,
+                                                                  float *dgamma, float *dbeta, long n4, int C)
+{
+    const int C4 = C / 4;
+    const double count = count_d ? *count_d : count_h;
+    if (blockIdx.x == 0 && dgamma) {
+        for (int c = threadIdx.x; c < C; c += EW_THREADS) {
+            dbeta[c] += (float)sums[c];
+            dgamma[c] += (float)sums[C + c];
+        }
+    }
+    const float inv_count = (float)(1.0 / count);
+    for (long i = (long)blockIdx.x * EW_THREADS + threadIdx.x; i < n4; i += (long)gridDim.x * EW_THREADS) {
+        const int c = (int)(i % C4) * 4;
+        f32x4 g = dz[i];
+        if (z) {
+            const f32x4 zz = z[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = zz[e] > 0.f ? g[e] : 0.f;
+        }
+        if (g_out) g_out[i] = g;
+        const f32x4 mu = *reinterpret_cast<const f32x4 *>(mean + c), is = *reinterpret_cast<const f32x4 *>(invstd + c);
+        const f32x4 ga = *reinterpret_cast<const f32x4 *>(gamma + c);
+        const f32x4 xh = (y[i] - mu) * is;
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float sdy = (float)sums[c + e] * inv_count, sdx = (float)sums[C + c + e] * inv_count;
+            o[e] = ga[e] * is[e] * (g[e] - sdy - xh[e] * sdx);
+        }
+        dx[i] = o;
+    }
+}
+
+// ---- ReLU / sums ---------------------------------------------------------------------------
+__global__ __launch_bounds__(EW_THREADS) void relu_fwd_kernel(const f32x4 *x, f32x4 *out, long n4)
+{
+    for (long i = (long)blockIdx.x * EW_THREADS + threadIdx.x; i < n4; i += (long)gridDim.x * EW_THREADS) {
+        f32x4 v = x[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+        out[i] = v;
+    }
+}
+
+// out = (g0 + g1 + ... ) * (z > 0 if z): gradient fan-in of a tensor with several consumers
+struct SumArgs { const f32x4 *g[8]; int n; };
+__global__ __launch_bounds__(EW_THREADS) void sum_n_kernel(SumArgs a, const f32x4 *z, f32x4 *out, long n4)
+{
+    for (long i = (long)blockIdx.x * EW_THREADS + threadIdx.x; i < n4; i += (long)gridDim.x * EW_THREADS) {
+        f32x4 v = a.g[0][i];
+        for (int k = 1; k < a.n; ++k) v += a.g[k][i];
+        if (z) {
+            const f32x4 zz = z[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = zz[e] > 0.f ? v[e] : 0.f;
+        }
+        out[i] = v;
+    }
+}
+
+// dx = dz * (z > 0); dbias[c] += column sums (head convs: conv + bias + ReLU)
+__global__ __launch_bounds__(EW_THREADS) void colsum_kernel(const float *dy, const float *z, float *dy_masked,
+                                                            float *dbias, long npix, int C)
+{
+    // generic C (heads have C = 10, 2, 1, 4, 256): thread = channel (strided), block walks pixel slices
+    __shared__ float red[EW_THREADS];
+    const int t = threadIdx.x;
+    const int cpb = C < EW_THREADS ? C : EW_THREADS;          // channels per pass
+    const int lanes = EW_THREADS / cpb;                        // pixel lanes
+    for (int c0 = 0; c0 < C; c0 += cpb) {
+        const int c = c0 + t % cpb, pl = t / cpb;
+        float s = 0.f;
+        if (c < C && pl < lanes) {
+            for (long p = (long)blockIdx.x * lanes + pl; p < npix; p += (long)gridDim.x * lanes) {
+                float g = dy[p * C + c];
+                if (z) {
+                    g = z[p * C + c] > 0.f ? g : 0.f;
+                    if (dy_masked) dy_masked[p * C + c] = g;
+                }
+                s += g;
+            }
+        }
+        red[t] = s;
+        __syncthreads();
+        if (t < cpb && c0 + t < C) {
+            float tot = 0.f;
+            for (int l = 0; l < lanes; ++l) tot += red[l * cpb + t];
+            if (dbias) unsafeAtomicAdd(dbias + c0 + t, tot);
+        }
+        __syncthreads();
+    }
+}
+
+// ---- hourglass up path ---------------------------------------------------------------------
+// out[n,h,w,:] = up1[n,h,w,:] + low[n,h/2,w/2,:]     (nn.Upsample(scale_factor=2), nearest; the
+// bilinear align_corners resize that follows in the reference is the identity at equal sizes)
+__global__ __launch_bounds__(EW_THREADS) void upsample2x_add_kernel(const f32x4 *up1, const f32x4 *low, f32x4 *out,
+                                                                    int N, int H, int W, int C4)
+{
+    const long n4 = (long)N * H * W * C4;
+    const int LH = H / 2, LW = W / 2;
+    for (long i = (long)blockIdx.x * EW_THREADS + threadIdx.x; i < n4; i += (long)gridDim.x * EW_THREADS) {
+        const int c = (int)(i % C4);
+        long p = i / C4;
+        const int w = (int)(p % W); p /= W;
+        const int h = (int)(p % H);
+        const int n = (int)(p / H);
+        out[i] = up1[i] + low[(((long)n * LH + h / 2) * LW + w / 2) * C4 + c];
+    }
+}
+
+// dlow[n,y,x,:] = sum of the 2x2 block of dout
+__global__ __launch_bounds__(EW_THREADS) void upsample2x_bwd_kernel(const f32x4 *dout, f32x4 *dlow, int N, int H, int W,
+                                                                    int C4)
+{
+    const int LH = H / 2, LW = W / 2;
+    const long n4 = (long)N * LH * LW * C4;
+    for (long i = (long)blockIdx.x * EW_THREADS + threadIdx.x; i < n4; i += (long)gridDim.x * EW_THREADS) {
+        const int c = (int)(i % C4);
+        long p = i / C4;
+        const int x = (int)(p % LW); p /= LW;
+        const int y = (int)(p % LH);
+        const int n = (int)(p / LH);
+        const long b = (((long)n * H + 2 * y) * W + 2 * x) * C4 + c;
+        dlow[i] = dout[b] + dout[b + C4] + dout[b + (long)W * C4] + dout[b + (long)W * C4 + C4];
+    }
+}
+
+// General path (odd feature sizes at eval scales): out = up1 + bilinear_align_corners(nearest2x(low)).
+// The nearest-2x image is never materialised: sample (yy, xx) of it is low[yy/2, xx/2].
+__global__ __launch_bounds__(EW_THREADS) void upsample_bilinear_add_kernel(const float *up1, const float *low, float *out,
+                                                                           int N, int H, int W, int LH, int LW, int C)
+{
+    const long total = (long)N * H * W * C;
+    const int UH = 2 * LH, UW = 2 * LW;
+    const float sy = H > 1 ? (float)(UH - 1) / (float)(H - 1) : 0.f;
+    const float sx = W > 1 ? (float)(UW - 1) / (float)(W - 1) : 0.f;
+    for (long i = (long)blockIdx.x * EW_THREADS + threadIdx.x; i < total; i += (long)gridDim.x * EW_THREADS) {
+        const int c = (int)(i % C);
+        long p = i / C;
+        const int w = (int)(p % W); p /= W;
+        const int h = (int)(p % H);
+        const int n = (int)(p / H);
+        const float fy = sy * h, fx = sx * w;
+        int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < UH - 1 ? 1 : 0), x1 = x0 + (x0 < UW - 1 ? 1 : 0);
+        const float ly = fy - y0, lx = fx - x0, hy = 1.f - ly, hx = 1.f - lx;
+        const float *b = low + (long)n * LH * LW * C + c;
+        const float v00 = b[((long)(y0 / 2) * LW + x0 / 2) * C], v01 = b[((long)(y0 / 2) * LW + x1 / 2) * C];
+        const float v10 = b[((long)(y1 / 2) * LW + x0 / 2) * C], v11 = b[((long)(y1 / 2) * LW + x1 / 2) * C];
+        out[i] = up1[i] + (hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11));
+    }
+}
+
+__global__ __launch_bounds__(EW_THREADS) void upsample_bilinear_bwd_kernel(const float *dout, float *dlow, int N, int H, int W,
+                                                                           int LH, int LW, int C)
+{
+    const long total = (long)N * H * W * C;
+    const int UH = 2 * LH, UW = 2 * LW;
+    const float sy = H > 1 ? (float)(UH - 1) / (float)(H - 1) : 0.f;
+    const float sx = W > 1 ? (float)(UW - 1) / (float)(W - 1) : 0.f;
+    for (long i = (long)blockIdx.x * EW_THREADS + threadIdx.x; i < total; i += (long)gridDim.x * EW_THREADS) {
+        const int c = (int)(i % C);
+        long p = i / C;
+        const int w = (int)(p % W); p /= W;
+        const int h = (int)(p % H);
+        const int n = (int)(p / H);
+        const float fy = sy * h, fx = sx * w;
+        int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < UH - 1 ? 1 : 0), x1 = x0 + (x0 < UW - 1 ? 1 : 0);
+        const float ly = fy - y0, lx = fx - x0, hy = 1.f - ly, hx = 1.f - lx;
+        float *b = dlow + (long)n * LH * LW * C + c;
+        const float g = dout[i];
+        unsafeAtomicAdd(b + ((long)(y0 / 2) * LW + x0 / 2) * C, g * hy * hx);
+        unsafeAtomicAdd(b + ((long)(y0 / 2) * LW + x1 / 2) * C, g * hy * lx);
+        unsafeAtomicAdd(b + ((long)(y1 / 2) * LW + x0 / 2) * C, g * ly * hx);
+        unsafeAtomicAdd(b + ((long)(y1 / 2) * LW + x1 / 2) * C, g * ly * lx);
+    }
+}
+
+// ---- 3x3 avg pool (stage-2 head: adaptive_avg_pool2d(1) on [R,256,3,3]) ---------------------
+__global__ __launch_bounds__(EW_THREADS) void avgpool_fwd_kernel(const float *x, float *out, long R, int HW, int C)
+{
+    const long total = R * C;
+    const float inv = 1.f / (float)HW;
+    for (long i = (long)blockIdx.x * EW_THREADS + threadIdx.x; i < total; i += (long)gridDim.x * EW_THREADS) {
+        const long r = i / C;
+        const int c = (int)(i % C);
+        float s = 0.f;
+        for (int k = 0; k < HW; ++k) s += x[(r * HW + k) * C + c];
+        out[i] = s * inv;
+    }
+}
+__global__ __launch_bounds__(EW_THREADS) void avgpool_bwd_kernel(const float *dout, float *dx, long R, int HW, int C)
+{
+    const long total = R * HW * C;
+    const float inv = 1.f / (float)HW;
+    for (long i = (long)blockIdx.x * EW_THREADS + threadIdx.x; i < total; i += (long)gridDim.x * EW_THREADS) {
+        const int c = (int)(i % C);
+        const long r = i / ((long)HW * C);
+        dx[i] = dout[r * C + c] * inv;
+    }
+}
+
+// ---- fused Adam over the flat parameter buffer (torch.optim.Adam defaults, no weight decay,
+//      no amsgrad; operators/rrnet_operator.py:29) -------------------------------------------
+__global__ __launch_bounds__(EW_THREADS) void adam_kernel(f32x4 *p, const f32x4 *g, f32x4 *m, f32x4 *v, long n4, float lr,
+                                                          float b1, float b2, float eps, float bc1, float bc2_sqrt,
+                                                          float grad_scale)
+{
+    const float step_size = lr / bc1;
+    for (long i = (long)blockIdx.x * EW_THREADS + threadIdx.x; i < n4; i += (long)gridDim.x * EW_THREADS) {
+        const f32x4 gg = g[i] * grad_scale;
+        f32x4 mm = m[i], vv = v[i], pp = p[i];
+        mm = mm * b1 + gg * (1.f - b1);
+        vv = vv * b2 + gg * gg * (1.f - b2);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float denom = sqrtf(vv[e]) / bc2_sqrt + eps;
+            pp[e] -= step_size * (mm[e] / denom);
+        }
+        m[i] = mm; v[i] = vv; p[i] = pp;
+    }
+}
+
+}  // namespace
+
+#define EW_LAUNCH(kern, n4, stream, ...)                                                        \
+    do {                                                                                        \
+        if ((n4) > 0) hipLaunchKernelGGL(kern, dim3(ew_blocks(n4)), dim3(EW_THREADS), 0, stream, __VA_ARGS__); \
+    } while (0)
+
+extern "C" int rr_bn_reduce_slab(const double *slab, int mtiles, int c, double *sums, hipStream_t stream)
+{
+    RR_CHECK_ARG(mtiles > 0 && c > 0, "rr_bn_reduce_slab: bad dims");
+    hipLaunchKernelGGL(bn_reduce_slab_kernel, dim3(rr_cdiv(2 * c, 128)), dim3(128), 0, stream, slab, mtiles, c, sums);
+    RR_CHECK_LAUNCH("rr_bn_reduce_slab");
+    return RR_OK;
+}
+
+extern "C" int rr_bn_finalize(const double *sums, double count, const double *count_dev, const float *gamma, const float *beta,
+                              float *running_mean, float *running_var, float momentum, float eps, float *mean,
+                              float *invstd, float *scale, float *shift, int c, hipStream_t stream)
+{
+    RR_CHECK_ARG(c > 0 && (count > 0 || count_dev), "rr_bn_finalize: bad dims");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(rr_cdiv(c, 128)), dim3(128), 0, stream, sums, count, count_dev, gamma, beta,
+                       running_mean, running_var, momentum, eps, mean, invstd, scale, shift, c);
+    RR_CHECK_LAUNCH("rr_bn_finalize");
+    return RR_OK;
+}
+
+extern "C" int rr_bn_eval_coeffs(const float *gamma, const float *beta, const float *running_mean,
+                                 const float *running_var, float eps, float *scale, float *shift, int c,
+                                 hipStream_t stream)
+{
+    hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3(rr_cdiv(c, 128)), dim3(128), 0, stream, gamma, beta, running_mean,
+                       running_var, eps, scale, shift, c);
+    RR_CHECK_LAUNCH("rr_bn_eval_coeffs");
+    return RR_OK;
+}
+
+extern "C" int rr_bn_apply(const float *y, const float *scale, const float *shift, const float *res,
+                           const float *res_scale, const float *res_shift, float *out, long total, int c, int relu,
+                           hipStream_t stream)
+{
+    RR_CHECK_ARG(c % 4 == 0 && total % c == 0, "rr_bn_apply: C=%d must be a multiple of 4", c);
+    const long n4 = total / 4;
+    EW_LAUNCH(bn_apply_kernel, n4, stream, (const f32x4 *)y, scale, shift, (const f32x4 *)res, res_scale, res_shift,
+              (f32x4 *)out, n4, c / 4, relu);
+    RR_CHECK_LAUNCH("rr_bn_apply");
+    return RR_OK;
+}
+
+extern "C" int rr_bn_bwd_reduce(const float *dz, const float *z, const float *y, const float *mean,
+                                const float *invstd, double *sums, long npix, int c, hipStream_t stream)
+{
+    RR_CHECK_ARG(c % 4 == 0 && c <= 1024, "rr_bn_bwd_reduce: C=%d must be a multiple of 4 and <= 1024", c);
+    hipMemsetAsync(sums, 0, sizeof(double) * 2 * c, stream);
+    const int c4 = c / 4;
+    const int lanes = EW_THREADS / c4 > 0 ? EW_THREADS / c4 : 1;
+    long blocks = (npix + lanes * 8 - 1) / (lanes * 8);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((int)blocks), dim3(EW_THREADS), 0, stream, dz, z, y, mean, invstd, sums,
+                       npix, c);
+    RR_CHECK_LAUNCH("rr_bn_bwd_reduce");
+    return RR_OK;
+}
+
+extern "C" int rr_bn_bwd_apply(const float *dz, const float *z, const float *y, const float *mean,
+                               const float *invstd, const float *gamma, const double *sums, double count,
+                               const double *count_dev, float *dx, float *g_out, float *dgamma, float *dbeta,
+                               long total, int c, hipStream_t stream)
+{
+    RR_CHECK_ARG(c % 4 == 0 && total % c == 0, "rr_bn_bwd_apply: C=%d must be a multiple of 4", c);
+    const long n4 = total / 4;
+    EW_LAUNCH(bn_bwd_apply_kernel, n4, stream, (const f32x4 *)dz, (const f32x4 *)z, (const f32x4 *)y, mean, invstd, gamma,
+              sums, count, count_dev, (f32x4 *)dx, (f32x4 *)g_out, dgamma, dbeta, n4, c);
+    RR_CHECK_LAUNCH("rr_bn_bwd_apply");
+    return RR_OK;
+}
+
+extern "C" int rr_relu_fwd(const float *x, float *out, long total, hipStream_t stream)
+{
+    RR_CHECK_ARG(total % 4 == 0, "rr_relu_fwd: element count must be a multiple of 4");
+    EW_LAUNCH(relu_fwd_kernel, total / 4, stream, (const f32x4 *)x, (f32x4 *)out, total / 4);
+    RR_CHECK_LAUNCH("rr_relu_fwd");
+    return RR_OK;
+}
+
+extern "C" int rr_sum_n(const float *const *grads, int n, const float *z, float *out, long total, hipStream_t stream)
+{
+    RR_CHECK_ARG(n >= 1 && n <= 8 && total % 4 == 0, "rr_sum_n: 1..8 inputs, element count multiple of 4");
+    SumArgs a;
+    for (int i = 0; i < 8; ++i) a.g[i] = (const f32x4 *)grads[i < n ? i : 0];
+    a.n = n;
+    EW_LAUNCH(sum_n_kernel, total / 4, stream, a, (const f32x4 *)z, (f32x4 *)out, total / 4);
+    RR_CHECK_LAUNCH("rr_sum_n");
+    return RR_OK;
+}
+
+extern "C" int rr_bias_relu_bwd(const float *dy, const float *z, float *dy_masked, float *dbias, long npix, int c,
+                                hipStream_t stream)
+{
+    RR_CHECK_ARG(c > 0 && npix >= 0, "rr_bias_relu_bwd: bad dims");
+    if (npix == 0) return RR_OK;
+    const int cpb = c < EW_THREADS ? c : EW_THREADS;
+    const int lanes = EW_THREADS / cpb;
+    long blocks = (npix + lanes * 16 - 1) / (lanes * 16);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(colsum_kernel, dim3((int)blocks), dim3(EW_THREADS), 0, stream, dy, z, dy_masked, dbias, npix, c);
+    RR_CHECK_LAUNCH("rr_bias_relu_bwd");
+    return RR_OK;
+}
+
+extern "C" int rr_upsample_add_fwd(const float *up1, const float *low, float *out, int n, int h, int w, int lh,
+                                   int lw, int c, hipStream_t stream)
+{
+    if (h == 2 * lh && w == 2 * lw && c % 4 == 0) {
+        const long n4 = (long)n * h * w * (c / 4);
+        EW_LAUNCH(upsample2x_add_kernel, n4, stream, (const f32x4 *)up1, (const f32x4 *)low, (f32x4 *)out, n, h, w, c / 4);
+    } else {
+        const long tot = (long)n * h * w * c;
+        EW_LAUNCH(upsample_bilinear_add_kernel, tot, stream, up1, low, out, n, h, w, lh, lw, c);
+    }
+    RR_CHECK_LAUNCH("rr_upsample_add_fwd");
+    return RR_OK;
+}
+
+extern "C" int rr_upsample_add_bwd(const float *dout, float *dlow, int n, int h, int w, int lh, int lw, int c,
+                                   hipStream_t stream)
+{
+    if (h == 2 * lh && w == 2 * lw && c % 4 == 0) {
+        const long n4 = (long)n * lh * lw * (c / 4);
+        EW_LAUNCH(upsample2x_bwd_kernel, n4, stream, (const f32x4 *)dout, (f32x4 *)dlow, n, h, w, c / 4);
+    } else {
+        hipMemsetAsync(dlow, 0, sizeof(float) * (size_t)n * lh * lw * c, stream);
+        const long tot = (long)n * h * w * c;
+        EW_LAUNCH(upsample_bilinear_bwd_kernel, tot, stream, dout, dlow, n, h, w, lh, lw, c);
+    }
+    RR_CHECK_LAUNCH("rr_upsample_add_bwd");
+    return RR_OK;
+}
+
+extern "C" int rr_avgpool_fwd(const float *x, float *out, long r, int hw, int c, hipStream_t stream)
+{
+    EW_LAUNCH(avgpool_fwd_kernel, r * c, stream, x, out, r, hw, c);
+    RR_CHECK_LAUNCH("rr_avgpool_fwd");
+    return RR_OK;
+}
+
+extern "C" int rr_avgpool_bwd(const float *dout, float *dx, long r, int hw, int c, hipStream_t stream)
+{
+    EW_LAUNCH(avgpool_bwd_kernel, r * hw * c, stream, dout, dx, r, hw, c);
+    RR_CHECK_LAUNCH("rr_avgpool_bwd");
+    return RR_OK;
+}
+
+extern "C" int rr_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, long n, float lr,
+                            float beta1, float beta2, float eps, int step, float grad_scale, hipStream_t stream)
+{
+    RR_CHECK_ARG(n % 4 == 0 && step >= 1, "rr_adam_step: n must be a multiple of 4 (pad the flat buffer), step >= 1");
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2 = 1.f - powf(beta2, (float)step);
+    EW_LAUNCH(adam_kernel, n / 4, stream, (f32x4 *)param, (const f32x4 *)grad, (f32x4 *)exp_avg, (f32x4 *)exp_avg_sq, n / 4,
+              lr, beta1, beta2, eps, bc1, sqrtf(bc2), grad_scale);
+    RR_CHECK_LAUNCH("rr_adam_step");
+    return RR_OK;
+}

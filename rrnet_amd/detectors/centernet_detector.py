@@ -1,0 +1,84 @@
+"""CenterNet heads on the MI355X kernels — module tree of the reference's
+detectors/centernet_detector.py (CenterNetDetector :6-23, CenterNetWHDetector :26-55,
+HCov :58-67, WCov :69-77, BasicCov :80-93); bias and ReLU run in the conv epilogue."""
+import torch
+import torch.nn as nn
+
+from rrnet_amd import functional as RF
+
+
+class BasicCov(nn.Module):
+    def __init__(self, k, inp_dim, out_dim, stride=1, with_bn=True):
+        super().__init__()
+        pad = (k - 1) // 2
+        self.conv = nn.Conv2d(inp_dim, out_dim, (k, k), padding=(pad, pad), stride=(stride, stride), bias=not with_bn)
+        self.bn = nn.BatchNorm2d(out_dim) if with_bn else nn.Sequential()
+        self.relu = nn.ReLU(inplace=True)
+
+    def forward(self, x):
+        if isinstance(self.bn, nn.Sequential):
+            return RF.conv_bias(x, self.conv, relu=True)
+        return RF.conv_bn_act(x, self.conv, self.bn, relu=True)
+
+
+class HCov(nn.Module):
+    """k x 1 convolution (a column of k taps)."""
+
+    def __init__(self, k, inp_dim, out_dim, stride=1, with_bn=True):
+        super().__init__()
+        self.conv = nn.Conv2d(inp_dim, out_dim, (k, 1), padding=((k - 1) // 2, 0), stride=(stride, stride), bias=not with_bn)
+
+    def forward(self, x):
+        return RF.conv_bias(x, self.conv)
+
+
+class WCov(nn.Module):
+    """1 x k convolution (a row of k taps)."""
+
+    def __init__(self, k, inp_dim, out_dim, stride=1, with_bn=True):
+        super().__init__()
+        self.conv = nn.Conv2d(inp_dim, out_dim, (1, k), padding=(0, (k - 1) // 2), stride=(stride, stride), bias=not with_bn)
+
+    def forward(self, x):
+        return RF.conv_bias(x, self.conv)
+
+
+class CenterNetDetector(nn.Module):
+    def __init__(self, planes, hm=True, num_stacks=2):
+        super().__init__()
+        self.hm = hm
+        self.num_stacks = num_stacks
+        self.detect_layer = nn.ModuleList([
+            nn.Sequential(BasicCov(3, 256, 256, with_bn=False), nn.Conv2d(256, planes, (1, 1)))
+            for _ in range(num_stacks)])
+        if self.hm:
+            for head in self.detect_layer:
+                head[-1].bias.data.fill_(-2.19)
+
+    def forward(self, input, index):
+        head = self.detect_layer[index]
+        return RF.conv_bias(head[0](input), head[1])
+
+
+class CenterNetWHDetector(nn.Module):
+    def __init__(self, planes, hm=True, num_stacks=2):
+        super().__init__()
+        self.hm = hm
+        self.num_stacks = num_stacks
+        self.detect_conv_layer = nn.ModuleList([nn.Sequential(BasicCov(3, 256, 256, with_bn=False))
+                                                for _ in range(num_stacks)])
+        self.detect_H_layer = nn.ModuleList([nn.Sequential(HCov(17, 256, planes, with_bn=False))
+                                             for _ in range(num_stacks)])
+        self.detect_W_layer = nn.ModuleList([nn.Sequential(WCov(17, 256, planes, with_bn=False))
+                                             for _ in range(num_stacks)])
+
+    def forward(self, input, index):
+        conv = self.detect_conv_layer[index][0](input)
+        ca, cb = RF.fanout(conv, 2)
+        H = self.detect_H_layer[index][0](ca)
+        W = self.detect_W_layer[index][0](cb)
+        # channels interleaved [W0, H0, W1, H1, ...] exactly as centernet_detector.py:50-53
+        H = H.reshape(H.size(0), -1, 1, H.size(2), H.size(3))
+        W = W.reshape(W.size(0), -1, 1, W.size(2), W.size(3))
+        out = torch.cat((W, H), dim=2).reshape(H.size(0), -1, H.size(3), H.size(4))
+        return out.contiguous(memory_format=torch.channels_last)

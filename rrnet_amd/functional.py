@@ -1,0 +1,330 @@
+"""Autograd plumbing over the HIP kernels (rrnet_amd/ops.py -> include/rrnet_hip.h).
+
+PyTorch is used for the graph bookkeeping only: every node below runs hand-written gfx950
+kernels forward and backward.  Activations are NHWC in memory (logical NCHW tensors with
+channels_last strides); convolution weights OHWI.
+
+Parameter gradients: when a parameter carries a pre-allocated gradient view (`_rr_grad`, set by
+rrnet_amd.flat.FlatParams — a slice of the one flat fp32 gradient buffer that the RCCL
+all-reduce and the fused Adam kernel operate on) the backward kernels accumulate straight into
+it (wgrad's float atomics, the BN apply kernel's dgamma/dbeta) and autograd sees `None`;
+otherwise a fresh gradient tensor is returned the usual way.
+"""
+import torch
+import torch.distributed as dist
+
+from rrnet_amd import ops
+
+
+def _grad_target(p):
+    return getattr(p, "_rr_grad", None)
+
+
+def _is_sync(bn):
+    return isinstance(bn, torch.nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized() \
+        and dist.get_world_size() > 1
+
+
+class _ConvBnAct(torch.autograd.Function):
+    """z = relu?( BN(conv(x, w)) [+ residual] ), training statistics fused into the conv epilogue.
+    Reference: conv->bn->relu->(+skip) sequences of backbones/hourglass.py:31-40,56-61,
+    backbones/resnet.py:33-53."""
+
+    @staticmethod
+    def forward(ctx, x, w, gamma, beta, residual, bn, stride, pad, relu):
+        x = ops.to_nhwc(x)
+        wc = ops.to_nhwc(w)
+        n, _, h, wd = x.shape
+        k = w.shape[0]
+        sync = _is_sync(bn)
+        if bn.training:
+            y, slab = ops.conv_fprop(x, wc, None, stride, pad, False, want_stats=True)
+            count = float(y.numel() // k)
+            sums = ops.bn_reduce_slab(slab, k, extra=1 if sync else 0)
+            cnt_dev = None
+            if sync:   # SyncBN exchange: one small all-reduce of [sum, sumsq, count] (C5 in SURVEY §2.2);
+                sums[2 * k] = count          # the global count stays on the device: no host sync per layer
+                dist.all_reduce(sums)
+                cnt_dev = sums[2 * k:]
+            mom = bn.momentum if bn.momentum is not None else 0.1
+            mean, invstd, scale, shift = ops.bn_finalize(sums, count, gamma, beta, bn.running_mean, bn.running_var,
+                                                         mom, bn.eps, cnt_dev)
+            if bn.num_batches_tracked is not None:
+                bn.num_batches_tracked += 1
+        else:
+            y = ops.conv_fprop(x, wc, None, stride, pad, False)
+            scale, shift = ops.bn_eval_coeffs(gamma, beta, bn.running_mean, bn.running_var, bn.eps)
+            mean = invstd = cnt_dev = None
+            count = 0.0
+        res = ops.to_nhwc(residual) if residual is not None else None
+        z = ops.bn_apply(y, scale, shift, res, relu)
+        if bn.training:
+            ctx.save_for_backward(x, wc, y, z if relu else None, mean, invstd, gamma, cnt_dev)
+        ctx.cfg = (stride, pad, relu, count, sync, residual is not None)
+        ctx.params = (w, gamma, beta)
+        ctx.xshape = tuple(x.shape)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, wc, y, z, mean, invstd, gamma, cnt_dev = ctx.saved_tensors
+        stride, pad, relu, count, sync, has_res = ctx.cfg
+        w, gamma_p, beta_p = ctx.params
+        dz = ops.to_nhwc(dz)
+        k = y.shape[1]
+        sums = ops.bn_bwd_reduce(dz, z, y, mean, invstd)
+        dg_t, db_t = _grad_target(gamma_p), _grad_target(beta_p)
+        ret_dg = ret_db = None
+        fused_affine = dg_t is not None and db_t is not None and not sync
+        if not fused_affine:
+            # gradients of gamma/beta come from the LOCAL sums (SyncBN averages them later like any grad)
+            db = sums[:k].float()
+            dg = sums[k:2 * k].float()
+            if dg_t is not None:
+                dg_t.add_(dg)
+                db_t.add_(db)
+            else:
+                ret_dg, ret_db = dg, db
+        if sync:
+            dist.all_reduce(sums)
+        want_g = has_res and relu
+        dy, g = ops.bn_bwd_apply(dz, z, y, mean, invstd, gamma, sums, count, want_g,
+                                 dg_t if fused_affine else None, db_t if fused_affine else None, cnt_dev)
+        dx = ops.conv_dgrad(dy, wc, ctx.xshape, stride, pad) if ctx.needs_input_grad[0] else None
+        w_t = _grad_target(w)
+        ret_dw = None
+        if w_t is not None:
+            ops.conv_wgrad(x, dy, w_t, stride, pad)
+        else:
+            dw = ops.zeros_nhwc(*w.shape, device=x.device)
+            ops.conv_wgrad(x, dy, dw, stride, pad)
+            ret_dw = dw
+        dres = None
+        if has_res and ctx.needs_input_grad[4]:
+            dres = g if relu else dz
+        return dx, ret_dw, ret_dg, ret_db, dres, None, None, None, None
+
+
+def conv_bn_act(x, conv, bn, relu=True, residual=None):
+    """conv: nn.Conv2d (bias-free), bn: nn.BatchNorm2d / nn.SyncBatchNorm used as parameter holders."""
+    return _ConvBnAct.apply(x, conv.weight, bn.weight, bn.bias, residual, bn, conv.stride[0], tuple(conv.padding), relu)
+
+
+class _ConvBias(torch.autograd.Function):
+    """y = relu?(conv(x, w) + b) — the bias / ReLU live in the conv epilogue
+    (detectors/centernet_detector.py:62,73,85-93; fasterrcnn_detector.py:17)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stride, pad, relu):
+        x = ops.to_nhwc(x)
+        wc = ops.to_nhwc(w)
+        y = ops.conv_fprop(x, wc, b, stride, pad, relu)
+        ctx.save_for_backward(x, wc, y if relu else None)
+        ctx.cfg = (stride, pad, relu)
+        ctx.params = (w, b)
+        ctx.xshape = tuple(x.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wc, y = ctx.saved_tensors
+        stride, pad, relu = ctx.cfg
+        w, b = ctx.params
+        dy = ops.to_nhwc(dy)
+        ret_db = None
+        if b is not None:
+            b_t = _grad_target(b)
+            tgt = b_t if b_t is not None else torch.zeros_like(b)
+            dy = ops.bias_relu_bwd(dy, y if relu else None, tgt)
+            ret_db = None if b_t is not None else tgt
+        elif relu:
+            dy = ops.sum_n([dy], y)
+        dx = ops.conv_dgrad(dy, wc, ctx.xshape, stride, pad) if ctx.needs_input_grad[0] else None
+        w_t = _grad_target(w)
+        ret_dw = None
+        if w_t is not None:
+            ops.conv_wgrad(x, dy, w_t, stride, pad)
+        else:
+            dw = ops.zeros_nhwc(*w.shape, device=x.device)
+            ops.conv_wgrad(x, dy, dw, stride, pad)
+            ret_dw = dw
+        return dx, ret_dw, ret_db, None, None, None
+
+
+def conv_bias(x, conv, relu=False):
+    return _ConvBias.apply(x, conv.weight, conv.bias, conv.stride[0], tuple(conv.padding), relu)
+
+
+class _FanOut(torch.autograd.Function):
+    """Identity with n consumers; backward sums the n incoming gradients in ONE pass
+    (what autograd would do with n-1 separate add kernels)."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.n = n
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        gs = [ops.to_nhwc(g) if g.dim() == 4 else g.contiguous() for g in grads if g is not None]
+        if not gs:
+            return None, None
+        if len(gs) == 1:
+            return gs[0], None
+        return ops.sum_n(gs), None
+
+
+def fanout(x, n):
+    if n == 1 or not x.requires_grad:
+        return (x,) * n
+    return _FanOut.apply(x, n)
+
+
+class _ReLU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = ops.to_nhwc(x) if x.dim() == 4 else x.contiguous()
+        z = ops.relu_fwd(x)
+        ctx.save_for_backward(z)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        (z,) = ctx.saved_tensors
+        dz = ops.to_nhwc(dz) if dz.dim() == 4 else dz.contiguous()
+        return ops.sum_n([dz], z)
+
+
+def relu(x):
+    return _ReLU.apply(x)
+
+
+class _UpsampleAdd(torch.autograd.Function):
+    """up1 + bilinear_align_corners(nearest2x(low), size(up1))  (backbones/hourglass.py:121-124)."""
+
+    @staticmethod
+    def forward(ctx, up1, low):
+        up1, low = ops.to_nhwc(up1), ops.to_nhwc(low)
+        ctx.low_shape = tuple(low.shape)
+        return ops.upsample_add_fwd(up1, low)
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = ops.to_nhwc(dout)
+        dlow = ops.upsample_add_bwd(dout, ctx.low_shape) if ctx.needs_input_grad[1] else None
+        return dout, dlow
+
+
+def upsample_add(up1, low):
+    return _UpsampleAdd.apply(up1, low)
+
+
+class _AvgPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = ops.to_nhwc(x)
+        ctx.shape = tuple(x.shape)
+        return ops.avgpool_fwd(x)
+
+    @staticmethod
+    def backward(ctx, dout):
+        return ops.avgpool_bwd(ops.to_nhwc(dout), ctx.shape)
+
+
+def global_avg_pool(x):
+    return _AvgPool.apply(x)
+
+
+class _RoIAlign(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, rois, out_size, spatial_scale, sampling_ratio):
+        feat = ops.to_nhwc(feat)
+        rois = rois.contiguous()
+        ctx.save_for_backward(rois)
+        ctx.cfg = (tuple(feat.shape), out_size, spatial_scale, sampling_ratio)
+        return ops.roi_align_fwd(feat, rois, out_size, spatial_scale, sampling_ratio)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (rois,) = ctx.saved_tensors
+        shape, out_size, scale, sr = ctx.cfg
+        return ops.roi_align_bwd(ops.to_nhwc(dout), rois, shape, out_size, scale, sr), None, None, None, None
+
+
+def roi_align(feat, rois, out_size, spatial_scale=1.0, sampling_ratio=-1):
+    """torchvision.ops.roi_align signature (models/rrnet.py:51)."""
+    if isinstance(out_size, int):
+        out_size = (out_size, out_size)
+    return _RoIAlign.apply(feat, rois.detach(), tuple(out_size), float(spatial_scale), int(sampling_ratio))
+
+
+# ---------------------------------------------------------------------------------------------
+# losses
+# ---------------------------------------------------------------------------------------------
+class _FocalHM(torch.autograd.Function):
+    """clamp(sigmoid(x),1e-4,1-1e-4) + focal_loss_for_hm in one fused pass
+    (operators/rrnet_operator.py:55-57, modules/loss/functional.py:25-51)."""
+
+    @staticmethod
+    def forward(ctx, logits, gt):
+        logits = ops.to_nhwc(logits)
+        gt = ops.to_nhwc(gt)
+        sums = ops.focal_fwd(logits, gt)
+        ctx.save_for_backward(logits, gt, sums)
+        npos = sums[2]
+        tot = sums[0] + sums[1]
+        loss = torch.where(npos > 0, -tot / torch.clamp(npos, min=1.0), -sums[1])
+        return loss.float()
+
+    @staticmethod
+    def backward(ctx, gout):
+        logits, gt, sums = ctx.saved_tensors
+        return ops.focal_bwd(logits, gt, sums, gout.contiguous().float()), None
+
+
+def focal_loss_hm_from_logits(logits, gt):
+    return _FocalHM.apply(logits, gt)
+
+
+class _RegL1(torch.autograd.Function):
+    """modules/loss/regl1loss.py:9-17 without the NHWC permute copy of the whole map."""
+
+    @staticmethod
+    def forward(ctx, pred, mask, ind, target):
+        pred = ops.to_nhwc(pred)
+        mask = mask.contiguous().float()
+        ind = ind.contiguous().float()
+        target = target.contiguous().float()
+        sums = ops.regl1_fwd(pred, mask, ind, target)
+        ctx.save_for_backward(pred, mask, ind, target, sums)
+        return (sums[0] / (sums[1] + 1e-4)).float()
+
+    @staticmethod
+    def backward(ctx, gout):
+        pred, mask, ind, target, sums = ctx.saved_tensors
+        return ops.regl1_bwd(pred, mask, ind, target, sums, gout.contiguous().float()), None, None, None
+
+
+def reg_l1_loss(pred, mask, ind, target):
+    return _RegL1.apply(pred, mask, ind, target)
+
+
+class _Stage2Loss(torch.autograd.Function):
+    """box_iou + positive matching + generate_bbox_target + smooth-L1 of
+    operators/rrnet_operator.py:63-102 as two small kernels (no per-image host loop, no sync)."""
+
+    @staticmethod
+    def forward(ctx, reg, rois, gt_xyxy, scale):
+        reg = reg.contiguous()
+        loss, dreg, _tgt, _pos, _npos = ops.stage2_loss(rois.contiguous(), reg, gt_xyxy.contiguous(), scale)
+        ctx.save_for_backward(dreg)
+        return loss[0].float()
+
+    @staticmethod
+    def backward(ctx, gout):
+        (dreg,) = ctx.saved_tensors
+        return dreg * gout, None, None, None
+
+
+def stage2_reg_loss(reg, rois, gt_xyxy, scale):
+    return _Stage2Loss.apply(reg, rois.detach(), gt_xyxy, float(scale))

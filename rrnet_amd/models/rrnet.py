@@ -1,0 +1,84 @@
+"""RRNet on the MI355X kernels — API of the reference's models/rrnet.py (RRNet :11-157).
+
+forward(x, k=1500) returns the same 7-tuple
+    (hms: list[num_stacks], whs, offsets, stage2_reg [R,4], bxyxys [R,5], scores [R], clses [R]).
+The reference's per-image x per-class Python loops with host round trips (:37-46, :56-80) are
+one batched sequence of launches here: decode (sigmoid + top-K + gather) -> stable grouping by
+class -> hard / soft NMS over all (image, class) segments at once -> packing; the row order is
+the reference's (images ascending, classes in unique() order, NMS order inside a class).
+"""
+import torch
+import torch.nn as nn
+
+from rrnet_amd import functional as RF
+from rrnet_amd import ops
+from rrnet_amd.detectors.centernet_detector import CenterNetDetector, CenterNetWHDetector
+from rrnet_amd.detectors.fasterrcnn_detector import FasterRCNNDetector
+from rrnet_amd.ext.nms.nms_wrapper import soft_nms_segments
+from rrnet_amd.utils.model_tools import get_backbone
+
+
+def stage1_proposals(hm, wh, offset, k, num_classes, nms_type='nms', nms_per_class=True, peak_filter=False):
+    """Decode + stage-1 NMS for the whole batch (models/rrnet.py:31-49, 56-138).
+    -> bxyxys [R,5], scores [R], clses [R], all detached device tensors."""
+    with torch.no_grad():
+        hm, wh, offset = ops.to_nhwc(hm.detach()), ops.to_nhwc(wh.detach()), ops.to_nhwc(offset.detach())
+        if peak_filter:     # optional `_ctnet_nms` semantics; the reference's decode never applies it
+            boxes = ops.decode_topk(ops.peak3x3(hm), wh, offset, k, is_logits=False)
+        else:
+            boxes = ops.decode_topk(hm, wh, offset, k, is_logits=True)
+        b = boxes.shape[0]
+        if nms_per_class:
+            grouped, seg_off = ops.group_by_class(boxes, num_classes)
+            segs_per_image = num_classes
+        else:
+            grouped = boxes.clone()
+            seg_off = torch.arange(0, (b + 1) * k, k, dtype=torch.int32, device=boxes.device)
+            segs_per_image = 1
+        rows = grouped.view(-1, 6)
+        if nms_type == 'soft_nms':
+            n_out = soft_nms_segments(rows, seg_off, k, sigma=0.5, Nt=0.7, threshold=0.1, method=2)
+        else:
+            n_out = ops.hard_nms_segments(rows, seg_off, k, 0.7)
+        rois, scores, clses, _ = ops.pack_segments(rows, seg_off, n_out, segs_per_image)
+    return rois, scores, clses
+
+
+class RRNet(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.num_stacks = cfg.Model.num_stacks
+        self.num_classes = cfg.num_classes
+        self.nms_type = cfg.Model.nms_type_for_stage1
+        self.nms_per_class = cfg.Model.nms_per_class_for_stage1
+        self.backbone = get_backbone(cfg.Model.backbone, num_stacks=self.num_stacks)
+        self.hm = CenterNetDetector(planes=self.num_classes, num_stacks=self.num_stacks, hm=True)
+        self.wh = CenterNetWHDetector(planes=1, num_stacks=self.num_stacks)
+        self.offset_reg = CenterNetDetector(planes=2, num_stacks=self.num_stacks)
+        self.head_detector = FasterRCNNDetector()
+
+    def forward(self, x, k=1500):
+        feats = self.backbone(x)
+        last_a, last_b = RF.fanout(feats[-1], 2)
+        hms, whs, offsets = self.forward_stage1(list(feats[:-1]) + [last_a])
+        bxyxys, scores, clses = stage1_proposals(hms[-1], whs[-1], offsets[-1], k, self.num_classes,
+                                                 self.nms_type, self.nms_per_class)
+        roi_feat = RF.roi_align(RF.relu(last_b), bxyxys, (3, 3))
+        stage2_reg = self.forward_stage2(roi_feat)
+        return hms, whs, offsets, stage2_reg, bxyxys, scores, clses
+
+    def forward_stage1(self, feats):
+        hms, whs, offsets = [], [], []
+        for i in range(self.num_stacks):
+            fa, fb, fc = RF.fanout(RF.relu(feats[i]), 3)
+            hms.append(self.hm(fa, i))
+            whs.append(self.wh(fb, i))
+            offsets.append(self.offset_reg(fc, i))
+        return hms, whs, offsets
+
+    def forward_stage2(self, feats):
+        return self.head_detector(feats)
+
+    def transform_bbox(self, hm, wh, offset, k=250):
+        """models/rrnet.py:117-138 -> [B,k,6] in feature coordinates."""
+        return ops.decode_topk(ops.to_nhwc(hm), ops.to_nhwc(wh), ops.to_nhwc(offset), k, is_logits=True)

@@ -81,3 +81,262 @@ def conv_wgrad(x, dy, dw, stride=1, pad=(0, 0)):
     _C.check(f(_C.ptr(x), _C.ptr(dy), _C.ptr(dw), n, h, wd, c, k, r, s, stride, pad[0], pad[1], _C.stream()),
              "rr_conv_wgrad")
     return dw
+
+
+# ---------------------------------------------------------------------------------------------
+# BatchNorm / elementwise
+# ---------------------------------------------------------------------------------------------
+def _f32(n, device):
+    return torch.empty(n, dtype=torch.float32, device=device)
+
+
+def bn_reduce_slab(slab, c, extra=0):
+    """slab [mtiles,2,c] doubles -> sums [2c (+extra)] doubles (extra slots zeroed: room for the
+    sample count in the SyncBN exchange)."""
+    sums = torch.zeros(2 * c + extra, dtype=torch.float64, device=slab.device)
+    mtiles = slab.numel() // (2 * c)
+    _C.check(_C.fn("rr_bn_reduce_slab")(_C.ptr(slab), mtiles, c, _C.ptr(sums), _C.stream()), "rr_bn_reduce_slab")
+    return sums
+
+
+def bn_finalize(sums, count, gamma, beta, running_mean, running_var, momentum, eps, count_dev=None):
+    c = gamma.numel()
+    dev = gamma.device
+    mean, invstd, scale, shift = _f32(c, dev), _f32(c, dev), _f32(c, dev), _f32(c, dev)
+    _C.check(_C.fn("rr_bn_finalize")(_C.ptr(sums), float(count), _C.ptr(count_dev), _C.ptr(gamma), _C.ptr(beta), _C.ptr(running_mean),
+                                     _C.ptr(running_var), float(momentum), float(eps), _C.ptr(mean), _C.ptr(invstd),
+                                     _C.ptr(scale), _C.ptr(shift), c, _C.stream()), "rr_bn_finalize")
+    return mean, invstd, scale, shift
+
+
+def bn_eval_coeffs(gamma, beta, running_mean, running_var, eps):
+    c = gamma.numel()
+    scale, shift = _f32(c, gamma.device), _f32(c, gamma.device)
+    _C.check(_C.fn("rr_bn_eval_coeffs")(_C.ptr(gamma), _C.ptr(beta), _C.ptr(running_mean), _C.ptr(running_var),
+                                        float(eps), _C.ptr(scale), _C.ptr(shift), c, _C.stream()), "rr_bn_eval_coeffs")
+    return scale, shift
+
+
+def bn_apply(y, scale, shift, residual=None, relu=False, res_scale=None, res_shift=None):
+    assert is_nhwc(y) and (residual is None or (is_nhwc(residual) and residual.shape == y.shape))
+    n, c, h, w = y.shape
+    out = empty_nhwc(n, c, h, w, y.device)
+    _C.check(_C.fn("rr_bn_apply")(_C.ptr(y), _C.ptr(scale), _C.ptr(shift), _C.ptr(residual), _C.ptr(res_scale),
+                                  _C.ptr(res_shift), _C.ptr(out), y.numel(), c, int(relu), _C.stream()), "rr_bn_apply")
+    return out
+
+
+def bn_bwd_reduce(dz, z, y, mean, invstd, extra=0):
+    n, c, h, w = y.shape
+    sums = torch.empty(2 * c + extra, dtype=torch.float64, device=y.device)
+    if extra:
+        sums[2 * c:].zero_()
+    _C.check(_C.fn("rr_bn_bwd_reduce")(_C.ptr(dz), _C.ptr(z), _C.ptr(y), _C.ptr(mean), _C.ptr(invstd), _C.ptr(sums),
+                                       n * h * w, c, _C.stream()), "rr_bn_bwd_reduce")
+    return sums
+
+
+def bn_bwd_apply(dz, z, y, mean, invstd, gamma, sums, count, want_g=False, dgamma=None, dbeta=None, count_dev=None):
+    n, c, h, w = y.shape
+    dx = empty_nhwc(n, c, h, w, y.device)
+    g = empty_nhwc(n, c, h, w, y.device) if want_g else None
+    _C.check(_C.fn("rr_bn_bwd_apply")(_C.ptr(dz), _C.ptr(z), _C.ptr(y), _C.ptr(mean), _C.ptr(invstd), _C.ptr(gamma),
+                                      _C.ptr(sums), float(count), _C.ptr(count_dev), _C.ptr(dx), _C.ptr(g), _C.ptr(dgamma), _C.ptr(dbeta),
+                                      y.numel(), c, _C.stream()), "rr_bn_bwd_apply")
+    return dx, g
+
+
+def relu_fwd(x):
+    out = torch.empty_like(x)
+    assert out.stride() == x.stride()
+    _C.check(_C.fn("rr_relu_fwd")(_C.ptr(x), _C.ptr(out), x.numel(), _C.stream()), "rr_relu_fwd")
+    return out
+
+
+def sum_n(grads, z=None):
+    """(sum of same-layout tensors) * (z > 0 if z is given) in one pass."""
+    import ctypes
+    g0 = grads[0]
+    for g in grads:
+        assert g.shape == g0.shape and g.stride() == g0.stride() and g.is_cuda
+    out = torch.empty_like(g0)
+    assert out.stride() == g0.stride()
+    arr = (ctypes.c_void_p * len(grads))(*[g.data_ptr() for g in grads])
+    _C.check(_C.fn("rr_sum_n")(ctypes.cast(arr, ctypes.c_void_p), len(grads), _C.ptr(z), _C.ptr(out), g0.numel(),
+                               _C.stream()), "rr_sum_n")
+    return out
+
+
+def bias_relu_bwd(dy, z, dbias):
+    """dy NHWC-memory [*, c]; returns dy*(z>0) (or dy itself when z is None) and adds column sums to dbias."""
+    c = dbias.numel()
+    npix = dy.numel() // c
+    masked = torch.empty_like(dy) if z is not None else None
+    _C.check(_C.fn("rr_bias_relu_bwd")(_C.ptr(dy), _C.ptr(z), _C.ptr(masked), _C.ptr(dbias), npix, c, _C.stream()),
+             "rr_bias_relu_bwd")
+    return masked if z is not None else dy
+
+
+def upsample_add_fwd(up1, low):
+    n, c, h, w = up1.shape
+    out = empty_nhwc(n, c, h, w, up1.device)
+    _C.check(_C.fn("rr_upsample_add_fwd")(_C.ptr(up1), _C.ptr(low), _C.ptr(out), n, h, w, low.shape[2], low.shape[3],
+                                          c, _C.stream()), "rr_upsample_add_fwd")
+    return out
+
+
+def upsample_add_bwd(dout, low_shape):
+    n, c, h, w = dout.shape
+    dlow = empty_nhwc(n, c, low_shape[2], low_shape[3], dout.device)
+    _C.check(_C.fn("rr_upsample_add_bwd")(_C.ptr(dout), _C.ptr(dlow), n, h, w, low_shape[2], low_shape[3], c,
+                                          _C.stream()), "rr_upsample_add_bwd")
+    return dlow
+
+
+def avgpool_fwd(x):
+    r, c, h, w = x.shape
+    out = empty_nhwc(r, c, 1, 1, x.device)
+    _C.check(_C.fn("rr_avgpool_fwd")(_C.ptr(x), _C.ptr(out), r, h * w, c, _C.stream()), "rr_avgpool_fwd")
+    return out
+
+
+def avgpool_bwd(dout, shape):
+    r, c, h, w = shape
+    dx = empty_nhwc(r, c, h, w, dout.device)
+    _C.check(_C.fn("rr_avgpool_bwd")(_C.ptr(dout), _C.ptr(dx), r, h * w, c, _C.stream()), "rr_avgpool_bwd")
+    return dx
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, grad_scale=1.0):
+    assert param.numel() % 4 == 0
+    _C.check(_C.fn("rr_adam_step")(_C.ptr(param), _C.ptr(grad), _C.ptr(exp_avg), _C.ptr(exp_avg_sq), param.numel(),
+                                   float(lr), float(beta1), float(beta2), float(eps), int(step), float(grad_scale),
+                                   _C.stream()), "rr_adam_step")
+
+
+# ---------------------------------------------------------------------------------------------
+# losses
+# ---------------------------------------------------------------------------------------------
+def focal_fwd(logits, gt):
+    sums = torch.empty(3, dtype=torch.float64, device=logits.device)
+    _C.check(_C.fn("rr_focal_loss_fwd")(_C.ptr(logits), _C.ptr(gt), logits.numel(), _C.ptr(sums), _C.stream()),
+             "rr_focal_loss_fwd")
+    return sums
+
+
+def focal_bwd(logits, gt, sums, gout, gscale=1.0):
+    d = torch.empty_like(logits)
+    assert d.stride() == logits.stride()
+    _C.check(_C.fn("rr_focal_loss_bwd")(_C.ptr(logits), _C.ptr(gt), logits.numel(), _C.ptr(sums), _C.ptr(gout),
+                                        float(gscale), _C.ptr(d), _C.stream()), "rr_focal_loss_bwd")
+    return d
+
+
+def regl1_fwd(pred, mask, ind, target):
+    b, c, h, w = pred.shape
+    m = ind.shape[1]
+    sums = torch.empty(3, dtype=torch.float64, device=pred.device)
+    _C.check(_C.fn("rr_regl1_fwd")(_C.ptr(pred), _C.ptr(mask), _C.ptr(ind), _C.ptr(target), b, m, c, h * w, _C.ptr(sums),
+                                   _C.stream()), "rr_regl1_fwd")
+    return sums
+
+
+def regl1_bwd(pred, mask, ind, target, sums, gout, gscale=1.0):
+    b, c, h, w = pred.shape
+    m = ind.shape[1]
+    d = empty_nhwc(b, c, h, w, pred.device)
+    _C.check(_C.fn("rr_regl1_bwd")(_C.ptr(pred), _C.ptr(mask), _C.ptr(ind), _C.ptr(target), b, m, c, h * w, _C.ptr(sums),
+                                   _C.ptr(gout), float(gscale), _C.ptr(d), _C.stream()), "rr_regl1_bwd")
+    return d
+
+
+def stage2_loss(rois, reg, gt_xyxy, scale):
+    """rois [R,5], reg [R,4], gt [B,G,>=4] (xyxy) -> loss (double[3], [0] is the loss), dreg_unit [R,4], pos, npos."""
+    r = rois.shape[0]
+    b, g, gs = gt_xyxy.shape
+    dev = rois.device
+    tgt = torch.empty((max(r, 1), 4), dtype=torch.float32, device=dev)
+    pos = torch.zeros(max(r, 1), dtype=torch.int32, device=dev)
+    npos = torch.empty(b, dtype=torch.int32, device=dev)
+    loss = torch.empty(3, dtype=torch.float64, device=dev)
+    dreg = torch.zeros((r, 4), dtype=torch.float32, device=dev)
+    _C.check(_C.fn("rr_stage2_loss")(_C.ptr(rois), _C.ptr(reg), r, _C.ptr(gt_xyxy), b, g, gs, float(scale), _C.ptr(tgt),
+                                     _C.ptr(pos), _C.ptr(npos), _C.ptr(loss), _C.ptr(dreg), _C.stream()), "rr_stage2_loss")
+    return loss, dreg, tgt[:r], pos[:r], npos
+
+
+# ---------------------------------------------------------------------------------------------
+# decode / NMS / RoIAlign
+# ---------------------------------------------------------------------------------------------
+def decode_topk(hm, wh, off, k, is_logits=True):
+    assert is_nhwc(hm) and is_nhwc(wh) and is_nhwc(off)
+    b, c, h, w = hm.shape
+    out = torch.empty((b, k, 6), dtype=torch.float32, device=hm.device)
+    _C.check(_C.fn("rr_decode_topk")(_C.ptr(hm), int(is_logits), _C.ptr(wh), _C.ptr(off), b, h, w, c, k, _C.ptr(out),
+                                     _C.stream()), "rr_decode_topk")
+    return out
+
+
+def peak3x3(hm):
+    b, c, h, w = hm.shape
+    out = empty_nhwc(b, c, h, w, hm.device)
+    _C.check(_C.fn("rr_peak3x3")(_C.ptr(hm), _C.ptr(out), b, h, w, c, _C.stream()), "rr_peak3x3")
+    return out
+
+
+def group_by_class(boxes, num_classes, cls_base=0):
+    """boxes [B,K,6] -> grouped [B,K,6], seg_off int32 [B*num_classes+1]."""
+    b, k, _ = boxes.shape
+    grouped = torch.empty_like(boxes)
+    seg_off = torch.empty(b * num_classes + 1, dtype=torch.int32, device=boxes.device)
+    _C.check(_C.fn("rr_group_by_class")(_C.ptr(boxes), b, k, num_classes, cls_base, _C.ptr(grouped), _C.ptr(seg_off),
+                                        _C.stream()), "rr_group_by_class")
+    return grouped, seg_off
+
+
+def hard_nms_segments(boxes6, seg_off, max_seg, thresh):
+    nseg = seg_off.numel() - 1
+    n_out = torch.zeros(nseg, dtype=torch.int32, device=boxes6.device)
+    _C.check(_C.fn("rr_hard_nms_segments")(_C.ptr(boxes6), _C.ptr(seg_off), nseg, int(max_seg), float(thresh),
+                                           _C.ptr(n_out), _C.stream()), "rr_hard_nms_segments")
+    return n_out
+
+
+def pack_segments(grouped, seg_off, n_out, segs_per_image, want_rois=True, want_rows=False):
+    """-> (rois [R,5], scores [R], clses [R]) and/or rows [R,6]; one host sync to learn R."""
+    nseg = n_out.numel()
+    dev = grouped.device
+    out_off = torch.empty(nseg + 1, dtype=torch.int32, device=dev)
+    f = _C.fn("rr_pack_segments")
+    nul = _C.c_void_p(0)
+    _C.check(f(_C.ptr(grouped), _C.ptr(seg_off), _C.ptr(n_out), nseg, segs_per_image, _C.ptr(out_off), nul, nul, nul,
+               nul, 0, _C.stream()), "rr_pack_segments")
+    r = int(out_off[-1].item())
+    rois = torch.empty((r, 5), dtype=torch.float32, device=dev) if want_rois else None
+    scores = torch.empty(r, dtype=torch.float32, device=dev) if want_rois else None
+    clses = torch.empty(r, dtype=torch.float32, device=dev) if want_rois else None
+    rows = torch.empty((r, 6), dtype=torch.float32, device=dev) if want_rows else None
+    _C.check(f(_C.ptr(grouped), _C.ptr(seg_off), _C.ptr(n_out), nseg, segs_per_image, _C.ptr(out_off), _C.ptr(rois),
+               _C.ptr(scores), _C.ptr(clses), _C.ptr(rows), 1, _C.stream()), "rr_pack_segments")
+    return rois, scores, clses, rows
+
+
+def roi_align_fwd(feat, rois, out_size, spatial_scale=1.0, sampling_ratio=-1):
+    assert is_nhwc(feat)
+    b, c, h, w = feat.shape
+    r = rois.shape[0]
+    ph, pw = out_size
+    out = empty_nhwc(r, c, ph, pw, feat.device)
+    _C.check(_C.fn("rr_roi_align_fwd")(_C.ptr(feat), _C.ptr(rois), r, h, w, c, ph, pw, float(spatial_scale),
+                                       int(sampling_ratio), _C.ptr(out), _C.stream()), "rr_roi_align_fwd")
+    return out
+
+
+def roi_align_bwd(dout, rois, feat_shape, out_size, spatial_scale=1.0, sampling_ratio=-1):
+    b, c, h, w = feat_shape
+    r = rois.shape[0]
+    ph, pw = out_size
+    dfeat = empty_nhwc(b, c, h, w, dout.device)
+    _C.check(_C.fn("rr_roi_align_bwd")(_C.ptr(dout), _C.ptr(rois), r, b, h, w, c, ph, pw, float(spatial_scale),
+                                       int(sampling_ratio), _C.ptr(dfeat), _C.stream()), "rr_roi_align_bwd")
+    return dfeat
