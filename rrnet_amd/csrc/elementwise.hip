@@ -102,36 +102,48 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_kernel(const float *
                                                                    const float *mean, const float *invstd,
                                                                    double *sums, long npix, int C)
 {
-    __shared__ float red[2][EW_THREADS * 4];
+    __shared__ double red[2][EW_THREADS * 4];
     const int C4 = C / 4;                      // <= EW_THREADS (checked by the launcher)
     const int lanes = EW_THREADS / C4;         // pixel lanes per pass
     const int t = threadIdx.x;
     const int cq = t % C4, pl = t / C4;
-    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+    // fp32 partial sums over at most 8 pixels, then double: the reduction runs over up to 10^6
+    // samples per channel and its terms cancel (torch-CPU accumulates in double as well)
+    double d1[4] = {0.0, 0.0, 0.0, 0.0}, d2[4] = {0.0, 0.0, 0.0, 0.0};
     if (pl < lanes) {
         const f32x4 mu = *reinterpret_cast<const f32x4 *>(mean + cq * 4);
         const f32x4 is = *reinterpret_cast<const f32x4 *>(invstd + cq * 4);
-        for (long p = (long)blockIdx.x * lanes + pl; p < npix; p += (long)gridDim.x * lanes) {
-            const long off = p * C + cq * 4;
-            f32x4 g = *reinterpret_cast<const f32x4 *>(dz + off);
-            if (z) {
-                const f32x4 zz = *reinterpret_cast<const f32x4 *>(z + off);
+        const long step = (long)gridDim.x * lanes;
+        for (long p0 = (long)blockIdx.x * lanes + pl; p0 < npix; p0 += step * 8) {
+            f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) g[e] = zz[e] > 0.f ? g[e] : 0.f;
+            for (int u = 0; u < 8; ++u) {
+                const long p = p0 + u * step;
+                if (p < npix) {
+                    const long off = p * C + cq * 4;
+                    f32x4 g = *reinterpret_cast<const f32x4 *>(dz + off);
+                    if (z) {
+                        const f32x4 zz = *reinterpret_cast<const f32x4 *>(z + off);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) g[e] = zz[e] > 0.f ? g[e] : 0.f;
+                    }
+                    const f32x4 xh = (*reinterpret_cast<const f32x4 *>(y + off) - mu) * is;
+                    s1 += g;
+                    s2 += g * xh;
+                }
             }
-            const f32x4 xh = (*reinterpret_cast<const f32x4 *>(y + off) - mu) * is;
-            s1 += g;
-            s2 += g * xh;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { d1[e] += (double)s1[e]; d2[e] += (double)s2[e]; }
         }
     }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { red[0][t * 4 + e] = s1[e]; red[1][t * 4 + e] = s2[e]; }
+    for (int e = 0; e < 4; ++e) { red[0][t * 4 + e] = d1[e]; red[1][t * 4 + e] = d2[e]; }
     __syncthreads();
     for (int c = t; c < C; c += EW_THREADS) {
         double a = 0.0, b = 0.0;
         for (int l = 0; l < lanes; ++l) {
-            a += (double)red[0][(l * C4 + c / 4) * 4 + (c & 3)];
-            b += (double)red[1][(l * C4 + c / 4) * 4 + (c & 3)];
+            a += red[0][(l * C4 + c / 4) * 4 + (c & 3)];
+            b += red[1][(l * C4 + c / 4) * 4 + (c & 3)];
         }
         unsafeAtomicAdd(sums + c, a);
         unsafeAtomicAdd(sums + C + c, b);

@@ -1,0 +1,95 @@
+"""Flat parameter / gradient storage + fused Adam + RCCL gradient exchange.
+
+MI355X-first replacement for what the reference gets from DistributedDataParallel + optim.Adam
+(operators/base_operator.py:24, operators/rrnet_operator.py:29,137-138): all parameters live in
+ONE fp32 buffer and all gradients in another (each tensor 16-byte aligned, conv weights kept in
+their OHWI physical layout), so that
+  * wgrad / BN-backward kernels accumulate straight into the gradient buffer (no per-tensor
+    gradient allocation, no autograd accumulation pass),
+  * the data-parallel exchange is a handful of large all-reduces over slices of that buffer
+    (RCCL over xGMI; 765 MB for hourglass-104) instead of DDP's 25 MB buckets + graph walk,
+  * Adam is a single kernel launch over 191 M elements instead of 519 small ones.
+`module.state_dict()` / `load_state_dict()` keep working: parameters stay nn.Parameters whose
+`.data` are views into the flat buffer.
+"""
+import torch
+import torch.distributed as dist
+
+from rrnet_amd import ops
+
+
+class FlatParams:
+    def __init__(self, module):
+        params = [p for p in module.parameters() if p.requires_grad]
+        assert params, "no trainable parameters"
+        dev = params[0].device
+        assert dev.type == "cuda", "FlatParams lives in HBM: move the module to the GPU first"
+        offs, total = [], 0
+        for p in params:
+            offs.append(total)
+            total += (p.numel() + 3) // 4 * 4
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.params = params
+        self.numel = total
+        for p, o in zip(params, offs):
+            n = p.numel()
+            if p.dim() == 4:          # physical OHWI, logical [K,C,R,S]
+                k, c, r, s = p.shape
+                view = self.flat[o:o + n].view(k, r, s, c).permute(0, 3, 1, 2)
+                gview = self.grad[o:o + n].view(k, r, s, c).permute(0, 3, 1, 2)
+            else:
+                view = self.flat[o:o + n].view(p.shape)
+                gview = self.grad[o:o + n].view(p.shape)
+            view.copy_(p.data)
+            p.data = view
+            p.grad = gview
+            p._rr_grad = gview
+
+    def zero_grad(self):
+        self.grad.zero_()
+        for p in self.params:        # keep .grad pointing at the flat views (set_to_none would drop them)
+            if p.grad is None or p.grad.data_ptr() != p._rr_grad.data_ptr():
+                p.grad = p._rr_grad
+
+    def broadcast(self, src=0):
+        """Initial parameter broadcast (C2 in SURVEY §2.2): one collective."""
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.broadcast(self.flat, src)
+
+    def all_reduce_grads(self, chunk_elems=64 * 1024 * 1024):
+        """Sum-all-reduce of the flat gradient in a few large slices (C3).  Returns the factor the
+        optimizer must scale the gradient with (DDP averages)."""
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return 1.0
+        works = []
+        for o in range(0, self.numel, chunk_elems):
+            works.append(dist.all_reduce(self.grad[o:o + chunk_elems], async_op=True))
+        for w in works:
+            w.wait()
+        return 1.0 / dist.get_world_size()
+
+
+class FlatAdam(torch.optim.Optimizer):
+    """torch.optim.Adam semantics (defaults of operators/rrnet_operator.py:29: betas (0.9,0.999),
+    eps 1e-8, no weight decay, no amsgrad) as one fused kernel over FlatParams, preceded by the
+    data-parallel gradient all-reduce.  Subclasses Optimizer so lr schedulers drive `param_groups`."""
+
+    def __init__(self, module_or_flat, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        self.fp = module_or_flat if isinstance(module_or_flat, FlatParams) else FlatParams(module_or_flat)
+        super().__init__(self.fp.params, dict(lr=lr, betas=betas, eps=eps))
+        self.exp_avg = torch.zeros_like(self.fp.flat)
+        self.exp_avg_sq = torch.zeros_like(self.fp.flat)
+        self.step_count = 0
+
+    def zero_grad(self, set_to_none=False):
+        self.fp.zero_grad()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        assert closure is None
+        scale = self.fp.all_reduce_grads()
+        g = self.param_groups[0]
+        self.step_count += 1
+        ops.adam_step(self.fp.flat, self.fp.grad, self.exp_avg, self.exp_avg_sq, g['lr'], g['betas'][0], g['betas'][1],
+                      g['eps'], self.step_count, scale)
