@@ -1,0 +1,184 @@
+"""bench.py — RRNet train-step throughput on MI355X (BASELINE.json metric: images/sec, train step).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): RRNet hourglass-104 (2 stacks), B=8 per GPU, 1024x1024
+synthetic VisDrone-shaped frames, fp32; one "step" = forward + focal/L1/stage-2 losses + backward
++ (RCCL gradient all-reduce when N>1) + fused Adam — nothing skipped.  Weak scaling: B=8 per GPU.
+Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line carrying
+`roofline` (dominant kernel = the implicit-GEMM forward convolution, MFMA-bound; per-launch
+durations measured live with HIP events on the launch stream) and `cpu_baseline` (the oracle's
+torch-CPU restatement of the same step, timed on this box's host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: Peak FP32 (matrix), dense
+ALGO_TFLOP_PER_IMAGE = 7.02        # fprop+dgrad+wgrad conv FLOPs of one 1024^2 image
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=8, help="images per GPU (BASELINE config: 8)")
+    ap.add_argument("--size", type=int, default=1024, help="frame height = width (BASELINE config: 1024)")
+    ap.add_argument("--backbone", default="hourglass", choices=["hourglass", "hourglass_tiny"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(seed, size=512, k=100):
+    """The oracle ("port": torch-CPU restatement of the reference graph, oracle/model.py + ops.py)
+    running one hourglass-104 RRNet train step (forward + losses + backward, no optimizer) on ONE
+    size x size frame on the host cores; conv FLOPs scale with the pixel count, so images/sec at
+    1024^2 = 1 / (t * (1024/size)^2)."""
+    from types import SimpleNamespace
+    from oracle import model as om, ops as oo
+    from rrnet_amd.datasets.synthetic import synth_batch
+    from rrnet_amd.models.rrnet import RRNet
+    cfg = SimpleNamespace(num_classes=10, Model=SimpleNamespace(num_stacks=2, backbone="hourglass",
+                          nms_type_for_stage1="nms", nms_per_class_for_stage1=True))
+    torch.manual_seed(seed)
+    net = RRNet(cfg)
+    sd = {kk: v.detach().clone() for kk, v in net.state_dict().items()}
+    for kk, p in net.named_parameters():
+        sd[kk].requires_grad_()
+    del net
+    imgs, annos, hms, whs, inds, offs, masks, _ = synth_batch(1, size, size, boxes_per_image=100, seed=seed)
+    P = om.Params(sd, training=True)
+    t0 = time.perf_counter()
+    outs = om.rrnet_forward(P, imgs, k=k)
+    losses = oo.criterion(outs, (hms, whs, inds, offs, masks, annos.clone()))
+    (losses[0] + 0.1 * losses[1] + losses[2] + losses[3] * 0).backward()
+    t = time.perf_counter() - t0
+    scale = (1024.0 / size) ** 2
+    return {"value": round(1.0 / (t * scale), 5), "unit": "images/sec", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": "oracle torch-CPU RRNet hourglass-104 train step (fwd+losses+bwd), 1 frame %dx%d, k=%d: %.2f s; "
+                      "scaled by (1024/%d)^2 conv-FLOP ratio to 1024x1024" % (size, size, k, t, size)}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and world == 1:
+        print("bench.py: --gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
+              % (a.gpus, a.gpus), file=sys.stderr)
+        sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible — the HIP path has no CPU fallback", file=sys.stderr)
+        sys.exit(3)
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group(backend="nccl", init_method="env://", world_size=world, rank=rank)
+
+    from rrnet_amd import ops
+    from rrnet_amd.configs.rrnet_config import Config as cfg
+    from rrnet_amd.operators.rrnet_operator import RRNetOperator
+
+    cfg.Train.batch_size = a.batch
+    cfg.Train.crop_size = (a.size, a.size)
+    cfg.Model.backbone = a.backbone
+    cfg.Distributed.gpu_id = local
+    cfg.Distributed.rank = rank
+    cfg.Distributed.world_size = world
+    torch.manual_seed(cfg.seed)                       # default torch init under seed 219 (same on every rank)
+    op = RRNetOperator(cfg)
+    op.model.train()
+    batches = [op.training_loader.get_batch() for _ in range(len(op.training_loader))]   # resident in HBM
+    torch.cuda.synchronize()
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def fresh(b):
+        # the criterion converts annos xywh -> xyxy IN PLACE (as the reference does): hand it a copy
+        return (b[0], b[1].clone()) + tuple(b[2:])
+
+    step_no = 0
+    for _ in range(a.warmup):
+        op.train_step(step_no, fresh(batches[step_no % len(batches)]))
+        step_no += 1
+    timer = None
+    if not a.no_kernel_timing:
+        timer = ops.KernelTimer()
+        ops.TIMER = timer
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        op.train_step(step_no, fresh(batches[step_no % len(batches)]))
+        step_no += 1
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    ops.TIMER = None
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        images = a.batch * world * a.steps
+        ms = elapsed / a.steps * 1e3
+        out = {
+            "metric": "images/sec (train step)", "value": round(images / elapsed, 4), "unit": "images/sec",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "RRNet %s (2 stacks) train step, %dx%d synthetic VisDrone frames, fp32" %
+                                   ("hourglass-104" if a.backbone == "hourglass" else "hourglass-tiny", a.size, a.size),
+                       "per_gpu_batch": a.batch, "global_batch": a.batch * world, "k": 1500,
+                       "parallelism": "dp%d" % world},
+        }
+        if timer is not None:
+            summ = timer.summary()
+            dom = "conv_fprop<BN=128,vec4>"
+            if dom in summ:
+                d = summ[dom]
+                achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+                out["roofline"] = {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
+                                   "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+                                   "traffic": None,
+                                   "kernel": "conv_igemm_kernel<128,0,false> (implicit-GEMM fprop, v_mfma_f32_32x32x2_f32)",
+                                   "launches": d["launches"], "avg_launch_ms": round(d["ms"] / d["launches"], 4),
+                                   "algorithmic_gflop_per_launch": round(d["flops"] / d["launches"] / 1e9, 3)}
+            out["kernels"] = {k: {"launches": v["launches"], "ms": round(v["ms"], 2),
+                                  "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else None}
+                              for k, v in sorted(summ.items())}
+            conv_ms = sum(v["ms"] for v in summ.values())
+            out["conv_time_fraction"] = round(conv_ms / (elapsed * 1e3), 4)
+        if a.backbone == "hourglass" and a.size == 1024:
+            out["step_mfma_frac"] = round(out["value"] / world * ALGO_TFLOP_PER_IMAGE / FP32_MFMA_PEAK_TFLOPS, 4)
+        if world == 1 and not a.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(cfg.seed)
+            except Exception as e:                                   # the baseline must never sink the GPU number
+                out["cpu_baseline"] = {"value": None, "unit": "images/sec", "cores": torch.get_num_threads(),
+                                       "kind": "port", "sample": "failed: %r" % (e,)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

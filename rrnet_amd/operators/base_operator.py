@@ -1,0 +1,55 @@
+"""operators/base_operator.py:11-51 of the reference.  `DistributedDataParallel(model, ...)` is
+replaced by RCCLDataParallel: parameters and gradients live in flat HBM buffers
+(rrnet_amd.flat), the initial broadcast is one collective and the gradient exchange is a few
+large RCCL all-reduces over xGMI issued from the optimizer step."""
+import os
+import random
+
+import torch
+import torch.nn as nn
+
+from rrnet_amd.flat import FlatParams
+
+
+class RCCLDataParallel(nn.Module):
+    """Keeps DDP's surface used by the reference (`self.model(x)`, `self.model.module`,
+    state_dict of `.module`)."""
+
+    def __init__(self, module, flat=None):
+        super().__init__()
+        self.module = module
+        self.flat = flat if flat is not None else FlatParams(module)
+        self.flat.broadcast(0)
+        # buffers (BN running stats) start identical on all ranks: rank 0's
+        if torch.distributed.is_available() and torch.distributed.is_initialized() \
+                and torch.distributed.get_world_size() > 1:
+            for b in module.buffers():
+                torch.distributed.broadcast(b, 0)
+
+    def forward(self, *a, **kw):
+        return self.module(*a, **kw)
+
+
+class BaseOperator(object):
+    def __init__(self, cfg, model, lr_sch=None, flat=None):
+        self.cfg = cfg
+        random.seed(cfg.seed)
+        torch.manual_seed(cfg.seed)
+        torch.cuda.manual_seed(cfg.seed)
+        self.model = RCCLDataParallel(model, flat)
+        self.lr_sch = lr_sch
+
+    def criterion(self, outs, labels):
+        raise NotImplementedError
+
+    def training_process(self):
+        raise NotImplementedError
+
+    def evaluation_process(self):
+        raise NotImplementedError
+
+    @staticmethod
+    def save_ckp(models, step, path):
+        """Same file format as the reference: state_dict of the bare module, reference key names."""
+        sd = {k: v.detach().cpu().contiguous() for k, v in models.state_dict().items()}
+        torch.save(sd, os.path.join(path, 'ckp-{}.pth'.format(step)))

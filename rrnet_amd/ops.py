@@ -9,6 +9,46 @@ _P, _I, _F = _C.c_void_p, _C.c_int, _C.c_float
 CL = torch.channels_last
 
 
+class KernelTimer:
+    """Optional live timing of individual conv launches with HIP events recorded on the launch
+    stream (bench.py's roofline leg).  Off (None) in normal operation: no events, no overhead."""
+
+    def __init__(self):
+        self.records = []      # (kernel name, flops, start event, end event)
+
+    def launch(self, name, flops, fn):
+        s = torch.cuda.Event(enable_timing=True)
+        e = torch.cuda.Event(enable_timing=True)
+        s.record()
+        rc = fn()
+        e.record()
+        self.records.append((name, flops, s, e))
+        return rc
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, flops, s, e in self.records:
+            d = out.setdefault(name, dict(launches=0, ms=0.0, flops=0.0))
+            d["launches"] += 1
+            d["ms"] += s.elapsed_time(e)
+            d["flops"] += flops
+        return out
+
+
+TIMER = None
+
+
+def _timed(name, flops, fn):
+    if TIMER is None:
+        return fn()
+    return TIMER.launch(name, flops, fn)
+
+
+def _igemm_name(kind, n_gemm, scalar):
+    return "conv_%s<BN=%d,%s>" % (kind, 128 if n_gemm > 32 else 32, "scalar" if scalar else "vec4")
+
+
 def is_nhwc(t):
     return t.dim() == 4 and t.permute(0, 2, 3, 1).is_contiguous()
 
@@ -48,8 +88,10 @@ def conv_fprop(x, w, bias=None, stride=1, pad=(0, 0), relu=False, want_stats=Fal
         nbytes = _C.fn("rr_conv_stat_slab_bytes")(n, p, q, k)
         slab = torch.empty(nbytes // 8, dtype=torch.float64, device=x.device)
     f = _C.fn("rr_conv_fprop")
-    _C.check(f(_C.ptr(x), _C.ptr(w), _C.ptr(bias), _C.ptr(y), _C.ptr(slab), n, h, wd, c, k, r, s, stride,
-               pad[0], pad[1], int(relu), _C.stream()), "rr_conv_fprop")
+    flops = 2.0 * n * p * q * k * c * r * s
+    _C.check(_timed(_igemm_name("fprop", k, c % 4 != 0), flops,
+                    lambda: f(_C.ptr(x), _C.ptr(w), _C.ptr(bias), _C.ptr(y), _C.ptr(slab), n, h, wd, c, k, r, s,
+                              stride, pad[0], pad[1], int(relu), _C.stream())), "rr_conv_fprop")
     return (y, slab) if want_stats else y
 
 
@@ -65,8 +107,10 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False)
         accumulate = False
     assert is_nhwc(out)
     f = _C.fn("rr_conv_dgrad")
-    _C.check(f(_C.ptr(dy), _C.ptr(w), _C.ptr(out), n, h, wd, c, k, r, s, stride, pad[0], pad[1],
-               int(accumulate), _C.stream()), "rr_conv_dgrad")
+    flops = 2.0 * dy.shape[0] * dy.shape[2] * dy.shape[3] * k * c * r * s
+    _C.check(_timed(_igemm_name("dgrad", c, (k % 4 != 0) or (c % 4 != 0)), flops,
+                    lambda: f(_C.ptr(dy), _C.ptr(w), _C.ptr(out), n, h, wd, c, k, r, s, stride, pad[0], pad[1],
+                              int(accumulate), _C.stream())), "rr_conv_dgrad")
     return out
 
 
@@ -78,8 +122,10 @@ def conv_wgrad(x, dy, dw, stride=1, pad=(0, 0)):
     k, c2, r, s = dw.shape
     assert c == c2 and dy.shape[1] == k
     f = _C.fn("rr_conv_wgrad")
-    _C.check(f(_C.ptr(x), _C.ptr(dy), _C.ptr(dw), n, h, wd, c, k, r, s, stride, pad[0], pad[1], _C.stream()),
-             "rr_conv_wgrad")
+    flops = 2.0 * dy.shape[0] * dy.shape[2] * dy.shape[3] * k * c * r * s
+    _C.check(_timed("conv_wgrad<BN=%d>" % (128 if c > 32 else 32), flops,
+                    lambda: f(_C.ptr(x), _C.ptr(dy), _C.ptr(dw), n, h, wd, c, k, r, s, stride, pad[0], pad[1],
+                              _C.stream())), "rr_conv_wgrad")
     return dw
 
 
