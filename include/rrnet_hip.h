@@ -75,7 +75,7 @@ int rr_conv_wgrad(const float *x, const float *dy, float *dw, int n, int h, int 
  * nn.Upsample x2 + bilinear(align_corners) resize + add of backbones/hourglass.py:113,121-124;
  * F.adaptive_avg_pool2d of detectors/fasterrcnn_detector.py:15; optim.Adam of
  * operators/rrnet_operator.py:29,138.  `total` = element count, `c` = channels (NHWC inner).
- * Training statistics: rr_conv_fprop's slab -> rr_bn_reduce_slab -> sums[2][c] (the SyncBN
+ * Training statistics: rr_conv_fprop's slab -> rr_bn_reduce_slab (adds into a zeroed) sums[2][c] (the SyncBN
  * exchange all-reduces exactly this buffer plus the sample count) -> rr_bn_finalize ->
  * mean/invstd (saved for backward), scale/shift (for rr_bn_apply), running stats updated with
  * `momentum` and the unbiased variance.

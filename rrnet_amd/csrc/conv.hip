@@ -47,6 +47,8 @@ struct ConvArgs {
     int M;             // N*DH*DW
     int Kg;            // R*S*SC
     int wK, wC;        // weight dims K, C
+    int parity;        // dgrad, stride 2: blockIdx.y = output parity class (h%2, w%2); only the taps that
+                       // can reach that class are visited (1/2/2/4 of a 3x3) instead of masking 3/4 of the MFMAs
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nb)
@@ -83,8 +85,21 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
     const int m0 = m_tile * BM, n0 = n_tile * BN;
 
     const int RS = a.R * a.S;
+    // tap sub-lattice visited by this block: all taps, or (parity mode) r = r0, r0+2, ..  s = s0, s0+2, ..
+    int r0 = 0, s0 = 0, tstep = 1, Rc = a.R, Sc = a.S;
+    int ph = 0, pw = 0, Hc = a.DH, Wc = a.DW, Mloc = a.M;
+    if (MODE == 1 && a.parity) {
+        ph = blockIdx.y >> 1; pw = blockIdx.y & 1;
+        Hc = (a.DH - ph + 1) / 2; Wc = (a.DW - pw + 1) / 2;
+        Mloc = a.N * Hc * Wc;
+        if (m0 >= Mloc) return;
+        r0 = (ph + a.pad_h) & 1; s0 = (pw + a.pad_w) & 1; tstep = 2;
+        Rc = r0 < a.R ? (a.R - r0 + 1) / 2 : 0;
+        Sc = s0 < a.S ? (a.S - s0 + 1) / 2 : 0;
+    }
+    const int RSc = Rc * Sc;
     const int cpt = (a.SC + BK - 1) / BK;                  // channel chunks per tap (vector mode)
-    const int nk = SCALAR ? (a.Kg + BK - 1) / BK : cpt * RS;
+    const int nk = SCALAR ? (a.Kg + BK - 1) / BK : cpt * RSc;
 
     // ---- per-thread A rows: destination pixel coordinates
     const int a_col = (t & 7) * 4;
@@ -92,11 +107,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
 #pragma unroll
     for (int j = 0; j < AJ; ++j) {
         const int m = m0 + (t >> 3) + 32 * j;
-        if (m < a.M) {
-            const int hw = a.DH * a.DW;
+        if (m < Mloc) {
+            const int hw = Hc * Wc;
             const int n = m / hw, rem = m - n * hw;
-            const int h = rem / a.DW;
-            a_n[j] = n; a_h[j] = h; a_w[j] = rem - h * a.DW;
+            const int h = rem / Wc;
+            a_n[j] = n; a_h[j] = h * tstep + ph; a_w[j] = (rem - h * Wc) * tstep + pw;
         } else {
             a_n[j] = -1; a_h[j] = 0; a_w[j] = 0;
         }
@@ -127,8 +142,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
 
     auto load_tiles = [&](int kc) {
         if (!SCALAR) {
-            const int cch = kc / RS, tap = kc - cch * RS;
-            const int r = tap / a.S, s = tap - r * a.S;
+            const int cch = kc / RSc, tl = kc - cch * RSc;
+            const int ri = tl / Sc;
+            const int r = r0 + tstep * ri, s = s0 + tstep * (tl - ri * Sc);
+            const int tap = r * a.S + s;
             const int c0 = cch * BK;
             // A: BM rows x 32 channels of one tap
 #pragma unroll
@@ -243,8 +260,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
 
     const int lr = lane & 31, lh = lane >> 5;
 
-    load_tiles(0);
-    store_tiles(0);
+    if (nk > 0) {
+        load_tiles(0);
+        store_tiles(0);
+    }
     __syncthreads();
     for (int kc = 0; kc < nk; ++kc) {
         const int buf = kc & 1;
@@ -295,8 +314,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
                 const int m = m0 + (wm * TM + i) * 32 + row;
                 float v = acc[i][j][e] + bv;
                 if (MODE == 0 && a.relu) v = v > 0.f ? v : 0.f;
-                if (m < a.M && n_ok) {
-                    float *p = a.dst + (long)m * a.DC + ncol;
+                if (m < Mloc && n_ok) {
+                    long pix = m;
+                    if (MODE == 1 && a.parity) {
+                        const int hw = Hc * Wc;
+                        const int n = m / hw, rem = m - n * hw;
+                        const int h = rem / Wc;
+                        pix = ((long)n * a.DH + (h * 2 + ph)) * a.DW + ((rem - h * Wc) * 2 + pw);
+                    }
+                    float *p = a.dst + pix * a.DC + ncol;
                     if (a.accumulate) v += *p;
                     *p = v;
                     s1 += v;
@@ -343,22 +369,27 @@ struct WgradArgs {
     int mt, nt;       // tiles along K and C
 };
 
-template <int BN, bool A_SCALAR, bool B_SCALAR>
+// BMW x BN output tile (ko x c).  128x128: 2x2 waves of 64x64; 128x32 / 32x128: 4 waves of one 32x32;
+// 32x32: the 4 waves split the 32-deep K-step between them (their partial sums meet in the atomics).
+template <int BMW, int BN, bool A_SCALAR, bool B_SCALAR>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a)
 {
-    constexpr int WN = BN / 64 ? BN / 64 : 1;
-    constexpr int WM = 4 / WN;
-    constexpr int TM = BM / (WM * 32);
+    constexpr int TILES = (BMW / 32) * (BN / 32);
+    constexpr int KS = TILES == 1 ? 4 : 1;                       // waves splitting K
+    constexpr int WN = TILES == 16 ? 2 : (BN / 32 >= 4 ? 4 : 1);
+    constexpr int WM = 4 / (WN * KS);
+    constexpr int TM = BMW / (WM * 32);
     constexpr int TN = BN / (WN * 32);
-    constexpr int A_ELEMS = BK * BM, B_ELEMS = BK * BN;
-    constexpr int AJ = BM / 32, BJ = BN / 32;
-    constexpr int TPR_B = BN / 4, RPP_B = 256 / TPR_B;
+    constexpr int A_ELEMS = BK * BMW, B_ELEMS = BK * BN;
+    constexpr int TPR_A = BMW / 4, RPP_A = 256 / TPR_A, AJ = BMW / 32;
+    constexpr int TPR_B = BN / 4, RPP_B = 256 / TPR_B, BJ = BN / 32;
 
     extern __shared__ __align__(16) float lds[];
     float *As = lds, *Bs = lds + 2 * A_ELEMS;
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int wm = wave / WN, wn = wave % WN;
+    const int wk = KS > 1 ? wave : 0;
+    const int wm = KS > 1 ? 0 : wave / WN, wn = KS > 1 ? 0 : wave % WN;
     const int RS = a.R * a.S;
     int logical = xcd_remap(blockIdx.x, gridDim.x);
     const int tap = logical % RS; logical /= RS;
@@ -366,7 +397,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a)
     const int m_tile = logical % a.mt;
     const int split = logical / a.mt;
     const int r = tap / a.S, s = tap - r * a.S;
-    const int ko0 = m_tile * BM, c0 = n_tile * BN;
+    const int ko0 = m_tile * BMW, c0 = n_tile * BN;
     const int total_chunks = (a.M + BK - 1) / BK;
     const int kc_begin = split * a.chunks_per_split;
     int kc_end = kc_begin + a.chunks_per_split;
@@ -374,13 +405,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a)
     if (kc_begin >= kc_end) return;
 
     f32x4 ra[AJ], rb[BJ];
-    const int a_row = t >> 5, a_col = (t & 31) * 4;            // A: 32 threads per pixel row, 8 rows per pass
+    const int a_row = t / TPR_A, a_col = (t % TPR_A) * 4;
     const int b_row = t / TPR_B, b_col = (t % TPR_B) * 4;
 
     auto load_tiles = [&](int kc) {
 #pragma unroll
         for (int j = 0; j < AJ; ++j) {
-            const int m = kc * BK + a_row + 8 * j;
+            const int m = kc * BK + a_row + RPP_A * j;
             const int ko = ko0 + a_col;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (m < a.M) {
@@ -421,7 +452,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a)
     auto store_tiles = [&](int buf) {
         float *A = As + buf * A_ELEMS, *B = Bs + buf * B_ELEMS;
 #pragma unroll
-        for (int j = 0; j < AJ; ++j) *reinterpret_cast<f32x4 *>(A + (a_row + 8 * j) * BM + a_col) = ra[j];
+        for (int j = 0; j < AJ; ++j) *reinterpret_cast<f32x4 *>(A + (a_row + RPP_A * j) * BMW + a_col) = ra[j];
 #pragma unroll
         for (int j = 0; j < BJ; ++j) *reinterpret_cast<f32x4 *>(B + (b_row + RPP_B * j) * BN + b_col) = rb[j];
     };
@@ -443,12 +474,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a)
         if (kc + 1 < kc_end) load_tiles(kc + 1);
         const float *A = As + buf * A_ELEMS, *B = Bs + buf * B_ELEMS;
 #pragma unroll
-        for (int k2 = 0; k2 < BK / 2; ++k2) {
+        for (int k2 = 0; k2 < BK / 2 / KS; ++k2) {
+            const int kr = 2 * (k2 + wk * (BK / 2 / KS)) + lh;
             float fa[TM], fb[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = A[(2 * k2 + lh) * BM + (wm * TM + i) * 32 + lr];
+            for (int i = 0; i < TM; ++i) fa[i] = A[kr * BMW + (wm * TM + i) * 32 + lr];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = B[(2 * k2 + lh) * BN + (wn * TN + j) * 32 + lr];
+            for (int j = 0; j < TN; ++j) fb[j] = B[kr * BN + (wn * TN + j) * 32 + lr];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -473,11 +505,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a)
 }
 
 template <typename K, typename A>
-int launch(K kern, int blocks, size_t lds, hipStream_t stream, const A &args, const char *name)
+int launch(K kern, int blocks, size_t lds, hipStream_t stream, const A &args, const char *name, int grid_y = 1)
 {
     if (lds > 48 * 1024)
         hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, stream, args);
+    hipLaunchKernelGGL(kern, dim3(blocks, grid_y), dim3(256), lds, stream, args);
     RR_CHECK_LAUNCH(name);
     return RR_OK;
 }
@@ -534,12 +566,18 @@ extern "C" int rr_conv_dgrad(const float *dy, const float *w, float *dx, int n, 
     a.M = (int)M; a.Kg = r * s * k; a.wK = k; a.wC = c;
     const bool scalar = (k % 4) != 0 || (c % 4) != 0;
     const int bn = c > 32 ? 128 : 32;
-    const int blocks = rr_cdiv(M, BM) * rr_cdiv(c, bn);
+    int blocks = rr_cdiv(M, BM) * rr_cdiv(c, bn);
+    int gy = 1;
+    if (stride == 2 && !scalar) {     // parity-decomposed: 4 classes of ceil(h/2) x ceil(w/2) pixels each
+        a.parity = 1;
+        gy = 4;
+        blocks = rr_cdiv((long)n * ((h + 1) / 2) * ((wd + 1) / 2), BM) * rr_cdiv(c, bn);
+    }
     const size_t lds = igemm_lds(bn, true);
-    if (bn == 128) return scalar ? launch(conv_igemm_kernel<128, 1, true>, blocks, lds, stream, a, "rr_conv_dgrad")
-                                 : launch(conv_igemm_kernel<128, 1, false>, blocks, lds, stream, a, "rr_conv_dgrad");
-    return scalar ? launch(conv_igemm_kernel<32, 1, true>, blocks, lds, stream, a, "rr_conv_dgrad")
-                  : launch(conv_igemm_kernel<32, 1, false>, blocks, lds, stream, a, "rr_conv_dgrad");
+    if (bn == 128) return scalar ? launch(conv_igemm_kernel<128, 1, true>, blocks, lds, stream, a, "rr_conv_dgrad", gy)
+                                 : launch(conv_igemm_kernel<128, 1, false>, blocks, lds, stream, a, "rr_conv_dgrad", gy);
+    return scalar ? launch(conv_igemm_kernel<32, 1, true>, blocks, lds, stream, a, "rr_conv_dgrad", gy)
+                  : launch(conv_igemm_kernel<32, 1, false>, blocks, lds, stream, a, "rr_conv_dgrad", gy);
 }
 
 extern "C" int rr_conv_wgrad(const float *x, const float *dy, float *dw, int n, int h, int wd, int c, int k,
@@ -554,24 +592,28 @@ extern "C" int rr_conv_wgrad(const float *x, const float *dy, float *dw, int n, 
     const long M = (long)n * a.P * a.Q;
     RR_CHECK_ARG(M > 0 && M < (1l << 31), "rr_conv_wgrad: bad pixel count");
     a.M = (int)M;
+    const int bmw = k > 32 ? 128 : 32;
     const int bn = c > 32 ? 128 : 32;
-    a.mt = rr_cdiv(k, BM); a.nt = rr_cdiv(c, bn);
+    a.mt = rr_cdiv(k, bmw); a.nt = rr_cdiv(c, bn);
     const int tiles = a.mt * a.nt * r * s;
     const int total_chunks = rr_cdiv(M, BK);
-    // enough splits to put ~6 workgroups on each of the 256 CUs, but never fewer than 8 K-steps per split
-    int splits = rr_cdiv(256 * 6, tiles);
+    // Split the pixel (K) dimension so that tiles*splits fills the 512 resident-workgroup slots
+    // (256 CUs x 2) exactly once: equal-length workgroups in more than one round pay a whole extra
+    // round for any remainder.  Never fewer than 8 K-steps per split.
+    int splits = tiles < 512 ? 512 / tiles : 1;
     if (splits > rr_cdiv(total_chunks, 8)) splits = rr_cdiv(total_chunks, 8);
     if (splits < 1) splits = 1;
     a.chunks_per_split = rr_cdiv(total_chunks, splits);
     splits = rr_cdiv(total_chunks, a.chunks_per_split);
     const int blocks = tiles * splits;
-    const size_t lds = sizeof(float) * 2 * (BK * BM + BK * bn);
+    const size_t lds = sizeof(float) * 2 * (BK * bmw + BK * bn);
     const bool as = (k % 4) != 0, bs = (c % 4) != 0;
-#define WG(BNv)                                                                                                   \
-    (as ? (bs ? launch(conv_wgrad_kernel<BNv, true, true>, blocks, lds, stream, a, "rr_conv_wgrad")              \
-              : launch(conv_wgrad_kernel<BNv, true, false>, blocks, lds, stream, a, "rr_conv_wgrad"))            \
-        : (bs ? launch(conv_wgrad_kernel<BNv, false, true>, blocks, lds, stream, a, "rr_conv_wgrad")             \
-              : launch(conv_wgrad_kernel<BNv, false, false>, blocks, lds, stream, a, "rr_conv_wgrad")))
-    return bn == 128 ? WG(128) : WG(32);
+#define WG(BMv, BNv)                                                                                                  \
+    (as ? (bs ? launch(conv_wgrad_kernel<BMv, BNv, true, true>, blocks, lds, stream, a, "rr_conv_wgrad")             \
+              : launch(conv_wgrad_kernel<BMv, BNv, true, false>, blocks, lds, stream, a, "rr_conv_wgrad"))           \
+        : (bs ? launch(conv_wgrad_kernel<BMv, BNv, false, true>, blocks, lds, stream, a, "rr_conv_wgrad")            \
+              : launch(conv_wgrad_kernel<BMv, BNv, false, false>, blocks, lds, stream, a, "rr_conv_wgrad")))
+    if (bmw == 128) return bn == 128 ? WG(128, 128) : WG(128, 32);
+    return bn == 128 ? WG(32, 128) : WG(32, 32);
 #undef WG
 }

@@ -20,14 +20,29 @@ constexpr int EW_THREADS = 256;
 inline int ew_blocks(long n4) { long b = (n4 + EW_THREADS - 1) / EW_THREADS; return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b)); }
 
 // ---- BatchNorm statistics ------------------------------------------------------------------
-// slab [mtiles][2][C] (doubles, written by rr_conv_fprop) -> sums [2][C]
-__global__ void bn_reduce_slab_kernel(const double *slab, int mtiles, int C, double *sums)
+// slab [mtiles][2][C] (doubles, written by rr_conv_fprop) -> sums [2][C].
+// block = 32 columns x 8 row lanes; grid.y slices the mtiles; one double atomic per column per block
+// (sums is zeroed by the caller).
+__global__ __launch_bounds__(256) void bn_reduce_slab_kernel(const double *slab, int mtiles, int C2, int rows_per_block,
+                                                             double *sums)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // over 2*C
-    if (i >= 2 * C) return;
+    __shared__ double red[8][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int col = blockIdx.x * 32 + tx;
+    const int m0 = blockIdx.y * rows_per_block;
+    int m1 = m0 + rows_per_block;
+    if (m1 > mtiles) m1 = mtiles;
     double s = 0.0;
-    for (int m = 0; m < mtiles; ++m) s += slab[(long)m * 2 * C + i];
-    sums[i] = s;
+    if (col < C2)
+        for (int m = m0 + ty; m < m1; m += 8) s += slab[(long)m * C2 + col];
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && col < C2) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[k][tx];
+        unsafeAtomicAdd(sums + col, t);
+    }
 }
 
 // sums [2][C] over `count` samples -> mean / invstd / scale / shift (+ running stats, momentum update
@@ -391,7 +406,11 @@ __global__ __launch_bounds__(EW_THREADS) void adam_kernel(f32x4 *p, const f32x4 
 extern "C" int rr_bn_reduce_slab(const double *slab, int mtiles, int c, double *sums, hipStream_t stream)
 {
     RR_CHECK_ARG(mtiles > 0 && c > 0, "rr_bn_reduce_slab: bad dims");
-    hipLaunchKernelGGL(bn_reduce_slab_kernel, dim3(rr_cdiv(2 * c, 128)), dim3(128), 0, stream, slab, mtiles, c, sums);
+    int parts = rr_cdiv(mtiles, 64);
+    if (parts > 64) parts = 64;
+    const int rows = rr_cdiv(mtiles, parts);
+    hipLaunchKernelGGL(bn_reduce_slab_kernel, dim3(rr_cdiv(2 * c, 32), rr_cdiv(mtiles, rows)), dim3(256), 0, stream, slab,
+                       mtiles, 2 * c, rows, sums);
     RR_CHECK_LAUNCH("rr_bn_reduce_slab");
     return RR_OK;
 }

@@ -29,6 +29,9 @@ SHAPES = [
     (2, 48, 8, 8, 24, 3, 3, 1, 1, 1, False, False),         # channels not a multiple of 32
     (2, 12, 6, 6, 8, 3, 3, 2, 1, 1, False, False),
     (1, 512, 4, 4, 512, 3, 3, 1, 1, 1, False, False),
+    (2, 16, 7, 9, 24, 3, 3, 2, 1, 1, False, False),         # stride-2 dgrad parity classes, odd H and W
+    (1, 64, 11, 11, 128, 3, 3, 2, 1, 1, False, False),
+    (3, 40, 5, 7, 40, 1, 1, 2, 0, 0, False, False),
 ]
 
 
