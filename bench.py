@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--backbone", default="hourglass", choices=["hourglass", "hourglass_tiny"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--detail", action="store_true", help="print a per-layer-shape conv time table to stderr")
     return ap.parse_args()
 
 
@@ -164,6 +165,11 @@ def main():
             out["kernels"] = {k: {"launches": v["launches"], "ms": round(v["ms"], 2),
                                   "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else None}
                               for k, v in sorted(summ.items())}
+            if a.detail:
+                rows = sorted(timer.by_shape().items(), key=lambda kv: -kv[1]["ms"])
+                for (name, shp), v in rows[:40]:
+                    print("%-28s %-38s n=%4d %8.2f ms %6.1f TF" % (name, shp, v["launches"], v["ms"],
+                          v["flops"] / (v["ms"] * 1e-3) / 1e12), file=sys.stderr)
             conv_ms = sum(v["ms"] for v in summ.values())
             out["conv_time_fraction"] = round(conv_ms / (elapsed * 1e3), 4)
         if a.backbone == "hourglass" and a.size == 1024:

@@ -47,6 +47,8 @@ struct ConvArgs {
     int M;             // N*DH*DW
     int Kg;            // R*S*SC
     int wK, wC;        // weight dims K, C
+    int ksplit;        // > 1: grid.z slices the K loop and the epilogue adds with float atomics (dst pre-zeroed
+                       // or holding the running sum); no bias / ReLU / statistics in that mode
     int parity;        // dgrad, stride 2: blockIdx.y = output parity class (h%2, w%2); only the taps that
                        // can reach that class are visited (1/2/2/4 of a 3x3) instead of masking 3/4 of the MFMAs
 };
@@ -58,7 +60,8 @@ __device__ __forceinline__ int xcd_remap(int bid, int nb)
 }
 
 // MODE 0 = fprop, 1 = dgrad.  SCALAR: source/weight channel counts not multiples of 4.
-template <int BN, int MODE, bool SCALAR>
+// BKT = K-step depth (32: 2 workgroups per CU by LDS; 16: 4 per CU).
+template <int BN, int MODE, bool SCALAR, int BKT>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
 {
     constexpr int WN = BN / 64 ? BN / 64 : 1;   // waves along N
@@ -66,11 +69,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
     constexpr int TM = BM / (WM * 32);
     constexpr int TN = BN / (WN * 32);
     constexpr bool B_KN = (MODE == 1);          // dgrad reads W as [k][n]
-    constexpr int LDB = B_KN ? BN : LDA;
-    constexpr int A_ELEMS = BM * LDA;
-    constexpr int B_ELEMS = B_KN ? BK * BN : BN * LDA;
-    constexpr int AJ = BM / 32;                 // float4 per thread for the A image
-    constexpr int BJ = BN / 32;                 // float4 per thread for the B image
+    constexpr int LDK = BKT + 4;                // [m][k] image row stride: conflict-free ds_read_b128
+    constexpr int LDB = B_KN ? BN : LDK;
+    constexpr int A_ELEMS = BM * LDK;
+    constexpr int B_ELEMS = B_KN ? BKT * BN : BN * LDK;
+    constexpr int CPR = BKT / 4;                // float4 columns per [m][k] row
+    constexpr int RPP = 256 / CPR;              // rows per pass of the 256 threads
+    constexpr int AJ = BM / RPP;                // float4 per thread for the A image
+    constexpr int BJ_NK = BN / RPP > 0 ? BN / RPP : 1;
+    constexpr int TPR = BN / 4;                 // [k][n] image: threads per k-row
+    constexpr int KRPP = 256 / TPR;             // k-rows per pass
+    constexpr int BJ_KN = BKT / KRPP > 0 ? BKT / KRPP : 1;
+    constexpr int BJ = B_KN ? BJ_KN : BJ_NK;
 
     extern __shared__ __align__(16) float lds[];
     float *As = lds;                    // [2][A_ELEMS]
@@ -98,15 +108,24 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
         Sc = s0 < a.S ? (a.S - s0 + 1) / 2 : 0;
     }
     const int RSc = Rc * Sc;
-    const int cpt = (a.SC + BK - 1) / BK;                  // channel chunks per tap (vector mode)
-    const int nk = SCALAR ? (a.Kg + BK - 1) / BK : cpt * RSc;
+    const int cpt = (a.SC + BKT - 1) / BKT;                // channel chunks per tap (vector mode)
+    const int nk_all = SCALAR ? (a.Kg + BKT - 1) / BKT : cpt * RSc;
+    // split-K (grid.z): small-spatial layers have too few output tiles for 256 CUs
+    int kc_lo = 0, kc_hi = nk_all;
+    if (a.ksplit > 1) {
+        const int per = (nk_all + a.ksplit - 1) / a.ksplit;
+        kc_lo = blockIdx.z * per;
+        kc_hi = kc_lo + per < nk_all ? kc_lo + per : nk_all;
+        if (kc_lo >= kc_hi) return;
+    }
 
     // ---- per-thread A rows: destination pixel coordinates
-    const int a_col = (t & 7) * 4;
+    const int a_col = (t % CPR) * 4;
+    const int a_row = t / CPR;
     int a_n[AJ], a_h[AJ], a_w[AJ];
 #pragma unroll
     for (int j = 0; j < AJ; ++j) {
-        const int m = m0 + (t >> 3) + 32 * j;
+        const int m = m0 + a_row + RPP * j;
         if (m < Mloc) {
             const int hw = Hc * Wc;
             const int n = m / hw, rem = m - n * hw;
@@ -118,6 +137,57 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
     }
 
     f32x4 ra[AJ], rb[BJ];
+
+    // ---- vector mode: branch-free gather.  Per row: element offset of the source pixel seen through
+    // local tap (0,0) and a bit mask of the taps that stay inside the source image; per K-step only a
+    // wave-uniform tap delta is added.  (fprop: ih = h*stride - pad + r; dgrad stride 1: ih = h + pad - r;
+    // dgrad parity class: ih = hh + (ph + pad - r0)/2 - ri.)
+    const int sgn = MODE == 0 ? 1 : -1;
+    long a_base[AJ];
+    unsigned long long a_mask[AJ];
+    long b_base[BJ];
+    bool b_ok[BJ];
+    if (!SCALAR) {
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) {
+            int ih0, iw0;
+            if (MODE == 0) {
+                ih0 = a_h[j] * a.stride - a.pad_h; iw0 = a_w[j] * a.stride - a.pad_w;
+            } else if (a.parity) {
+                ih0 = (a_h[j] - ph) / 2 + (ph + a.pad_h - r0) / 2; iw0 = (a_w[j] - pw) / 2 + (pw + a.pad_w - s0) / 2;
+            } else {
+                ih0 = a_h[j] + a.pad_h; iw0 = a_w[j] + a.pad_w;
+            }
+            unsigned long long mk = 0ull;
+            if (a_n[j] >= 0) {
+                for (int ri = 0; ri < Rc; ++ri) {
+                    const int ih = ih0 + sgn * ri;
+                    if (ih < 0 || ih >= a.SH) continue;
+                    for (int si = 0; si < Sc; ++si) {
+                        const int iw = iw0 + sgn * si;
+                        if (iw >= 0 && iw < a.SW) mk |= 1ull << (ri * Sc + si);
+                    }
+                }
+            }
+            a_mask[j] = mk;
+            a_base[j] = (((long)(a_n[j] < 0 ? 0 : a_n[j]) * a.SH + ih0) * a.SW + iw0) * a.SC + a_col;
+        }
+        if (!B_KN) {
+#pragma unroll
+            for (int j = 0; j < BJ; ++j) {
+                const int ko = n0 + a_row + RPP * j;
+                b_ok[j] = ko < a.wK && (a_row + RPP * j) < BN;
+                b_base[j] = (long)ko * RS * a.wC + a_col;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < BJ; ++j) {
+                const int c = n0 + (t % TPR) * 4;
+                b_ok[j] = c < a.wC && (t / TPR + KRPP * j) < BKT;
+                b_base[j] = (long)(t / TPR + KRPP * j) * RS * a.wC + c;
+            }
+        }
+    }
 
     auto src_offset = [&](int j, int r, int s, long &off) -> bool {
         if (a_n[j] < 0) return false;
@@ -141,42 +211,40 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
     };
 
     auto load_tiles = [&](int kc) {
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
         if (!SCALAR) {
             const int cch = kc / RSc, tl = kc - cch * RSc;
-            const int ri = tl / Sc;
-            const int r = r0 + tstep * ri, s = s0 + tstep * (tl - ri * Sc);
-            const int tap = r * a.S + s;
-            const int c0 = cch * BK;
-            // A: BM rows x 32 channels of one tap
+            const int ri = tl / Sc, si = tl - ri * Sc;
+            const int tap = (r0 + tstep * ri) * a.S + (s0 + tstep * si);
+            const int c0 = cch * BKT;
+            const long a_delta = (long)sgn * ((long)ri * a.SW + si) * a.SC + c0;
+            const bool c_ok = c0 + a_col < a.SC;
+            // A: BM rows x BKT channels of one tap; out-of-image rows read a safe address and are zeroed
 #pragma unroll
             for (int j = 0; j < AJ; ++j) {
-                long off;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if ((c0 + a_col < a.SC) && src_offset(j, r, s, off))
-                    v = *reinterpret_cast<const f32x4 *>(a.src + off + c0 + a_col);
-                ra[j] = v;
+                const bool ok = c_ok && ((a_mask[j] >> tl) & 1ull);
+                const float *p = ok ? a.src + a_base[j] + a_delta : a.src;
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(p);
+                ra[j] = ok ? v : zero;
             }
             if (!B_KN) {  // fprop: B[n = ko][k = (tap, c)] = w[ko][tap][c]
+                const long w_delta = (long)tap * a.wC + c0;
+                const bool wc_ok = c0 + a_col < a.wC;
 #pragma unroll
                 for (int j = 0; j < BJ; ++j) {
-                    const int ko = n0 + (t >> 3) + 32 * j;
-                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                    if (ko < a.wK && c0 + a_col < a.wC)
-                        v = *reinterpret_cast<const f32x4 *>(a.w + ((long)ko * RS + tap) * a.wC + c0 + a_col);
-                    rb[j] = v;
+                    const bool ok = b_ok[j] && wc_ok;
+                    const float *p = ok ? a.w + b_base[j] + w_delta : a.w;
+                    const f32x4 v = *reinterpret_cast<const f32x4 *>(p);
+                    rb[j] = ok ? v : zero;
                 }
-            } else {      // dgrad: B[k = (tap, ko)][n = c] = w[ko][tap][c]
-                constexpr int TPR = BN / 4;          // threads per k-row
-                constexpr int RPP = 256 / TPR;       // k-rows per pass
+            } else {      // dgrad: B[k = (tap, ko)][n = c] = w[ko][tap][c]; c0 indexes the source channels = K
+                const long w_delta = ((long)c0 * RS + tap) * a.wC;
 #pragma unroll
                 for (int j = 0; j < BJ; ++j) {
-                    const int kk = t / TPR + RPP * j;
-                    const int ko = c0 + kk;          // c0 indexes the source channels = K here
-                    const int c = n0 + (t % TPR) * 4;
-                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                    if (ko < a.wK && c < a.wC)
-                        v = *reinterpret_cast<const f32x4 *>(a.w + ((long)ko * RS + tap) * a.wC + c);
-                    rb[j] = v;
+                    const bool ok = b_ok[j] && (c0 + t / TPR + KRPP * j < a.wK);
+                    const float *p = ok ? a.w + b_base[j] + w_delta : a.w;
+                    const f32x4 v = *reinterpret_cast<const f32x4 *>(p);
+                    rb[j] = ok ? v : zero;
                 }
             }
         } else {
@@ -185,14 +253,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
             bool e_ok[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int k = kc * BK + a_col + e;
+                const int k = kc * BKT + a_col + e;
                 e_ok[e] = k < a.Kg;
                 e_tap[e] = k / a.SC;
                 e_c[e] = k - e_tap[e] * a.SC;
             }
 #pragma unroll
             for (int j = 0; j < AJ; ++j) {
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                f32x4 v = zero;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     long off;
@@ -204,27 +272,26 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
             if (!B_KN) {  // w[ko][k] with k linear — OHWI is already [K][R*S*C]
 #pragma unroll
                 for (int j = 0; j < BJ; ++j) {
-                    const int ko = n0 + (t >> 3) + 32 * j;
-                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    const int ko = n0 + a_row + RPP * j;
+                    f32x4 v = zero;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const int k = kc * BK + a_col + e;
-                        if (ko < a.wK && k < a.Kg) v[e] = a.w[(long)ko * a.Kg + k];
+                        const int k = kc * BKT + a_col + e;
+                        if (ko < a.wK && (a_row + RPP * j) < BN && k < a.Kg) v[e] = a.w[(long)ko * a.Kg + k];
                     }
                     rb[j] = v;
                 }
             } else {
-                constexpr int TPR = BN / 4;
-                constexpr int RPP = 256 / TPR;
 #pragma unroll
                 for (int j = 0; j < BJ; ++j) {
-                    const int k = kc * BK + t / TPR + RPP * j;   // k = tap * K + ko
+                    const int kl = t / TPR + KRPP * j;
+                    const int k = kc * BKT + kl;                 // k = tap * K + ko
                     const int tap = k / a.SC, ko = k - tap * a.SC;
                     const int c = n0 + (t % TPR) * 4;
-                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    f32x4 v = zero;
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        if (k < a.Kg && c + e < a.wC) v[e] = a.w[((long)ko * RS + tap) * a.wC + c + e];
+                        if (kl < BKT && k < a.Kg && c + e < a.wC) v[e] = a.w[((long)ko * RS + tap) * a.wC + c + e];
                     rb[j] = v;
                 }
             }
@@ -236,17 +303,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
         float *B = Bs + buf * B_ELEMS;
 #pragma unroll
         for (int j = 0; j < AJ; ++j)
-            *reinterpret_cast<f32x4 *>(A + ((t >> 3) + 32 * j) * LDA + a_col) = ra[j];
+            *reinterpret_cast<f32x4 *>(A + (a_row + RPP * j) * LDK + a_col) = ra[j];
         if (!B_KN) {
 #pragma unroll
             for (int j = 0; j < BJ; ++j)
-                *reinterpret_cast<f32x4 *>(B + ((t >> 3) + 32 * j) * LDA + a_col) = rb[j];
+                if ((a_row + RPP * j) < BN)
+                    *reinterpret_cast<f32x4 *>(B + (a_row + RPP * j) * LDK + a_col) = rb[j];
         } else {
-            constexpr int TPR = BN / 4;
-            constexpr int RPP = 256 / TPR;
 #pragma unroll
             for (int j = 0; j < BJ; ++j)
-                *reinterpret_cast<f32x4 *>(B + (t / TPR + RPP * j) * LDB + (t % TPR) * 4) = rb[j];
+                if ((t / TPR + KRPP * j) < BKT)
+                    *reinterpret_cast<f32x4 *>(B + (t / TPR + KRPP * j) * LDB + (t % TPR) * 4) = rb[j];
         }
     };
 
@@ -260,26 +327,26 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
 
     const int lr = lane & 31, lh = lane >> 5;
 
-    if (nk > 0) {
-        load_tiles(0);
+    if (kc_lo < kc_hi) {
+        load_tiles(kc_lo);
         store_tiles(0);
     }
     __syncthreads();
-    for (int kc = 0; kc < nk; ++kc) {
-        const int buf = kc & 1;
-        if (kc + 1 < nk) load_tiles(kc + 1);
+    for (int kc = kc_lo; kc < kc_hi; ++kc) {
+        const int buf = (kc - kc_lo) & 1;
+        if (kc + 1 < kc_hi) load_tiles(kc + 1);
         const float *A = As + buf * A_ELEMS;
         const float *B = Bs + buf * B_ELEMS;
 #pragma unroll
-        for (int kk = 0; kk < BK / 8; ++kk) {
+        for (int kk = 0; kk < BKT / 8; ++kk) {
             f32x4 fa[TM], fb[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-                fa[i] = *reinterpret_cast<const f32x4 *>(A + ((wm * TM + i) * 32 + lr) * LDA + kk * 8 + lh * 4);
+                fa[i] = *reinterpret_cast<const f32x4 *>(A + ((wm * TM + i) * 32 + lr) * LDK + kk * 8 + lh * 4);
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 if (!B_KN) {
-                    fb[j] = *reinterpret_cast<const f32x4 *>(B + ((wn * TN + j) * 32 + lr) * LDA + kk * 8 + lh * 4);
+                    fb[j] = *reinterpret_cast<const f32x4 *>(B + ((wn * TN + j) * 32 + lr) * LDK + kk * 8 + lh * 4);
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) fb[j][e] = B[(kk * 8 + lh * 4 + e) * LDB + (wn * TN + j) * 32 + lr];
@@ -293,13 +360,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
         }
-        if (kc + 1 < nk) store_tiles(buf ^ 1);
+        if (kc + 1 < kc_hi) store_tiles(buf ^ 1);
         __syncthreads();
     }
 
     // ---- epilogue.  D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     double *sred = reinterpret_cast<double *>(lds);   // [WM][BN][2], reuses the staging LDS
-    const bool do_stats = (MODE == 0) && a.stat_slab != nullptr;
+    const bool do_stats = (MODE == 0) && a.stat_slab != nullptr && a.ksplit <= 1;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int ncol = n0 + (wn * TN + j) * 32 + lr;
@@ -323,10 +390,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
                         pix = ((long)n * a.DH + (h * 2 + ph)) * a.DW + ((rem - h * Wc) * 2 + pw);
                     }
                     float *p = a.dst + pix * a.DC + ncol;
-                    if (a.accumulate) v += *p;
-                    *p = v;
-                    s1 += v;
-                    s2 += v * v;
+                    if (a.ksplit > 1) {
+                        unsafeAtomicAdd(p, v);        // partial sums of the K slices meet in a zeroed / running dst
+                    } else {
+                        if (a.accumulate) v += *p;
+                        *p = v;
+                        s1 += v;
+                        s2 += v * v;
+                    }
                 }
             }
         }
@@ -408,45 +479,68 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a)
     const int a_row = t / TPR_A, a_col = (t % TPR_A) * 4;
     const int b_row = t / TPR_B, b_col = (t % TPR_B) * 4;
 
+    // running (n, p, q) of every B row: advanced by BK pixels per K-step instead of two integer
+    // divisions per row per step
+    int bn_[BJ], bp_[BJ], bq_[BJ];
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) {
+        const long m = (long)kc_begin * BK + b_row + RPP_B * j;
+        const int pq = a.P * a.Q;
+        bn_[j] = (int)(m / pq);
+        const int rem = (int)(m - (long)bn_[j] * pq);
+        bp_[j] = rem / a.Q;
+        bq_[j] = rem - bp_[j] * a.Q;
+    }
+    const bool a_ko_ok = ko0 + a_col < a.K;
+    const bool b_c_ok = c0 + b_col < a.C;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
     auto load_tiles = [&](int kc) {
 #pragma unroll
         for (int j = 0; j < AJ; ++j) {
             const int m = kc * BK + a_row + RPP_A * j;
             const int ko = ko0 + a_col;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (m < a.M) {
-                if (!A_SCALAR) {
-                    if (ko < a.K) v = *reinterpret_cast<const f32x4 *>(a.dy + (long)m * a.K + ko);
-                } else {
+            if (!A_SCALAR) {
+                const bool ok = a_ko_ok && m < a.M;
+                const float *p = ok ? a.dy + (long)m * a.K + ko : a.dy;
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(p);
+                ra[j] = ok ? v : zero4;
+            } else {
+                f32x4 v = zero4;
+                if (m < a.M) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         if (ko + e < a.K) v[e] = a.dy[(long)m * a.K + ko + e];
                 }
+                ra[j] = v;
             }
-            ra[j] = v;
         }
 #pragma unroll
         for (int j = 0; j < BJ; ++j) {
-            const int m = kc * BK + b_row + RPP_B * j;
             const int c = c0 + b_col;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (m < a.M) {
-                const int pq = a.P * a.Q;
-                const int n = m / pq, rem = m - n * pq;
-                const int p = rem / a.Q, q = rem - p * a.Q;
-                const int ih = p * a.stride - a.pad_h + r, iw = q * a.stride - a.pad_w + s;
-                if (ih >= 0 && iw >= 0 && ih < a.H && iw < a.W) {
-                    const long off = (((long)n * a.H + ih) * a.W + iw) * a.C + c;
-                    if (!B_SCALAR) {
-                        if (c < a.C) v = *reinterpret_cast<const f32x4 *>(a.x + off);
-                    } else {
+            const int ih = bp_[j] * a.stride - a.pad_h + r, iw = bq_[j] * a.stride - a.pad_w + s;
+            const bool in = bn_[j] < a.N && ih >= 0 && iw >= 0 && ih < a.H && iw < a.W;
+            const long off = (((long)bn_[j] * a.H + ih) * a.W + iw) * a.C + c;
+            if (!B_SCALAR) {
+                const bool ok = in && b_c_ok;
+                const float *p = ok ? a.x + off : a.x;
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(p);
+                rb[j] = ok ? v : zero4;
+            } else {
+                f32x4 v = zero4;
+                if (in) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (c + e < a.C) v[e] = a.x[off + e];
-                    }
+                    for (int e = 0; e < 4; ++e)
+                        if (c + e < a.C) v[e] = a.x[off + e];
                 }
+                rb[j] = v;
             }
-            rb[j] = v;
+            // advance this row by BK pixels
+            bq_[j] += BK;
+            while (bq_[j] >= a.Q) {
+                bq_[j] -= a.Q;
+                if (++bp_[j] == a.P) { bp_[j] = 0; ++bn_[j]; }
+            }
         }
     };
     auto store_tiles = [&](int buf) {
@@ -505,16 +599,72 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a)
 }
 
 template <typename K, typename A>
-int launch(K kern, int blocks, size_t lds, hipStream_t stream, const A &args, const char *name, int grid_y = 1)
+int launch(K kern, int blocks, size_t lds, hipStream_t stream, const A &args, const char *name, int grid_y = 1,
+           int grid_z = 1)
 {
     if (lds > 48 * 1024)
         hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3(blocks, grid_y), dim3(256), lds, stream, args);
+    hipLaunchKernelGGL(kern, dim3(blocks, grid_y, grid_z), dim3(256), lds, stream, args);
     RR_CHECK_LAUNCH(name);
     return RR_OK;
 }
 
-size_t igemm_lds(int bn, bool b_kn) { return sizeof(float) * 2 * (BM * LDA + (b_kn ? BK * bn : bn * LDA)); }
+size_t igemm_lds(int bn, bool b_kn, int bk) { return sizeof(float) * 2 * (BM * (bk + 4) + (b_kn ? bk * bn : bn * (bk + 4))); }
+
+int conv_bk()
+{
+    static int bk = -1;
+    if (bk < 0) {
+        const char *e = getenv("RR_CONV_BK");
+        bk = (e && atoi(e) == 32) ? 32 : 16;
+    }
+    return bk;
+}
+
+// split-K factor for layers whose output has too few tiles to fill the chip
+int pick_ksplit(int blocks, int nk)
+{
+    static int enabled = -1;
+    if (enabled < 0) {
+        const char *e = getenv("RR_CONV_SPLITK");
+        enabled = (e && atoi(e) == 0) ? 0 : 1;
+    }
+    if (!enabled || blocks >= 256 || nk < 16) return 1;
+    int ks = 512 / blocks;
+    if (ks > nk / 8) ks = nk / 8;
+    return ks < 1 ? 1 : ks;
+}
+
+// per-m-tile column sums of y (used when split-K keeps the statistics out of the conv epilogue)
+__global__ __launch_bounds__(256) void tile_colstats_kernel(const float *y, long M, int C, double *slab)
+{
+    const long m0 = (long)blockIdx.x * BM;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int r = 0; r < BM && m0 + r < M; ++r) {
+            const float v = y[(m0 + r) * C + c];
+            s1 += (double)v;
+            s2 += (double)v * (double)v;
+        }
+        slab[(long)blockIdx.x * 2 * C + c] = s1;
+        slab[(long)blockIdx.x * 2 * C + C + c] = s2;
+    }
+}
+
+template <int MODE>
+int launch_igemm(ConvArgs &a, int bn, bool scalar, int blocks, int gy, int gz, hipStream_t stream, const char *name)
+{
+    const int bk = conv_bk();
+    const size_t lds = igemm_lds(bn, MODE == 1, bk);
+#define IG(BNv, SCv, BKv) launch(conv_igemm_kernel<BNv, MODE, SCv, BKv>, blocks, lds, stream, a, name, gy, gz)
+    if (bk == 32) {
+        if (bn == 128) return scalar ? IG(128, true, 32) : IG(128, false, 32);
+        return scalar ? IG(32, true, 32) : IG(32, false, 32);
+    }
+    if (bn == 128) return scalar ? IG(128, true, 16) : IG(128, false, 16);
+    return scalar ? IG(32, true, 16) : IG(32, false, 16);
+#undef IG
+}
 
 }  // namespace
 
@@ -535,18 +685,26 @@ extern "C" int rr_conv_fprop(const float *x, const float *w, const float *bias, 
     a.DH = (h + 2 * pad_h - r) / stride + 1; a.DW = (wd + 2 * pad_w - s) / stride + 1; a.DC = k;
     RR_CHECK_ARG(a.DH > 0 && a.DW > 0, "rr_conv_fprop: empty output");
     a.R = r; a.S = s; a.stride = stride; a.pad_h = pad_h; a.pad_w = pad_w;
-    a.relu = relu; a.accumulate = 0;
+    a.relu = relu; a.accumulate = 0; a.ksplit = 1;
     const long M = (long)n * a.DH * a.DW;
     RR_CHECK_ARG(M < (1l << 31) && (long)n * h * wd * c < (1l << 40), "rr_conv_fprop: tensor too large");
     a.M = (int)M; a.Kg = r * s * c; a.wK = k; a.wC = c;
-    const bool scalar = (c % 4) != 0;
+    const bool scalar = (c % 4) != 0 || r * s > 64;   // the vector path keeps a 64-bit tap mask per row
     const int bn = k > 32 ? 128 : 32;
     const int blocks = rr_cdiv(M, BM) * rr_cdiv(k, bn);
-    const size_t lds = igemm_lds(bn, false);
-    if (bn == 128) return scalar ? launch(conv_igemm_kernel<128, 0, true>, blocks, lds, stream, a, "rr_conv_fprop")
-                                 : launch(conv_igemm_kernel<128, 0, false>, blocks, lds, stream, a, "rr_conv_fprop");
-    return scalar ? launch(conv_igemm_kernel<32, 0, true>, blocks, lds, stream, a, "rr_conv_fprop")
-                  : launch(conv_igemm_kernel<32, 0, false>, blocks, lds, stream, a, "rr_conv_fprop");
+    const int bk = conv_bk();
+    const int nk = scalar ? rr_cdiv(a.Kg, bk) : rr_cdiv(c, bk) * r * s;
+    int ks = (bias == nullptr && !relu) ? pick_ksplit(blocks, nk) : 1;
+    if (ks > 1) {
+        a.ksplit = ks;
+        hipMemsetAsync(y, 0, sizeof(float) * (size_t)M * k, stream);
+    }
+    int rc = launch_igemm<0>(a, bn, scalar, blocks, 1, ks, stream, "rr_conv_fprop");
+    if (rc == RR_OK && ks > 1 && stat_slab != nullptr) {
+        hipLaunchKernelGGL(tile_colstats_kernel, dim3(rr_cdiv(M, BM)), dim3(256), 0, stream, y, M, k, stat_slab);
+        RR_CHECK_LAUNCH("rr_conv_fprop(stats)");
+    }
+    return rc;
 }
 
 extern "C" int rr_conv_dgrad(const float *dy, const float *w, float *dx, int n, int h, int wd, int c, int k,
@@ -560,24 +718,28 @@ extern "C" int rr_conv_dgrad(const float *dy, const float *w, float *dx, int n, 
     a.SH = (h + 2 * pad_h - r) / stride + 1; a.SW = (wd + 2 * pad_w - s) / stride + 1; a.SC = k;
     a.DH = h; a.DW = wd; a.DC = c;
     a.R = r; a.S = s; a.stride = stride; a.pad_h = pad_h; a.pad_w = pad_w;
-    a.relu = 0; a.accumulate = accumulate;
+    a.relu = 0; a.accumulate = accumulate; a.ksplit = 1;
     const long M = (long)n * h * wd;
     RR_CHECK_ARG(M < (1l << 31), "rr_conv_dgrad: tensor too large");
     a.M = (int)M; a.Kg = r * s * k; a.wK = k; a.wC = c;
-    const bool scalar = (k % 4) != 0 || (c % 4) != 0;
+    const bool scalar = (k % 4) != 0 || (c % 4) != 0 || r * s > 64 || stride > 2;
     const int bn = c > 32 ? 128 : 32;
     int blocks = rr_cdiv(M, BM) * rr_cdiv(c, bn);
     int gy = 1;
+    const int bk = conv_bk();
+    int nk = scalar ? rr_cdiv(a.Kg, bk) : rr_cdiv(k, bk) * r * s;
     if (stride == 2 && !scalar) {     // parity-decomposed: 4 classes of ceil(h/2) x ceil(w/2) pixels each
         a.parity = 1;
         gy = 4;
         blocks = rr_cdiv((long)n * ((h + 1) / 2) * ((wd + 1) / 2), BM) * rr_cdiv(c, bn);
+        nk = rr_cdiv(k, bk) * ((r + 1) / 2) * ((s + 1) / 2);
     }
-    const size_t lds = igemm_lds(bn, true);
-    if (bn == 128) return scalar ? launch(conv_igemm_kernel<128, 1, true>, blocks, lds, stream, a, "rr_conv_dgrad", gy)
-                                 : launch(conv_igemm_kernel<128, 1, false>, blocks, lds, stream, a, "rr_conv_dgrad", gy);
-    return scalar ? launch(conv_igemm_kernel<32, 1, true>, blocks, lds, stream, a, "rr_conv_dgrad", gy)
-                  : launch(conv_igemm_kernel<32, 1, false>, blocks, lds, stream, a, "rr_conv_dgrad", gy);
+    int ks = a.parity ? 1 : pick_ksplit(blocks * gy, nk);
+    if (ks > 1) {
+        a.ksplit = ks;
+        if (!accumulate) hipMemsetAsync(dx, 0, sizeof(float) * (size_t)M * c, stream);
+    }
+    return launch_igemm<1>(a, bn, scalar, blocks, gy, ks, stream, "rr_conv_dgrad");
 }
 
 extern "C" int rr_conv_wgrad(const float *x, const float *dy, float *dw, int n, int h, int wd, int c, int k,

@@ -16,19 +16,29 @@ class KernelTimer:
     def __init__(self):
         self.records = []      # (kernel name, flops, start event, end event)
 
-    def launch(self, name, flops, fn):
+    def launch(self, name, flops, fn, detail=None):
         s = torch.cuda.Event(enable_timing=True)
         e = torch.cuda.Event(enable_timing=True)
         s.record()
         rc = fn()
         e.record()
-        self.records.append((name, flops, s, e))
+        self.records.append((name, flops, s, e, detail))
         return rc
+
+    def by_shape(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, flops, s, e, detail in self.records:
+            d = out.setdefault((name, detail), dict(launches=0, ms=0.0, flops=0.0))
+            d["launches"] += 1
+            d["ms"] += s.elapsed_time(e)
+            d["flops"] += flops
+        return out
 
     def summary(self):
         torch.cuda.synchronize()
         out = {}
-        for name, flops, s, e in self.records:
+        for name, flops, s, e, _ in self.records:
             d = out.setdefault(name, dict(launches=0, ms=0.0, flops=0.0))
             d["launches"] += 1
             d["ms"] += s.elapsed_time(e)
@@ -39,10 +49,10 @@ class KernelTimer:
 TIMER = None
 
 
-def _timed(name, flops, fn):
+def _timed(name, flops, fn, detail=None):
     if TIMER is None:
         return fn()
-    return TIMER.launch(name, flops, fn)
+    return TIMER.launch(name, flops, fn, detail)
 
 
 def _igemm_name(kind, n_gemm, scalar):
@@ -91,7 +101,8 @@ def conv_fprop(x, w, bias=None, stride=1, pad=(0, 0), relu=False, want_stats=Fal
     flops = 2.0 * n * p * q * k * c * r * s
     _C.check(_timed(_igemm_name("fprop", k, c % 4 != 0), flops,
                     lambda: f(_C.ptr(x), _C.ptr(w), _C.ptr(bias), _C.ptr(y), _C.ptr(slab), n, h, wd, c, k, r, s,
-                              stride, pad[0], pad[1], int(relu), _C.stream())), "rr_conv_fprop")
+                              stride, pad[0], pad[1], int(relu), _C.stream()),
+                    (n, h, wd, c, k, r, s, stride)), "rr_conv_fprop")
     return (y, slab) if want_stats else y
 
 
@@ -110,7 +121,7 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False)
     flops = 2.0 * dy.shape[0] * dy.shape[2] * dy.shape[3] * k * c * r * s
     _C.check(_timed(_igemm_name("dgrad", c, (k % 4 != 0) or (c % 4 != 0)), flops,
                     lambda: f(_C.ptr(dy), _C.ptr(w), _C.ptr(out), n, h, wd, c, k, r, s, stride, pad[0], pad[1],
-                              int(accumulate), _C.stream())), "rr_conv_dgrad")
+                              int(accumulate), _C.stream()), (n, h, wd, c, k, r, s, stride)), "rr_conv_dgrad")
     return out
 
 
@@ -125,7 +136,7 @@ def conv_wgrad(x, dy, dw, stride=1, pad=(0, 0)):
     flops = 2.0 * dy.shape[0] * dy.shape[2] * dy.shape[3] * k * c * r * s
     _C.check(_timed("conv_wgrad<BN=%d>" % (128 if c > 32 else 32), flops,
                     lambda: f(_C.ptr(x), _C.ptr(dy), _C.ptr(dw), n, h, wd, c, k, r, s, stride, pad[0], pad[1],
-                              _C.stream())), "rr_conv_wgrad")
+                              _C.stream()), (n, h, wd, c, k, r, s, stride)), "rr_conv_wgrad")
     return dw
 
 
