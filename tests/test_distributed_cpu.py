@@ -1,0 +1,100 @@
+"""N>1 path on CPU (gloo, world_size 2): flat-buffer broadcast + gradient all-reduce bookkeeping and
+the SyncBN statistics exchange arithmetic.  The HIP kernels themselves are not involved (no GPU
+here); what is checked is everything around them that only exists when world_size > 1."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from rrnet_amd.flat import FlatParams
+        torch.manual_seed(100 + rank)                      # ranks start with DIFFERENT weights
+        net = nn.Sequential(nn.Conv2d(3, 8, 3, bias=False), nn.BatchNorm2d(8), nn.Conv2d(8, 5, 1))
+        net = net.to(memory_format=torch.channels_last)
+        fp = FlatParams(net)
+        fp.broadcast(0)                                    # C2: one collective
+        w0 = [p.detach().clone() for p in net.parameters()]
+        fp.zero_grad()
+        for p in net.parameters():                         # rank-dependent "gradients" written into the flat views
+            p.grad.copy_(torch.full_like(p, float(rank + 1)))
+        scale = fp.all_reduce_grads(chunk_elems=64)        # several slices
+        g = [p.grad.detach().clone() * scale for p in net.parameters()]
+        # SyncBN exchange arithmetic: [sum, sumsq, count] all-reduced == statistics of the concatenated batch
+        gen = torch.Generator().manual_seed(7 + rank)
+        n = 5 + 3 * rank                                   # ragged per-rank sample counts
+        x = torch.randn(n, 8, generator=gen, dtype=torch.float64) * (rank + 1) + rank
+        sums = torch.cat([x.sum(0), (x * x).sum(0), torch.tensor([float(n)], dtype=torch.float64)])
+        dist.all_reduce(sums)
+        cnt = sums[16]
+        mean = sums[:8] / cnt
+        var = sums[8:16] / cnt - mean * mean
+        xs = [torch.zeros(5 + 3 * r, 8, dtype=torch.float64) for r in range(world)]
+        dist.all_gather_object(obj := [None] * world, x.numpy().tolist())
+        full = torch.tensor(sum(obj, []), dtype=torch.float64)
+        q.put((rank, [t.numpy() for t in w0], [t.numpy() for t in g], mean.numpy(), var.numpy(),
+               full.mean(0).numpy(), full.var(0, unbiased=False).numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_flat_broadcast_allreduce_and_syncbn_stats_gloo():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, w_a, g_a, m_a, v_a, fm_a, fv_a), (_, w_b, g_b, m_b, v_b, fm_b, fv_b) = res
+    for a, b in zip(w_a, w_b):
+        assert np.array_equal(a, b)                        # broadcast made the replicas identical
+    for a, b in zip(g_a, g_b):
+        assert np.array_equal(a, b)
+        assert np.allclose(a, 1.5)                         # mean of the rank gradients 1 and 2 (DDP averages)
+    np.testing.assert_allclose(m_a, fm_a, rtol=1e-12)
+    np.testing.assert_allclose(v_a, fv_a, rtol=1e-10)
+    np.testing.assert_allclose(m_a, m_b)
+
+
+def test_flat_params_views_and_state_dict_cpu():
+    sys.path.insert(0, ROOT)
+    from rrnet_amd.flat import FlatParams
+    net = nn.Sequential(nn.Conv2d(4, 8, 3, bias=True), nn.BatchNorm2d(8)).to(memory_format=torch.channels_last)
+    sd0 = {k: v.clone() for k, v in net.state_dict().items()}
+    fp = FlatParams(net)
+    for k, v in net.state_dict().items():
+        assert torch.equal(v, sd0[k])
+    w = net[0].weight
+    assert w.shape == (8, 4, 3, 3) and w.permute(0, 2, 3, 1).is_contiguous()     # OHWI in memory
+    assert fp.numel % 4 == 0 and w.grad.data_ptr() == w._rr_grad.data_ptr()
+    w.grad.fill_(2.0)
+    fp.zero_grad()
+    assert float(fp.grad.abs().sum()) == 0.0
+    net.load_state_dict({k: v + 1 if v.is_floating_point() else v for k, v in sd0.items()})
+    assert torch.equal(net[0].weight, sd0["0.weight"] + 1)
