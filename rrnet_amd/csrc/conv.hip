@@ -29,6 +29,10 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// 16 zero bytes in global memory: masked lanes of the gathers load from here, so padding needs no
+// select on the loaded value (a select right behind the load would pin an s_waitcnt vmcnt in the stream)
+__device__ float rr_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+
 constexpr int BM = 128;
 constexpr int BK = 32;
 constexpr int LDA = 36;  // [m][k] image row stride (floats): conflict-free ds_read_b128
@@ -47,6 +51,7 @@ struct ConvArgs {
     int M;             // N*DH*DW
     int Kg;            // R*S*SC
     int wK, wC;        // weight dims K, C
+    const float *zero; // 16 zero bytes (rr_zero16) for masked gather lanes
     int ksplit;        // > 1: grid.z slices the K loop and the epilogue adds with float atomics (dst pre-zeroed
                        // or holding the running sum); no bias / ReLU / statistics in that mode
     int parity;        // dgrad, stride 2: blockIdx.y = output parity class (h%2, w%2); only the taps that
@@ -61,7 +66,10 @@ __device__ __forceinline__ int xcd_remap(int bid, int nb)
 
 // MODE 0 = fprop, 1 = dgrad.  SCALAR: source/weight channel counts not multiples of 4.
 // BKT = K-step depth (32: 2 workgroups per CU by LDS; 16: 4 per CU).
-template <int BN, int MODE, bool SCALAR, int BKT>
+// PIPE: software-pipelined main loop (global loads two K-steps ahead, LDS fragments one 8-deep group
+// ahead, barrier placed between the third and fourth MFMA group) so that a wave's MFMA stream never
+// waits on a barrier or on LDS latency.
+template <int BN, int MODE, bool SCALAR, int BKT, bool PIPE>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
 {
     constexpr int WN = BN / 64 ? BN / 64 : 1;   // waves along N
@@ -223,9 +231,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
 #pragma unroll
             for (int j = 0; j < AJ; ++j) {
                 const bool ok = c_ok && ((a_mask[j] >> tl) & 1ull);
-                const float *p = ok ? a.src + a_base[j] + a_delta : a.src;
-                const f32x4 v = *reinterpret_cast<const f32x4 *>(p);
-                ra[j] = ok ? v : zero;
+                const float *p = ok ? a.src + a_base[j] + a_delta : a.zero;
+                ra[j] = *reinterpret_cast<const f32x4 *>(p);
             }
             if (!B_KN) {  // fprop: B[n = ko][k = (tap, c)] = w[ko][tap][c]
                 const long w_delta = (long)tap * a.wC + c0;
@@ -233,18 +240,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
 #pragma unroll
                 for (int j = 0; j < BJ; ++j) {
                     const bool ok = b_ok[j] && wc_ok;
-                    const float *p = ok ? a.w + b_base[j] + w_delta : a.w;
-                    const f32x4 v = *reinterpret_cast<const f32x4 *>(p);
-                    rb[j] = ok ? v : zero;
+                    const float *p = ok ? a.w + b_base[j] + w_delta : a.zero;
+                    rb[j] = *reinterpret_cast<const f32x4 *>(p);
                 }
             } else {      // dgrad: B[k = (tap, ko)][n = c] = w[ko][tap][c]; c0 indexes the source channels = K
                 const long w_delta = ((long)c0 * RS + tap) * a.wC;
 #pragma unroll
                 for (int j = 0; j < BJ; ++j) {
                     const bool ok = b_ok[j] && (c0 + t / TPR + KRPP * j < a.wK);
-                    const float *p = ok ? a.w + b_base[j] + w_delta : a.w;
-                    const f32x4 v = *reinterpret_cast<const f32x4 *>(p);
-                    rb[j] = ok ? v : zero;
+                    const float *p = ok ? a.w + b_base[j] + w_delta : a.zero;
+                    rb[j] = *reinterpret_cast<const f32x4 *>(p);
                 }
             }
         } else {
@@ -327,6 +332,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
 
     const int lr = lane & 31, lh = lane >> 5;
 
+    if constexpr (!PIPE) {
     if (kc_lo < kc_hi) {
         load_tiles(kc_lo);
         store_tiles(0);
@@ -362,6 +368,122 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
         }
         if (kc + 1 < kc_hi) store_tiles(buf ^ 1);
         __syncthreads();
+    }
+    } else {
+    static_assert(!PIPE || (BKT == 32 && !SCALAR && BN == 128), "pipelined loop: 4 groups of 8 per K-step, vector gather, 128x128 tile");
+    // Each K-step = 4 groups x 4 sub-groups of 4 MFMAs.  Memory instructions are dealt out between the
+    // sub-groups (never clustered): a VMEM / DS issue that would stall this wave's in-order stream then
+    // overlaps the 64-cycle MFMAs already in the pipe (probe: clustered ds_write+barrier costs 5 %,
+    // clustered global loads another 7 % of MFMA throughput).
+    f32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+    auto read_frags = [&](int buf, int kk, f32x4 (&fa)[TM], f32x4 (&fb)[TN]) {
+        const float *A = As + buf * A_ELEMS;
+        const float *B = Bs + buf * B_ELEMS;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+            fa[i] = *reinterpret_cast<const f32x4 *>(A + ((wm * TM + i) * 32 + lr) * LDK + kk * 8 + lh * 4);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            if (!B_KN) {
+                fb[j] = *reinterpret_cast<const f32x4 *>(B + ((wn * TN + j) * 32 + lr) * LDK + kk * 8 + lh * 4);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) fb[j][e] = B[(kk * 8 + lh * 4 + e) * LDB + (wn * TN + j) * 32 + lr];
+            }
+        }
+    };
+    auto sub = [&](const f32x4 (&fa)[TM], const f32x4 (&fb)[TN], int e) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // wave-uniform state of the K-step being fetched
+    long p_adelta = 0, p_wdelta = 0;
+    int p_tl = 0, p_c0 = 0;
+    bool p_cok = false, p_wcok = false;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    auto prep = [&](int kc) {
+        const int cch = kc / RSc;
+        p_tl = kc - cch * RSc;
+        const int ri = p_tl / Sc, si = p_tl - ri * Sc;
+        const int tap = (r0 + tstep * ri) * a.S + (s0 + tstep * si);
+        p_c0 = cch * BKT;
+        p_adelta = (long)sgn * ((long)ri * a.SW + si) * a.SC + p_c0;
+        p_cok = p_c0 + a_col < a.SC;
+        p_wdelta = B_KN ? ((long)p_c0 * RS + tap) * a.wC : (long)tap * a.wC + p_c0;
+        p_wcok = p_c0 + a_col < a.wC;
+    };
+    auto load_a = [&](int j) {
+        const bool ok = p_cok && ((a_mask[j] >> p_tl) & 1ull);
+        const float *p = ok ? a.src + a_base[j] + p_adelta : a.zero;
+        ra[j] = *reinterpret_cast<const f32x4 *>(p);
+    };
+    auto load_b = [&](int j) {
+        const bool ok = B_KN ? (b_ok[j] && (p_c0 + t / TPR + KRPP * j < a.wK)) : (b_ok[j] && p_wcok);
+        const float *p = ok ? a.w + b_base[j] + p_wdelta : a.zero;
+        rb[j] = *reinterpret_cast<const f32x4 *>(p);
+    };
+    auto store_a = [&](int j, int buf) {
+        *reinterpret_cast<f32x4 *>(As + buf * A_ELEMS + (a_row + RPP * j) * LDK + a_col) = ra[j];
+    };
+    auto store_b = [&](int j, int buf) {
+        if (!B_KN) *reinterpret_cast<f32x4 *>(Bs + buf * B_ELEMS + (a_row + RPP * j) * LDK + a_col) = rb[j];
+        else *reinterpret_cast<f32x4 *>(Bs + buf * B_ELEMS + (t / TPR + KRPP * j) * LDB + (t % TPR) * 4) = rb[j];
+    };
+    static_assert(!PIPE || (AJ == 4 && BJ == 4), "piece schedule below assumes 4 + 4 float4 per thread");
+    if (kc_lo < kc_hi) {
+        prep(kc_lo);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { load_a(j); load_b(j); }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { store_a(j, 0); store_b(j, 0); }
+        if (kc_lo + 1 < kc_hi) {      // stays in registers until the first phase's group 1
+            prep(kc_lo + 1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { load_a(j); load_b(j); }
+        }
+    }
+    __syncthreads();
+    if (kc_lo < kc_hi) read_frags(0, 0, fa0, fb0);
+    for (int kc = kc_lo; kc < kc_hi; ++kc) {
+        const int buf = (kc - kc_lo) & 1;
+        const bool has1 = kc + 1 < kc_hi, has2 = kc + 2 < kc_hi;
+        // group 0 (fragment set 0); prefetch set 1 <- group 1's fragments
+        read_frags(buf, 1, fa1, fb1);
+        sub(fa0, fb0, 0); sub(fa0, fb0, 1); sub(fa0, fb0, 2); sub(fa0, fb0, 3);
+        // group 1 (set 1); prefetch set 0 <- group 2; stage the next K-step into the other LDS buffer
+        read_frags(buf, 2, fa0, fb0);
+        if (has1) { store_a(0, buf ^ 1); store_a(1, buf ^ 1); }
+        sub(fa1, fb1, 0);
+        if (has1) { store_a(2, buf ^ 1); store_a(3, buf ^ 1); }
+        sub(fa1, fb1, 1);
+        if (has1) { store_b(0, buf ^ 1); store_b(1, buf ^ 1); }
+        sub(fa1, fb1, 2);
+        if (has1) { store_b(2, buf ^ 1); store_b(3, buf ^ 1); }
+        sub(fa1, fb1, 3);
+        // group 2 (set 0); prefetch set 1 <- group 3; refill the registers two K-steps ahead
+        if (has2) prep(kc + 2);
+        read_frags(buf, 3, fa1, fb1);
+        if (has2) { load_a(0); load_a(1); }
+        sub(fa0, fb0, 0);
+        if (has2) { load_a(2); load_a(3); }
+        sub(fa0, fb0, 1);
+        if (has2) { load_b(0); load_b(1); }
+        sub(fa0, fb0, 2);
+        if (has2) { load_b(2); load_b(3); }
+        sub(fa0, fb0, 3);
+        // the only barrier of the step: this wave's fragment reads of `buf` have landed and its share of
+        // the next tile is written (lgkmcnt(0)); the global loads just issued stay in flight across it
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // group 3 (set 1) overlaps the first fragment reads of the next K-step
+        if (has1) read_frags(buf ^ 1, 0, fa0, fb0);
+        sub(fa1, fb1, 0); sub(fa1, fb1, 1); sub(fa1, fb1, 2); sub(fa1, fb1, 3);
+    }
     }
 
     // ---- epilogue.  D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
@@ -434,6 +556,7 @@ struct WgradArgs {
     const float *x;   // [N,H,W,C]
     const float *dy;  // [N,P,Q,K]
     float *dw;        // [K][R][S][C], accumulated with float atomics
+    const float *zero; // 16 zero bytes for masked gather lanes
     int N, H, W, C, K, R, S, P, Q, stride, pad_h, pad_w;
     int M;            // N*P*Q
     int chunks_per_split;
@@ -502,9 +625,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a)
             const int ko = ko0 + a_col;
             if (!A_SCALAR) {
                 const bool ok = a_ko_ok && m < a.M;
-                const float *p = ok ? a.dy + (long)m * a.K + ko : a.dy;
-                const f32x4 v = *reinterpret_cast<const f32x4 *>(p);
-                ra[j] = ok ? v : zero4;
+                const float *p = ok ? a.dy + (long)m * a.K + ko : a.zero;
+                ra[j] = *reinterpret_cast<const f32x4 *>(p);
             } else {
                 f32x4 v = zero4;
                 if (m < a.M) {
@@ -523,9 +645,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a)
             const long off = (((long)bn_[j] * a.H + ih) * a.W + iw) * a.C + c;
             if (!B_SCALAR) {
                 const bool ok = in && b_c_ok;
-                const float *p = ok ? a.x + off : a.x;
-                const f32x4 v = *reinterpret_cast<const f32x4 *>(p);
-                rb[j] = ok ? v : zero4;
+                const float *p = ok ? a.x + off : a.zero;
+                rb[j] = *reinterpret_cast<const f32x4 *>(p);
             } else {
                 f32x4 v = zero4;
                 if (in) {
@@ -598,6 +719,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a)
     }
 }
 
+const float *zero_page()
+{
+    static float *p = nullptr;
+    if (!p) hipGetSymbolAddress(reinterpret_cast<void **>(&p), HIP_SYMBOL(rr_zero16));
+    return p;
+}
+
 template <typename K, typename A>
 int launch(K kern, int blocks, size_t lds, hipStream_t stream, const A &args, const char *name, int grid_y = 1,
            int grid_z = 1)
@@ -616,7 +744,7 @@ int conv_bk()
     static int bk = -1;
     if (bk < 0) {
         const char *e = getenv("RR_CONV_BK");
-        bk = (e && atoi(e) == 32) ? 32 : 16;
+        bk = (e && atoi(e) == 16) ? 16 : 32;
     }
     return bk;
 }
@@ -651,18 +779,28 @@ __global__ __launch_bounds__(256) void tile_colstats_kernel(const float *y, long
     }
 }
 
+int conv_pipe()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("RR_CONV_PIPE");
+        v = (e && atoi(e) == 0) ? 0 : 1;
+    }
+    return v;
+}
+
 template <int MODE>
 int launch_igemm(ConvArgs &a, int bn, bool scalar, int blocks, int gy, int gz, hipStream_t stream, const char *name)
 {
     const int bk = conv_bk();
     const size_t lds = igemm_lds(bn, MODE == 1, bk);
-#define IG(BNv, SCv, BKv) launch(conv_igemm_kernel<BNv, MODE, SCv, BKv>, blocks, lds, stream, a, name, gy, gz)
+#define IG(BNv, SCv, BKv, PIPEv) launch(conv_igemm_kernel<BNv, MODE, SCv, BKv, PIPEv>, blocks, lds, stream, a, name, gy, gz)
     if (bk == 32) {
-        if (bn == 128) return scalar ? IG(128, true, 32) : IG(128, false, 32);
-        return scalar ? IG(32, true, 32) : IG(32, false, 32);
+        if (bn == 128) return scalar ? IG(128, true, 32, false) : (conv_pipe() ? IG(128, false, 32, true) : IG(128, false, 32, false));
+        return scalar ? IG(32, true, 32, false) : IG(32, false, 32, false);
     }
-    if (bn == 128) return scalar ? IG(128, true, 16) : IG(128, false, 16);
-    return scalar ? IG(32, true, 16) : IG(32, false, 16);
+    if (bn == 128) return scalar ? IG(128, true, 16, false) : IG(128, false, 16, false);
+    return scalar ? IG(32, true, 16, false) : IG(32, false, 16, false);
 #undef IG
 }
 
@@ -685,7 +823,7 @@ extern "C" int rr_conv_fprop(const float *x, const float *w, const float *bias, 
     a.DH = (h + 2 * pad_h - r) / stride + 1; a.DW = (wd + 2 * pad_w - s) / stride + 1; a.DC = k;
     RR_CHECK_ARG(a.DH > 0 && a.DW > 0, "rr_conv_fprop: empty output");
     a.R = r; a.S = s; a.stride = stride; a.pad_h = pad_h; a.pad_w = pad_w;
-    a.relu = relu; a.accumulate = 0; a.ksplit = 1;
+    a.relu = relu; a.accumulate = 0; a.ksplit = 1; a.zero = zero_page();
     const long M = (long)n * a.DH * a.DW;
     RR_CHECK_ARG(M < (1l << 31) && (long)n * h * wd * c < (1l << 40), "rr_conv_fprop: tensor too large");
     a.M = (int)M; a.Kg = r * s * c; a.wK = k; a.wC = c;
@@ -718,7 +856,7 @@ extern "C" int rr_conv_dgrad(const float *dy, const float *w, float *dx, int n, 
     a.SH = (h + 2 * pad_h - r) / stride + 1; a.SW = (wd + 2 * pad_w - s) / stride + 1; a.SC = k;
     a.DH = h; a.DW = wd; a.DC = c;
     a.R = r; a.S = s; a.stride = stride; a.pad_h = pad_h; a.pad_w = pad_w;
-    a.relu = 0; a.accumulate = accumulate; a.ksplit = 1;
+    a.relu = 0; a.accumulate = accumulate; a.ksplit = 1; a.zero = zero_page();
     const long M = (long)n * h * wd;
     RR_CHECK_ARG(M < (1l << 31), "rr_conv_dgrad: tensor too large");
     a.M = (int)M; a.Kg = r * s * k; a.wK = k; a.wC = c;
@@ -747,7 +885,7 @@ extern "C" int rr_conv_wgrad(const float *x, const float *dy, float *dw, int n, 
 {
     RR_CHECK_ARG(n > 0 && h > 0 && wd > 0 && c > 0 && k > 0 && r > 0 && s > 0 && stride > 0, "rr_conv_wgrad: bad dims");
     WgradArgs a{};
-    a.x = x; a.dy = dy; a.dw = dw;
+    a.x = x; a.dy = dy; a.dw = dw; a.zero = zero_page();
     a.N = n; a.H = h; a.W = wd; a.C = c; a.K = k; a.R = r; a.S = s;
     a.P = (h + 2 * pad_h - r) / stride + 1; a.Q = (wd + 2 * pad_w - s) / stride + 1;
     a.stride = stride; a.pad_h = pad_h; a.pad_w = pad_w;
