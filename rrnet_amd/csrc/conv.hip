@@ -681,6 +681,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a)
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int lr = lane & 31, lh = lane >> 5;
+    constexpr bool WPIPE = (BMW == 128 && BN == 128 && !A_SCALAR && !B_SCALAR);
+    if constexpr (!WPIPE) {
     load_tiles(kc_begin);
     store_tiles(0);
     __syncthreads();
@@ -704,6 +706,86 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a)
         }
         if (kc + 1 < kc_end) store_tiles(buf ^ 1);
         __syncthreads();
+    }
+    } else {
+    // Software-pipelined form (same scheme as conv_igemm_kernel<PIPE>): 16 sub-steps of 4 MFMAs per
+    // K-step; fragments one sub-step ahead in registers, the next tile's ds_writes in sub-steps 1-4, the
+    // global loads two K-steps ahead in sub-steps 6-9, the only barrier after sub-step 14.
+    float fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+    auto rd = [&](int buf, int k2, float (&fa)[TM], float (&fb)[TN]) {
+        const float *A = As + buf * A_ELEMS, *B = Bs + buf * B_ELEMS;
+        const int kr = 2 * k2 + lh;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[i] = A[kr * BMW + (wm * TM + i) * 32 + lr];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[j] = B[kr * BN + (wn * TN + j) * 32 + lr];
+    };
+    auto sub = [&](const float (&fa)[TM], const float (&fb)[TN]) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto load_a = [&](int j, int kc) {
+        const int m = kc * BK + a_row + RPP_A * j;
+        const bool ok = a_ko_ok && m < a.M;
+        const float *p = ok ? a.dy + (long)m * a.K + ko0 + a_col : a.zero;
+        ra[j] = *reinterpret_cast<const f32x4 *>(p);
+    };
+    auto load_b = [&](int j) {
+        const int ih = bp_[j] * a.stride - a.pad_h + r, iw = bq_[j] * a.stride - a.pad_w + s;
+        const bool ok = b_c_ok && bn_[j] < a.N && ih >= 0 && iw >= 0 && ih < a.H && iw < a.W;
+        const long off = (((long)bn_[j] * a.H + ih) * a.W + iw) * a.C + c0 + b_col;
+        const float *p = ok ? a.x + off : a.zero;
+        rb[j] = *reinterpret_cast<const f32x4 *>(p);
+        bq_[j] += BK;
+        while (bq_[j] >= a.Q) {
+            bq_[j] -= a.Q;
+            if (++bp_[j] == a.P) { bp_[j] = 0; ++bn_[j]; }
+        }
+    };
+    auto st_a = [&](int j, int buf) {
+        *reinterpret_cast<f32x4 *>(As + buf * A_ELEMS + (a_row + RPP_A * j) * BMW + a_col) = ra[j];
+    };
+    auto st_b = [&](int j, int buf) {
+        *reinterpret_cast<f32x4 *>(Bs + buf * B_ELEMS + (b_row + RPP_B * j) * BN + b_col) = rb[j];
+    };
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { load_a(j, kc_begin); load_b(j); }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { st_a(j, 0); st_b(j, 0); }
+    if (kc_begin + 1 < kc_end) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { load_a(j, kc_begin + 1); load_b(j); }
+    }
+    __syncthreads();
+    rd(0, 0, fa0, fb0);
+    for (int kc = kc_begin; kc < kc_end; ++kc) {
+        const int buf = (kc - kc_begin) & 1;
+        const bool has1 = kc + 1 < kc_end, has2 = kc + 2 < kc_end;
+#pragma unroll
+        for (int sp = 0; sp < 8; ++sp) {           // two sub-steps per iteration: even -> set 0, odd -> set 1
+            const int s0_ = 2 * sp, s1_ = 2 * sp + 1;
+            // even sub-step
+            rd(buf, s0_ + 1, fa1, fb1);
+            if (has1 && s0_ >= 1 && s0_ <= 4) { st_a(s0_ - 1, buf ^ 1); st_b(s0_ - 1, buf ^ 1); }
+            if (has2 && s0_ >= 6 && s0_ <= 9) { load_a(s0_ - 6, kc + 2); load_b(s0_ - 6); }
+            sub(fa0, fb0);
+            if (s0_ == 14) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // odd sub-step
+            if (s1_ < 15) rd(buf, s1_ + 1, fa0, fb0);
+            else if (has1) rd(buf ^ 1, 0, fa0, fb0);
+            if (has1 && s1_ >= 1 && s1_ <= 4) { st_a(s1_ - 1, buf ^ 1); st_b(s1_ - 1, buf ^ 1); }
+            if (has2 && s1_ >= 6 && s1_ <= 9) { load_a(s1_ - 6, kc + 2); load_b(s1_ - 6); }
+            sub(fa1, fb1);
+        }
+    }
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
