@@ -116,6 +116,14 @@ int rr_upsample_add_bwd(const float *dout, float *dlow, int n, int h, int w, int
                         hipStream_t stream);
 int rr_avgpool_fwd(const float *x, float *out, long r, int hw, int c, hipStream_t stream);
 int rr_avgpool_bwd(const float *dout, float *dx, long r, int hw, int c, hipStream_t stream);
+/* WH head, detectors/centernet_detector.py:26-77 (HCov k x 1 and WCov 1 x k to one channel each,
+ * interleaved [W,H]): t [n,h,w,ct] (ct >= 2k, a multiple of 4 keeps the vector conv paths) = 1x1
+ * convolution of the 256-channel map with the 2k tap vectors (rows 0..k-1 = HCov taps, k..2k-1 = WCov
+ * taps, the rest zero; computed by rr_conv_fprop); out [n,h,w,2]:
+ * out[..,0] = bias_w + sum_s t[h, w+s-k/2, k+s], out[..,1] = bias_h + sum_r t[h+r-k/2, w, r]. */
+int rr_wh_shift_sum_fwd(const float *t, const float *bias_w, const float *bias_h, float *out, int n, int h,
+                        int w, int k, int ct, hipStream_t stream);
+int rr_wh_shift_sum_bwd(const float *dout, float *dt, int n, int h, int w, int k, int ct, hipStream_t stream);
 int rr_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, long n, float lr,
                  float beta1, float beta2, float eps, int step, float grad_scale, hipStream_t stream);
 

@@ -740,10 +740,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a)
         const long off = (((long)bn_[j] * a.H + ih) * a.W + iw) * a.C + c0 + b_col;
         const float *p = ok ? a.x + off : a.zero;
         rb[j] = *reinterpret_cast<const f32x4 *>(p);
+        // advance by BK pixels: one wrap handled with selects (the only case when Q >= BK), the rest by a loop
         bq_[j] += BK;
-        while (bq_[j] >= a.Q) {
-            bq_[j] -= a.Q;
-            if (++bp_[j] == a.P) { bp_[j] = 0; ++bn_[j]; }
+        const bool w1 = bq_[j] >= a.Q;
+        bq_[j] -= w1 ? a.Q : 0;
+        bp_[j] += w1 ? 1 : 0;
+        const bool w2 = bp_[j] >= a.P;
+        bp_[j] = w2 ? 0 : bp_[j];
+        bn_[j] += w2 ? 1 : 0;
+        if (a.Q < BK) {
+            while (bq_[j] >= a.Q) {
+                bq_[j] -= a.Q;
+                if (++bp_[j] == a.P) { bp_[j] = 0; ++bn_[j]; }
+            }
         }
     };
     auto st_a = [&](int j, int buf) {

@@ -375,6 +375,53 @@ __global__ __launch_bounds__(EW_THREADS) void avgpool_bwd_kernel(const float *do
     }
 }
 
+// ---- WH head (detectors/centernet_detector.py:26-77): the 17x1 and 1x17 convolutions to ONE channel
+// are computed as a 1x1 convolution to 2*k per-tap partial products T (MFMA, reads the 256-channel
+// map once) followed by this shift-sum: out[...,0] = bW + sum_s T[h, w+s-k/2, k+s],
+// out[...,1] = bH + sum_r T[h+r-k/2, w, r].  (Direct 17-tap convolutions to 1 channel run the
+// matrix cores at 1/32 occupancy and read the map 17 times.)
+__global__ __launch_bounds__(EW_THREADS) void wh_shift_sum_fwd_kernel(const float *T, const float *bw, const float *bh,
+                                                                      float *out, int N, int H, int W, int k, int C)
+{
+    const long total = (long)N * H * W;
+    const int half = k / 2;
+    for (long i = (long)blockIdx.x * EW_THREADS + threadIdx.x; i < total; i += (long)gridDim.x * EW_THREADS) {
+        const int w = (int)(i % W);
+        const int h = (int)((i / W) % H);
+        const float *base = T + (i - (long)h * W - w) * C;     // start of this image
+        float sh = bh[0], sw = bw[0];
+        for (int r = 0; r < k; ++r) {
+            const int hh = h + r - half;
+            if (hh >= 0 && hh < H) sh += base[((long)hh * W + w) * C + r];
+            const int ww = w + r - half;
+            if (ww >= 0 && ww < W) sw += base[((long)h * W + ww) * C + k + r];
+        }
+        out[i * 2 + 0] = sw;
+        out[i * 2 + 1] = sh;
+    }
+}
+
+__global__ __launch_bounds__(EW_THREADS) void wh_shift_sum_bwd_kernel(const float *dout, float *dT, int N, int H, int W, int k, int C)
+{
+    const int half = k / 2;
+    const long total = (long)N * H * W * C;
+    for (long i = (long)blockIdx.x * EW_THREADS + threadIdx.x; i < total; i += (long)gridDim.x * EW_THREADS) {
+        const int c = (int)(i % C);
+        const long p = i / C;
+        const int w = (int)(p % W);
+        const int h = (int)((p / W) % H);
+        float g = 0.f;
+        if (c < k) {                 // T[h, w, r] feeds out_H[h - (r - half), w]
+            const int ho = h - (c - half);
+            if (ho >= 0 && ho < H) g = dout[(p + (long)(ho - h) * W) * 2 + 1];
+        } else if (c < 2 * k) {      // T[h, w, k + s] feeds out_W[h, w - (s - half)]
+            const int wo = w - (c - k - half);
+            if (wo >= 0 && wo < W) g = dout[(p + (wo - w)) * 2 + 0];
+        }
+        dT[i] = g;
+    }
+}
+
 // ---- fused Adam over the flat parameter buffer (torch.optim.Adam defaults, no weight decay,
 //      no amsgrad; operators/rrnet_operator.py:29) -------------------------------------------
 __global__ __launch_bounds__(EW_THREADS) void adam_kernel(f32x4 *p, const f32x4 *g, f32x4 *m, f32x4 *v, long n4, float lr,
@@ -550,6 +597,25 @@ extern "C" int rr_avgpool_bwd(const float *dout, float *dx, long r, int hw, int 
 {
     EW_LAUNCH(avgpool_bwd_kernel, r * hw * c, stream, dout, dx, r, hw, c);
     RR_CHECK_LAUNCH("rr_avgpool_bwd");
+    return RR_OK;
+}
+
+extern "C" int rr_wh_shift_sum_fwd(const float *t, const float *bias_w, const float *bias_h, float *out, int n, int h,
+                                   int w, int k, int ct, hipStream_t stream)
+{
+    RR_CHECK_ARG(n > 0 && h > 0 && w > 0 && k > 0 && (k & 1) && ct >= 2 * k, "rr_wh_shift_sum_fwd: bad dims (k odd, ct >= 2k)");
+    const long tot = (long)n * h * w;
+    EW_LAUNCH(wh_shift_sum_fwd_kernel, tot, stream, t, bias_w, bias_h, out, n, h, w, k, ct);
+    RR_CHECK_LAUNCH("rr_wh_shift_sum_fwd");
+    return RR_OK;
+}
+
+extern "C" int rr_wh_shift_sum_bwd(const float *dout, float *dt, int n, int h, int w, int k, int ct, hipStream_t stream)
+{
+    RR_CHECK_ARG(n > 0 && h > 0 && w > 0 && k > 0 && (k & 1) && ct >= 2 * k, "rr_wh_shift_sum_bwd: bad dims (k odd, ct >= 2k)");
+    const long tot = (long)n * h * w * ct;
+    EW_LAUNCH(wh_shift_sum_bwd_kernel, tot, stream, dout, dt, n, h, w, k, ct);
+    RR_CHECK_LAUNCH("rr_wh_shift_sum_bwd");
     return RR_OK;
 }
 

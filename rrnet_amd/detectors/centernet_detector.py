@@ -74,6 +74,17 @@ class CenterNetWHDetector(nn.Module):
 
     def forward(self, input, index):
         conv = self.detect_conv_layer[index][0](input)
+        hc, wc = self.detect_H_layer[index][0].conv, self.detect_W_layer[index][0].conv
+        if hc.out_channels == 1 and wc.out_channels == 1 and hc.kernel_size[0] == wc.kernel_size[1]:
+            # planes == 1 (the only configuration the reference instantiates): both 17-tap convolutions as
+            # ONE 1x1 convolution to 34 per-tap partial products + a shift-sum (see rr_wh_shift_sum_fwd)
+            k = hc.kernel_size[0]
+            c = hc.in_channels
+            ct = (2 * k + 3) // 4 * 4       # pad the tap count to a multiple of 4 (vector dgrad path)
+            taps = torch.cat((hc.weight.permute(0, 2, 3, 1).reshape(k, c), wc.weight.permute(0, 2, 3, 1).reshape(k, c),
+                              hc.weight.new_zeros(ct - 2 * k, c)))
+            t = RF.conv_weight(conv, taps.view(ct, 1, 1, c).permute(0, 3, 1, 2))
+            return RF.wh_shift_sum(t, wc.bias, hc.bias, k)
         ca, cb = RF.fanout(conv, 2)
         H = self.detect_H_layer[index][0](ca)
         W = self.detect_W_layer[index][0](cb)

@@ -155,6 +155,41 @@ def conv_bias(x, conv, relu=False):
     return _ConvBias.apply(x, conv.weight, conv.bias, conv.stride[0], tuple(conv.padding), relu)
 
 
+def conv_weight(x, weight, bias=None, stride=1, pad=(0, 0), relu=False):
+    """_ConvBias on a bare weight tensor (e.g. one assembled from several parameters)."""
+    return _ConvBias.apply(x, weight, bias, stride, tuple(pad), relu)
+
+
+class _WHShiftSum(torch.autograd.Function):
+    """Second half of the fused WH head: per-tap partial products -> the two 17-tap sums + biases."""
+
+    @staticmethod
+    def forward(ctx, t, bias_w, bias_h, k):
+        t = ops.to_nhwc(t)
+        ctx.k = k
+        ctx.ct = t.shape[1]
+        ctx.params = (bias_w, bias_h)
+        return ops.wh_shift_sum_fwd(t, bias_w, bias_h, k)
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = ops.to_nhwc(dout)
+        bias_w, bias_h = ctx.params
+        db = torch.zeros(2, dtype=torch.float32, device=dout.device)
+        ops.bias_relu_bwd(dout, None, db)                     # column sums of [pixels, 2]
+        dbw, dbh = db[0:1].view_as(bias_w), db[1:2].view_as(bias_h)
+        tw, th = _grad_target(bias_w), _grad_target(bias_h)
+        if tw is not None and th is not None:
+            tw.add_(dbw)
+            th.add_(dbh)
+            dbw = dbh = None
+        return ops.wh_shift_sum_bwd(dout, ctx.k, ctx.ct), dbw, dbh, None
+
+
+def wh_shift_sum(t, bias_w, bias_h, k):
+    return _WHShiftSum.apply(t, bias_w, bias_h, k)
+
+
 class _FanOut(torch.autograd.Function):
     """Identity with n consumers; backward sums the n incoming gradients in ONE pass
     (what autograd would do with n-1 separate add kernels)."""

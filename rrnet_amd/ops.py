@@ -264,6 +264,22 @@ def avgpool_bwd(dout, shape):
     return dx
 
 
+def wh_shift_sum_fwd(t, bias_w, bias_h, k):
+    n, c, h, w = t.shape
+    assert c >= 2 * k and is_nhwc(t)
+    out = empty_nhwc(n, 2, h, w, t.device)
+    _C.check(_C.fn("rr_wh_shift_sum_fwd")(_C.ptr(t), _C.ptr(bias_w), _C.ptr(bias_h), _C.ptr(out), n, h, w, k, c,
+                                          _C.stream()), "rr_wh_shift_sum_fwd")
+    return out
+
+
+def wh_shift_sum_bwd(dout, k, ct):
+    n, _, h, w = dout.shape
+    dt = empty_nhwc(n, ct, h, w, dout.device)
+    _C.check(_C.fn("rr_wh_shift_sum_bwd")(_C.ptr(dout), _C.ptr(dt), n, h, w, k, ct, _C.stream()), "rr_wh_shift_sum_bwd")
+    return dt
+
+
 def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, grad_scale=1.0):
     assert param.numel() % 4 == 0
     _C.check(_C.fn("rr_adam_step")(_C.ptr(param), _C.ptr(grad), _C.ptr(exp_avg), _C.ptr(exp_avg_sq), param.numel(),
