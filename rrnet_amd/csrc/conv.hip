@@ -400,31 +400,55 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     };
-    // wave-uniform state of the K-step being fetched
-    long p_adelta = 0, p_wdelta = 0;
-    int p_tl = 0, p_c0 = 0;
-    bool p_cok = false, p_wcok = false;
-    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    auto prep = [&](int kc) {
-        const int cch = kc / RSc;
-        p_tl = kc - cch * RSc;
-        const int ri = p_tl / Sc, si = p_tl - ri * Sc;
-        const int tap = (r0 + tstep * ri) * a.S + (s0 + tstep * si);
-        p_c0 = cch * BKT;
-        p_adelta = (long)sgn * ((long)ri * a.SW + si) * a.SC + p_c0;
+    // Buffer-addressed gathers: 32-bit byte offsets, out-of-range => hardware returns 0 (no zero-page
+    // select, no 64-bit pointer arithmetic per load).  The host only takes this path when both tensors are
+    // smaller than 2 GiB.
+    // descriptor inputs pass through readfirstlane so that hipcc can PROVE the SRD wave-uniform; otherwise it
+    // wraps every buffer_load in a waterfall loop (cdna_hip_programming.md T20)
+    auto make_srd = [](const float *p, long bytes) {
+        const unsigned long long u = reinterpret_cast<unsigned long long>(p);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u);
+        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+        void *q = reinterpret_cast<void *>(((unsigned long long)hi << 32) | lo);
+        return __builtin_amdgcn_make_buffer_rsrc(q, 0, __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
+    };
+    const __amdgpu_buffer_rsrc_t rs_src = make_srd(a.src, (long)a.N * a.SH * a.SW * a.SC * 4);
+    const __amdgpu_buffer_rsrc_t rs_w = make_srd(a.w, (long)a.wK * RS * a.wC * 4);
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+    int a_boff[AJ], b_boff[BJ];
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) a_boff[j] = (int)(a_base[j] * 4);
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) b_boff[j] = (int)(b_base[j] * 4);
+    // wave-uniform state of the K-step being fetched, advanced incrementally (tap inner, channel chunk outer)
+    int p_cch = kc_lo / RSc, p_tl = kc_lo - (kc_lo / RSc) * RSc;
+    int p_ri = p_tl / Sc, p_si = p_tl - (p_tl / Sc) * Sc;
+    int p_adelta = 0, p_wdelta = 0, p_c0 = 0, p_tlc = 0;
+    bool p_cok = false, p_wcok = false, p_live = true;
+    auto prep = [&]() {            // describes step (p_cch, p_ri, p_si), then advances to the next one
+        const int tap = (r0 + tstep * p_ri) * a.S + (s0 + tstep * p_si);
+        p_c0 = p_cch * BKT;
+        p_tlc = p_tl;
+        p_adelta = (sgn * (p_ri * a.SW + p_si) * a.SC + p_c0) * 4;
         p_cok = p_c0 + a_col < a.SC;
-        p_wdelta = B_KN ? ((long)p_c0 * RS + tap) * a.wC : (long)tap * a.wC + p_c0;
+        p_wdelta = (B_KN ? (p_c0 * RS + tap) * a.wC : tap * a.wC + p_c0) * 4;
         p_wcok = p_c0 + a_col < a.wC;
+        ++p_tl;
+        if (++p_si == Sc) { p_si = 0; ++p_ri; }
+        if (p_tl == RSc) { p_tl = 0; p_ri = 0; p_si = 0; ++p_cch; }
     };
     auto load_a = [&](int j) {
-        const bool ok = p_cok && ((a_mask[j] >> p_tl) & 1ull);
-        const float *p = ok ? a.src + a_base[j] + p_adelta : a.zero;
-        ra[j] = *reinterpret_cast<const f32x4 *>(p);
+        // bitwise, not &&: a short-circuit on the per-lane p_cok becomes a divergent branch whose arms share
+        // destination registers, and hipcc then parks an s_waitcnt vmcnt(0) between consecutive loads
+        const unsigned ok = (unsigned)p_cok & (unsigned)((a_mask[j] >> p_tlc) & 1ull) & (unsigned)p_live;
+        const unsigned off = ok ? (unsigned)(a_boff[j] + p_adelta) : OOB;
+        ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_src, off, 0, 0));
     };
     auto load_b = [&](int j) {
-        const bool ok = B_KN ? (b_ok[j] && (p_c0 + t / TPR + KRPP * j < a.wK)) : (b_ok[j] && p_wcok);
-        const float *p = ok ? a.w + b_base[j] + p_wdelta : a.zero;
-        rb[j] = *reinterpret_cast<const f32x4 *>(p);
+        const unsigned ok = (B_KN ? ((unsigned)b_ok[j] & (unsigned)(p_c0 + t / TPR + KRPP * j < a.wK))
+                                  : ((unsigned)b_ok[j] & (unsigned)p_wcok)) & (unsigned)p_live;
+        const unsigned off = ok ? (unsigned)(b_boff[j] + p_wdelta) : OOB;
+        rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, off, 0, 0));
     };
     auto store_a = [&](int j, int buf) {
         *reinterpret_cast<f32x4 *>(As + buf * A_ELEMS + (a_row + RPP * j) * LDK + a_col) = ra[j];
@@ -435,13 +459,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
     };
     static_assert(!PIPE || (AJ == 4 && BJ == 4), "piece schedule below assumes 4 + 4 float4 per thread");
     if (kc_lo < kc_hi) {
-        prep(kc_lo);
+        prep();
 #pragma unroll
         for (int j = 0; j < 4; ++j) { load_a(j); load_b(j); }
 #pragma unroll
         for (int j = 0; j < 4; ++j) { store_a(j, 0); store_b(j, 0); }
         if (kc_lo + 1 < kc_hi) {      // stays in registers until the first phase's group 1
-            prep(kc_lo + 1);
+            prep();
 #pragma unroll
             for (int j = 0; j < 4; ++j) { load_a(j); load_b(j); }
         }
@@ -450,30 +474,34 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
     if (kc_lo < kc_hi) read_frags(0, 0, fa0, fb0);
     for (int kc = kc_lo; kc < kc_hi; ++kc) {
         const int buf = (kc - kc_lo) & 1;
-        const bool has1 = kc + 1 < kc_hi, has2 = kc + 2 < kc_hi;
+        // The body is branch-free on purpose: past the end of the K range the loads turn into out-of-range
+        // buffer reads (zeros) and the stores / fragment reads touch an LDS buffer nobody consumes.  With
+        // `if (has_next)` arms hipcc's waitcnt pass loses track of which loads the ds_writes already retired
+        // and parks s_waitcnt vmcnt(1) between consecutive load pairs, serialising them.
+        p_live = kc + 2 < kc_hi;
         // group 0 (fragment set 0); prefetch set 1 <- group 1's fragments
         read_frags(buf, 1, fa1, fb1);
         sub(fa0, fb0, 0); sub(fa0, fb0, 1); sub(fa0, fb0, 2); sub(fa0, fb0, 3);
         // group 1 (set 1); prefetch set 0 <- group 2; stage the next K-step into the other LDS buffer
         read_frags(buf, 2, fa0, fb0);
-        if (has1) { store_a(0, buf ^ 1); store_a(1, buf ^ 1); }
+        store_a(0, buf ^ 1); store_a(1, buf ^ 1);
         sub(fa1, fb1, 0);
-        if (has1) { store_a(2, buf ^ 1); store_a(3, buf ^ 1); }
+        store_a(2, buf ^ 1); store_a(3, buf ^ 1);
         sub(fa1, fb1, 1);
-        if (has1) { store_b(0, buf ^ 1); store_b(1, buf ^ 1); }
+        store_b(0, buf ^ 1); store_b(1, buf ^ 1);
         sub(fa1, fb1, 2);
-        if (has1) { store_b(2, buf ^ 1); store_b(3, buf ^ 1); }
+        store_b(2, buf ^ 1); store_b(3, buf ^ 1);
         sub(fa1, fb1, 3);
         // group 2 (set 0); prefetch set 1 <- group 3; refill the registers two K-steps ahead
-        if (has2) prep(kc + 2);
+        prep();
         read_frags(buf, 3, fa1, fb1);
-        if (has2) { load_a(0); load_a(1); }
+        load_a(0); load_a(1);
         sub(fa0, fb0, 0);
-        if (has2) { load_a(2); load_a(3); }
+        load_a(2); load_a(3);
         sub(fa0, fb0, 1);
-        if (has2) { load_b(0); load_b(1); }
+        load_b(0); load_b(1);
         sub(fa0, fb0, 2);
-        if (has2) { load_b(2); load_b(3); }
+        load_b(2); load_b(3);
         sub(fa0, fb0, 3);
         // the only barrier of the step: this wave's fragment reads of `buf` have landed and its share of
         // the next tile is written (lgkmcnt(0)); the global loads just issued stay in flight across it
@@ -481,7 +509,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         // group 3 (set 1) overlaps the first fragment reads of the next K-step
-        if (has1) read_frags(buf ^ 1, 0, fa0, fb0);
+        read_frags(buf ^ 1, 0, fa0, fb0);
         sub(fa1, fb1, 0); sub(fa1, fb1, 1); sub(fa1, fb1, 2); sub(fa1, fb1, 3);
     }
     }
@@ -887,7 +915,10 @@ int launch_igemm(ConvArgs &a, int bn, bool scalar, int blocks, int gy, int gz, h
     const size_t lds = igemm_lds(bn, MODE == 1, bk);
 #define IG(BNv, SCv, BKv, PIPEv) launch(conv_igemm_kernel<BNv, MODE, SCv, BKv, PIPEv>, blocks, lds, stream, a, name, gy, gz)
     if (bk == 32) {
-        if (bn == 128) return scalar ? IG(128, true, 32, false) : (conv_pipe() ? IG(128, false, 32, true) : IG(128, false, 32, false));
+        // the pipelined kernel addresses both tensors through 32-bit buffer offsets
+        const bool small = (long)a.N * a.SH * a.SW * a.SC * 4 < (1l << 31) && (long)a.wK * a.R * a.S * a.wC * 4 < (1l << 31);
+        if (bn == 128) return scalar ? IG(128, true, 32, false)
+                                     : (conv_pipe() && small ? IG(128, false, 32, true) : IG(128, false, 32, false));
         return scalar ? IG(32, true, 32, false) : IG(32, false, 32, false);
     }
     if (bn == 128) return scalar ? IG(128, true, 16, false) : IG(128, false, 16, false);
