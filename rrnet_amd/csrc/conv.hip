@@ -593,7 +593,7 @@ struct WgradArgs {
 
 // BMW x BN output tile (ko x c).  128x128: 2x2 waves of 64x64; 128x32 / 32x128: 4 waves of one 32x32;
 // 32x32: the 4 waves split the 32-deep K-step between them (their partial sums meet in the atomics).
-template <int BMW, int BN, bool A_SCALAR, bool B_SCALAR>
+template <int BMW, int BN, bool A_SCALAR, bool B_SCALAR, bool PIPE>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a)
 {
     constexpr int TILES = (BMW / 32) * (BN / 32);
@@ -709,7 +709,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a)
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int lr = lane & 31, lh = lane >> 5;
-    constexpr bool WPIPE = (BMW == 128 && BN == 128 && !A_SCALAR && !B_SCALAR);
+    constexpr bool WPIPE = PIPE && (BMW == 128 && BN == 128 && !A_SCALAR && !B_SCALAR);
     if constexpr (!WPIPE) {
     load_tiles(kc_begin);
     store_tiles(0);
@@ -756,18 +756,29 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     };
+    auto make_srd = [](const float *p, long bytes) {   // provably wave-uniform descriptor (T20)
+        const unsigned long long u = reinterpret_cast<unsigned long long>(p);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u);
+        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+        void *q = reinterpret_cast<void *>(((unsigned long long)hi << 32) | lo);
+        return __builtin_amdgcn_make_buffer_rsrc(q, 0, __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
+    };
+    const __amdgpu_buffer_rsrc_t rs_dy = make_srd(a.dy, (long)a.M * a.K * 4);
+    const __amdgpu_buffer_rsrc_t rs_x = make_srd(a.x, (long)a.N * a.H * a.W * a.C * 4);
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+    const int a_off0 = ((a_row)*a.K + ko0 + a_col) * 4;      // + m0 * K * 4 per K-step
     auto load_a = [&](int j, int kc) {
         const int m = kc * BK + a_row + RPP_A * j;
-        const bool ok = a_ko_ok && m < a.M;
-        const float *p = ok ? a.dy + (long)m * a.K + ko0 + a_col : a.zero;
-        ra[j] = *reinterpret_cast<const f32x4 *>(p);
+        const unsigned ok = (unsigned)a_ko_ok & (unsigned)(m < a.M) & (unsigned)(kc < kc_end);
+        const unsigned off = ok ? (unsigned)(a_off0 + (kc * BK + RPP_A * j) * a.K * 4) : OOB;
+        ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, off, 0, 0));
     };
     auto load_b = [&](int j) {
         const int ih = bp_[j] * a.stride - a.pad_h + r, iw = bq_[j] * a.stride - a.pad_w + s;
-        const bool ok = b_c_ok && bn_[j] < a.N && ih >= 0 && iw >= 0 && ih < a.H && iw < a.W;
-        const long off = (((long)bn_[j] * a.H + ih) * a.W + iw) * a.C + c0 + b_col;
-        const float *p = ok ? a.x + off : a.zero;
-        rb[j] = *reinterpret_cast<const f32x4 *>(p);
+        const unsigned ok = (unsigned)b_c_ok & (unsigned)(bn_[j] < a.N) & (unsigned)(ih >= 0) & (unsigned)(iw >= 0) &
+                            (unsigned)(ih < a.H) & (unsigned)(iw < a.W);
+        const unsigned off = ok ? (unsigned)((((bn_[j] * a.H + ih) * a.W + iw) * a.C + c0 + b_col) * 4) : OOB;
+        rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0));
         // advance by BK pixels: one wrap handled with selects (the only case when Q >= BK), the rest by a loop
         bq_[j] += BK;
         const bool w1 = bq_[j] >= a.Q;
@@ -801,14 +812,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a)
     rd(0, 0, fa0, fb0);
     for (int kc = kc_begin; kc < kc_end; ++kc) {
         const int buf = (kc - kc_begin) & 1;
-        const bool has1 = kc + 1 < kc_end, has2 = kc + 2 < kc_end;
+        // branch-free body (see conv_igemm_kernel<PIPE>): past the end of this split's K range the loads are
+        // out-of-range buffer reads and the stores / fragment reads touch an LDS buffer nobody consumes
 #pragma unroll
         for (int sp = 0; sp < 8; ++sp) {           // two sub-steps per iteration: even -> set 0, odd -> set 1
             const int s0_ = 2 * sp, s1_ = 2 * sp + 1;
             // even sub-step
             rd(buf, s0_ + 1, fa1, fb1);
-            if (has1 && s0_ >= 1 && s0_ <= 4) { st_a(s0_ - 1, buf ^ 1); st_b(s0_ - 1, buf ^ 1); }
-            if (has2 && s0_ >= 6 && s0_ <= 9) { load_a(s0_ - 6, kc + 2); load_b(s0_ - 6); }
+            if (s0_ >= 1 && s0_ <= 4) { st_a(s0_ - 1, buf ^ 1); st_b(s0_ - 1, buf ^ 1); }
+            if (s0_ >= 6 && s0_ <= 9) { load_a(s0_ - 6, kc + 2); load_b(s0_ - 6); }
             sub(fa0, fb0);
             if (s0_ == 14) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -817,9 +829,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a)
             }
             // odd sub-step
             if (s1_ < 15) rd(buf, s1_ + 1, fa0, fb0);
-            else if (has1) rd(buf ^ 1, 0, fa0, fb0);
-            if (has1 && s1_ >= 1 && s1_ <= 4) { st_a(s1_ - 1, buf ^ 1); st_b(s1_ - 1, buf ^ 1); }
-            if (has2 && s1_ >= 6 && s1_ <= 9) { load_a(s1_ - 6, kc + 2); load_b(s1_ - 6); }
+            else rd(buf ^ 1, 0, fa0, fb0);
+            if (s1_ >= 1 && s1_ <= 4) { st_a(s1_ - 1, buf ^ 1); st_b(s1_ - 1, buf ^ 1); }
+            if (s1_ >= 6 && s1_ <= 9) { load_a(s1_ - 6, kc + 2); load_b(s1_ - 6); }
             sub(fa1, fb1);
         }
     }
@@ -1031,10 +1043,14 @@ extern "C" int rr_conv_wgrad(const float *x, const float *dy, float *dw, int n, 
     const size_t lds = sizeof(float) * 2 * (BK * bmw + BK * bn);
     const bool as = (k % 4) != 0, bs = (c % 4) != 0;
 #define WG(BMv, BNv)                                                                                                  \
-    (as ? (bs ? launch(conv_wgrad_kernel<BMv, BNv, true, true>, blocks, lds, stream, a, "rr_conv_wgrad")             \
-              : launch(conv_wgrad_kernel<BMv, BNv, true, false>, blocks, lds, stream, a, "rr_conv_wgrad"))           \
-        : (bs ? launch(conv_wgrad_kernel<BMv, BNv, false, true>, blocks, lds, stream, a, "rr_conv_wgrad")            \
-              : launch(conv_wgrad_kernel<BMv, BNv, false, false>, blocks, lds, stream, a, "rr_conv_wgrad")))
+    (as ? (bs ? launch(conv_wgrad_kernel<BMv, BNv, true, true, false>, blocks, lds, stream, a, "rr_conv_wgrad")      \
+              : launch(conv_wgrad_kernel<BMv, BNv, true, false, false>, blocks, lds, stream, a, "rr_conv_wgrad"))    \
+        : (bs ? launch(conv_wgrad_kernel<BMv, BNv, false, true, false>, blocks, lds, stream, a, "rr_conv_wgrad")     \
+              : launch(conv_wgrad_kernel<BMv, BNv, false, false, false>, blocks, lds, stream, a, "rr_conv_wgrad")))
+    // pipelined 128x128 variant: 32-bit buffer offsets, both tensors below 2 GiB
+    if (bmw == 128 && bn == 128 && !as && !bs && conv_pipe() && M * k * 4 < (1l << 31) &&
+        (long)n * h * wd * c * 4 < (1l << 31))
+        return launch(conv_wgrad_kernel<128, 128, false, false, true>, blocks, lds, stream, a, "rr_conv_wgrad");
     if (bmw == 128) return bn == 128 ? WG(128, 128) : WG(128, 32);
     return bn == 128 ? WG(32, 128) : WG(32, 32);
 #undef WG
