@@ -517,6 +517,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
     // ---- epilogue.  D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     double *sred = reinterpret_cast<double *>(lds);   // [WM][BN][2], reuses the staging LDS
     const bool do_stats = (MODE == 0) && a.stat_slab != nullptr && a.ksplit <= 1;
+    const int mode_e = a.ksplit > 1 ? 2 : (a.accumulate ? 1 : 0);   // wave-uniform: hoisted out of the store loops
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int ncol = n0 + (wn * TN + j) * 32 + lr;
@@ -540,10 +541,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
                         pix = ((long)n * a.DH + (h * 2 + ph)) * a.DW + ((rem - h * Wc) * 2 + pw);
                     }
                     float *p = a.dst + pix * a.DC + ncol;
-                    if (a.ksplit > 1) {
+                    if (mode_e == 2) {
                         unsafeAtomicAdd(p, v);        // partial sums of the K slices meet in a zeroed / running dst
                     } else {
-                        if (a.accumulate) v += *p;
+                        if (mode_e == 1) v += *p;
                         *p = v;
                         s1 += v;
                         s2 += v * v;
@@ -766,20 +767,28 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a)
     const __amdgpu_buffer_rsrc_t rs_dy = make_srd(a.dy, (long)a.M * a.K * 4);
     const __amdgpu_buffer_rsrc_t rs_x = make_srd(a.x, (long)a.N * a.H * a.W * a.C * 4);
     constexpr unsigned OOB = 0xFFFFFFF0u;
-    const int a_off0 = ((a_row)*a.K + ko0 + a_col) * 4;      // + m0 * K * 4 per K-step
+    // A rows: byte offset of row j at K-step 0 of this split is a_off[j]; every K-step adds BK*K*4 (scalar)
+    int a_off[AJ], a_m[AJ];
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+        a_m[j] = a_row + RPP_A * j;
+        a_off[j] = (a_m[j] * a.K + ko0 + a_col) * 4;
+    }
+    const int a_step = BK * a.K * 4;
+    const int rr_off = r - a.pad_h, ss_off = s - a.pad_w;
     auto load_a = [&](int j, int kc) {
-        const int m = kc * BK + a_row + RPP_A * j;
-        const unsigned ok = (unsigned)a_ko_ok & (unsigned)(m < a.M) & (unsigned)(kc < kc_end);
-        const unsigned off = ok ? (unsigned)(a_off0 + (kc * BK + RPP_A * j) * a.K * 4) : OOB;
+        const unsigned ok = (unsigned)a_ko_ok & (unsigned)(kc * BK + a_m[j] < a.M) & (unsigned)(kc < kc_end);
+        const unsigned off = ok ? (unsigned)(a_off[j] + kc * a_step) : OOB;
         ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, off, 0, 0));
     };
     auto load_b = [&](int j) {
-        const int ih = bp_[j] * a.stride - a.pad_h + r, iw = bq_[j] * a.stride - a.pad_w + s;
-        const unsigned ok = (unsigned)b_c_ok & (unsigned)(bn_[j] < a.N) & (unsigned)(ih >= 0) & (unsigned)(iw >= 0) &
-                            (unsigned)(ih < a.H) & (unsigned)(iw < a.W);
+        const int ih = bp_[j] * a.stride + rr_off, iw = bq_[j] * a.stride + ss_off;
+        const unsigned ok = (unsigned)b_c_ok & (unsigned)(bn_[j] < a.N) & (unsigned)((unsigned)ih < (unsigned)a.H) &
+                            (unsigned)((unsigned)iw < (unsigned)a.W);
         const unsigned off = ok ? (unsigned)((((bn_[j] * a.H + ih) * a.W + iw) * a.C + c0 + b_col) * 4) : OOB;
         rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0));
-        // advance by BK pixels: one wrap handled with selects (the only case when Q >= BK), the rest by a loop
+    };
+    auto adv_b = [&](int j) {   // advance row j by BK pixels (kept apart from the load to keep VALU clusters short)
         bq_[j] += BK;
         const bool w1 = bq_[j] >= a.Q;
         bq_[j] -= w1 ? a.Q : 0;
@@ -801,13 +810,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a)
         *reinterpret_cast<f32x4 *>(Bs + buf * B_ELEMS + (b_row + RPP_B * j) * BN + b_col) = rb[j];
     };
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { load_a(j, kc_begin); load_b(j); }
+    for (int j = 0; j < 4; ++j) { load_a(j, kc_begin); load_b(j); adv_b(j); }
 #pragma unroll
     for (int j = 0; j < 4; ++j) { st_a(j, 0); st_b(j, 0); }
-    if (kc_begin + 1 < kc_end) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { load_a(j, kc_begin + 1); load_b(j); }
-    }
+    for (int j = 0; j < 4; ++j) { load_a(j, kc_begin + 1); load_b(j); adv_b(j); }
     __syncthreads();
     rd(0, 0, fa0, fb0);
     for (int kc = kc_begin; kc < kc_end; ++kc) {
@@ -820,7 +827,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a)
             // even sub-step
             rd(buf, s0_ + 1, fa1, fb1);
             if (s0_ >= 1 && s0_ <= 4) { st_a(s0_ - 1, buf ^ 1); st_b(s0_ - 1, buf ^ 1); }
-            if (s0_ >= 6 && s0_ <= 9) { load_a(s0_ - 6, kc + 2); load_b(s0_ - 6); }
+            if (s0_ >= 5 && s0_ <= 12) { if ((s0_ - 5) & 1) { load_b((s0_ - 5) >> 1); } else { load_a((s0_ - 5) >> 1, kc + 2); } }
+            if (s0_ >= 6 && s0_ <= 13 && ((s0_ - 6) & 1)) adv_b((s0_ - 6) >> 1);
             sub(fa0, fb0);
             if (s0_ == 14) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -831,7 +839,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a)
             if (s1_ < 15) rd(buf, s1_ + 1, fa0, fb0);
             else rd(buf ^ 1, 0, fa0, fb0);
             if (s1_ >= 1 && s1_ <= 4) { st_a(s1_ - 1, buf ^ 1); st_b(s1_ - 1, buf ^ 1); }
-            if (s1_ >= 6 && s1_ <= 9) { load_a(s1_ - 6, kc + 2); load_b(s1_ - 6); }
+            if (s1_ >= 5 && s1_ <= 12) { if ((s1_ - 5) & 1) { load_b((s1_ - 5) >> 1); } else { load_a((s1_ - 5) >> 1, kc + 2); } }
+            if (s1_ >= 6 && s1_ <= 13 && ((s1_ - 6) & 1)) adv_b((s1_ - 6) >> 1);
             sub(fa1, fb1);
         }
     }
@@ -894,19 +903,32 @@ int pick_ksplit(int blocks, int nk)
     return ks < 1 ? 1 : ks;
 }
 
-// per-m-tile column sums of y (used when split-K keeps the statistics out of the conv epilogue)
-__global__ __launch_bounds__(256) void tile_colstats_kernel(const float *y, long M, int C, double *slab)
+// column sums / sums of squares of y -> slab row 0 (the other rows are zeroed by the caller); used when
+// split-K keeps the statistics out of the conv epilogue.  Thread = (pixel lane, channel quad), LDS reduce
+// over the pixel lanes, one double atomic per channel per workgroup.
+__global__ __launch_bounds__(256) void colstats_kernel(const float *y, long M, int C, double *slab)
 {
-    const long m0 = (long)blockIdx.x * BM;
-    for (int c = threadIdx.x; c < C; c += 256) {
-        double s1 = 0.0, s2 = 0.0;
-        for (int r = 0; r < BM && m0 + r < M; ++r) {
-            const float v = y[(m0 + r) * C + c];
-            s1 += (double)v;
-            s2 += (double)v * (double)v;
+    __shared__ double red[2][256 * 4];
+    const int C4 = C / 4, lanes = 256 / C4;
+    const int t = threadIdx.x, cq = t % C4, pl = t / C4;
+    double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    if (pl < lanes)
+        for (long p = (long)blockIdx.x * lanes + pl; p < M; p += (long)gridDim.x * lanes) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(y + p * C + cq * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { s1[e] += (double)v[e]; s2[e] += (double)v[e] * (double)v[e]; }
         }
-        slab[(long)blockIdx.x * 2 * C + c] = s1;
-        slab[(long)blockIdx.x * 2 * C + C + c] = s2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[0][t * 4 + e] = s1[e]; red[1][t * 4 + e] = s2[e]; }
+    __syncthreads();
+    for (int c = t; c < C; c += 256) {
+        double a1 = 0.0, a2 = 0.0;
+        for (int l = 0; l < lanes; ++l) {
+            a1 += red[0][(l * C4 + c / 4) * 4 + (c & 3)];
+            a2 += red[1][(l * C4 + c / 4) * 4 + (c & 3)];
+        }
+        unsafeAtomicAdd(slab + c, a1);
+        unsafeAtomicAdd(slab + C + c, a2);
     }
 }
 
@@ -966,14 +988,18 @@ extern "C" int rr_conv_fprop(const float *x, const float *w, const float *bias, 
     const int blocks = rr_cdiv(M, BM) * rr_cdiv(k, bn);
     const int bk = conv_bk();
     const int nk = scalar ? rr_cdiv(a.Kg, bk) : rr_cdiv(c, bk) * r * s;
-    int ks = (bias == nullptr && !relu) ? pick_ksplit(blocks, nk) : 1;
+    int ks = (bias == nullptr && !relu && k % 4 == 0 && k <= 1024) ? pick_ksplit(blocks, nk) : 1;
     if (ks > 1) {
         a.ksplit = ks;
         hipMemsetAsync(y, 0, sizeof(float) * (size_t)M * k, stream);
     }
     int rc = launch_igemm<0>(a, bn, scalar, blocks, 1, ks, stream, "rr_conv_fprop");
     if (rc == RR_OK && ks > 1 && stat_slab != nullptr) {
-        hipLaunchKernelGGL(tile_colstats_kernel, dim3(rr_cdiv(M, BM)), dim3(256), 0, stream, y, M, k, stat_slab);
+        hipMemsetAsync(stat_slab, 0, rr_conv_stat_slab_bytes(n, a.DH, a.DW, k), stream);
+        const int lanes = 256 / (k / 4);
+        int sblocks = rr_cdiv(M, (long)lanes * 8);
+        if (sblocks > 256) sblocks = 256;
+        hipLaunchKernelGGL(colstats_kernel, dim3(sblocks), dim3(256), 0, stream, y, M, k, stat_slab);
         RR_CHECK_LAUNCH("rr_conv_fprop(stats)");
     }
     return rc;
