@@ -59,7 +59,9 @@ int rr_soft_nms_segments(float *boxes, const int *seg_off, int nseg, int max_seg
  *   sums and sums of squares of y, reduced by rr_bn_finalize).
  * dgrad: dx [n,h,w,c] = conv-transpose of dy [n,p,q,k]; accumulate != 0 adds into dx.
  * wgrad: dw [k][r][s][c] += x (*) dy, split over the n*p*q pixels and summed with float
- *   atomics (the caller zeroes dw once per step; the flat gradient buffer is that target). */
+ *   atomics (the caller zeroes dw once per step; the flat gradient buffer is that target).
+ *   out_h/out_w > 0 give dy's spatial size explicitly (asymmetric padding: pad_h/pad_w are the leading
+ *   pads); 0 derives it from the symmetric formula. */
 size_t rr_conv_stat_slab_bytes(int n, int p, int q, int k);
 int rr_conv_fprop(const float *x, const float *w, const float *bias, float *y, double *stat_slab,
                   int n, int h, int wd, int c, int k, int r, int s, int stride, int pad_h, int pad_w,
@@ -67,7 +69,7 @@ int rr_conv_fprop(const float *x, const float *w, const float *bias, float *y, d
 int rr_conv_dgrad(const float *dy, const float *w, float *dx, int n, int h, int wd, int c, int k,
                   int r, int s, int stride, int pad_h, int pad_w, int accumulate, hipStream_t stream);
 int rr_conv_wgrad(const float *x, const float *dy, float *dw, int n, int h, int wd, int c, int k,
-                  int r, int s, int stride, int pad_h, int pad_w, hipStream_t stream);
+                  int r, int s, int stride, int pad_h, int pad_w, int out_h, int out_w, hipStream_t stream);
 
 /* ---- BatchNorm / ReLU / residual / up-path / Adam (HBM-bound NHWC elementwise) -------- *
  * Replace nn.BatchNorm2d (SyncBatchNorm via operators/rrnet_operator.py:27) + ReLU + residual

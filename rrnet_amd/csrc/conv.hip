@@ -1041,13 +1041,17 @@ extern "C" int rr_conv_dgrad(const float *dy, const float *w, float *dx, int n, 
 }
 
 extern "C" int rr_conv_wgrad(const float *x, const float *dy, float *dw, int n, int h, int wd, int c, int k,
-                             int r, int s, int stride, int pad_h, int pad_w, hipStream_t stream)
+                             int r, int s, int stride, int pad_h, int pad_w, int out_h, int out_w,
+                             hipStream_t stream)
 {
     RR_CHECK_ARG(n > 0 && h > 0 && wd > 0 && c > 0 && k > 0 && r > 0 && s > 0 && stride > 0, "rr_conv_wgrad: bad dims");
     WgradArgs a{};
     a.x = x; a.dy = dy; a.dw = dw; a.zero = zero_page();
     a.N = n; a.H = h; a.W = wd; a.C = c; a.K = k; a.R = r; a.S = s;
-    a.P = (h + 2 * pad_h - r) / stride + 1; a.Q = (wd + 2 * pad_w - s) / stride + 1;
+    // out_h/out_w > 0 override the symmetric-padding output size (pad_h/pad_w are the LEADING pads; taps that
+    // fall past the far edge are masked), which is how asymmetric padding is expressed
+    a.P = out_h > 0 ? out_h : (h + 2 * pad_h - r) / stride + 1;
+    a.Q = out_w > 0 ? out_w : (wd + 2 * pad_w - s) / stride + 1;
     a.stride = stride; a.pad_h = pad_h; a.pad_w = pad_w;
     const long M = (long)n * a.P * a.Q;
     RR_CHECK_ARG(M > 0 && M < (1l << 31), "rr_conv_wgrad: bad pixel count");

@@ -93,11 +93,14 @@ class _ConvBnAct(torch.autograd.Function):
         dx = ops.conv_dgrad(dy, wc, ctx.xshape, stride, pad) if ctx.needs_input_grad[0] else None
         w_t = _grad_target(w)
         ret_dw = None
+        stem = (tuple(w.shape[1:]) == (3, 7, 7) and stride == 2 and tuple(pad) == (3, 3)
+                and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0)
+        wg = (lambda tgt: ops.stem_wgrad_s2d(x, dy, tgt)) if stem else (lambda tgt: ops.conv_wgrad(x, dy, tgt, stride, pad))
         if w_t is not None:
-            ops.conv_wgrad(x, dy, w_t, stride, pad)
+            wg(w_t)
         else:
             dw = ops.zeros_nhwc(*w.shape, device=x.device)
-            ops.conv_wgrad(x, dy, dw, stride, pad)
+            wg(dw)
             ret_dw = dw
         dres = None
         if has_res and ctx.needs_input_grad[4]:

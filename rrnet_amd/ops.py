@@ -106,6 +106,24 @@ def conv_fprop(x, w, bias=None, stride=1, pad=(0, 0), relu=False, want_stats=Fal
     return (y, slab) if want_stats else y
 
 
+def stem_wgrad_s2d(x, dy, dw):
+    """wgrad of the 7x7 stride-2 pad-3 stem on a 3-channel image, computed on the space-to-depth image:
+    y[p] = sum_r x[2p-3+r] w[r]  ==  sum_{a<4,i<2} x2[p-2+a, i] w'[2a+i],  x2[u,i] = x[2u+i], w'[r+1] = w[r]
+    i.e. a 4x4 stride-1 convolution over 12 channels with leading pad 2 (trailing 1).  Per tap the MFMA
+    tile then carries 12 useful channels instead of 3 (49 taps x 32 padded -> 16 taps x 32 padded)."""
+    n, c, h, w = x.shape
+    k = dw.shape[0]
+    assert c == 3 and h % 2 == 0 and w % 2 == 0 and tuple(dw.shape[1:]) == (3, 7, 7)
+    xm = x.permute(0, 2, 3, 1)                                   # NHWC view of the memory
+    x2 = xm.reshape(n, h // 2, 2, w // 2, 2, 3).permute(0, 1, 3, 2, 4, 5).reshape(n, h // 2, w // 2, 12)
+    x2 = x2.contiguous().permute(0, 3, 1, 2)                     # logical [n,12,h/2,w/2], NHWC memory
+    dw2 = zeros_nhwc(k, 12, 4, 4, x.device)                      # OHWI [k][a][b][(i,j,c)]
+    conv_wgrad(x2, dy, dw2, 1, (2, 2), explicit_out=True)
+    g = dw2.permute(0, 2, 3, 1).reshape(k, 4, 4, 2, 2, 3).permute(0, 1, 3, 2, 4, 5).reshape(k, 8, 8, 3)
+    dw.permute(0, 2, 3, 1).add_(g[:, 1:, 1:, :])                 # drop the phantom taps r' = 0 / s' = 0
+    return dw
+
+
 def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False):
     """dy [N,K,P,Q], w [K,C,R,S] -> dx [N,C,H,W]; with `out` and accumulate adds into it."""
     _C.require_cuda(dy, w)
@@ -125,8 +143,9 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False)
     return out
 
 
-def conv_wgrad(x, dy, dw, stride=1, pad=(0, 0)):
-    """dw [K,C,R,S] (OHWI memory) += x (*) dy.  dw must be pre-zeroed / hold the running gradient."""
+def conv_wgrad(x, dy, dw, stride=1, pad=(0, 0), explicit_out=False):
+    """dw [K,C,R,S] (OHWI memory) += x (*) dy.  dw must be pre-zeroed / hold the running gradient.
+    explicit_out: take the output size from dy (asymmetric padding, `pad` = leading pads)."""
     _C.require_cuda(x, dy, dw)
     assert is_nhwc(x) and is_nhwc(dy) and is_nhwc(dw)
     n, c, h, wd = x.shape
@@ -136,6 +155,7 @@ def conv_wgrad(x, dy, dw, stride=1, pad=(0, 0)):
     flops = 2.0 * dy.shape[0] * dy.shape[2] * dy.shape[3] * k * c * r * s
     _C.check(_timed("conv_wgrad<BN=%d>" % (128 if c > 32 else 32), flops,
                     lambda: f(_C.ptr(x), _C.ptr(dy), _C.ptr(dw), n, h, wd, c, k, r, s, stride, pad[0], pad[1],
+                              dy.shape[2] if explicit_out else 0, dy.shape[3] if explicit_out else 0,
                               _C.stream()), (n, h, wd, c, k, r, s, stride)), "rr_conv_wgrad")
     return dw
 
