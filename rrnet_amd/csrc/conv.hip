@@ -740,21 +740,27 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a)
     // Software-pipelined form (same scheme as conv_igemm_kernel<PIPE>): 16 sub-steps of 4 MFMAs per
     // K-step; fragments one sub-step ahead in registers, the next tile's ds_writes in sub-steps 1-4, the
     // global loads two K-steps ahead in sub-steps 6-9, the only barrier after sub-step 14.
-    float fa0[TM], fb0[TN], fa1[TM], fb1[TN];
-    auto rd = [&](int buf, int k2, float (&fa)[TM], float (&fb)[TN]) {
+    // fragments of one GROUP (4 sub-steps = 8 pixels of K) per register set, two sets: the reads of the next
+    // group are issued a whole group (16 MFMAs) ahead, as in conv_igemm_kernel<PIPE> — with one sub-step of
+    // lead the ds_read_b32 latency under load was still exposed every 4 MFMAs
+    float fa0[4][TM], fb0[4][TN], fa1[4][TM], fb1[4][TN];
+    auto rdg = [&](int buf, int g, float (&fa)[4][TM], float (&fb)[4][TN]) {
         const float *A = As + buf * A_ELEMS, *B = Bs + buf * B_ELEMS;
-        const int kr = 2 * k2 + lh;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) fa[i] = A[kr * BMW + (wm * TM + i) * 32 + lr];
+        for (int q = 0; q < 4; ++q) {
+            const int kr = 2 * (4 * g + q) + lh;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) fb[j] = B[kr * BN + (wn * TN + j) * 32 + lr];
+            for (int i = 0; i < TM; ++i) fa[q][i] = A[kr * BMW + (wm * TM + i) * 32 + lr];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[q][j] = B[kr * BN + (wn * TN + j) * 32 + lr];
+        }
     };
-    auto sub = [&](const float (&fa)[TM], const float (&fb)[TN]) {
+    auto sub = [&](const float (&fa)[4][TM], const float (&fb)[4][TN], int q) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][i], fb[q][j], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     };
     auto make_srd = [](const float *p, long bytes) {   // provably wave-uniform descriptor (T20)
@@ -816,33 +822,45 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a)
 #pragma unroll
     for (int j = 0; j < 4; ++j) { load_a(j, kc_begin + 1); load_b(j); adv_b(j); }
     __syncthreads();
-    rd(0, 0, fa0, fb0);
+    rdg(0, 0, fa0, fb0);
     for (int kc = kc_begin; kc < kc_end; ++kc) {
         const int buf = (kc - kc_begin) & 1;
         // branch-free body (see conv_igemm_kernel<PIPE>): past the end of this split's K range the loads are
         // out-of-range buffer reads and the stores / fragment reads touch an LDS buffer nobody consumes
-#pragma unroll
-        for (int sp = 0; sp < 8; ++sp) {           // two sub-steps per iteration: even -> set 0, odd -> set 1
-            const int s0_ = 2 * sp, s1_ = 2 * sp + 1;
-            // even sub-step
-            rd(buf, s0_ + 1, fa1, fb1);
-            if (s0_ >= 1 && s0_ <= 4) { st_a(s0_ - 1, buf ^ 1); st_b(s0_ - 1, buf ^ 1); }
-            if (s0_ >= 5 && s0_ <= 12) { if ((s0_ - 5) & 1) { load_b((s0_ - 5) >> 1); } else { load_a((s0_ - 5) >> 1, kc + 2); } }
-            if (s0_ >= 6 && s0_ <= 13 && ((s0_ - 6) & 1)) adv_b((s0_ - 6) >> 1);
-            sub(fa0, fb0);
-            if (s0_ == 14) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            // odd sub-step
-            if (s1_ < 15) rd(buf, s1_ + 1, fa0, fb0);
-            else rd(buf ^ 1, 0, fa0, fb0);
-            if (s1_ >= 1 && s1_ <= 4) { st_a(s1_ - 1, buf ^ 1); st_b(s1_ - 1, buf ^ 1); }
-            if (s1_ >= 5 && s1_ <= 12) { if ((s1_ - 5) & 1) { load_b((s1_ - 5) >> 1); } else { load_a((s1_ - 5) >> 1, kc + 2); } }
-            if (s1_ >= 6 && s1_ <= 13 && ((s1_ - 6) & 1)) adv_b((s1_ - 6) >> 1);
-            sub(fa1, fb1);
-        }
+        // group 0
+        rdg(buf, 1, fa1, fb1);
+        sub(fa0, fb0, 0); sub(fa0, fb0, 1); sub(fa0, fb0, 2); sub(fa0, fb0, 3);
+        // group 1: stage the next K-step
+        rdg(buf, 2, fa0, fb0);
+        st_a(0, buf ^ 1); st_a(1, buf ^ 1);
+        sub(fa1, fb1, 0);
+        st_a(2, buf ^ 1); st_a(3, buf ^ 1);
+        sub(fa1, fb1, 1);
+        st_b(0, buf ^ 1); st_b(1, buf ^ 1);
+        sub(fa1, fb1, 2);
+        st_b(2, buf ^ 1); st_b(3, buf ^ 1);
+        sub(fa1, fb1, 3);
+        // group 2: refill the registers two K-steps ahead
+        rdg(buf, 3, fa1, fb1);
+        load_a(0, kc + 2); load_a(1, kc + 2);
+        sub(fa0, fb0, 0);
+        load_a(2, kc + 2); load_a(3, kc + 2);
+        sub(fa0, fb0, 1);
+        load_b(0); load_b(1);
+        sub(fa0, fb0, 2);
+        load_b(2); load_b(3);
+        sub(fa0, fb0, 3);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // group 3 overlaps the first fragment reads of the next K-step and the row bookkeeping
+        rdg(buf ^ 1, 0, fa0, fb0);
+        adv_b(0); adv_b(1);
+        sub(fa1, fb1, 0);
+        adv_b(2); adv_b(3);
+        sub(fa1, fb1, 1);
+        sub(fa1, fb1, 2);
+        sub(fa1, fb1, 3);
     }
     }
 #pragma unroll
