@@ -87,9 +87,14 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible — the HIP path has no CPU fallback", file=sys.stderr)
         sys.exit(3)
+    # RR_SINGLE_DEVICE=1 + RR_DIST_BACKEND=gloo: builder-side check of the N>1 code path on a 1-GPU box (every
+    # rank on cuda:0, collectives through gloo).  The driver's multi-GPU runs use neither: one GPU per rank, RCCL.
+    if os.environ.get("RR_SINGLE_DEVICE") == "1":
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group(backend="nccl", init_method="env://", world_size=world, rank=rank)
+        dist.init_process_group(backend=os.environ.get("RR_DIST_BACKEND", "nccl"), init_method="env://",
+                                world_size=world, rank=rank)
 
     from rrnet_amd import ops
     from rrnet_amd.configs.rrnet_config import Config as cfg

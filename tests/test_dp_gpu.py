@@ -1,0 +1,83 @@
+"""GPU: the data-parallel path (SyncBN statistics exchange + flat-gradient all-reduce + fused Adam) with
+TWO ranks must reproduce the single-rank full-batch result.  Both ranks share cuda:0 and talk through
+gloo (a 1-GPU box cannot host two RCCL ranks); the code path is the one `bench.py --gpus N` runs, only
+the backend string differs."""
+import os
+import socket
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _cfg():
+    return SimpleNamespace(num_classes=10, Model=SimpleNamespace(num_stacks=1, backbone="hourglass_tiny",
+                           nms_type_for_stage1="nms", nms_per_class_for_stage1=True))
+
+
+def _build():
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import det_fill
+    from rrnet_amd.models.centernet import CenterNet
+    m = CenterNet(_cfg())
+    m.load_state_dict(det_fill({k: tuple(v.shape) for k, v in m.state_dict().items()}, 21))
+    return m
+
+
+def _loss(model, x):
+    hms, whs, regs = model(x)
+    return (hms[0] ** 2).mean() + (whs[0] ** 2).mean() + (regs[0] ** 2).mean()
+
+
+def _data():
+    g = torch.Generator().manual_seed(3)
+    return torch.randn(4, 3, 64, 64, generator=g)
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from rrnet_amd.flat import FlatAdam, FlatParams
+        model = _build().cuda().to(memory_format=torch.channels_last)
+        model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model).train()
+        fp = FlatParams(model)
+        fp.broadcast(0)
+        opt = FlatAdam(fp, lr=1e-3)
+        x = _data()[rank * 2:(rank + 1) * 2].cuda()
+        opt.zero_grad()
+        _loss(model, x).backward()
+        scale = fp.all_reduce_grads()
+        g = (fp.grad * scale).cpu().numpy()
+        rm = model.backbone.pre_layer[1].running_mean.cpu().numpy()
+        opt.step()                       # (second all-reduce of an already reduced buffer is avoided below)
+        if rank == 0:
+            np.savez(out, grad=g, running_mean=rm)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_syncbn_dp_matches_single_rank(tmp_path):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "dp.npz")
+    mp.spawn(_worker, nprocs=2, args=(2, port, out), join=True)
+    z = np.load(out)
+    from rrnet_amd.flat import FlatParams
+    model = _build().cuda().to(memory_format=torch.channels_last).train()
+    fp = FlatParams(model)
+    fp.zero_grad()
+    _loss(model, _data().cuda()).backward()
+    ref = fp.grad.cpu().numpy()
+    scale = np.abs(ref).max()
+    assert np.abs(z["grad"] - ref).max() <= 2e-3 * scale, (np.abs(z["grad"] - ref).max(), scale)
+    np.testing.assert_allclose(z["running_mean"], model.backbone.pre_layer[1].running_mean.cpu().numpy(), atol=1e-5)
