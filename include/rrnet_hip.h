@@ -142,7 +142,9 @@ int rr_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg
  *   definition) against gt [b,g,gstride>=4] xyxy, positives IoU > 0.5, Faster-RCNN targets with
  *   the +1 width convention, smooth-L1 mean per image / b; images without positives add 0.
  *   rois [r,5] = (image, x1,y1,x2,y2) in feature coords, scaled by `scale`.  Outputs: tgt [r,4],
- *   pos [r], npos [b], loss[0] (double), dreg_unit [r,4] = dloss/dreg. */
+ *   pos [r], npos [b], loss[0] (double), dreg_unit [r,4] = dloss/dreg, droi_unit [r,4] (optional) =
+ *   dloss/droi — the reference's smooth-L1 also differentiates its TARGETS, which depend on the boxes
+ *   (rrnet_operator.py:82 with the hard-NMS-selected boxes of models/rrnet.py:70). */
 int rr_focal_loss_fwd(const float *logits, const float *gt, long n, double *sums, hipStream_t stream);
 int rr_focal_loss_bwd(const float *logits, const float *gt, long n, const double *sums, const float *gout,
                       float gscale, float *dlogits, hipStream_t stream);
@@ -153,13 +155,15 @@ int rr_regl1_bwd(const float *pred, const float *mask, const float *ind, const f
                  hipStream_t stream);
 int rr_stage2_loss(const float *rois, const float *reg, int r, const float *gt, int b, int g, int gstride,
                    float scale, float *tgt, int *pos, int *npos, double *loss, float *dreg_unit,
-                   hipStream_t stream);
+                   float *droi_unit, hipStream_t stream);
 
 /* ---- decode / NMS plumbing ------------------------------------------------------------ *
  * rr_decode_topk: models/rrnet.py:93-138 (_topk + gathers + transform_bbox).  hm NHWC
  *   [b,h,w,c] logits (is_logits=1: sigmoid applied) or ready scores (0); wh, off NHWC [b,h,w,2];
  *   out [b,k,6] = x1,y1,x2,y2,score,cls in feature coordinates, score-descending, ties by the
- *   reference's flat index.  k <= min(4096, c*h*w).  No 3x3 peak filter (the reference never
+ *   reference's flat index; pix_out (optional) [b,k] = y*w+x of every row.  rr_roi_provenance maps
+ *   packed RoIs back to that pixel; rr_proposal_bwd is the backward of the box assembly (d wh, d off maps
+ *   from d roi).  k <= min(4096, c*h*w).  No 3x3 peak filter (the reference never
  *   applies one); rr_peak3x3 provides operators/centernet_operator.py:204-210 as an option.
  * rr_group_by_class: stable regrouping of each image's k rows by class (classes ascending =
  *   torch.unique order of models/rrnet.py:59); seg_off [b*num_classes+1] row offsets.
@@ -168,7 +172,11 @@ int rr_stage2_loss(const float *rois, const float *reg, int r, const float *gt, 
  * rr_pack_segments: phase 0 -> out_off [nseg+1] exclusive prefix of n_out (out_off[nseg] = R);
  *   phase 1 -> rois [R,5], scores [R], clses [R] (models/rrnet.py:37-49) and/or rows6 [R,6]. */
 int rr_decode_topk(const float *hm, int is_logits, const float *wh, const float *off, int b, int h, int w,
-                   int c, int k, float *out, hipStream_t stream);
+                   int c, int k, float *out, int *pix_out, hipStream_t stream);
+int rr_roi_provenance(const float *rois, const float *scores, const float *clses, int r, const float *decoded,
+                      const int *pix, int k, int *roi_pix, hipStream_t stream);
+int rr_proposal_bwd(const float *droi, const float *rois, const int *roi_pix, int r, const float *wh, int b, int h,
+                    int w, float *dwh, float *doff, hipStream_t stream);
 int rr_peak3x3(const float *hm, float *scores, int b, int h, int w, int c, hipStream_t stream);
 int rr_group_by_class(const float *boxes, int b, int k, int num_classes, int cls_base, float *grouped,
                       int *seg_off, hipStream_t stream);

@@ -65,7 +65,7 @@ __device__ void find_bin(const int *hist, int nbins, int need, int *result)
 }
 
 __global__ __launch_bounds__(DT) void decode_topk_kernel(const float *hm, int is_logits, const float *wh, const float *off,
-                                                         int H, int W, int C, int K, int KP, float *out)
+                                                         int H, int W, int C, int K, int KP, float *out, int *pix_out)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned long long *keys = reinterpret_cast<unsigned long long *>(smem);  // [KP]
@@ -168,7 +168,49 @@ __global__ __launch_bounds__(DT) void decode_topk_kernel(const float *hm, int is
         const float px = xs - w_ / 2.f, py = ys - h_ / 2.f;
         float *o = out + ((long)blockIdx.x * K + k) * 6;
         o[0] = px; o[1] = py; o[2] = w_ + px; o[3] = h_ + py; o[4] = score; o[5] = (float)cls;
+        if (pix_out) pix_out[(long)blockIdx.x * K + k] = (int)pix;
     }
+}
+
+// For every packed RoI: the heat-map pixel it was decoded from, found by matching its six floats against
+// the image's decode rows (grouping / hard NMS / packing copy rows bit for bit).  -1 if no row matches.
+__global__ void roi_provenance_kernel(const float *rois, const float *scores, const float *clses, int R, const float *decoded,
+                                      const int *pix, int K, int *roi_pix)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const float *q = rois + (long)r * 5;
+    const int b = (int)q[0];
+    const float *d = decoded + (long)b * K * 6;
+    int found = -1;
+    for (int k = 0; k < K; ++k) {
+        const float *e = d + k * 6;
+        if (e[4] == scores[r] && e[5] == clses[r] && e[0] == q[1] && e[1] == q[2] && e[2] == q[3] && e[3] == q[4]) {
+            found = pix[(long)b * K + k];
+            break;
+        }
+    }
+    roi_pix[r] = found;
+}
+
+// Backward of the box assembly (models/rrnet.py:122-137): x1 = xs + off_x - w/2, x2 = x1 + w, w = max(wh_x, 0)
+// => d off_x = dx1 + dx2, d wh_x = (dx2 - dx1)/2 where wh_x >= 0; same for y.  Scatter with float atomics.
+__global__ void proposal_bwd_kernel(const float *droi, const float *rois, const int *roi_pix, int R, const float *wh, long HW,
+                                    float *dwh, float *doff)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const int p = roi_pix[r];
+    if (p < 0) return;
+    const int b = (int)rois[(long)r * 5];
+    const float *g = droi + (long)r * 4;
+    const long o = ((long)b * HW + p) * 2;
+    const float gx = g[0] + g[2], gy = g[1] + g[3];
+    if (gx != 0.f) atomicAdd(doff + o, gx);
+    if (gy != 0.f) atomicAdd(doff + o + 1, gy);
+    const float hx = 0.5f * (g[2] - g[0]), hy = 0.5f * (g[3] - g[1]);
+    if (wh[o] >= 0.f && hx != 0.f) atomicAdd(dwh + o, hx);
+    if (wh[o + 1] >= 0.f && hy != 0.f) atomicAdd(dwh + o + 1, hy);
 }
 
 // scores[b,y,x,c] = sigmoid(hm) if it is the maximum of its 3x3 window (same class) else 0
@@ -291,7 +333,7 @@ __global__ void pack_segments_kernel(const float *grouped, const int *seg_off, c
 }  // namespace
 
 extern "C" int rr_decode_topk(const float *hm, int is_logits, const float *wh, const float *off, int b, int h, int w,
-                              int c, int k, float *out, hipStream_t stream)
+                              int c, int k, float *out, int *pix_out, hipStream_t stream)
 {
     RR_CHECK_ARG(b > 0 && h > 0 && w > 0 && c > 0, "rr_decode_topk: bad dims");
     RR_CHECK_ARG(k > 0 && k <= 4096 && (long)k <= (long)h * w * c, "rr_decode_topk: k=%d out of range (1..min(4096, C*H*W))", k);
@@ -299,8 +341,31 @@ extern "C" int rr_decode_topk(const float *hm, int is_logits, const float *wh, c
     int kp = 2;
     while (kp < k) kp <<= 1;
     const size_t lds = (size_t)kp * 8 + 2048 * 4 + (DT / 64 + 1) * 4;
-    hipLaunchKernelGGL(decode_topk_kernel, dim3(b), dim3(DT), lds, stream, hm, is_logits, wh, off, h, w, c, k, kp, out);
+    hipLaunchKernelGGL(decode_topk_kernel, dim3(b), dim3(DT), lds, stream, hm, is_logits, wh, off, h, w, c, k, kp, out, pix_out);
     RR_CHECK_LAUNCH("rr_decode_topk");
+    return RR_OK;
+}
+
+extern "C" int rr_roi_provenance(const float *rois, const float *scores, const float *clses, int r, const float *decoded,
+                                 const int *pix, int k, int *roi_pix, hipStream_t stream)
+{
+    if (r <= 0) return RR_OK;
+    hipLaunchKernelGGL(roi_provenance_kernel, dim3(rr_cdiv(r, 128)), dim3(128), 0, stream, rois, scores, clses, r, decoded, pix,
+                       k, roi_pix);
+    RR_CHECK_LAUNCH("rr_roi_provenance");
+    return RR_OK;
+}
+
+extern "C" int rr_proposal_bwd(const float *droi, const float *rois, const int *roi_pix, int r, const float *wh, int b, int h,
+                               int w, float *dwh, float *doff, hipStream_t stream)
+{
+    RR_CHECK_ARG(b > 0 && h > 0 && w > 0, "rr_proposal_bwd: bad dims");
+    hipMemsetAsync(dwh, 0, sizeof(float) * (size_t)b * h * w * 2, stream);
+    hipMemsetAsync(doff, 0, sizeof(float) * (size_t)b * h * w * 2, stream);
+    if (r > 0)
+        hipLaunchKernelGGL(proposal_bwd_kernel, dim3(rr_cdiv(r, 128)), dim3(128), 0, stream, droi, rois, roi_pix, r, wh,
+                           (long)h * w, dwh, doff);
+    RR_CHECK_LAUNCH("rr_proposal_bwd");
     return RR_OK;
 }
 

@@ -179,6 +179,30 @@ __global__ __launch_bounds__(T) void stage2_loss_kernel(const float *rois, const
     block_add3(ls, 0.0, 0.0, loss);
 }
 
+// d loss / d roi: the reference lets the smooth-L1 gradient flow into the TARGETS as well
+// (rrnet_operator.py:82 with the hard-NMS-selected, still differentiable boxes of models/rrnet.py:70).
+// tgt = ((gcx-ecx)/ew, (gcy-ecy)/eh, log(gw/ew), log(gh/eh)), e = roi*scale, ew = ex2-ex1+1, ecx = ex1 + ew/2.
+__global__ __launch_bounds__(T) void stage2_droi_kernel(const float *rois, const float *tgt, const int *pos,
+                                                        const float *dreg_unit, int R, float scale, float *droi)
+{
+    const int r = blockIdx.x * T + threadIdx.x;
+    if (r >= R) return;
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;
+    if (pos[r]) {
+        const float *q = rois + (long)r * 5;
+        const float ew = (q[3] - q[1]) * scale + 1.0f, eh = (q[4] - q[2]) * scale + 1.0f;
+        const float *t = tgt + (long)r * 4;
+        const float *d = dreg_unit + (long)r * 4;
+        const float u0 = -d[0], u1 = -d[1], u2 = -d[2], u3 = -d[3];     // dL/dtgt = -dL/dreg
+        g0 = (u0 * (t[0] - 0.5f) + u2) / ew;      // d/dex1
+        g2 = (u0 * (-t[0] - 0.5f) - u2) / ew;     // d/dex2
+        g1 = (u1 * (t[1] - 0.5f) + u3) / eh;
+        g3 = (u1 * (-t[1] - 0.5f) - u3) / eh;
+    }
+    float *o = droi + (long)r * 4;
+    o[0] = g0 * scale; o[1] = g1 * scale; o[2] = g2 * scale; o[3] = g3 * scale;
+}
+
 }  // namespace
 
 static inline int grid_for(long n) { long b = (n + T - 1) / T; return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b)); }
@@ -224,7 +248,7 @@ extern "C" int rr_regl1_bwd(const float *pred, const float *mask, const float *i
 
 extern "C" int rr_stage2_loss(const float *rois, const float *reg, int r, const float *gt, int b, int g, int gstride,
                               float scale, float *tgt, int *pos, int *npos, double *loss, float *dreg_unit,
-                              hipStream_t stream)
+                              float *droi_unit, hipStream_t stream)
 {
     RR_CHECK_ARG(gstride >= 4 && b > 0, "rr_stage2_loss: bad dims");
     hipMemsetAsync(npos, 0, sizeof(int) * b, stream);
@@ -235,6 +259,9 @@ extern "C" int rr_stage2_loss(const float *rois, const float *reg, int r, const 
                            pos, npos);
         hipLaunchKernelGGL(stage2_loss_kernel, dim3(grid_for((long)r * 4)), dim3(T), 0, stream, rois, reg, tgt, pos, npos, r,
                            b, loss, dreg_unit);
+        if (droi_unit)
+            hipLaunchKernelGGL(stage2_droi_kernel, dim3(rr_cdiv(r, T)), dim3(T), 0, stream, rois, tgt, pos, dreg_unit, r, scale,
+                               droi_unit);
     }
     RR_CHECK_LAUNCH("rr_stage2_loss");
     return RR_OK;

@@ -349,20 +349,50 @@ def reg_l1_loss(pred, mask, ind, target):
 
 class _Stage2Loss(torch.autograd.Function):
     """box_iou + positive matching + generate_bbox_target + smooth-L1 of
-    operators/rrnet_operator.py:63-102 as two small kernels (no per-image host loop, no sync)."""
+    operators/rrnet_operator.py:63-102 as small kernels (no per-image host loop, no sync).  Like the
+    reference's F.smooth_l1_loss it differentiates its targets too: when `rois` carries a graph (hard-NMS
+    proposals, models/rrnet.py:70) dloss/drois is returned."""
 
     @staticmethod
     def forward(ctx, reg, rois, gt_xyxy, scale):
         reg = reg.contiguous()
-        loss, dreg, _tgt, _pos, _npos = ops.stage2_loss(rois.contiguous(), reg, gt_xyxy.contiguous(), scale)
-        ctx.save_for_backward(dreg)
+        want = rois.requires_grad
+        loss, dreg, _tgt, _pos, _npos, droi = ops.stage2_loss(rois.detach().contiguous(), reg, gt_xyxy.contiguous(),
+                                                             scale, want_droi=want)
+        ctx.save_for_backward(dreg, droi)
         return loss[0].float()
 
     @staticmethod
     def backward(ctx, gout):
-        (dreg,) = ctx.saved_tensors
-        return dreg * gout, None, None, None
+        dreg, droi = ctx.saved_tensors
+        d_rois = None
+        if droi is not None:
+            d_rois = torch.zeros((droi.shape[0], 5), dtype=droi.dtype, device=droi.device)
+            d_rois[:, 1:] = droi * gout
+        return dreg * gout, d_rois, None, None
 
 
 def stage2_reg_loss(reg, rois, gt_xyxy, scale):
-    return _Stage2Loss.apply(reg, rois.detach(), gt_xyxy, float(scale))
+    return _Stage2Loss.apply(reg, rois, gt_xyxy, float(scale))
+
+
+class _Proposals(torch.autograd.Function):
+    """Makes the packed stage-1 boxes a differentiable function of the last stack's wh / offset maps, as they
+    are in the reference's hard-NMS path (transform_bbox's arithmetic + index selects).  Forward = identity
+    on the precomputed RoIs; backward = scatter of d roi through the box assembly."""
+
+    @staticmethod
+    def forward(ctx, wh, offset, rois, roi_pix):
+        ctx.save_for_backward(ops.to_nhwc(wh), rois, roi_pix)
+        return rois.clone()
+
+    @staticmethod
+    def backward(ctx, d_rois):
+        wh, rois, roi_pix = ctx.saved_tensors
+        droi = d_rois[:, 1:].contiguous()
+        dwh, doff = ops.proposal_bwd(droi, rois, roi_pix, wh)
+        return dwh, doff, None, None
+
+
+def differentiable_proposals(wh, offset, rois, roi_pix):
+    return _Proposals.apply(wh, offset, rois, roi_pix)

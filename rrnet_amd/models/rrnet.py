@@ -18,15 +18,15 @@ from rrnet_amd.ext.nms.nms_wrapper import soft_nms_segments
 from rrnet_amd.utils.model_tools import get_backbone
 
 
-def stage1_proposals(hm, wh, offset, k, num_classes, nms_type='nms', nms_per_class=True, peak_filter=False):
+def stage1_proposals(hm, wh, offset, k, num_classes, nms_type='nms', nms_per_class=True, peak_filter=False,
+                     want_provenance=False):
     """Decode + stage-1 NMS for the whole batch (models/rrnet.py:31-49, 56-138).
-    -> bxyxys [R,5], scores [R], clses [R], all detached device tensors."""
+    -> bxyxys [R,5], scores [R], clses [R] (detached device tensors) and, on request, the heat-map pixel
+    every RoI was decoded from (for the backward of the box assembly)."""
     with torch.no_grad():
         hm, wh, offset = ops.to_nhwc(hm.detach()), ops.to_nhwc(wh.detach()), ops.to_nhwc(offset.detach())
-        if peak_filter:     # optional `_ctnet_nms` semantics; the reference's decode never applies it
-            boxes = ops.decode_topk(ops.peak3x3(hm), wh, offset, k, is_logits=False)
-        else:
-            boxes = ops.decode_topk(hm, wh, offset, k, is_logits=True)
+        src = ops.peak3x3(hm) if peak_filter else hm   # optional `_ctnet_nms`; the reference's decode never applies it
+        boxes, pix = ops.decode_topk(src, wh, offset, k, is_logits=not peak_filter, want_pix=True)
         b = boxes.shape[0]
         if nms_per_class:
             grouped, seg_off = ops.group_by_class(boxes, num_classes)
@@ -41,7 +41,8 @@ def stage1_proposals(hm, wh, offset, k, num_classes, nms_type='nms', nms_per_cla
         else:
             n_out = ops.hard_nms_segments(rows, seg_off, k, 0.7)
         rois, scores, clses, _ = ops.pack_segments(rows, seg_off, n_out, segs_per_image)
-    return rois, scores, clses
+        roi_pix = ops.roi_provenance(rois, scores, clses, boxes, pix) if want_provenance else None
+    return (rois, scores, clses, roi_pix) if want_provenance else (rois, scores, clses)
 
 
 class RRNet(nn.Module):
@@ -61,8 +62,16 @@ class RRNet(nn.Module):
         feats = self.backbone(x)
         last_a, last_b = RF.fanout(feats[-1], 2)
         hms, whs, offsets = self.forward_stage1(list(feats[:-1]) + [last_a])
-        bxyxys, scores, clses = stage1_proposals(hms[-1], whs[-1], offsets[-1], k, self.num_classes,
-                                                 self.nms_type, self.nms_per_class)
+        # hard NMS keeps the boxes attached to the graph in the reference (models/rrnet.py:69-70: index select
+        # of a differentiable tensor); the soft-NMS path detaches them (:65)
+        diff = torch.is_grad_enabled() and self.nms_type != 'soft_nms' and whs[-1].requires_grad
+        if diff:
+            bxyxys, scores, clses, roi_pix = stage1_proposals(hms[-1], whs[-1], offsets[-1], k, self.num_classes,
+                                                              self.nms_type, self.nms_per_class, want_provenance=True)
+            bxyxys = RF.differentiable_proposals(whs[-1], offsets[-1], bxyxys, roi_pix)
+        else:
+            bxyxys, scores, clses = stage1_proposals(hms[-1], whs[-1], offsets[-1], k, self.num_classes,
+                                                     self.nms_type, self.nms_per_class)
         roi_feat = RF.roi_align(RF.relu(last_b), bxyxys, (3, 3))
         stage2_reg = self.forward_stage2(roi_feat)
         return hms, whs, offsets, stage2_reg, bxyxys, scores, clses

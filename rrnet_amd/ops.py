@@ -343,8 +343,9 @@ def regl1_bwd(pred, mask, ind, target, sums, gout, gscale=1.0):
     return d
 
 
-def stage2_loss(rois, reg, gt_xyxy, scale):
-    """rois [R,5], reg [R,4], gt [B,G,>=4] (xyxy) -> loss (double[3], [0] is the loss), dreg_unit [R,4], pos, npos."""
+def stage2_loss(rois, reg, gt_xyxy, scale, want_droi=False):
+    """rois [R,5], reg [R,4], gt [B,G,>=4] (xyxy) -> loss (double[3], [0] is the loss), dreg_unit [R,4], tgt, pos,
+    npos, droi_unit [R,4] | None."""
     r = rois.shape[0]
     b, g, gs = gt_xyxy.shape
     dev = rois.device
@@ -353,21 +354,40 @@ def stage2_loss(rois, reg, gt_xyxy, scale):
     npos = torch.empty(b, dtype=torch.int32, device=dev)
     loss = torch.empty(3, dtype=torch.float64, device=dev)
     dreg = torch.zeros((r, 4), dtype=torch.float32, device=dev)
+    droi = torch.zeros((r, 4), dtype=torch.float32, device=dev) if want_droi else None
     _C.check(_C.fn("rr_stage2_loss")(_C.ptr(rois), _C.ptr(reg), r, _C.ptr(gt_xyxy), b, g, gs, float(scale), _C.ptr(tgt),
-                                     _C.ptr(pos), _C.ptr(npos), _C.ptr(loss), _C.ptr(dreg), _C.stream()), "rr_stage2_loss")
-    return loss, dreg, tgt[:r], pos[:r], npos
+                                     _C.ptr(pos), _C.ptr(npos), _C.ptr(loss), _C.ptr(dreg), _C.ptr(droi), _C.stream()),
+             "rr_stage2_loss")
+    return loss, dreg, tgt[:r], pos[:r], npos, droi
 
 
 # ---------------------------------------------------------------------------------------------
 # decode / NMS / RoIAlign
 # ---------------------------------------------------------------------------------------------
-def decode_topk(hm, wh, off, k, is_logits=True):
+def decode_topk(hm, wh, off, k, is_logits=True, want_pix=False):
     assert is_nhwc(hm) and is_nhwc(wh) and is_nhwc(off)
     b, c, h, w = hm.shape
     out = torch.empty((b, k, 6), dtype=torch.float32, device=hm.device)
+    pix = torch.empty((b, k), dtype=torch.int32, device=hm.device) if want_pix else None
     _C.check(_C.fn("rr_decode_topk")(_C.ptr(hm), int(is_logits), _C.ptr(wh), _C.ptr(off), b, h, w, c, k, _C.ptr(out),
-                                     _C.stream()), "rr_decode_topk")
-    return out
+                                     _C.ptr(pix), _C.stream()), "rr_decode_topk")
+    return (out, pix) if want_pix else out
+
+
+def roi_provenance(rois, scores, clses, decoded, pix):
+    r = rois.shape[0]
+    roi_pix = torch.full((max(r, 1),), -1, dtype=torch.int32, device=rois.device)
+    _C.check(_C.fn("rr_roi_provenance")(_C.ptr(rois), _C.ptr(scores), _C.ptr(clses), r, _C.ptr(decoded), _C.ptr(pix),
+                                        decoded.shape[1], _C.ptr(roi_pix), _C.stream()), "rr_roi_provenance")
+    return roi_pix[:r]
+
+
+def proposal_bwd(droi, rois, roi_pix, wh):
+    b, _, h, w = wh.shape
+    dwh, doff = empty_nhwc(b, 2, h, w, wh.device), empty_nhwc(b, 2, h, w, wh.device)
+    _C.check(_C.fn("rr_proposal_bwd")(_C.ptr(droi), _C.ptr(rois), _C.ptr(roi_pix), rois.shape[0], _C.ptr(wh), b, h, w,
+                                      _C.ptr(dwh), _C.ptr(doff), _C.stream()), "rr_proposal_bwd")
+    return dwh, doff
 
 
 def peak3x3(hm):

@@ -291,6 +291,16 @@ def g6_stage2():
     s2_loss.backward()
     d.update(crit_bxyxy=bxyxy, crit_s2_reg=s2_reg, crit_scores=scores, crit_clses=clses, crit_gt_annos=gt_annos,
              crit_s2_loss=s2_loss, crit_s2_reg_grad=s2_reg.grad, tv_unpinned=1)
+    # the same criterion with the boxes attached to the graph (what the hard-NMS path of models/rrnet.py:69-70
+    # hands over): F.smooth_l1_loss differentiates its target, so d loss / d boxes is non-zero
+    bx = bxyxy.clone().requires_grad_()
+    s2b = s2_reg.detach().clone().requires_grad_()
+    outs_b = (zeros, z2[:2], z2[2:], s2b, bx, scores, clses)
+    targets_b = (torch.zeros(bs, 10, hf, hf), torch.zeros(bs, 4, 2), torch.zeros(bs, 4, 1), torch.zeros(bs, 4, 2),
+                 torch.zeros(bs, 4, 1), gt_annos.clone())
+    _, _, _, s2_loss_b = RRNetOperator.criterion(ns, outs_b, targets_b)
+    s2_loss_b.backward()
+    d.update(crit_bxyxy_grad=bx.grad, crit_s2_reg_grad_attached=s2b.grad)
     with torch.no_grad():
         for b in range(bs):
             outs_b = (None, None, None, s2_reg.detach(), bxyxy.clone(), scores, clses)
