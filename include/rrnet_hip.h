@@ -194,6 +194,28 @@ int rr_roi_align_fwd(const float *feat, const float *rois, int r, int h, int w, 
 int rr_roi_align_bwd(const float *dout, const float *rois, int r, int b, int h, int w, int c, int ph, int pw,
                      float spatial_scale, int sampling_ratio, float *dfeat, hipStream_t stream);
 
+/* ---- Modulated deformable convolution (DCNv2) -- BASELINE config 4 ------------------------- *
+ * Replaces ext/dcn: `dcn_v2_forward` / `dcn_v2_backward` of src/vision.cpp:3-8 (src/cuda/dcn_v2_cuda.cu:42-172,
+ * 206-335, kernels src/cuda/dcn_v2_im2col_cuda.cu:125-327), bound by ext/dcn/dcn_v2.py:25,40.
+ * x NHWC [n,h,w,c]; offset NHWC [n,p,q,2*dg*r*s] (per deformable group: interleaved (dh,dw) per tap);
+ * mask NHWC [n,p,q,dg*r*s]; w OHWI [k][r][s][c]; y NHWC [n,p,q,k].
+ * rr_dcn_fwd is one fused gather-GEMM (no column buffer).  The backward is assembled by the host layer:
+ *   col  = rr_dcn_im2col(x, offset, mask)            [M, r*s*c], M = n*p*q   (rr_dcn_col_bytes)
+ *   dw  += rr_conv_wgrad(col as [1,M,1,r*s*c], dy as [1,M,1,k])              (1x1 layer)
+ *   dcol = rr_conv_dgrad(dy, w as [k, r*s*c, 1, 1])
+ *   rr_dcn_col2im(x, offset, mask, dcol) -> dx (zeroed + float atomics), doffset, dmask
+ * Requires c % 4 == 0, c % dg == 0 and (dg == 1 or (c/dg) % 32 == 0). */
+int rr_dcn_fwd(const float *x, const float *offset, const float *mask, const float *w, const float *bias, float *y,
+               int n, int h, int wd, int c, int k, int r, int s, int stride, int pad_h, int pad_w, int dilation,
+               int deformable_groups, hipStream_t stream);
+size_t rr_dcn_col_bytes(int n, int h, int wd, int c, int r, int s, int stride, int pad_h, int pad_w, int dilation);
+int rr_dcn_im2col(const float *x, const float *offset, const float *mask, float *col, int n, int h, int wd, int c,
+                  int r, int s, int stride, int pad_h, int pad_w, int dilation, int deformable_groups,
+                  hipStream_t stream);
+int rr_dcn_col2im(const float *x, const float *offset, const float *mask, const float *dcol, float *dx,
+                  float *doffset, float *dmask, int n, int h, int wd, int c, int r, int s, int stride, int pad_h,
+                  int pad_w, int dilation, int deformable_groups, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

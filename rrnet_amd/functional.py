@@ -396,3 +396,52 @@ class _Proposals(torch.autograd.Function):
 
 def differentiable_proposals(wh, offset, rois, roi_pix):
     return _Proposals.apply(wh, offset, rois, roi_pix)
+
+
+# ---------------------------------------------------------------------------------------------
+# DCNv2 (ext/dcn/dcn_v2.py:16-52)
+# ---------------------------------------------------------------------------------------------
+class _DCNv2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, input, offset, mask, weight, bias, stride, padding, dilation, deformable_groups):
+        x, off, m, w = ops.to_nhwc(input), ops.to_nhwc(offset), ops.to_nhwc(mask), ops.to_nhwc(weight)
+        ctx.cfg = (int(stride), tuple(padding), int(dilation), int(deformable_groups))
+        ctx.save_for_backward(x, off, m, w)
+        ctx.params = (weight, bias)
+        return ops.dcn_fwd(x, off, m, w, bias, *ctx.cfg)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, off, m, w = ctx.saved_tensors
+        stride, pad, dil, dg = ctx.cfg
+        weight, bias = ctx.params
+        dy = ops.to_nhwc(dy)
+        k, c, r, s = w.shape
+        mtot = dy.shape[0] * dy.shape[2] * dy.shape[3]
+        dy1 = dy.permute(0, 2, 3, 1).reshape(1, mtot, 1, k).permute(0, 3, 1, 2)            # [1,k,M,1] view
+        w1 = w.permute(0, 2, 3, 1).reshape(k, 1, 1, r * s * c).permute(0, 3, 1, 2)          # [k, r*s*c, 1, 1] view
+        # weight gradient: columns (materialised, as in the reference) x dy
+        col = ops.dcn_im2col(x, off, m, r, s, stride, pad, dil, dg)
+        w_t = _grad_target(weight)
+        dw = w_t if w_t is not None else ops.zeros_nhwc(*weight.shape, device=x.device)
+        dw1 = dw.permute(0, 2, 3, 1).reshape(k, 1, 1, r * s * c).permute(0, 3, 1, 2)
+        ops.conv_wgrad(col, dy1, dw1, 1, (0, 0))
+        del col
+        # column gradient, then d input / d offset / d mask
+        dcol = ops.conv_dgrad(dy1, w1, (1, r * s * c, mtot, 1), 1, (0, 0))
+        dx, doff, dmask = ops.dcn_col2im(x, off, m, dcol, r, s, stride, pad, dil, dg)
+        db = None
+        if bias is not None:
+            b_t = _grad_target(bias)
+            tgt = b_t if b_t is not None else torch.zeros_like(bias)
+            ops.bias_relu_bwd(dy, None, tgt)
+            db = None if b_t is not None else tgt
+        return dx, doff, dmask, (None if w_t is not None else dw), db, None, None, None, None
+
+
+def dcn_v2_conv(input, offset, mask, weight, bias, stride, padding, dilation, deformable_groups):
+    """Reference signature (ext/dcn/dcn_v2.py:52).  stride / dilation: int or equal pair; padding: int or pair."""
+    st = stride if isinstance(stride, int) else stride[0]
+    dl = dilation if isinstance(dilation, int) else dilation[0]
+    pd = (padding, padding) if isinstance(padding, int) else tuple(padding)
+    return _DCNv2.apply(input, offset, mask, weight, bias, st, pd, dl, deformable_groups)

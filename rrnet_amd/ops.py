@@ -453,3 +453,38 @@ def roi_align_bwd(dout, rois, feat_shape, out_size, spatial_scale=1.0, sampling_
     _C.check(_C.fn("rr_roi_align_bwd")(_C.ptr(dout), _C.ptr(rois), r, b, h, w, c, ph, pw, float(spatial_scale),
                                        int(sampling_ratio), _C.ptr(dfeat), _C.stream()), "rr_roi_align_bwd")
     return dfeat
+
+
+# ---------------------------------------------------------------------------------------------
+# DCNv2
+# ---------------------------------------------------------------------------------------------
+def dcn_fwd(x, offset, mask, w, bias, stride, pad, dilation, dg):
+    assert is_nhwc(x) and is_nhwc(offset) and is_nhwc(mask) and is_nhwc(w)
+    n, c, h, wd = x.shape
+    k, _, r, s = w.shape
+    p, q = offset.shape[2], offset.shape[3]
+    y = empty_nhwc(n, k, p, q, x.device)
+    _C.check(_C.fn("rr_dcn_fwd")(_C.ptr(x), _C.ptr(offset), _C.ptr(mask), _C.ptr(w), _C.ptr(bias), _C.ptr(y), n, h, wd,
+                                 c, k, r, s, stride, pad[0], pad[1], dilation, dg, _C.stream()), "rr_dcn_fwd")
+    return y
+
+
+def dcn_im2col(x, offset, mask, r, s, stride, pad, dilation, dg):
+    n, c, h, wd = x.shape
+    m = offset.shape[0] * offset.shape[2] * offset.shape[3]
+    col = torch.empty((1, m, 1, r * s * c), dtype=torch.float32, device=x.device).permute(0, 3, 1, 2)
+    _C.check(_C.fn("rr_dcn_im2col")(_C.ptr(x), _C.ptr(offset), _C.ptr(mask), _C.ptr(col), n, h, wd, c, r, s, stride,
+                                    pad[0], pad[1], dilation, dg, _C.stream()), "rr_dcn_im2col")
+    return col                                           # logical [1, r*s*c, M, 1], memory [M][r*s*c]
+
+
+def dcn_col2im(x, offset, mask, dcol, r, s, stride, pad, dilation, dg):
+    n, c, h, wd = x.shape
+    dx = empty_nhwc(n, c, h, wd, x.device)
+    doff = torch.empty_like(offset)
+    dmask = torch.empty_like(mask)
+    assert doff.stride() == offset.stride() and dmask.stride() == mask.stride()
+    _C.check(_C.fn("rr_dcn_col2im")(_C.ptr(x), _C.ptr(offset), _C.ptr(mask), _C.ptr(dcol), _C.ptr(dx), _C.ptr(doff),
+                                    _C.ptr(dmask), n, h, wd, c, r, s, stride, pad[0], pad[1], dilation, dg,
+                                    _C.stream()), "rr_dcn_col2im")
+    return dx, doff, dmask
