@@ -161,10 +161,19 @@ def main():
             if dom in summ:
                 d = summ[dom]
                 achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+                # HBM traffic per launch of this kernel: last committed rocprofv3 PMC pass over this same command
+                # (tools/prof_bench.sh -> tools/pmc_traffic.py -> profiles/r01_traffic_pmc.json); PMC counters
+                # cannot be read from inside the process
+                traffic = None
+                tpath = os.path.join(ROOT, "profiles", "r01_traffic_pmc.json")
+                if os.path.exists(tpath) and a.backbone == "hourglass" and a.size == 1024 and a.batch == 8:
+                    with open(tpath) as f:
+                        traffic = json.load(f).get("conv_igemm_kernel<128, 0, false, 32, true>", {}).get("traffic_bytes_per_launch")
                 out["roofline"] = {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
                                    "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
-                                   "traffic": None,
-                                   "kernel": "conv_igemm_kernel<128,0,false> (implicit-GEMM fprop, v_mfma_f32_32x32x2_f32)",
+                                   "traffic": traffic,
+                                   "algorithmic_bytes_per_launch": round(timer.bytes.get(dom, 0.0) / d["launches"]),
+                                   "kernel": "conv_igemm_kernel<128, 0, false, 32, true> (implicit-GEMM fprop, v_mfma_f32_32x32x2_f32)",
                                    "launches": d["launches"], "avg_launch_ms": round(d["ms"] / d["launches"], 4),
                                    "algorithmic_gflop_per_launch": round(d["flops"] / d["launches"] / 1e9, 3)}
             out["kernels"] = {k: {"launches": v["launches"], "ms": round(v["ms"], 2),

@@ -15,8 +15,10 @@ class KernelTimer:
 
     def __init__(self):
         self.records = []      # (kernel name, flops, start event, end event)
+        self.bytes = {}        # kernel name -> algorithmic bytes (operands read once + result written once)
 
-    def launch(self, name, flops, fn, detail=None):
+    def launch(self, name, flops, fn, detail=None, nbytes=0.0):
+        self.bytes[name] = self.bytes.get(name, 0.0) + nbytes
         s = torch.cuda.Event(enable_timing=True)
         e = torch.cuda.Event(enable_timing=True)
         s.record()
@@ -49,10 +51,10 @@ class KernelTimer:
 TIMER = None
 
 
-def _timed(name, flops, fn, detail=None):
+def _timed(name, flops, fn, detail=None, nbytes=0.0):
     if TIMER is None:
         return fn()
-    return TIMER.launch(name, flops, fn, detail)
+    return TIMER.launch(name, flops, fn, detail, nbytes)
 
 
 def _igemm_name(kind, n_gemm, scalar):
@@ -102,7 +104,7 @@ def conv_fprop(x, w, bias=None, stride=1, pad=(0, 0), relu=False, want_stats=Fal
     _C.check(_timed(_igemm_name("fprop", k, c % 4 != 0), flops,
                     lambda: f(_C.ptr(x), _C.ptr(w), _C.ptr(bias), _C.ptr(y), _C.ptr(slab), n, h, wd, c, k, r, s,
                               stride, pad[0], pad[1], int(relu), _C.stream()),
-                    (n, h, wd, c, k, r, s, stride)), "rr_conv_fprop")
+                    (n, h, wd, c, k, r, s, stride), 4.0 * (x.numel() + y.numel() + w.numel())), "rr_conv_fprop")
     return (y, slab) if want_stats else y
 
 
