@@ -82,7 +82,9 @@ int rr_conv_wgrad(const float *x, const float *dy, float *dw, int n, int h, int 
  * mean/invstd (saved for backward), scale/shift (for rr_bn_apply), running stats updated with
  * `momentum` and the unbiased variance.
  * rr_bn_apply: out = relu?(y*scale+shift [+ res | + res*res_scale+res_shift]).
- * rr_bn_bwd_reduce: sums[2][c] = per-channel sum(dy), sum(dy*xhat), dy = dz*(z>0) if z.
+ * rr_bn_bwd_reduce: sums[2][c] = per-channel sum(dy), sum(dy*xhat), dy = dz*(z>0) if z; with z NULL and
+ *   mask_scale/mask_shift given the ReLU mask is recomputed as (y*scale+shift > 0) — layers without a
+ *   residual input need not re-read their output.
  * rr_bn_bwd_apply: dx = gamma*invstd*(dy - sums0/count - xhat*sums1/count); g_out (optional)
  *   receives dy for the residual branch; dgamma/dbeta (optional) are accumulated from sums.
  *   `count_dev` (optional, both finalize and bwd_apply): sample count read from device memory
@@ -103,9 +105,11 @@ int rr_bn_apply(const float *y, const float *scale, const float *shift, const fl
                 const float *res_scale, const float *res_shift, float *out, long total, int c, int relu,
                 hipStream_t stream);
 int rr_bn_bwd_reduce(const float *dz, const float *z, const float *y, const float *mean,
-                     const float *invstd, double *sums, long npix, int c, hipStream_t stream);
+                     const float *invstd, const float *mask_scale, const float *mask_shift, double *sums,
+                     long npix, int c, hipStream_t stream);
 int rr_bn_bwd_apply(const float *dz, const float *z, const float *y, const float *mean,
-                    const float *invstd, const float *gamma, const double *sums, double count,
+                    const float *invstd, const float *gamma, const float *mask_scale, const float *mask_shift,
+                    const double *sums, double count,
                     const double *count_dev, float *dx, float *g_out, float *dgamma, float *dbeta, long total,
                     int c, hipStream_t stream);
 int rr_relu_fwd(const float *x, float *out, long total, hipStream_t stream);

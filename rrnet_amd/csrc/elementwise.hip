@@ -115,6 +115,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_apply_kernel(const f32x4 *y, co
 // double per channel per workgroup to sums[2][C].
 __global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_kernel(const float *dz, const float *z, const float *y,
                                                                    const float *mean, const float *invstd,
+                                                                   const float *mscale, const float *mshift,
                                                                    double *sums, long npix, int C)
 {
     __shared__ double red[2][EW_THREADS * 4];
@@ -128,6 +129,8 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_kernel(const float *
     if (pl < lanes) {
         const f32x4 mu = *reinterpret_cast<const f32x4 *>(mean + cq * 4);
         const f32x4 is = *reinterpret_cast<const f32x4 *>(invstd + cq * 4);
+        f32x4 msc = {0.f, 0.f, 0.f, 0.f}, msh = msc;
+        if (mscale) { msc = *reinterpret_cast<const f32x4 *>(mscale + cq * 4); msh = *reinterpret_cast<const f32x4 *>(mshift + cq * 4); }
         const long step = (long)gridDim.x * lanes;
         for (long p0 = (long)blockIdx.x * lanes + pl; p0 < npix; p0 += step * 8) {
             f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
@@ -137,12 +140,17 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_kernel(const float *
                 if (p < npix) {
                     const long off = p * C + cq * 4;
                     f32x4 g = *reinterpret_cast<const f32x4 *>(dz + off);
+                    const f32x4 yy = *reinterpret_cast<const f32x4 *>(y + off);
                     if (z) {
                         const f32x4 zz = *reinterpret_cast<const f32x4 *>(z + off);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) g[e] = zz[e] > 0.f ? g[e] : 0.f;
+                    } else if (mscale) {      // ReLU mask recomputed from y: z = relu(y*scale+shift), no residual
+                        const f32x4 zz = yy * msc + msh;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) g[e] = zz[e] > 0.f ? g[e] : 0.f;
                     }
-                    const f32x4 xh = (*reinterpret_cast<const f32x4 *>(y + off) - mu) * is;
+                    const f32x4 xh = (yy - mu) * is;
                     s1 += g;
                     s2 += g * xh;
                 }
@@ -169,7 +177,8 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_kernel(const float *
 // gradient, for the residual branch); workgroup 0 also accumulates dgamma / dbeta.
 __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(const f32x4 *dz, const f32x4 *z, const f32x4 *y,
                                                                   const float *mean, const float *invstd,
-                                                                  const float *gamma, const double *sums, double count_h,
+                                                                  const float *gamma, const float *mscale, const float *mshift,
+                                                                  const double *sums, double count_h,
                                                                   const double *count_d, f32x4 *dx, f32x4 *g_out,
                                                                   float *dgamma, float *dbeta, long n4, int C)
 {
@@ -185,15 +194,20 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(const f32x4 *d
     for (long i = (long)blockIdx.x * EW_THREADS + threadIdx.x; i < n4; i += (long)gridDim.x * EW_THREADS) {
         const int c = (int)(i % C4) * 4;
         f32x4 g = dz[i];
+        const f32x4 yy = y[i];
         if (z) {
             const f32x4 zz = z[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = zz[e] > 0.f ? g[e] : 0.f;
+        } else if (mscale) {
+            const f32x4 zz = yy * *reinterpret_cast<const f32x4 *>(mscale + c) + *reinterpret_cast<const f32x4 *>(mshift + c);
 #pragma unroll
             for (int e = 0; e < 4; ++e) g[e] = zz[e] > 0.f ? g[e] : 0.f;
         }
         if (g_out) g_out[i] = g;
         const f32x4 mu = *reinterpret_cast<const f32x4 *>(mean + c), is = *reinterpret_cast<const f32x4 *>(invstd + c);
         const f32x4 ga = *reinterpret_cast<const f32x4 *>(gamma + c);
-        const f32x4 xh = (y[i] - mu) * is;
+        const f32x4 xh = (yy - mu) * is;
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -496,7 +510,8 @@ extern "C" int rr_bn_apply(const float *y, const float *scale, const float *shif
 }
 
 extern "C" int rr_bn_bwd_reduce(const float *dz, const float *z, const float *y, const float *mean,
-                                const float *invstd, double *sums, long npix, int c, hipStream_t stream)
+                                const float *invstd, const float *mask_scale, const float *mask_shift, double *sums,
+                                long npix, int c, hipStream_t stream)
 {
     RR_CHECK_ARG(c % 4 == 0 && c <= 1024, "rr_bn_bwd_reduce: C=%d must be a multiple of 4 and <= 1024", c);
     hipMemsetAsync(sums, 0, sizeof(double) * 2 * c, stream);
@@ -505,21 +520,22 @@ extern "C" int rr_bn_bwd_reduce(const float *dz, const float *z, const float *y,
     long blocks = (npix + lanes * 8 - 1) / (lanes * 8);
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((int)blocks), dim3(EW_THREADS), 0, stream, dz, z, y, mean, invstd, sums,
-                       npix, c);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((int)blocks), dim3(EW_THREADS), 0, stream, dz, z, y, mean, invstd, mask_scale,
+                       mask_shift, sums, npix, c);
     RR_CHECK_LAUNCH("rr_bn_bwd_reduce");
     return RR_OK;
 }
 
 extern "C" int rr_bn_bwd_apply(const float *dz, const float *z, const float *y, const float *mean,
-                               const float *invstd, const float *gamma, const double *sums, double count,
+                               const float *invstd, const float *gamma, const float *mask_scale,
+                               const float *mask_shift, const double *sums, double count,
                                const double *count_dev, float *dx, float *g_out, float *dgamma, float *dbeta,
                                long total, int c, hipStream_t stream)
 {
     RR_CHECK_ARG(c % 4 == 0 && total % c == 0, "rr_bn_bwd_apply: C=%d must be a multiple of 4", c);
     const long n4 = total / 4;
     EW_LAUNCH(bn_bwd_apply_kernel, n4, stream, (const f32x4 *)dz, (const f32x4 *)z, (const f32x4 *)y, mean, invstd, gamma,
-              sums, count, count_dev, (f32x4 *)dx, (f32x4 *)g_out, dgamma, dbeta, n4, c);
+              mask_scale, mask_shift, sums, count, count_dev, (f32x4 *)dx, (f32x4 *)g_out, dgamma, dbeta, n4, c);
     RR_CHECK_LAUNCH("rr_bn_bwd_apply");
     return RR_OK;
 }

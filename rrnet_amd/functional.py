@@ -59,7 +59,11 @@ class _ConvBnAct(torch.autograd.Function):
         res = ops.to_nhwc(residual) if residual is not None else None
         z = ops.bn_apply(y, scale, shift, res, relu)
         if bn.training:
-            ctx.save_for_backward(x, wc, y, z if relu else None, mean, invstd, gamma, cnt_dev)
+            # ReLU mask: layers with a residual need their output z; the others recompute it from y (one tensor
+            # read less in each of the two backward passes)
+            remask = relu and residual is None
+            ctx.save_for_backward(x, wc, y, z if (relu and not remask) else None, mean, invstd, gamma, cnt_dev,
+                                  scale if remask else None, shift if remask else None)
         ctx.cfg = (stride, pad, relu, count, sync, residual is not None)
         ctx.params = (w, gamma, beta)
         ctx.xshape = tuple(x.shape)
@@ -67,12 +71,12 @@ class _ConvBnAct(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dz):
-        x, wc, y, z, mean, invstd, gamma, cnt_dev = ctx.saved_tensors
+        x, wc, y, z, mean, invstd, gamma, cnt_dev, msc, msh = ctx.saved_tensors
         stride, pad, relu, count, sync, has_res = ctx.cfg
         w, gamma_p, beta_p = ctx.params
         dz = ops.to_nhwc(dz)
         k = y.shape[1]
-        sums = ops.bn_bwd_reduce(dz, z, y, mean, invstd)
+        sums = ops.bn_bwd_reduce(dz, z, y, mean, invstd, mask_scale=msc, mask_shift=msh)
         dg_t, db_t = _grad_target(gamma_p), _grad_target(beta_p)
         ret_dg = ret_db = None
         fused_affine = dg_t is not None and db_t is not None and not sync
@@ -89,7 +93,7 @@ class _ConvBnAct(torch.autograd.Function):
             dist.all_reduce(sums)
         want_g = has_res and relu
         dy, g = ops.bn_bwd_apply(dz, z, y, mean, invstd, gamma, sums, count, want_g,
-                                 dg_t if fused_affine else None, db_t if fused_affine else None, cnt_dev)
+                                 dg_t if fused_affine else None, db_t if fused_affine else None, cnt_dev, msc, msh)
         dx = ops.conv_dgrad(dy, wc, ctx.xshape, stride, pad) if ctx.needs_input_grad[0] else None
         w_t = _grad_target(w)
         ret_dw = None

@@ -205,22 +205,24 @@ def bn_apply(y, scale, shift, residual=None, relu=False, res_scale=None, res_shi
     return out
 
 
-def bn_bwd_reduce(dz, z, y, mean, invstd, extra=0):
+def bn_bwd_reduce(dz, z, y, mean, invstd, extra=0, mask_scale=None, mask_shift=None):
     n, c, h, w = y.shape
     sums = torch.empty(2 * c + extra, dtype=torch.float64, device=y.device)
     if extra:
         sums[2 * c:].zero_()
-    _C.check(_C.fn("rr_bn_bwd_reduce")(_C.ptr(dz), _C.ptr(z), _C.ptr(y), _C.ptr(mean), _C.ptr(invstd), _C.ptr(sums),
+    _C.check(_C.fn("rr_bn_bwd_reduce")(_C.ptr(dz), _C.ptr(z), _C.ptr(y), _C.ptr(mean), _C.ptr(invstd),
+                                       _C.ptr(mask_scale), _C.ptr(mask_shift), _C.ptr(sums),
                                        n * h * w, c, _C.stream()), "rr_bn_bwd_reduce")
     return sums
 
 
-def bn_bwd_apply(dz, z, y, mean, invstd, gamma, sums, count, want_g=False, dgamma=None, dbeta=None, count_dev=None):
+def bn_bwd_apply(dz, z, y, mean, invstd, gamma, sums, count, want_g=False, dgamma=None, dbeta=None, count_dev=None,
+                 mask_scale=None, mask_shift=None):
     n, c, h, w = y.shape
     dx = empty_nhwc(n, c, h, w, y.device)
     g = empty_nhwc(n, c, h, w, y.device) if want_g else None
     _C.check(_C.fn("rr_bn_bwd_apply")(_C.ptr(dz), _C.ptr(z), _C.ptr(y), _C.ptr(mean), _C.ptr(invstd), _C.ptr(gamma),
-                                      _C.ptr(sums), float(count), _C.ptr(count_dev), _C.ptr(dx), _C.ptr(g), _C.ptr(dgamma), _C.ptr(dbeta),
+                                      _C.ptr(mask_scale), _C.ptr(mask_shift), _C.ptr(sums), float(count), _C.ptr(count_dev), _C.ptr(dx), _C.ptr(g), _C.ptr(dgamma), _C.ptr(dbeta),
                                       y.numel(), c, _C.stream()), "rr_bn_bwd_apply")
     return dx, g
 
