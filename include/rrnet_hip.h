@@ -47,6 +47,12 @@ size_t rr_soft_nms_workspace_bytes(int total_boxes, int max_seg_boxes);
 int rr_soft_nms_segments(float *boxes, const int *seg_off, int nseg, int max_seg_boxes, int stride,
                          float sigma, float Nt, float threshold, int method, int *n_out,
                          int *err_flag, void *workspace, hipStream_t stream);
+/* Same, with explicit segment lengths: segment s = rows [seg_off[s], seg_off[s] + seg_len[s]) (rows between the
+ * length and the next offset are ignored) — the layout rr_refine_boxes leaves behind. */
+int rr_soft_nms_ragged(float *boxes, const int *seg_off, const int *seg_len, int nseg, int max_seg_boxes, int stride,
+                       float sigma, float Nt, float threshold, int method, int *n_out, int *err_flag,
+                       void *workspace, hipStream_t stream);
+
 
 /* ---- Convolutions (NHWC fp32, implicit GEMM on v_mfma_f32_32x32x2_f32) --------------- *
  * Replace what the reference delegates to cuDNN through nn.Conv2d:
@@ -189,6 +195,22 @@ int rr_hard_nms_segments(float *boxes, const int *seg_off, int nseg, int max_seg
 int rr_pack_segments(const float *grouped, const int *seg_off, const int *n_out, int nseg, int segs_per_image,
                      int *out_off, float *rois, float *scores, float *clses, float *rows6, int phase,
                      hipStream_t stream);
+
+/* ---- inference post-process (config 5: decode -> re-regression -> Soft-NMS) ------------------ *
+ * rr_refine_boxes: operators/rrnet_operator.py:188-209 `generate_bbox` (stage-2 boxes from the packed RoIs
+ *   [r,5] = image,x1,y1,x2,y2 in feature coordinates, the regression [r,4], scores, classes), the score filter
+ *   `pred_bbox[:, 4] > score_thr` (:266-267) and the xywh -> xyxy step of `_ext_nms` (:222-223), for all
+ *   (frame, class) segments of a batch in one launch.  seg_off [nseg+1] = row offsets of the stage-1 segments in
+ *   the packed list (rr_pack_segments phase 0).  out6 rows = x1,y1,x2,y2,score,cls+1, order preserved, written
+ *   to the front of each segment's row range; seg_len [nseg] = rows kept.  Feed to rr_soft_nms_ragged.
+ * rr_finalize_frames: `np.concatenate` of the per-class results (:225), xyxy -> xywh (:231) and the final
+ *   `torch.sort(score, descending)` (:278-279; ties keep concatenation order) per frame.  out_off [nseg+1] =
+ *   exclusive prefix of n_out (rr_pack_segments phase 0); frame f's rows land at out6[out_off[f*segs_per_frame]]. */
+int rr_refine_boxes(const float *rois, const float *reg, const float *scores, const float *clses,
+                    const int *seg_off, int nseg, float scale, float score_thr, float *out6, int *seg_len,
+                    hipStream_t stream);
+int rr_finalize_frames(const float *boxes6, const int *seg_off, const int *n_out, const int *out_off,
+                       int nframes, int segs_per_frame, int max_frame_boxes, float *out6, hipStream_t stream);
 
 /* ---- RoIAlign --------------------------------------------------------------------------- *
  * torchvision.ops.roi_align(feat, rois, (ph,pw)) at models/rrnet.py:51 (spatial_scale 1,

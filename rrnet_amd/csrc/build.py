@@ -19,6 +19,7 @@ COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-I", INC, "-I"
 PER_FILE = {
     "softnms.hip": ["-ffp-contract=off"],
     "hardnms.hip": ["-ffp-contract=off"],
+    "refine.hip": ["-ffp-contract=off"],
 }
 
 

@@ -879,9 +879,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a)
 
 const float *zero_page()
 {
-    static float *p = nullptr;
-    if (!p) hipGetSymbolAddress(reinterpret_cast<void **>(&p), HIP_SYMBOL(rr_zero16));
-    return p;
+    // a __device__ symbol has one instance per device: cache per device id
+    static float *p[64] = {};
+    int dev = 0;
+    hipGetDevice(&dev);
+    dev &= 63;
+    if (!p[dev]) hipGetSymbolAddress(reinterpret_cast<void **>(&p[dev]), HIP_SYMBOL(rr_zero16));
+    return p[dev];
 }
 
 template <typename K, typename A>

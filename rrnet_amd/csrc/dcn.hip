@@ -291,9 +291,12 @@ int fill_args(DcnArgs &a, const float *x, const float *offset, const float *mask
     const long M = (long)n * a.P * a.Q;
     RR_CHECK_ARG(M < (1l << 31), "rr_dcn: too many output pixels");
     a.M = (int)M;
-    static float *zp = nullptr;
-    if (!zp) hipGetSymbolAddress(reinterpret_cast<void **>(&zp), HIP_SYMBOL(rr_dcn_zero16));
-    a.zero = zp;
+    static float *zp[64] = {};
+    int dev = 0;
+    hipGetDevice(&dev);
+    dev &= 63;
+    if (!zp[dev]) hipGetSymbolAddress(reinterpret_cast<void **>(&zp[dev]), HIP_SYMBOL(rr_dcn_zero16));
+    a.zero = zp[dev];
     return RR_OK;
 }
 

@@ -239,14 +239,17 @@ __global__ void peak3x3_kernel(const float *hm, float *scores, int B, int H, int
 // ---- stable grouping of each image's rows by class (rows arrive score-descending) ------------
 // boxes [B,K,6] -> grouped [B,K,6] with classes ascending, order inside a class preserved;
 // seg_off [B*NC+1] row offsets of every (image, class) segment in the flattened [B*K] row space.
-__global__ __launch_bounds__(256) void group_by_class_kernel(const float *boxes, int K, int NC, int cls_base,
+__global__ __launch_bounds__(256) void group_by_class_kernel(const float *boxes, int K, int NC, int cls_base, int KP,
                                                              float *grouped, int *seg_off)
 {
-    extern __shared__ int sm[];   // count[NC], start[NC]
-    int *count = sm, *start = sm + NC;
+    extern __shared__ int sm[];   // count[NC], then (LDS sort path) keys[KP]
+    int *count = sm;
+    unsigned int *keys = reinterpret_cast<unsigned int *>(sm + NC);
+    __shared__ int n_valid;
     const int b = blockIdx.x;
     const int n = K;
     const float *src = boxes + (long)b * K * 6;
+    float *dst = grouped + (long)b * K * 6;
     for (int c = threadIdx.x; c < NC; c += 256) count[c] = 0;
     __syncthreads();
     for (int i = threadIdx.x; i < n; i += 256) {
@@ -257,17 +260,49 @@ __global__ __launch_bounds__(256) void group_by_class_kernel(const float *boxes,
     if (threadIdx.x == 0) {
         int run = 0;
         for (int c = 0; c < NC; ++c) {
-            start[c] = run;
+            const int cnt = count[c];
+            count[c] = run;                    // becomes the segment's start row
             seg_off[b * NC + c] = b * K + run;
-            run += count[c];
+            run += cnt;
         }
         if (b == gridDim.x - 1) seg_off[(b + 1) * NC] = b * K + run;
+        n_valid = run;
     }
     __syncthreads();
-    // one thread per class keeps the order stable
+    if (KP > 0) {
+        // stable grouping = ascending sort of (class << 22 | row): LDS bitonic network, rows of classes outside
+        // [cls_base, cls_base+NC) sort to the end and are dropped
+        for (int i = threadIdx.x; i < KP; i += 256) {
+            unsigned int key = 0xffffffffu;
+            if (i < n) {
+                const int c = (int)src[i * 6 + 5] - cls_base;
+                if (c >= 0 && c < NC) key = ((unsigned int)c << 22) | (unsigned int)i;
+            }
+            keys[i] = key;
+        }
+        __syncthreads();
+        for (int k2 = 2; k2 <= KP; k2 <<= 1) {
+            for (int j = k2 >> 1; j > 0; j >>= 1) {
+                for (int t = threadIdx.x; t < KP / 2; t += 256) {
+                    const int lo = ((t / j) * 2 * j) + (t % j);
+                    const int hi2 = lo + j;
+                    const bool asc = ((lo & k2) == 0);
+                    const unsigned int a = keys[lo], c = keys[hi2];
+                    if ((a > c) == asc) { keys[lo] = c; keys[hi2] = a; }
+                }
+                __syncthreads();
+            }
+        }
+        const int nv = n_valid;
+        for (int e = threadIdx.x; e < nv * 6; e += 256) {
+            const int r = e / 6, col = e - r * 6;
+            dst[e] = src[(keys[r] & 0x3fffffu) * 6 + col];
+        }
+        return;
+    }
+    // very long inputs (beyond the LDS sort): one thread per class keeps the order stable
     for (int c = threadIdx.x; c < NC; c += 256) {
-        int w = start[c];
-        float *dst = grouped + (long)b * K * 6;
+        int w = count[c];
         for (int i = 0; i < n; ++i) {
             if ((int)src[i * 6 + 5] - cls_base == c) {
 #pragma unroll
@@ -383,8 +418,15 @@ extern "C" int rr_group_by_class(const float *boxes, int b, int k, int num_class
                                  float *grouped, int *seg_off, hipStream_t stream)
 {
     RR_CHECK_ARG(b > 0 && k > 0 && num_classes > 0 && num_classes <= 1024, "rr_group_by_class: bad dims");
-    hipLaunchKernelGGL(group_by_class_kernel, dim3(b), dim3(256), 2 * num_classes * sizeof(int), stream, boxes, k,
-                       num_classes, cls_base, grouped, seg_off);
+    int kp = 2;
+    while (kp < k) kp <<= 1;
+    if (kp > 16384 || num_classes > 1023) kp = 0;   // LDS sort path: <= 64 KB of keys, class id in 10 bits
+    const size_t lds = (size_t)(num_classes + kp) * sizeof(int);
+    if (lds > 48 * 1024)
+        hipFuncSetAttribute(reinterpret_cast<const void *>(group_by_class_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(group_by_class_kernel, dim3(b), dim3(256), lds, stream, boxes, k, num_classes, cls_base, kp,
+                       grouped, seg_off);
     RR_CHECK_LAUNCH("rr_group_by_class");
     return RR_OK;
 }

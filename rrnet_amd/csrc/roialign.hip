@@ -13,6 +13,8 @@
 
 namespace {
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 struct Tap { long o00, o01, o10, o11; float w00, w01, w10, w11; bool ok; };
 
 __device__ __forceinline__ Tap make_tap(float y, float x, int H, int W, long C)
@@ -74,6 +76,109 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const float *feat, float
         }
     }
 }
+// ---- forward, separable form ---------------------------------------------------------------
+// The samples of a bin form a product grid and the bilinear weights (and the inside-the-map test) factor into a
+// row part and a column part, so  sum_{iy,ix} bilinear(y_iy, x_ix) = sum_r sum_c Wy[r] * Wx[c] * f[r][c]  with
+// Wy[r] = total weight the bin's sample rows put on pixel row r.  Every footprint pixel is read once per bin
+// ((gh+1)*(gw+1) rows of C floats) instead of 4 taps per sample (4*gh*gw): 2.25x fewer reads at a 3x3 grid.
+// One wave per RoI, 16 bytes per lane (a 256-channel row is one 1 KB wave access), 4 RoIs per workgroup.
+constexpr int SEP_MAXG = 16;           // samples per bin per axis handled here (larger RoIs: generic kernel)
+constexpr int SEP_SLOTS = SEP_MAXG + 2;
+constexpr int SEP_MAXBINS = 8;
+
+struct AxisW {
+    float w[SEP_MAXBINS][SEP_SLOTS];
+    int base[SEP_MAXBINS], n[SEP_MAXBINS];
+};
+
+// weights of one bin along one axis: `start` = roi start + bin * bin_size, g samples, map extent `size`
+__device__ void axis_weights(float start, float bin, int g, int size, float *w, int *base_out, int *n_out)
+{
+    for (int i = 0; i < SEP_SLOTS; ++i) w[i] = 0.f;
+    int base = -1, last = -1;
+    for (int i = 0; i < g; ++i) {
+        float y = start + ((float)i + 0.5f) * bin / (float)g;
+        if (y < -1.0f || y > (float)size) continue;
+        if (y <= 0.f) y = 0.f;
+        int yl = (int)y, yh;
+        if (yl >= size - 1) { yh = yl = size - 1; y = (float)yl; } else yh = yl + 1;
+        const float ly = y - yl, hy = 1.f - ly;
+        if (base < 0) base = yl;
+        w[yl - base] += hy;
+        w[yh - base] += ly;
+        last = yh - base;
+    }
+    *base_out = base < 0 ? 0 : base;
+    *n_out = last + 1;
+}
+
+__global__ __launch_bounds__(256) void roi_align_sep_kernel(const float *feat, const float *rois, float *out, int R, int H,
+                                                            int W, int C, int PH, int PW, float scale, int sampling)
+{
+    __shared__ AxisW ay[4], ax[4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + wave;
+    const bool live = r < R;
+    const float *q = rois + (long)(live ? r : 0) * 5;
+    const int b = (int)q[0];
+    const float x1 = q[1] * scale, y1 = q[2] * scale, x2 = q[3] * scale, y2 = q[4] * scale;
+    const float rw = fmaxf(x2 - x1, 1.f), rh = fmaxf(y2 - y1, 1.f);
+    const float bh = rh / (float)PH, bw = rw / (float)PW;
+    const int gh = sampling > 0 ? sampling : (int)ceilf(rh / (float)PH);
+    const int gw = sampling > 0 ? sampling : (int)ceilf(rw / (float)PW);
+    // wave-uniform; samples at most one pixel apart so that a bin's footprint fits the slot arrays (always true for
+    // adaptive sampling, g = ceil(bin size))
+    const bool sep = gh <= SEP_MAXG && gw <= SEP_MAXG && bh <= (float)gh && bw <= (float)gw;
+    if (sep) {
+        if (lane < PH) axis_weights(y1 + lane * bh, bh, gh, H, ay[wave].w[lane], &ay[wave].base[lane], &ay[wave].n[lane]);
+        else if (lane < PH + PW) {
+            const int p = lane - PH;
+            axis_weights(x1 + p * bw, bw, gw, W, ax[wave].w[p], &ax[wave].base[p], &ax[wave].n[p]);
+        }
+    }
+    __syncthreads();
+    if (!live) return;
+    const float count = (float)(gh * gw);
+    const float *img = feat + (long)b * H * W * C;
+    if (!sep) {   // very large RoI: per-sample taps, as the generic kernel
+        for (int c0 = lane * 4; c0 < C; c0 += 256)
+            for (int bin = 0; bin < PH * PW; ++bin) {
+                const int ph = bin / PW, pw = bin % PW;
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                for (int iy = 0; iy < gh; ++iy) {
+                    const float y = y1 + ph * bh + ((float)iy + 0.5f) * bh / (float)gh;
+                    for (int ix = 0; ix < gw; ++ix) {
+                        const float x = x1 + pw * bw + ((float)ix + 0.5f) * bw / (float)gw;
+                        const Tap t = make_tap(y, x, H, W, C);
+                        if (!t.ok) continue;
+                        const float *f = img + c0;
+                        acc += t.w00 * *reinterpret_cast<const f32x4 *>(f + t.o00) + t.w01 * *reinterpret_cast<const f32x4 *>(f + t.o01) +
+                               t.w10 * *reinterpret_cast<const f32x4 *>(f + t.o10) + t.w11 * *reinterpret_cast<const f32x4 *>(f + t.o11);
+                    }
+                }
+                *reinterpret_cast<f32x4 *>(out + ((long)r * PH * PW + bin) * C + c0) = acc / count;
+            }
+        return;
+    }
+    for (int c0 = lane * 4; c0 < C; c0 += 256) {
+        for (int ph = 0; ph < PH; ++ph) {
+            const int ny = ay[wave].n[ph], by = ay[wave].base[ph];
+            for (int pw = 0; pw < PW; ++pw) {
+                const int nx = ax[wave].n[pw], bx = ax[wave].base[pw];
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                for (int rr = 0; rr < ny; ++rr) {
+                    const float wy = ay[wave].w[ph][rr];
+                    const float *row = img + ((long)(by + rr) * W + bx) * C + c0;
+                    for (int cc = 0; cc < nx; ++cc) {
+                        const float wgt = wy * ax[wave].w[pw][cc];
+                        acc += wgt * *reinterpret_cast<const f32x4 *>(row + (long)cc * C);
+                    }
+                }
+                *reinterpret_cast<f32x4 *>(out + (((long)r * PH + ph) * PW + pw) * C + c0) = acc / count;
+            }
+        }
+    }
+}
 }  // namespace
 
 extern "C" int rr_roi_align_fwd(const float *feat, const float *rois, int r, int h, int w, int c, int ph, int pw,
@@ -81,6 +186,12 @@ extern "C" int rr_roi_align_fwd(const float *feat, const float *rois, int r, int
 {
     RR_CHECK_ARG(h > 0 && w > 0 && c > 0 && ph > 0 && pw > 0 && r >= 0, "rr_roi_align_fwd: bad dims");
     if (r == 0) return RR_OK;
+    if (c % 4 == 0 && ph <= SEP_MAXBINS && pw <= SEP_MAXBINS) {
+        hipLaunchKernelGGL(roi_align_sep_kernel, dim3((r + 3) / 4), dim3(256), 0, stream, feat, rois, out, r, h, w, c, ph, pw,
+                           spatial_scale, sampling_ratio);
+        RR_CHECK_LAUNCH("rr_roi_align_fwd");
+        return RR_OK;
+    }
     hipLaunchKernelGGL(roi_align_kernel<false>, dim3(r), dim3(256), 0, stream, feat, (float *)nullptr, rois, out,
                        (const float *)nullptr, h, w, c, ph, pw, spatial_scale, sampling_ratio);
     RR_CHECK_LAUNCH("rr_roi_align_fwd");

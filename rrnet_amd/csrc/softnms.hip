@@ -208,7 +208,7 @@ __device__ void soft_nms_segment(SegView v, const int n, const float sigma, cons
 
 // LDS-resident: dynamic LDS = n_max * 25 bytes (rounded), boxes are loaded AoS->SoA and stored back.
 template <int T>
-__global__ __launch_bounds__(T) void soft_nms_kernel(float *boxes, const int *seg_off, int stride,
+__global__ __launch_bounds__(T) void soft_nms_kernel(float *boxes, const int *seg_off, const int *seg_len, int stride,
                                                      float sigma, float Nt, float thr, int method,
                                                      int cap, int *n_out, int *err, float *gws)
 {
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(T) void soft_nms_kernel(float *boxes, const int *se
     __shared__ int red[20];
     const int seg = blockIdx.x;
     const int off = seg_off[seg];
-    const int n = seg_off[seg + 1] - off;
+    const int n = seg_len ? seg_len[seg] : seg_off[seg + 1] - off;
     float *b = boxes + (size_t)off * stride;
     SegView v;
     if (gws == nullptr) {
@@ -258,9 +258,9 @@ extern "C" size_t rr_soft_nms_workspace_bytes(int total_boxes, int max_seg_boxes
     return max_seg_boxes > RR_SOFT_NMS_LDS_MAX ? (size_t)total_boxes * 28 + 64 : 0;
 }
 
-extern "C" int rr_soft_nms_segments(float *boxes, const int *seg_off, int nseg, int max_seg_boxes,
-                                    int stride, float sigma, float Nt, float threshold, int method,
-                                    int *n_out, int *err_flag, void *workspace, hipStream_t stream)
+static int soft_nms_launch(float *boxes, const int *seg_off, const int *seg_len, int nseg, int max_seg_boxes,
+                           int stride, float sigma, float Nt, float threshold, int method,
+                           int *n_out, int *err_flag, void *workspace, hipStream_t stream)
 {
     RR_CHECK_ARG(stride >= 5, "rr_soft_nms_segments: stride %d < 5", stride);
     RR_CHECK_ARG(nseg >= 0 && max_seg_boxes >= 0, "rr_soft_nms_segments: negative size");
@@ -278,7 +278,7 @@ extern "C" int rr_soft_nms_segments(float *boxes, const int *seg_off, int nseg, 
             hipFuncSetAttribute(reinterpret_cast<const void *>(soft_nms_kernel<T>),                   \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                \
         hipLaunchKernelGGL(soft_nms_kernel<T>, dim3(nseg), dim3(T), lds, stream, boxes, seg_off,      \
-                           stride, sigma, Nt, threshold, method, cap, n_out, err_flag, gws);          \
+                           seg_len, stride, sigma, Nt, threshold, method, cap, n_out, err_flag, gws);          \
     } while (0)
     if (max_seg_boxes <= 192) LAUNCH(64);
     else if (max_seg_boxes <= 2560) LAUNCH(256);
@@ -286,4 +286,21 @@ extern "C" int rr_soft_nms_segments(float *boxes, const int *seg_off, int nseg, 
 #undef LAUNCH
     RR_CHECK_LAUNCH("rr_soft_nms_segments");
     return RR_OK;
+}
+
+extern "C" int rr_soft_nms_segments(float *boxes, const int *seg_off, int nseg, int max_seg_boxes,
+                                    int stride, float sigma, float Nt, float threshold, int method,
+                                    int *n_out, int *err_flag, void *workspace, hipStream_t stream)
+{
+    return soft_nms_launch(boxes, seg_off, nullptr, nseg, max_seg_boxes, stride, sigma, Nt, threshold, method, n_out,
+                           err_flag, workspace, stream);
+}
+
+extern "C" int rr_soft_nms_ragged(float *boxes, const int *seg_off, const int *seg_len, int nseg, int max_seg_boxes,
+                                  int stride, float sigma, float Nt, float threshold, int method,
+                                  int *n_out, int *err_flag, void *workspace, hipStream_t stream)
+{
+    RR_CHECK_ARG(seg_len != nullptr, "rr_soft_nms_ragged: seg_len is null");
+    return soft_nms_launch(boxes, seg_off, seg_len, nseg, max_seg_boxes, stride, sigma, Nt, threshold, method, n_out,
+                           err_flag, workspace, stream);
 }

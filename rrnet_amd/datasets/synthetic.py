@@ -78,3 +78,28 @@ def make_dataloader(cfg, collate_fn='rrnet'):
     h, w = cfg.Train.crop_size
     train = SyntheticDronesDET(cfg, cfg.Train.batch_size, h, w, rank=rank)
     return train, None
+
+
+def synth_head_outputs(n_frames, hf, wf, num_classes=10, seed=219, device="cpu", planted=200, cluster=5):
+    """Stage-1 head outputs + backbone feature of `n_frames` frames for the inference-only workload
+    (BASELINE.json configs[4]; recipe SURVEY §8(d)): hm logits -2.19 + N(0,1) with `planted` peaks (+U[3,8])
+    placed in clusters of `cluster` neighbouring pixels of one class so that NMS has work to do,
+    wh = 2 + 8|N(0,1)|, offset U[0,1), feature relu(N(0,1)) [256,hf,wf].  Generated on `device` from a
+    seeded torch generator (the CUDA and CPU streams differ; a test moves the CPU tensors over)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    kw = dict(generator=g, device=device)
+    hm = torch.randn((n_frames, num_classes, hf, wf), **kw) - 2.19
+    n_cl = max(planted // cluster, 1)
+    for f in range(n_frames):
+        cy = torch.randint(2, hf - 2, (n_cl,), **kw)
+        cx = torch.randint(2, wf - 2, (n_cl,), **kw)
+        cc = torch.randint(0, num_classes, (n_cl,), **kw)
+        dy = torch.randint(-2, 3, (n_cl, cluster), **kw)
+        dx = torch.randint(-2, 3, (n_cl, cluster), **kw)
+        amp = 3.0 + 5.0 * torch.rand((n_cl, cluster), **kw)
+        hm[f].index_put_((cc[:, None].expand(-1, cluster), cy[:, None] + dy, cx[:, None] + dx), amp, accumulate=True)
+    wh = 2.0 + 8.0 * torch.randn((n_frames, 2, hf, wf), **kw).abs()
+    off = torch.rand((n_frames, 2, hf, wf), **kw)
+    feat = torch.relu(torch.randn((n_frames, 256, hf, wf), **kw))
+    return hm, wh, off, feat

@@ -14,10 +14,13 @@ from rrnet_amd import _C
 _P = _C.c_void_p
 
 
-def soft_nms_segments(boxes, seg_off, max_seg, sigma=0.5, Nt=0.3, threshold=0.001, method=1):
-    """boxes: cuda float32 [total, stride>=5] (modified in place); seg_off: cuda int32 [nseg+1].
+def soft_nms_segments(boxes, seg_off, max_seg, sigma=0.5, Nt=0.3, threshold=0.001, method=1, seg_len=None,
+                      check=True):
+    """boxes: cuda float32 [total, stride>=5] (modified in place); seg_off: cuda int32 [nseg+1];
+    seg_len (optional cuda int32 [nseg]): explicit segment lengths (rows past the length are ignored).
     Returns n_out cuda int32 [nseg]; rows [seg_off[s], seg_off[s]+n_out[s]) are the kept boxes in
-    the reference's order.  Raises ZeroDivisionError where the reference would."""
+    the reference's order.  Raises ZeroDivisionError where the reference would (`check=False` skips the
+    host read of the flag and returns (n_out, err) for a caller that synchronises later)."""
     _C.require_cuda(boxes, seg_off)
     assert boxes.dtype == torch.float32 and boxes.is_contiguous() and boxes.dim() == 2
     assert seg_off.dtype == torch.int32
@@ -31,10 +34,16 @@ def soft_nms_segments(boxes, seg_off, max_seg, sigma=0.5, Nt=0.3, threshold=0.00
     f_ws = _C.fn("rr_soft_nms_workspace_bytes")
     nbytes = f_ws(boxes.size(0), int(max_seg))
     ws = torch.empty(nbytes, dtype=torch.uint8, device=boxes.device) if nbytes else None
-    f = _C.fn("rr_soft_nms_segments")
-    _C.check(f(_C.ptr(boxes), _C.ptr(seg_off), nseg, int(max_seg), boxes.size(1), float(np.float32(sigma)),
-               float(np.float32(Nt)), float(np.float32(threshold)), int(method), _C.ptr(n_out), _C.ptr(err),
-               _C.ptr(ws), _C.stream()), "rr_soft_nms_segments")
+    tail = (int(max_seg), boxes.size(1), float(np.float32(sigma)), float(np.float32(Nt)), float(np.float32(threshold)),
+            int(method), _C.ptr(n_out), _C.ptr(err), _C.ptr(ws), _C.stream())
+    if seg_len is None:
+        _C.check(_C.fn("rr_soft_nms_segments")(_C.ptr(boxes), _C.ptr(seg_off), nseg, *tail), "rr_soft_nms_segments")
+    else:
+        assert seg_len.dtype == torch.int32 and seg_len.numel() == nseg
+        _C.check(_C.fn("rr_soft_nms_ragged")(_C.ptr(boxes), _C.ptr(seg_off), _C.ptr(seg_len), nseg, *tail),
+                 "rr_soft_nms_ragged")
+    if not check:
+        return n_out, err
     if int(err.item()) != 0:
         raise ZeroDivisionError("float division")
     return n_out

@@ -19,7 +19,7 @@ from rrnet_amd.utils.model_tools import get_backbone
 
 
 def stage1_proposals(hm, wh, offset, k, num_classes, nms_type='nms', nms_per_class=True, peak_filter=False,
-                     want_provenance=False):
+                     want_provenance=False, want_offsets=False):
     """Decode + stage-1 NMS for the whole batch (models/rrnet.py:31-49, 56-138).
     -> bxyxys [R,5], scores [R], clses [R] (detached device tensors) and, on request, the heat-map pixel
     every RoI was decoded from (for the backward of the box assembly)."""
@@ -40,8 +40,10 @@ def stage1_proposals(hm, wh, offset, k, num_classes, nms_type='nms', nms_per_cla
             n_out = soft_nms_segments(rows, seg_off, k, sigma=0.5, Nt=0.7, threshold=0.1, method=2)
         else:
             n_out = ops.hard_nms_segments(rows, seg_off, k, 0.7)
-        rois, scores, clses, _ = ops.pack_segments(rows, seg_off, n_out, segs_per_image)
+        rois, scores, clses, _, row_off = ops.pack_segments(rows, seg_off, n_out, segs_per_image, want_offsets=True)
         roi_pix = ops.roi_provenance(rois, scores, clses, boxes, pix) if want_provenance else None
+    if want_offsets:   # row offsets of the (image, class) segments inside the packed list
+        return rois, scores, clses, row_off
     return (rois, scores, clses, roi_pix) if want_provenance else (rois, scores, clses)
 
 

@@ -419,15 +419,22 @@ def hard_nms_segments(boxes6, seg_off, max_seg, thresh):
     return n_out
 
 
-def pack_segments(grouped, seg_off, n_out, segs_per_image, want_rois=True, want_rows=False):
+def seg_prefix(n_out):
+    """Exclusive prefix of per-segment counts -> int32 [nseg+1] (last entry = total)."""
+    nseg = n_out.numel()
+    out_off = torch.empty(nseg + 1, dtype=torch.int32, device=n_out.device)
+    nul = _C.c_void_p(0)
+    _C.check(_C.fn("rr_pack_segments")(nul, nul, _C.ptr(n_out), nseg, 1, _C.ptr(out_off), nul, nul, nul, nul, 0,
+                                       _C.stream()), "rr_pack_segments")
+    return out_off
+
+
+def pack_segments(grouped, seg_off, n_out, segs_per_image, want_rois=True, want_rows=False, want_offsets=False):
     """-> (rois [R,5], scores [R], clses [R]) and/or rows [R,6]; one host sync to learn R."""
     nseg = n_out.numel()
     dev = grouped.device
-    out_off = torch.empty(nseg + 1, dtype=torch.int32, device=dev)
     f = _C.fn("rr_pack_segments")
-    nul = _C.c_void_p(0)
-    _C.check(f(_C.ptr(grouped), _C.ptr(seg_off), _C.ptr(n_out), nseg, segs_per_image, _C.ptr(out_off), nul, nul, nul,
-               nul, 0, _C.stream()), "rr_pack_segments")
+    out_off = seg_prefix(n_out)
     r = int(out_off[-1].item())
     rois = torch.empty((r, 5), dtype=torch.float32, device=dev) if want_rois else None
     scores = torch.empty(r, dtype=torch.float32, device=dev) if want_rois else None
@@ -435,7 +442,35 @@ def pack_segments(grouped, seg_off, n_out, segs_per_image, want_rois=True, want_
     rows = torch.empty((r, 6), dtype=torch.float32, device=dev) if want_rows else None
     _C.check(f(_C.ptr(grouped), _C.ptr(seg_off), _C.ptr(n_out), nseg, segs_per_image, _C.ptr(out_off), _C.ptr(rois),
                _C.ptr(scores), _C.ptr(clses), _C.ptr(rows), 1, _C.stream()), "rr_pack_segments")
+    if want_offsets:
+        return rois, scores, clses, rows, out_off
     return rois, scores, clses, rows
+
+
+def refine_boxes(rois, reg, scores, clses, seg_off, scale, score_thr):
+    """generate_bbox + score filter + xywh->xyxy for every (frame, class) segment of the packed RoI list.
+    -> boxes6 [R,6] (kept rows at the front of each segment's range), seg_len int32 [nseg]."""
+    _C.require_cuda(rois, reg, scores, clses, seg_off)
+    r = rois.shape[0]
+    nseg = seg_off.numel() - 1
+    out6 = torch.empty((r, 6), dtype=torch.float32, device=rois.device)
+    seg_len = torch.zeros(max(nseg, 0), dtype=torch.int32, device=rois.device)
+    _C.check(_C.fn("rr_refine_boxes")(_C.ptr(rois), _C.ptr(reg.contiguous()), _C.ptr(scores), _C.ptr(clses),
+                                      _C.ptr(seg_off), nseg, float(scale), float(score_thr), _C.ptr(out6),
+                                      _C.ptr(seg_len), _C.stream()), "rr_refine_boxes")
+    return out6, seg_len
+
+
+def finalize_frames(boxes6, seg_off, n_out, nframes, segs_per_frame, max_frame_boxes):
+    """Per frame: concatenate kept segment rows, xyxy->xywh, sort by score descending.
+    -> out6 [R,6] (R = upper bound rows; frame f occupies rows [frame_off[f], frame_off[f+1])), frame_off int32
+    [nframes+1] (device)."""
+    out_off = seg_prefix(n_out)
+    out6 = torch.empty_like(boxes6)
+    _C.check(_C.fn("rr_finalize_frames")(_C.ptr(boxes6), _C.ptr(seg_off), _C.ptr(n_out), _C.ptr(out_off), nframes,
+                                         segs_per_frame, int(max_frame_boxes), _C.ptr(out6), _C.stream()),
+             "rr_finalize_frames")
+    return out6, out_off[::segs_per_frame]
 
 
 def roi_align_fwd(feat, rois, out_size, spatial_scale=1.0, sampling_ratio=-1):

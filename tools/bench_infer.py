@@ -1,0 +1,123 @@
+"""Inference-only post-process throughput (BASELINE.json configs[4]):
+heat-map decode + stage-1 NMS + RoIAlign + re-regression head + Soft-NMS on a stream of 1920x1080 frames
+(stride-4 maps 270x480), K=1500 candidate boxes per frame, one MI355X.
+
+  python tools/bench_infer.py [--frames 10000] [--batch 128] [--pool 128] [--cpu-frames 3]
+
+Inputs (stage-1 head outputs + backbone feature, recipe in rrnet_amd/datasets/synthetic.py
+`synth_head_outputs`) are generated on the device and stay resident in HBM: `--pool` distinct frames, cycled
+until `--frames` frames have been processed.  Prints ONE JSON line: frames/sec, candidate boxes/sec
+(= frames/sec * K: every candidate is decoded, NMS'd, pooled, re-regressed and Soft-NMS'd), output
+boxes/frame, per-stage GPU time, and `cpu_baseline` = the CPU oracle (oracle/infer.py) on `--cpu-frames`
+frames of the same pool plus the CPU Soft-NMS alone (the reference's own compiled cpu_soft_nms from
+oracle/_ref when present, else the C restatement) on the same segments.
+Replicas only across GPUs: frames are independent, there is no collective on this path."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=10000)
+    ap.add_argument("--batch", type=int, default=128)
+    ap.add_argument("--pool", type=int, default=128)
+    ap.add_argument("--hf", type=int, default=270)
+    ap.add_argument("--wf", type=int, default=480)
+    ap.add_argument("--k", type=int, default=1500)
+    ap.add_argument("--cpu-frames", type=int, default=3)
+    ap.add_argument("--stages", action="store_true", help="time every stage with events (adds syncs)")
+    return ap.parse_args()
+
+
+def cpu_baseline(head_sd, pool, n_frames, k):
+    from oracle import infer as oinfer, model as omodel, nms as onms, ops as oops
+    P = omodel.Params({"head_detector." + kk: v.cpu() for kk, v in head_sd.items()}, training=False)
+    hm, wh, off, feat = pool
+    t_full, t_nms, n_boxes, nms_rows = 0.0, 0.0, 0, 0
+    mod = onms.load_reference_cpu_nms()
+    ref = mod.cpu_soft_nms if mod is not None else None
+    for f in range(n_frames):
+        args = [t[f:f + 1].cpu() for t in (hm, wh, off, feat)]
+        t0 = time.perf_counter()
+        out = oinfer.postprocess_frame(P, *args, k=k, relu_feat=False)
+        t_full += time.perf_counter() - t0
+        n_boxes += out.shape[0]
+        # Soft-NMS alone on the segments this frame hands to ext/nms: rebuild the stage-2 boxes once more
+        with torch.no_grad():
+            bb = oops.transform_bbox(args[0], args[1], args[2], k)
+            kept = oops.stage1_nms(bb[0], 'nms', True)
+        boxes = kept.numpy().copy()
+        boxes[:, :4] *= 4
+        for c in np.unique(boxes[:, 5]):
+            seg = np.ascontiguousarray(boxes[boxes[:, 5] == c][:, :5], dtype=np.float32)
+            t0 = time.perf_counter()
+            if ref is not None:
+                ref(seg, np.float32(0.5), np.float32(0.7), np.float32(0.1), np.uint8(2))
+            else:
+                onms.cpu_soft_nms(seg, 0.5, 0.7, 0.1, 2)
+            t_nms += time.perf_counter() - t0
+            nms_rows += seg.shape[0]
+    return {"value": round(n_frames * k / t_full, 1), "unit": "boxes/sec", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": "oracle/infer.py post-process of %d frames %dx%d K=%d: %.2f s/frame, %.0f output boxes/frame"
+                      % (n_frames, hm.shape[2], hm.shape[3], k, t_full / n_frames, n_boxes / n_frames),
+            "ext_nms_only": {"value": round(nms_rows / t_nms, 1), "unit": "boxes/sec", "cores": 1,
+                             "kind": "reference" if ref is not None else "port",
+                             "sample": "cpu_soft_nms (Nt .7, thr .1, gaussian) per class on the same frames: %.2f ms/frame"
+                                       % (1e3 * t_nms / n_frames)}}
+
+
+def main():
+    a = parse()
+    from rrnet_amd import inference, ops
+    from rrnet_amd.datasets.synthetic import synth_head_outputs
+    from rrnet_amd.detectors.fasterrcnn_detector import FasterRCNNDetector
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    torch.manual_seed(219)
+    head = FasterRCNNDetector().to(dev).eval()
+    head_sd = {k: v.detach().clone() for k, v in head.state_dict().items()}
+    pool = synth_head_outputs(a.pool, a.hf, a.wf, seed=219, device=dev)
+    hm, wh, off, feat = [ops.to_nhwc(t) for t in pool]
+    nb = a.pool // a.batch
+    assert nb >= 1, "--pool must be >= --batch"
+    batches = [tuple(t[i * a.batch:(i + 1) * a.batch] for t in (hm, wh, off, feat)) for i in range(nb)]
+
+    def run(bt):
+        return inference.refine_frames(bt[0], bt[1], bt[2], bt[3], head, k=a.k, relu_feat=False)
+
+    for i in range(2):
+        out, fo = run(batches[i % nb])
+    torch.cuda.synchronize()
+    n_iter = max(a.frames // a.batch, 1)
+    kept = 0
+    t0 = time.perf_counter()
+    for i in range(n_iter):
+        out, fo = run(batches[i % nb])
+        kept += out.shape[0]
+    torch.cuda.synchronize()
+    t = time.perf_counter() - t0
+    frames = n_iter * a.batch
+    res = {"metric": "boxes/sec (decode + re-regression + Soft-NMS)", "value": round(frames * a.k / t, 1),
+           "unit": "boxes/sec", "frames_per_sec": round(frames / t, 1), "frames": frames, "n_gpus": 1,
+           "ms_per_batch": round(1e3 * t / n_iter, 3), "output_boxes_per_frame": round(kept / frames, 1),
+           "higher_is_better": True, "dtype": "f32", "data": "synthetic", "vs_baseline": None,
+           "config": {"workload": "RRNet inference-only post-process, %d frames of 1920x1080 (maps %dx%d), K=%d, "
+                                  "batch %d, pool of %d resident frames" % (frames, a.hf, a.wf, a.k, a.batch, a.pool)}}
+    if a.cpu_frames > 0:
+        res["cpu_baseline"] = cpu_baseline(head_sd, pool, a.cpu_frames, a.k)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
