@@ -975,6 +975,7 @@ int launch_igemm(ConvArgs &a, int bn, bool scalar, int blocks, int gy, int gz, h
         const bool small = (long)a.N * a.SH * a.SW * a.SC * 4 < (1l << 31) && (long)a.wK * a.R * a.S * a.wC * 4 < (1l << 31);
         if (bn == 128) return scalar ? IG(128, true, 32, false)
                                      : (conv_pipe() && small ? IG(128, false, 32, true) : IG(128, false, 32, false));
+        if (bn == 64) return IG(64, false, 32, false);   // 4 waves along M, 32x64 each: 33..64-column layers
         return scalar ? IG(32, true, 32, false) : IG(32, false, 32, false);
     }
     if (bn == 128) return scalar ? IG(128, true, 16, false) : IG(128, false, 16, false);
@@ -1006,9 +1007,9 @@ extern "C" int rr_conv_fprop(const float *x, const float *w, const float *bias, 
     RR_CHECK_ARG(M < (1l << 31) && (long)n * h * wd * c < (1l << 40), "rr_conv_fprop: tensor too large");
     a.M = (int)M; a.Kg = r * s * c; a.wK = k; a.wC = c;
     const bool scalar = (c % 4) != 0 || r * s > 64;   // the vector path keeps a 64-bit tap mask per row
-    const int bn = k > 32 ? 128 : 32;
-    const int blocks = rr_cdiv(M, BM) * rr_cdiv(k, bn);
     const int bk = conv_bk();
+    const int bn = k > 64 ? 128 : (k > 32 ? (!scalar && bk == 32 ? 64 : 128) : 32);
+    const int blocks = rr_cdiv(M, BM) * rr_cdiv(k, bn);
     const int nk = scalar ? rr_cdiv(a.Kg, bk) : rr_cdiv(c, bk) * r * s;
     int ks = (bias == nullptr && !relu && k % 4 == 0 && k <= 1024) ? pick_ksplit(blocks, nk) : 1;
     if (ks > 1) {
@@ -1043,10 +1044,10 @@ extern "C" int rr_conv_dgrad(const float *dy, const float *w, float *dx, int n, 
     RR_CHECK_ARG(M < (1l << 31), "rr_conv_dgrad: tensor too large");
     a.M = (int)M; a.Kg = r * s * k; a.wK = k; a.wC = c;
     const bool scalar = (k % 4) != 0 || (c % 4) != 0 || r * s > 64 || stride > 2;
-    const int bn = c > 32 ? 128 : 32;
+    const int bk = conv_bk();
+    const int bn = c > 64 ? 128 : (c > 32 ? (!scalar && bk == 32 ? 64 : 128) : 32);
     int blocks = rr_cdiv(M, BM) * rr_cdiv(c, bn);
     int gy = 1;
-    const int bk = conv_bk();
     int nk = scalar ? rr_cdiv(a.Kg, bk) : rr_cdiv(k, bk) * r * s;
     if (stride == 2 && !scalar) {     // parity-decomposed: 4 classes of ceil(h/2) x ceil(w/2) pixels each
         a.parity = 1;

@@ -64,12 +64,97 @@ __device__ void find_bin(const int *hist, int nbins, int need, int *result)
     }
 }
 
+constexpr int DEC_CAP = 8192;      // candidate slots of the fast path (64 KB of LDS)
+constexpr int DEC_SAMPLES = 16384;  // strided sample that places the candidate threshold
+
+// Fast path (all but degenerate maps): the threshold is placed from a strided sample so that ~2K..3K of the
+// n raw values lie above it, ONE scan collects them into LDS, and the exact top-K is taken from the
+// candidates.  Raw values are compared (sigmoid is monotone), so expf runs on the candidates only.  The result is
+// identical to the exact radix path below whenever the K-th score is strictly above the score of the threshold
+// (no outsider can tie with it); otherwise, or when the sample misjudges the count, the exact path runs.
+// Returns the number of candidates left in `keys` (sorted, score-descending) or -1.
+__device__ int decode_fast_path(const float *x, long n, int is_logits, int C, long HW, int K,
+                                unsigned long long *keys, int *hist, int *res, int *cnt)
+{
+    const int tid = threadIdx.x;
+    unsigned int t0 = 0;                      // ordered key of the candidate threshold (0: take everything)
+    if (n > DEC_CAP) {
+        const long stride = n / DEC_SAMPLES > 0 ? n / DEC_SAMPLES : 1;
+        const long ns = (n + stride - 1) / stride;
+        long target = 2l * K > K + 1024l ? 2l * K : K + 1024l;
+        if (target > DEC_CAP / 2) target = DEC_CAP / 2;
+        if (target < K) return -1;            // K too close to the candidate capacity
+        int need = (int)((double)target * (double)ns / (double)n);
+        if (need < 8) need = 8;
+        if (need > ns) return -1;
+        unsigned int prefix = 0;
+        for (int pass = 0; pass < 2; ++pass) {
+            const int shift = pass == 0 ? 21 : 10;
+            for (int i = tid; i < 2048; i += DT) hist[i] = 0;
+            __syncthreads();
+            for (long j = tid; j < ns; j += DT) {
+                const unsigned int o = f2ord(x[j * stride]);
+                if (pass == 0 || (o >> 21) == (prefix >> 21)) atomicAdd(&hist[(o >> shift) & 2047], 1);
+            }
+            __syncthreads();
+            find_bin(hist, 2048, need, res);
+            __syncthreads();
+            prefix |= (unsigned int)res[0] << shift;
+            need -= res[1];
+            __syncthreads();
+        }
+        t0 = prefix;                          // low 10 bits zero: at or just below the sampled rank
+    }
+    if (tid == 0) *cnt = 0;
+    __syncthreads();
+    for (long i = tid; i < n; i += DT) {
+        const unsigned int o = f2ord(x[i]);
+        if (o >= t0) {
+            const int p = atomicAdd(cnt, 1);
+            if (p < DEC_CAP) keys[p] = ((unsigned long long)o << 32) | (unsigned long long)i;
+        }
+    }
+    __syncthreads();
+    const int m = *cnt;
+    if (m < K || m > DEC_CAP) return -1;
+    // candidates -> (score, reference flat index) keys
+    for (int p = tid; p < m; p += DT) {
+        const unsigned long long cand = keys[p];
+        const long i = (long)(cand & 0xffffffffull);
+        const float sc = score_of(ord2f((unsigned int)(cand >> 32)), is_logits);
+        const unsigned int ref = (unsigned int)((i % C) * HW + i / C);
+        keys[p] = ((unsigned long long)f2ord(sc) << 32) | (unsigned long long)(0xffffffffu - ref);
+    }
+    int mp = 2;
+    while (mp < m) mp <<= 1;
+    for (int p = m + tid; p < mp; p += DT) keys[p] = 0ull;
+    __syncthreads();
+    for (int k2 = 2; k2 <= mp; k2 <<= 1) {
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < mp / 2; t += DT) {
+                const int lo = ((t / j) * 2 * j) + (t % j);
+                const int hi2 = lo + j;
+                const bool desc = ((lo & k2) == 0);
+                const unsigned long long a = keys[lo], b = keys[hi2];
+                if ((a < b) == desc) { keys[lo] = b; keys[hi2] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    if (t0 != 0) {
+        const unsigned int kth = (unsigned int)(keys[K - 1] >> 32);
+        const unsigned int edge = f2ord(score_of(ord2f(t0), is_logits));
+        if (kth <= edge) return -1;           // an outsider could tie with the K-th score: exact path decides
+    }
+    return m;
+}
+
 __global__ __launch_bounds__(DT) void decode_topk_kernel(const float *hm, int is_logits, const float *wh, const float *off,
                                                          int H, int W, int C, int K, int KP, float *out, int *pix_out)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    unsigned long long *keys = reinterpret_cast<unsigned long long *>(smem);  // [KP]
-    int *hist = reinterpret_cast<int *>(keys + KP);                           // [2048]
+    unsigned long long *keys = reinterpret_cast<unsigned long long *>(smem);  // [max(KP, DEC_CAP)]
+    int *hist = reinterpret_cast<int *>(keys + (KP > DEC_CAP ? KP : DEC_CAP)); // [2048]
     int *scan = hist + 2048;                                                  // [DT/64 + 1]
     __shared__ int res[2];
     __shared__ int cnt_gt;
@@ -79,6 +164,9 @@ __global__ __launch_bounds__(DT) void decode_topk_kernel(const float *hm, int is
     const long n = HW * C;
     const float *x = hm + (long)blockIdx.x * n;
 
+    const int fast = decode_fast_path(x, n, is_logits, C, HW, K, keys, hist, res, &cnt_gt);
+    __syncthreads();
+    if (fast < 0) {
     // ---- radix select of the K-th largest ordered key
     unsigned int prefix = 0;   // bits fixed so far (top-aligned)
     int need = K;
@@ -152,6 +240,7 @@ __global__ __launch_bounds__(DT) void decode_topk_kernel(const float *hm, int is
             __syncthreads();
         }
     }
+    }   // exact path
 
     // ---- gather + box assembly (models/rrnet.py:122-137)
     for (int k = tid; k < K; k += DT) {
@@ -375,7 +464,9 @@ extern "C" int rr_decode_topk(const float *hm, int is_logits, const float *wh, c
     RR_CHECK_ARG((long)h * w * c < (1l << 31), "rr_decode_topk: map too large");
     int kp = 2;
     while (kp < k) kp <<= 1;
-    const size_t lds = (size_t)kp * 8 + 2048 * 4 + (DT / 64 + 1) * 4;
+    const size_t lds = (size_t)(kp > DEC_CAP ? kp : DEC_CAP) * 8 + 2048 * 4 + (DT / 64 + 1) * 4;
+    hipFuncSetAttribute(reinterpret_cast<const void *>(decode_topk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        (int)lds);
     hipLaunchKernelGGL(decode_topk_kernel, dim3(b), dim3(DT), lds, stream, hm, is_logits, wh, off, h, w, c, k, kp, out, pix_out);
     RR_CHECK_LAUNCH("rr_decode_topk");
     return RR_OK;

@@ -52,10 +52,15 @@ class _ConvBnAct(torch.autograd.Function):
             if bn.num_batches_tracked is not None:
                 bn.num_batches_tracked += 1
         else:
-            y = ops.conv_fprop(x, wc, None, stride, pad, False)
             scale, shift = ops.bn_eval_coeffs(gamma, beta, bn.running_mean, bn.running_var, bn.eps)
             mean = invstd = cnt_dev = None
             count = 0.0
+            if residual is None:
+                # inference: BN is a per-channel affine map -> folded into the weights and the conv epilogue's
+                # bias (+ReLU); no separate pass over the output
+                ctx.cfg = (stride, pad, relu, count, sync, False)
+                return ops.conv_fprop(x, ops.to_nhwc(wc * scale.view(-1, 1, 1, 1)), shift, stride, pad, relu)
+            y = ops.conv_fprop(x, wc, None, stride, pad, False)
         res = ops.to_nhwc(residual) if residual is not None else None
         z = ops.bn_apply(y, scale, shift, res, relu)
         if bn.training:
