@@ -594,7 +594,10 @@ struct WgradArgs {
 
 // BMW x BN output tile (ko x c).  128x128: 2x2 waves of 64x64; 128x32 / 32x128: 4 waves of one 32x32;
 // 32x32: the 4 waves split the 32-deep K-step between them (their partial sums meet in the atomics).
-template <int BMW, int BN, bool A_SCALAR, bool B_SCALAR, bool PIPE>
+// PIPE: 0 plain double-buffered loop; 1 software-pipelined; 2 software-pipelined for Q % BK == 0, where the BK pixels
+// of a K-step lie in one output row: the row walk (n, p, q0) is wave-uniform and lives in SGPRs, the tensor offsets go
+// through the buffer instruction's scalar offset, and the per-lane work per load is one add, one compare, one select.
+template <int BMW, int BN, bool A_SCALAR, bool B_SCALAR, int PIPE>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a)
 {
     constexpr int TILES = (BMW / 32) * (BN / 32);
@@ -710,7 +713,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a)
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int lr = lane & 31, lh = lane >> 5;
-    constexpr bool WPIPE = PIPE && (BMW == 128 && BN == 128 && !A_SCALAR && !B_SCALAR);
+    constexpr bool WPIPE = PIPE != 0 && (BMW == 128 && BN == 128 && !A_SCALAR && !B_SCALAR);
+    constexpr bool ALIGNED = PIPE == 2;
     if constexpr (!WPIPE) {
     load_tiles(kc_begin);
     store_tiles(0);
@@ -782,19 +786,64 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a)
     }
     const int a_step = BK * a.K * 4;
     const int rr_off = r - a.pad_h, ss_off = s - a.pad_w;
+    constexpr unsigned FAR = 0x80000000u;   // beyond any (< 2 GiB) tensor, no 32-bit wrap when a scalar offset is added
+    // ---- aligned mode state: uniform pixel-row walk + per-lane constants
+    int s_n = 0, s_p = 0, s_q0 = 0;
+    unsigned a_voff[AJ], b_voff[BJ];
+    int b_iw0[BJ];
+    if constexpr (ALIGNED) {
+        const int m0 = kc_begin * BK, pq = a.P * a.Q;
+        s_n = m0 / pq;
+        const int rem = m0 - s_n * pq;
+        s_p = rem / a.Q;
+        s_q0 = rem - s_p * a.Q;
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) a_voff[j] = a_ko_ok ? (unsigned)a_off[j] : FAR;
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) {
+            const int lq = b_row + RPP_B * j;                     // pixel of this row inside the K-step
+            b_iw0[j] = lq * a.stride + ss_off;                    // iw = q0*stride + b_iw0
+            // lanes whose iw is negative get a negative (wrapped) offset here; the iw test masks them
+            b_voff[j] = b_c_ok ? (unsigned)(((lq * a.stride + ss_off) * a.C + c0 + b_col) * 4) : FAR;
+        }
+    }
     auto load_a = [&](int j, int kc) {
-        const unsigned ok = (unsigned)a_ko_ok & (unsigned)(kc * BK + a_m[j] < a.M) & (unsigned)(kc < kc_end);
-        const unsigned off = ok ? (unsigned)(a_off[j] + kc * a_step) : OOB;
-        ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, off, 0, 0));
+        if constexpr (ALIGNED) {
+            const int kcl = kc < kc_end ? kc : kc_end - 1;        // past the end: re-read the last chunk (never consumed)
+            const int soff = __builtin_amdgcn_readfirstlane(kcl * a_step);
+            ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, a_voff[j], soff, 0));
+        } else {
+            const unsigned ok = (unsigned)a_ko_ok & (unsigned)(kc * BK + a_m[j] < a.M) & (unsigned)(kc < kc_end);
+            const unsigned off = ok ? (unsigned)(a_off[j] + kc * a_step) : OOB;
+            ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, off, 0, 0));
+        }
     };
     auto load_b = [&](int j) {
-        const int ih = bp_[j] * a.stride + rr_off, iw = bq_[j] * a.stride + ss_off;
-        const unsigned ok = (unsigned)b_c_ok & (unsigned)(bn_[j] < a.N) & (unsigned)((unsigned)ih < (unsigned)a.H) &
-                            (unsigned)((unsigned)iw < (unsigned)a.W);
-        const unsigned off = ok ? (unsigned)((((bn_[j] * a.H + ih) * a.W + iw) * a.C + c0 + b_col) * 4) : OOB;
-        rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0));
+        if constexpr (ALIGNED) {
+            const int ih = s_p * a.stride + rr_off;
+            const bool s_ok = (s_n < a.N) & ((unsigned)ih < (unsigned)a.H);
+            // scalar part of the address: pixel (n, ih, q0*stride), never negative
+            const int sbase = s_ok ? (((s_n * a.H + ih) * a.W + s_q0 * a.stride) * a.C) * 4 : 0;
+            const int iw = s_q0 * a.stride + b_iw0[j];
+            const bool ok = s_ok & ((unsigned)iw < (unsigned)a.W);
+            const unsigned voff = ok ? b_voff[j] : FAR;
+            rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                  rs_x, voff, __builtin_amdgcn_readfirstlane(sbase), 0));
+        } else {
+            const int ih = bp_[j] * a.stride + rr_off, iw = bq_[j] * a.stride + ss_off;
+            const unsigned ok = (unsigned)b_c_ok & (unsigned)(bn_[j] < a.N) & (unsigned)((unsigned)ih < (unsigned)a.H) &
+                                (unsigned)((unsigned)iw < (unsigned)a.W);
+            const unsigned off = ok ? (unsigned)((((bn_[j] * a.H + ih) * a.W + iw) * a.C + c0 + b_col) * 4) : OOB;
+            rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0));
+        }
     };
     auto adv_b = [&](int j) {   // advance row j by BK pixels (kept apart from the load to keep VALU clusters short)
+        if constexpr (ALIGNED) {
+            if (j == BJ - 1) {                                    // one uniform step per K-step
+                s_q0 += BK;
+                if (s_q0 >= a.Q) { s_q0 = 0; if (++s_p == a.P) { s_p = 0; ++s_n; } }
+            }
+        } else {
         bq_[j] += BK;
         const bool w1 = bq_[j] >= a.Q;
         bq_[j] -= w1 ? a.Q : 0;
@@ -807,6 +856,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a)
                 bq_[j] -= a.Q;
                 if (++bp_[j] == a.P) { bp_[j] = 0; ++bn_[j]; }
             }
+        }
         }
     };
     auto st_a = [&](int j, int buf) {
@@ -900,6 +950,16 @@ int launch(K kern, int blocks, size_t lds, hipStream_t stream, const A &args, co
 }
 
 size_t igemm_lds(int bn, bool b_kn, int bk) { return sizeof(float) * 2 * (BM * (bk + 4) + (b_kn ? bk * bn : bn * (bk + 4))); }
+
+int wgrad_aligned()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("RR_WGRAD_ALIGNED");
+        v = (e && atoi(e) == 0) ? 0 : 1;
+    }
+    return v;
+}
 
 int conv_bk()
 {
@@ -1096,14 +1156,16 @@ extern "C" int rr_conv_wgrad(const float *x, const float *dy, float *dw, int n, 
     const size_t lds = sizeof(float) * 2 * (BK * bmw + BK * bn);
     const bool as = (k % 4) != 0, bs = (c % 4) != 0;
 #define WG(BMv, BNv)                                                                                                  \
-    (as ? (bs ? launch(conv_wgrad_kernel<BMv, BNv, true, true, false>, blocks, lds, stream, a, "rr_conv_wgrad")      \
-              : launch(conv_wgrad_kernel<BMv, BNv, true, false, false>, blocks, lds, stream, a, "rr_conv_wgrad"))    \
-        : (bs ? launch(conv_wgrad_kernel<BMv, BNv, false, true, false>, blocks, lds, stream, a, "rr_conv_wgrad")     \
-              : launch(conv_wgrad_kernel<BMv, BNv, false, false, false>, blocks, lds, stream, a, "rr_conv_wgrad")))
+    (as ? (bs ? launch(conv_wgrad_kernel<BMv, BNv, true, true, 0>, blocks, lds, stream, a, "rr_conv_wgrad")      \
+              : launch(conv_wgrad_kernel<BMv, BNv, true, false, 0>, blocks, lds, stream, a, "rr_conv_wgrad"))    \
+        : (bs ? launch(conv_wgrad_kernel<BMv, BNv, false, true, 0>, blocks, lds, stream, a, "rr_conv_wgrad")     \
+              : launch(conv_wgrad_kernel<BMv, BNv, false, false, 0>, blocks, lds, stream, a, "rr_conv_wgrad")))
     // pipelined 128x128 variant: 32-bit buffer offsets, both tensors below 2 GiB
     if (bmw == 128 && bn == 128 && !as && !bs && conv_pipe() && M * k * 4 < (1l << 31) &&
         (long)n * h * wd * c * 4 < (1l << 31))
-        return launch(conv_wgrad_kernel<128, 128, false, false, true>, blocks, lds, stream, a, "rr_conv_wgrad");
+        return a.Q % BK == 0 && wgrad_aligned()
+                   ? launch(conv_wgrad_kernel<128, 128, false, false, 2>, blocks, lds, stream, a, "rr_conv_wgrad")
+                   : launch(conv_wgrad_kernel<128, 128, false, false, 1>, blocks, lds, stream, a, "rr_conv_wgrad");
     if (bmw == 128) return bn == 128 ? WG(128, 128) : WG(128, 32);
     return bn == 128 ? WG(32, 128) : WG(32, 32);
 #undef WG
