@@ -74,6 +74,13 @@ int rr_conv_fprop(const float *x, const float *w, const float *bias, float *y, d
                   int relu, hipStream_t stream);
 int rr_conv_dgrad(const float *dy, const float *w, float *dx, int n, int h, int wd, int c, int k,
                   int r, int s, int stride, int pad_h, int pad_w, int accumulate, hipStream_t stream);
+/* Stride-1 data gradient through the forward kernel (its [n][k] weight fragments are read 16 bytes at a time):
+ * rr_weight_flip_transpose writes wt[c][r-1-i][s-1-j][k] = w[k][i][j][c] (k*r*s*c floats of caller scratch), then
+ * rr_conv_dgrad_s1(dy [n,p,q,k], wt) = dx [n,h,w,c], p = h + 2*pad_h - r + 1.  Same result as rr_conv_dgrad
+ * (different summation order inside the fp32 accumulation chain). */
+int rr_weight_flip_transpose(const float *w, float *wt, int k, int c, int r, int s, hipStream_t stream);
+int rr_conv_dgrad_s1(const float *dy, const float *wt, float *dx, int n, int h, int wd, int c, int k,
+                     int r, int s, int pad_h, int pad_w, int accumulate, hipStream_t stream);
 int rr_conv_wgrad(const float *x, const float *dy, float *dw, int n, int h, int wd, int c, int k,
                   int r, int s, int stride, int pad_h, int pad_w, int out_h, int out_w, hipStream_t stream);
 

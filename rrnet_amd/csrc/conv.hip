@@ -1051,9 +1051,9 @@ extern "C" size_t rr_conv_stat_slab_bytes(int n, int p, int q, int k)
     return (size_t)((M + BM - 1) / BM) * 2 * k * sizeof(double);
 }
 
-extern "C" int rr_conv_fprop(const float *x, const float *w, const float *bias, float *y, double *stat_slab,
-                             int n, int h, int wd, int c, int k, int r, int s, int stride, int pad_h,
-                             int pad_w, int relu, hipStream_t stream)
+static int fprop_impl(const float *x, const float *w, const float *bias, float *y, double *stat_slab,
+                      int n, int h, int wd, int c, int k, int r, int s, int stride, int pad_h,
+                      int pad_w, int relu, int accumulate, hipStream_t stream)
 {
     RR_CHECK_ARG(n > 0 && h > 0 && wd > 0 && c > 0 && k > 0 && r > 0 && s > 0 && stride > 0, "rr_conv_fprop: bad dims");
     ConvArgs a{};
@@ -1062,7 +1062,7 @@ extern "C" int rr_conv_fprop(const float *x, const float *w, const float *bias, 
     a.DH = (h + 2 * pad_h - r) / stride + 1; a.DW = (wd + 2 * pad_w - s) / stride + 1; a.DC = k;
     RR_CHECK_ARG(a.DH > 0 && a.DW > 0, "rr_conv_fprop: empty output");
     a.R = r; a.S = s; a.stride = stride; a.pad_h = pad_h; a.pad_w = pad_w;
-    a.relu = relu; a.accumulate = 0; a.ksplit = 1; a.zero = zero_page();
+    a.relu = relu; a.accumulate = accumulate; a.ksplit = 1; a.zero = zero_page();
     const long M = (long)n * a.DH * a.DW;
     RR_CHECK_ARG(M < (1l << 31) && (long)n * h * wd * c < (1l << 40), "rr_conv_fprop: tensor too large");
     a.M = (int)M; a.Kg = r * s * c; a.wK = k; a.wC = c;
@@ -1074,7 +1074,7 @@ extern "C" int rr_conv_fprop(const float *x, const float *w, const float *bias, 
     int ks = (bias == nullptr && !relu && k % 4 == 0 && k <= 1024) ? pick_ksplit(blocks, nk) : 1;
     if (ks > 1) {
         a.ksplit = ks;
-        hipMemsetAsync(y, 0, sizeof(float) * (size_t)M * k, stream);
+        if (!accumulate) hipMemsetAsync(y, 0, sizeof(float) * (size_t)M * k, stream);
     }
     int rc = launch_igemm<0>(a, bn, scalar, blocks, 1, ks, stream, "rr_conv_fprop");
     if (rc == RR_OK && ks > 1 && stat_slab != nullptr) {
@@ -1086,6 +1086,51 @@ extern "C" int rr_conv_fprop(const float *x, const float *w, const float *bias, 
         RR_CHECK_LAUNCH("rr_conv_fprop(stats)");
     }
     return rc;
+}
+
+extern "C" int rr_conv_fprop(const float *x, const float *w, const float *bias, float *y, double *stat_slab,
+                             int n, int h, int wd, int c, int k, int r, int s, int stride, int pad_h,
+                             int pad_w, int relu, hipStream_t stream)
+{
+    return fprop_impl(x, w, bias, y, stat_slab, n, h, wd, c, k, r, s, stride, pad_h, pad_w, relu, 0, stream);
+}
+
+// wt[c][R-1-r][S-1-s][k] = w[k][r][s][c]: 32x32 tiles of the (k, c) plane through LDS, one tap per grid.z
+__global__ __launch_bounds__(256) void weight_flip_transpose_kernel(const float *w, float *wt, int K, int C, int RS)
+{
+    __shared__ float tile[32][33];
+    const int tap = blockIdx.z, k0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        const int k = k0 + i, c = c0 + tx;
+        tile[i][tx] = (k < K && c < C) ? w[((long)k * RS + tap) * C + c] : 0.f;
+    }
+    __syncthreads();
+    const int ftap = RS - 1 - tap;   // (R-1-r)*S + (S-1-s)
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, k = k0 + tx;
+        if (k < K && c < C) wt[((long)c * RS + ftap) * K + k] = tile[tx][i];
+    }
+}
+
+extern "C" int rr_weight_flip_transpose(const float *w, float *wt, int k, int c, int r, int s, hipStream_t stream)
+{
+    RR_CHECK_ARG(k > 0 && c > 0 && r > 0 && s > 0 && r * s < 65536, "rr_weight_flip_transpose: bad dims");
+    hipLaunchKernelGGL(weight_flip_transpose_kernel, dim3(rr_cdiv(c, 32), rr_cdiv(k, 32), r * s), dim3(256), 0, stream, w, wt,
+                       k, c, r * s);
+    RR_CHECK_LAUNCH("rr_weight_flip_transpose");
+    return RR_OK;
+}
+
+extern "C" int rr_conv_dgrad_s1(const float *dy, const float *wt, float *dx, int n, int h, int wd, int c, int k,
+                                int r, int s, int pad_h, int pad_w, int accumulate, hipStream_t stream)
+{
+    RR_CHECK_ARG(pad_h < r && pad_w < s && pad_h >= 0 && pad_w >= 0, "rr_conv_dgrad_s1: pad must be in [0, kernel)");
+    const int p = h + 2 * pad_h - r + 1, q = wd + 2 * pad_w - s + 1;
+    RR_CHECK_ARG(p > 0 && q > 0, "rr_conv_dgrad_s1: empty dy");
+    // a stride-1 data gradient IS a forward convolution of dy with the flipped, transposed filter
+    return fprop_impl(dy, wt, nullptr, dx, nullptr, n, p, q, k, c, r, s, 1, r - 1 - pad_h, s - 1 - pad_w, 0, accumulate,
+                      stream);
 }
 
 extern "C" int rr_conv_dgrad(const float *dy, const float *w, float *dx, int n, int h, int wd, int c, int k,

@@ -1,6 +1,8 @@
 """Thin, autograd-free wrappers over the C ABI (include/rrnet_hip.h).  Tensors are torch CUDA
 tensors used purely as device-memory handles: logical shape NCHW with channels_last strides,
 i.e. NHWC in memory; conv weights logical [K,C,R,S] with channels_last strides = OHWI."""
+import os
+
 import torch
 
 from rrnet_amd import _C
@@ -126,6 +128,10 @@ def stem_wgrad_s2d(x, dy, dw):
     return dw
 
 
+_DGRAD_VIA_FPROP = os.environ.get("RR_DGRAD_VIA_FPROP", "1") != "0"
+_DGRAD_VIA_FPROP_MIN_PIXELS = int(os.environ.get("RR_DGRAD_VIA_FPROP_MIN_PIXELS", "4096"))  # below: the dgrad kernel's split-K wins
+
+
 def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False):
     """dy [N,K,P,Q], w [K,C,R,S] -> dx [N,C,H,W]; with `out` and accumulate adds into it."""
     _C.require_cuda(dy, w)
@@ -137,8 +143,19 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False)
         out = empty_nhwc(n, c, h, wd, dy.device)
         accumulate = False
     assert is_nhwc(out)
-    f = _C.fn("rr_conv_dgrad")
     flops = 2.0 * dy.shape[0] * dy.shape[2] * dy.shape[3] * k * c * r * s
+    if (stride == 1 and k % 4 == 0 and c % 4 == 0 and r * s <= 64 and pad[0] < r and pad[1] < s and _DGRAD_VIA_FPROP
+            and dy.shape[2] * dy.shape[3] >= _DGRAD_VIA_FPROP_MIN_PIXELS):
+        # the forward kernel on dy with the flipped / transposed filter (one tiny transpose per layer and step)
+        wt = torch.empty(k * c * r * s, dtype=torch.float32, device=dy.device)
+        _C.check(_C.fn("rr_weight_flip_transpose")(_C.ptr(w), _C.ptr(wt), k, c, r, s, _C.stream()),
+                 "rr_weight_flip_transpose")
+        f1 = _C.fn("rr_conv_dgrad_s1")
+        _C.check(_timed(_igemm_name("dgrad", c, False), flops,
+                        lambda: f1(_C.ptr(dy), _C.ptr(wt), _C.ptr(out), n, h, wd, c, k, r, s, pad[0], pad[1],
+                                   int(accumulate), _C.stream()), (n, h, wd, c, k, r, s, stride)), "rr_conv_dgrad_s1")
+        return out
+    f = _C.fn("rr_conv_dgrad")
     _C.check(_timed(_igemm_name("dgrad", c, (k % 4 != 0) or (c % 4 != 0)), flops,
                     lambda: f(_C.ptr(dy), _C.ptr(w), _C.ptr(out), n, h, wd, c, k, r, s, stride, pad[0], pad[1],
                               int(accumulate), _C.stream()), (n, h, wd, c, k, r, s, stride)), "rr_conv_dgrad")

@@ -72,14 +72,22 @@ def test_conv_fprop_dgrad_wgrad(cfg):
     if relu:
         gy_eff = gy_eff * (y_ref.detach() > 0).float()
     gyd = ops.to_nhwc(gy_eff.cuda())
-    dx = ops.conv_dgrad(gyd, wd, (n, c, h, w), stride, (ph, pw))
     tol = 2e-5 * np.sqrt(k * r * s)
-    np.testing.assert_allclose(dx.cpu().numpy(), xr.grad.numpy(), atol=tol, rtol=1e-4)
-    # accumulate form
     base = _mk((n, c, h, w), 5)
-    acc = ops.to_nhwc(base.cuda()).clone(memory_format=torch.channels_last)
-    ops.conv_dgrad(gyd, wd, (n, c, h, w), stride, (ph, pw), out=acc, accumulate=True)
-    np.testing.assert_allclose(acc.cpu().numpy(), (xr.grad + base).numpy(), atol=tol, rtol=1e-4)
+    saved = ops._DGRAD_VIA_FPROP, ops._DGRAD_VIA_FPROP_MIN_PIXELS
+    ops._DGRAD_VIA_FPROP_MIN_PIXELS = 0
+    try:
+        # both data-gradient routes: the dgrad kernel, and (stride 1) the forward kernel on flipped weights
+        for via_fprop in (False, True):
+            ops._DGRAD_VIA_FPROP = via_fprop
+            dx = ops.conv_dgrad(gyd, wd, (n, c, h, w), stride, (ph, pw))
+            np.testing.assert_allclose(dx.cpu().numpy(), xr.grad.numpy(), atol=tol, rtol=1e-4)
+            # accumulate form
+            acc = ops.to_nhwc(base.cuda()).clone(memory_format=torch.channels_last)
+            ops.conv_dgrad(gyd, wd, (n, c, h, w), stride, (ph, pw), out=acc, accumulate=True)
+            np.testing.assert_allclose(acc.cpu().numpy(), (xr.grad + base).numpy(), atol=tol, rtol=1e-4)
+    finally:
+        ops._DGRAD_VIA_FPROP, ops._DGRAD_VIA_FPROP_MIN_PIXELS = saved
 
     dw = torch.zeros((k, r, s, c), device="cuda").permute(0, 3, 1, 2)
     ops.conv_wgrad(xd, gyd, dw, stride, (ph, pw))
