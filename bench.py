@@ -128,7 +128,8 @@ def main():
         step_no += 1
     timer = None
     if not a.no_kernel_timing:
-        timer = ops.KernelTimer()
+        # HIP events around every launch of the dominant kernel (the roofline leg); --detail times all conv kernels
+        timer = ops.KernelTimer(None if a.detail else {"conv_fprop<BN=128,vec4>"})
         ops.TIMER = timer
     sync_all()
     t0 = time.perf_counter()
@@ -184,8 +185,9 @@ def main():
                 for (name, shp), v in rows[:40]:
                     print("%-28s %-38s n=%4d %8.2f ms %6.1f TF" % (name, shp, v["launches"], v["ms"],
                           v["flops"] / (v["ms"] * 1e-3) / 1e12), file=sys.stderr)
-            conv_ms = sum(v["ms"] for v in summ.values())
-            out["conv_time_fraction"] = round(conv_ms / (elapsed * 1e3), 4)
+            if a.detail:
+                conv_ms = sum(v["ms"] for v in summ.values())
+                out["conv_time_fraction"] = round(conv_ms / (elapsed * 1e3), 4)
         if a.backbone == "hourglass" and a.size == 1024:
             out["step_mfma_frac"] = round(out["value"] / world * ALGO_TFLOP_PER_IMAGE / FP32_MFMA_PEAK_TFLOPS, 4)
         if world == 1 and not a.no_cpu_baseline:

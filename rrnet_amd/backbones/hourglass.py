@@ -42,14 +42,17 @@ class ResidualBlock(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        xa, xb = RF.fanout(x, 2)
-        out = RF.conv_bn_act(xa, self.conv1, self.bn1, relu=True)
+        # both consumers of x (conv1 and the skip path) accumulate their input gradients into one buffer
+        xa, xb, acc = RF.fanout_shared(x, 2)
+        out = RF.conv_bn_act(xa, self.conv1, self.bn1, relu=True, x_acc=acc)
         if len(self.skip_connection):
-            skip = RF.conv_bn_act(xb, self.skip_connection[0], self.skip_connection[1], relu=False)
+            skip = RF.conv_bn_act(xb, self.skip_connection[0], self.skip_connection[1], relu=False, x_acc=acc)
+            res_acc = None
         else:
             skip = xb
+            res_acc = acc
         # relu(bn2(conv2(out)) + skip): BN apply, residual add and ReLU are one kernel
-        return RF.conv_bn_act(out, self.conv2, self.bn2, relu=True, residual=skip)
+        return RF.conv_bn_act(out, self.conv2, self.bn2, relu=True, residual=skip, res_acc=res_acc)
 
 
 class ConvBNRelu(nn.Module):

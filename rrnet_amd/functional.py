@@ -10,6 +10,8 @@ all-reduce and the fused Adam kernel operate on) the backward kernels accumulate
 it (wgrad's float atomics, the BN apply kernel's dgamma/dbeta) and autograd sees `None`;
 otherwise a fresh gradient tensor is returned the usual way.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -31,7 +33,8 @@ class _ConvBnAct(torch.autograd.Function):
     backbones/resnet.py:33-53."""
 
     @staticmethod
-    def forward(ctx, x, w, gamma, beta, residual, bn, stride, pad, relu):
+    def forward(ctx, x, w, gamma, beta, residual, bn, stride, pad, relu, x_acc=None, res_acc=None):
+        ctx.accs = (x_acc, res_acc)
         x = ops.to_nhwc(x)
         wc = ops.to_nhwc(w)
         n, _, h, wd = x.shape
@@ -99,7 +102,16 @@ class _ConvBnAct(torch.autograd.Function):
         want_g = has_res and relu
         dy, g = ops.bn_bwd_apply(dz, z, y, mean, invstd, gamma, sums, count, want_g,
                                  dg_t if fused_affine else None, db_t if fused_affine else None, cnt_dev, msc, msh)
-        dx = ops.conv_dgrad(dy, wc, ctx.xshape, stride, pad) if ctx.needs_input_grad[0] else None
+        x_acc, res_acc = ctx.accs
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if x_acc is not None and x_acc.buf is not None:
+                # another consumer of x already produced its gradient: add into it inside the dgrad epilogue
+                ops.conv_dgrad(dy, wc, ctx.xshape, stride, pad, out=x_acc.buf, accumulate=True)
+            else:
+                dx = ops.conv_dgrad(dy, wc, ctx.xshape, stride, pad)
+                if x_acc is not None:
+                    x_acc.buf = dx
         w_t = _grad_target(w)
         ret_dw = None
         stem = (tuple(w.shape[1:]) == (3, 7, 7) and stride == 2 and tuple(pad) == (3, 3)
@@ -114,12 +126,20 @@ class _ConvBnAct(torch.autograd.Function):
         dres = None
         if has_res and ctx.needs_input_grad[4]:
             dres = g if relu else dz
-        return dx, ret_dw, ret_dg, ret_db, dres, None, None, None, None
+            if res_acc is not None and relu:           # g is a fresh tensor of ours: it may serve as the fan-in target
+                if res_acc.buf is None:
+                    res_acc.buf = g
+                else:
+                    res_acc.buf.add_(g)
+                    dres = None
+        return dx, ret_dw, ret_dg, ret_db, dres, None, None, None, None, None, None
 
 
-def conv_bn_act(x, conv, bn, relu=True, residual=None):
-    """conv: nn.Conv2d (bias-free), bn: nn.BatchNorm2d / nn.SyncBatchNorm used as parameter holders."""
-    return _ConvBnAct.apply(x, conv.weight, bn.weight, bn.bias, residual, bn, conv.stride[0], tuple(conv.padding), relu)
+def conv_bn_act(x, conv, bn, relu=True, residual=None, x_acc=None, res_acc=None):
+    """conv: nn.Conv2d (bias-free), bn: nn.BatchNorm2d / nn.SyncBatchNorm used as parameter holders.
+    x_acc / res_acc: the GradAcc of the fan-out `x` / `residual` came from (see fanout_shared)."""
+    return _ConvBnAct.apply(x, conv.weight, bn.weight, bn.bias, residual, bn, conv.stride[0], tuple(conv.padding), relu,
+                            x_acc, res_acc)
 
 
 class _ConvBias(torch.autograd.Function):
@@ -209,6 +229,7 @@ class _FanOut(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, n):
         ctx.n = n
+        ctx.set_materialize_grads(False)   # a consumer that accumulated into a shared GradAcc hands back None
         return tuple(x.view_as(x) for _ in range(n))
 
     @staticmethod
@@ -225,6 +246,26 @@ def fanout(x, n):
     if n == 1 or not x.requires_grad:
         return (x,) * n
     return _FanOut.apply(x, n)
+
+
+_SHARED_ACC = os.environ.get("RR_SHARED_ACC", "1") != "0"
+
+
+class GradAcc:
+    """Fan-in target shared by the consumers of one fan-out: the first consumer to run its backward publishes its
+    input gradient here, the others add into it (inside their dgrad epilogue) and hand autograd `None`, so the
+    fan-out's backward finds one complete gradient and launches no sum kernel."""
+    __slots__ = ("buf",)
+
+    def __init__(self):
+        self.buf = None
+
+
+def fanout_shared(x, n):
+    """fanout + the GradAcc its consumers may share (None when x carries no gradient)."""
+    if n == 1 or not x.requires_grad:
+        return (x,) * n + (None,)
+    return _FanOut.apply(x, n) + (GradAcc() if _SHARED_ACC else None,)
 
 
 class _ReLU(torch.autograd.Function):

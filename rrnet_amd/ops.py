@@ -15,11 +15,14 @@ class KernelTimer:
     """Optional live timing of individual conv launches with HIP events recorded on the launch
     stream (bench.py's roofline leg).  Off (None) in normal operation: no events, no overhead."""
 
-    def __init__(self):
+    def __init__(self, only=None):
         self.records = []      # (kernel name, flops, start event, end event)
         self.bytes = {}        # kernel name -> algorithmic bytes (operands read once + result written once)
+        self.only = only       # optional set of kernel names: the others run without events (each pair costs ~10 us)
 
     def launch(self, name, flops, fn, detail=None, nbytes=0.0):
+        if self.only is not None and name not in self.only:
+            return fn()
         self.bytes[name] = self.bytes.get(name, 0.0) + nbytes
         s = torch.cuda.Event(enable_timing=True)
         e = torch.cuda.Event(enable_timing=True)
