@@ -63,7 +63,9 @@ def _timed(name, flops, fn, detail=None, nbytes=0.0):
 
 
 def _igemm_name(kind, n_gemm, scalar):
-    return "conv_%s<BN=%d,%s>" % (kind, 128 if n_gemm > 32 else 32, "scalar" if scalar else "vec4")
+    """Timer key = the HIP kernel instance that runs (tile width as picked in csrc/conv.hip)."""
+    bn = 128 if n_gemm > 64 or (scalar and n_gemm > 32) else (64 if n_gemm > 32 else 32)
+    return "conv_%s<BN=%d,%s>" % (kind, bn, "scalar" if scalar else "vec4")
 
 
 def is_nhwc(t):
@@ -154,9 +156,11 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False)
         _C.check(_C.fn("rr_weight_flip_transpose")(_C.ptr(w), _C.ptr(wt), k, c, r, s, _C.stream()),
                  "rr_weight_flip_transpose")
         f1 = _C.fn("rr_conv_dgrad_s1")
-        _C.check(_timed(_igemm_name("dgrad", c, False), flops,
+        # same HIP kernel instance as a forward convolution: timed under its name
+        _C.check(_timed(_igemm_name("fprop", c, False), flops,
                         lambda: f1(_C.ptr(dy), _C.ptr(wt), _C.ptr(out), n, h, wd, c, k, r, s, pad[0], pad[1],
-                                   int(accumulate), _C.stream()), (n, h, wd, c, k, r, s, stride)), "rr_conv_dgrad_s1")
+                                   int(accumulate), _C.stream()), (n, h, wd, c, k, r, s, stride),
+                        4.0 * (dy.numel() + out.numel() * (2 if accumulate else 1) + w.numel())), "rr_conv_dgrad_s1")
         return out
     f = _C.fn("rr_conv_dgrad")
     _C.check(_timed(_igemm_name("dgrad", c, (k % 4 != 0) or (c % 4 != 0)), flops,
