@@ -199,6 +199,18 @@ int rr_group_by_class(const float *boxes, int b, int k, int num_classes, int cls
                       int *seg_off, hipStream_t stream);
 int rr_hard_nms_segments(float *boxes, const int *seg_off, int nseg, int max_seg_boxes, float thresh,
                          int *n_out, hipStream_t stream);
+
+/* ---- the reference's own hard-NMS family: ext/nms/nms/nms_kernel.cu (`_nms`), cpu_nms.pyx:129-176, py_cpu_nms.py,
+ * bound by ext/nms/nms_wrapper.py:23-33 `nms(dets, thresh, gpu_id)`.  Legacy "+1" IoU; boxes [n,stride>=4] on the
+ * device, already score-descending; inclusive = 0 suppresses at IoU > thresh (nms_kernel.cu:71, py_cpu_nms.py:29),
+ * 1 at IoU >= thresh (cpu_nms.pyx:170).  keep [n] (device) receives the kept row indices in order, *num_out their
+ * count; workspace = rr_nms_workspace_bytes(n) bytes (the n x ceil(n/64) suppression bit matrix).
+ * `_nms` is the reference's C entry itself (gpu_nms.hpp:1-2): host pointers, synchronous, own scratch. */
+size_t rr_nms_workspace_bytes(int n);
+int rr_nms_sorted(const float *boxes, int n, int stride, float thresh, int inclusive, void *workspace,
+                  int *keep, int *num_out, hipStream_t stream);
+void _nms(int *keep_out, int *num_out, const float *boxes_host, int boxes_num, int boxes_dim,
+          float nms_overlap_thresh, int device_id);
 int rr_pack_segments(const float *grouped, const int *seg_off, const int *n_out, int nseg, int segs_per_image,
                      int *out_off, float *rois, float *scores, float *clses, float *rows6, int phase,
                      hipStream_t stream);

@@ -127,3 +127,35 @@ def load_reference_cpu_nms():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     return mod
+
+
+def legacy_nms(dets, thresh, inclusive=False):
+    """Restatement of the reference's hard-NMS family on a float32 [N,>=5] array -> kept indices.
+    ext/nms/nms/cpu_nms.pyx:129-176 (`ovr >= thresh` suppresses: inclusive=True) and
+    ext/nms/nms/nms_kernel.cu:23-31,62-75 + gpu_nms.pyx:17-31 / py_cpu_nms.py (`ovr > thresh`): the "+1" pixel
+    convention, visiting order `scores.argsort()[::-1]`, all arithmetic in float32.
+    Pinned by the known answer in ext/nms/nms_wrapper.py:36-57 (thresh 0.3 -> keep [2, 3]); cpu_nms.pyx as a whole
+    does not cythonize under numpy 2 (np.int_t, np.int), so there is no compiled reference for it here."""
+    dets = np.ascontiguousarray(dets, dtype=np.float32)
+    x1, y1, x2, y2, sc = (dets[:, i] for i in range(5))
+    one = np.float32(1)
+    areas = (x2 - x1 + one) * (y2 - y1 + one)
+    order = sc.argsort()[::-1]
+    n = dets.shape[0]
+    suppressed = np.zeros(n, dtype=bool)
+    keep = []
+    for _i in range(n):
+        i = order[_i]
+        if suppressed[i]:
+            continue
+        keep.append(int(i))
+        rest = order[_i + 1:]
+        xx1 = np.maximum(x1[i], x1[rest]); yy1 = np.maximum(y1[i], y1[rest])
+        xx2 = np.minimum(x2[i], x2[rest]); yy2 = np.minimum(y2[i], y2[rest])
+        w = np.maximum(np.float32(0), xx2 - xx1 + one)
+        h = np.maximum(np.float32(0), yy2 - yy1 + one)
+        inter = w * h
+        ovr = inter / (areas[i] + areas[rest] - inter)
+        hit = (ovr >= np.float32(thresh)) if inclusive else (ovr > np.float32(thresh))
+        suppressed[rest[hit]] = True
+    return keep

@@ -66,7 +66,7 @@ def header_signatures():
     path = next(p for p in cands if os.path.exists(p))
     text = re.sub(r"/\*.*?\*/", "", open(path).read(), flags=re.S)
     sigs = {}
-    for m in re.finditer(r"(?m)^\s*(const\s+char\s*\*|int\s|size_t\s|void\s|double\s)\s*(rr_\w+)\s*\(([^;{]*?)\)\s*;", text):
+    for m in re.finditer(r"(?m)^\s*(const\s+char\s*\*|int\s|size_t\s|void\s|double\s)\s*(rr_\w+|_nms)\s*\(([^;{]*?)\)\s*;", text):
         ret, name, args = m.group(1), m.group(2), m.group(3).strip()
         restype = ctypes.c_char_p if "char" in ret else _CTYPE[ret.strip()]
         argtypes = []

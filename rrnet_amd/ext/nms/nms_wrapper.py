@@ -66,3 +66,41 @@ def soft_nms(dets, sigma=0.5, Nt=0.3, threshold=0.001, method=1):
     if not isinstance(dets, np.ndarray):
         dets = np.asarray(dets)
     return dets[list(range(k))]
+
+
+def _nms_device(dets, thresh, inclusive):
+    """Shared body of gpu_nms / cpu_nms: numpy [N,>=5] -> list of kept row indices (original numbering)."""
+    dets = np.asarray(dets)
+    n = dets.shape[0]
+    if n == 0:
+        return []
+    work = np.ascontiguousarray(dets[:, :5], dtype=np.float32)
+    order = work[:, 4].argsort()[::-1]                      # the reference's own ordering (gpu_nms.pyx:25-28)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    d = torch.from_numpy(work[order]).to(dev)
+    ws = torch.empty(_C.fn("rr_nms_workspace_bytes")(n), dtype=torch.uint8, device=dev)
+    keep = torch.empty(n, dtype=torch.int32, device=dev)
+    num = torch.zeros(1, dtype=torch.int32, device=dev)
+    _C.check(_C.fn("rr_nms_sorted")(_C.ptr(d), n, 5, float(np.float32(thresh)), int(inclusive), _C.ptr(ws), _C.ptr(keep),
+                                    _C.ptr(num), _C.stream()), "rr_nms_sorted")
+    k = int(num.item())
+    return list(order[keep[:k].cpu().numpy()])
+
+
+def gpu_nms(dets, thresh, device_id=0):
+    """ext/nms/nms/gpu_nms.pyx:17-31: kept indices, IoU(+1) > thresh suppresses."""
+    return _nms_device(dets, thresh, inclusive=0)
+
+
+def cpu_nms(dets, thresh):
+    """ext/nms/nms/cpu_nms.pyx:129-176: kept indices, IoU(+1) >= thresh suppresses."""
+    return _nms_device(dets, thresh, inclusive=1)
+
+
+def nms(dets, thresh, gpu_id=0):
+    """Reference signature (nms_wrapper.py:23-33): the kept rows; gpu_id None selects the cpu_nms convention."""
+    dets = np.asarray(dets)
+    if dets.shape[0] == 0:
+        return []
+    keep = gpu_nms(dets[:, :5], thresh, device_id=gpu_id) if gpu_id is not None else cpu_nms(dets[:, :5], thresh)
+    return dets[keep]

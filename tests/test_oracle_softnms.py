@@ -79,3 +79,16 @@ def test_hard_nms_basic():
     scores = np.array([0.9, 0.8, 0.7, 0.95], dtype=np.float32)
     keep = nms.hard_nms(boxes, scores, 0.5)
     assert keep.tolist() == [3, 2]
+
+
+def test_legacy_hard_nms_known_answer():
+    """ext/nms/nms_wrapper.py:36-57: nms(anchor, thresh=0.3) keeps boxes [2, 3] (both threshold conventions)."""
+    from oracle import nms as onms
+    a = np.array([[10, 9, 20, 19, 0.5], [10, 10, 15, 30, 0.45], [10, 10, 26, 26, 0.7], [8, 9, 14, 16, 0.3],
+                  [8, 8, 15, 15, 0.1]], np.float32)
+    assert onms.legacy_nms(a, 0.3) == [2, 3]
+    assert onms.legacy_nms(a, 0.3, inclusive=True) == [2, 3]
+    # the two conventions differ exactly at IoU == thresh: two boxes with IoU(+1) = 0.5
+    b = np.array([[0, 0, 9, 9, 0.9], [0, 0, 9, 4, 0.8]], np.float32)     # areas 100 and 50, inter 50 -> 0.5
+    assert onms.legacy_nms(b, 0.5) == [0, 1]
+    assert onms.legacy_nms(b, 0.5, inclusive=True) == [0]

@@ -98,3 +98,36 @@ def test_idempotent_round_trip_property():
     assert n_out2[0] == n_out[0]
     assert np.array_equal(outs2[0], outs[0])
     assert np.all(np.diff(outs[0][:, 4]) <= 0)        # selection order = non-increasing score
+
+
+def test_legacy_hard_nms_family_vs_oracle():
+    """rr_nms_sorted (+ the `_nms` host entry) against the oracle's restatement of gpu_nms / cpu_nms: kept index
+    lists equal, both threshold conventions, sizes around the 64-box mask words."""
+    import ctypes
+    from oracle import nms as onms
+    from rrnet_amd import _C
+    from rrnet_amd.ext.nms import nms_wrapper as W
+    a = np.array([[10, 9, 20, 19, 0.5], [10, 10, 15, 30, 0.45], [10, 10, 26, 26, 0.7], [8, 9, 14, 16, 0.3],
+                  [8, 8, 15, 15, 0.1]], np.float32)
+    assert [int(i) for i in W.gpu_nms(a, 0.3)] == [2, 3]
+    np.testing.assert_array_equal(W.nms(a, 0.3), a[[2, 3]])
+    b = np.array([[0, 0, 9, 9, 0.9], [0, 0, 9, 4, 0.8]], np.float32)
+    assert [int(i) for i in W.gpu_nms(b, 0.5)] == [0, 1] and [int(i) for i in W.cpu_nms(b, 0.5)] == [0]
+    rng = np.random.default_rng(8)
+    for n in [1, 2, 63, 64, 65, 128, 129, 1000, 5000]:
+        xy = rng.uniform(0, 300, (n, 2)).astype(np.float32)
+        wh = rng.uniform(5, 80, (n, 2)).astype(np.float32)
+        d = np.concatenate([xy, xy + wh, rng.uniform(0.01, 1, (n, 1)).astype(np.float32)], 1)
+        for thr in (0.3, 0.5, 0.7):
+            assert [int(i) for i in W.gpu_nms(d, thr)] == onms.legacy_nms(d, thr)
+            assert [int(i) for i in W.cpu_nms(d, thr)] == onms.legacy_nms(d, thr, inclusive=True)
+        # the reference's C entry point: host pointers, pre-sorted boxes
+        order = d[:, 4].argsort()[::-1]
+        sd = np.ascontiguousarray(d[order])
+        keep = np.zeros(n, np.int32)
+        num = ctypes.c_int(0)
+        f = _C.fn("_nms")
+        f(keep.ctypes.data_as(ctypes.c_void_p), ctypes.cast(ctypes.pointer(num), ctypes.c_void_p),
+          sd.ctypes.data_as(ctypes.c_void_p), n, 5, 0.5, torch.cuda.current_device())
+        assert list(order[keep[:num.value]]) == onms.legacy_nms(d, 0.5)
+    assert W.nms(np.zeros((0, 5), np.float32), 0.5) == []
