@@ -215,6 +215,16 @@ int rr_pack_segments(const float *grouped, const int *seg_off, const int *n_out,
                      int *out_off, float *rois, float *scores, float *clses, float *rows6, int phase,
                      hipStream_t stream);
 
+/* ---- training targets ------------------------------------------------------------ *
+ * rr_ctnet_targets: datasets/transforms/functional.py:177-262 (gaussian_radius, gaussian2d, draw_umich_gaussian,
+ *   to_heatmap) + the zero padding of datasets/drones_det.py:70-94 (collate_fn_ctnet) for a whole batch.
+ *   annos [b,m,anno_stride>=6] = x,y,w,h,score,cls(1-based),.. in image pixels (rows >= counts[i] are padding),
+ *   counts [b] int32.  Outputs: hm NHWC [b,img_h/sf,img_w/sf,num_classes] (zeroed here), wh [b,m,2] = (w,h)/sf,
+ *   ind [b,m] = cy_int*(img_w/4)+cx_int as float, offset [b,m,2], reg_mask [b,m] (0/1 floats). */
+int rr_ctnet_targets(const float *annos, const int *counts, int b, int m, int anno_stride, int img_h, int img_w,
+                     int scale_factor, int num_classes, float *hm, float *wh, float *ind, float *offset,
+                     float *reg_mask, hipStream_t stream);
+
 /* ---- inference post-process (config 5: decode -> re-regression -> Soft-NMS) ------------------ *
  * rr_refine_boxes: operators/rrnet_operator.py:188-209 `generate_bbox` (stage-2 boxes from the packed RoIs
  *   [r,5] = image,x1,y1,x2,y2 in feature coordinates, the regression [r,4], scores, classes), the score filter

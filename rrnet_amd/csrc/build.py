@@ -20,6 +20,7 @@ PER_FILE = {
     "softnms.hip": ["-ffp-contract=off"],
     "hardnms.hip": ["-ffp-contract=off"],
     "refine.hip": ["-ffp-contract=off"],
+    "targets.hip": ["-ffp-contract=off"],
 }
 
 

@@ -38,6 +38,21 @@ def collate_ctnet(samples):
     return torch.cat(imgs), annos, torch.cat(hms), whs, inds, offs, masks, names
 
 
+def collate_ctnet_device(annos_list, height, width, scale_factor=4, num_classes=10, device="cuda"):
+    """collate_fn_ctnet (datasets/drones_det.py:70-94) with the targets built on the device by rr_ctnet_targets:
+    list of per-image annotation tensors [n_i, 8] -> (annos [B,M,8], hm, whs, inds, offsets, reg_masks) on `device`."""
+    from rrnet_amd import ops
+    bs = len(annos_list)
+    m = max(int(a.size(0)) for a in annos_list)
+    annos = torch.zeros(bs, m, 8)
+    for i, a in enumerate(annos_list):
+        annos[i, :a.size(0)] = a[:, :8]
+    counts = torch.tensor([int(a.size(0)) for a in annos_list], dtype=torch.int32)
+    annos_d = annos.to(device)
+    hm, wh, ind, off, mask = ops.ctnet_targets(annos_d, counts.to(device), height, width, scale_factor, num_classes)
+    return annos_d, hm, wh, ind, off, mask
+
+
 def synth_batch(batch_size, height, width, boxes_per_image=100, seed=219, rank=0, scale_factor=4, num_classes=10):
     rng = np.random.default_rng(seed + rank)
     mean = torch.tensor(MEAN).view(3, 1, 1)

@@ -471,6 +471,25 @@ def pack_segments(grouped, seg_off, n_out, segs_per_image, want_rois=True, want_
     return rois, scores, clses, rows
 
 
+def ctnet_targets(annos, counts, img_h, img_w, scale_factor=4, num_classes=10):
+    """annos [B,M,>=6] cuda float32 (padded), counts [B] cuda int32 -> hm (logical [B,C,Hf,Wf], NHWC memory),
+    wh [B,M,2], ind [B,M,1], offset [B,M,2], reg_mask [B,M,1]  (collate_fn_ctnet contract)."""
+    _C.require_cuda(annos, counts)
+    assert annos.dtype == torch.float32 and annos.is_contiguous() and counts.dtype == torch.int32
+    b, m, st = annos.shape
+    hf, wf = img_h // scale_factor, img_w // scale_factor
+    dev = annos.device
+    hm = empty_nhwc(b, num_classes, hf, wf, dev)
+    wh = torch.empty((b, m, 2), dtype=torch.float32, device=dev)
+    ind = torch.empty((b, m, 1), dtype=torch.float32, device=dev)
+    off = torch.empty((b, m, 2), dtype=torch.float32, device=dev)
+    mask = torch.empty((b, m, 1), dtype=torch.float32, device=dev)
+    _C.check(_C.fn("rr_ctnet_targets")(_C.ptr(annos), _C.ptr(counts), b, m, st, img_h, img_w, scale_factor, num_classes,
+                                       _C.ptr(hm), _C.ptr(wh), _C.ptr(ind), _C.ptr(off), _C.ptr(mask), _C.stream()),
+             "rr_ctnet_targets")
+    return hm, wh, ind, off, mask
+
+
 def refine_boxes(rois, reg, scores, clses, seg_off, scale, score_thr):
     """generate_bbox + score filter + xywh->xyxy for every (frame, class) segment of the packed RoI list.
     -> boxes6 [R,6] (kept rows at the front of each segment's range), seg_len int32 [nseg]."""
