@@ -174,7 +174,8 @@ def main():
                                    "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
                                    "traffic": traffic,
                                    "algorithmic_bytes_per_launch": round(timer.bytes.get(dom, 0.0) / d["launches"]),
-                                   "kernel": "conv_igemm_kernel<128, 0, false, 32, true> (implicit-GEMM fprop, v_mfma_f32_32x32x2_f32)",
+                                   "kernel": "conv_igemm_kernel<128, 0, false, 32, true> (implicit-GEMM forward kernel, v_mfma_f32_32x32x2_f32; "
+                                             "launched for fprop and for stride-1 dgrad on flipped weights)",
                                    "launches": d["launches"], "avg_launch_ms": round(d["ms"] / d["launches"], 4),
                                    "algorithmic_gflop_per_launch": round(d["flops"] / d["launches"] / 1e9, 3)}
             out["kernels"] = {k: {"launches": v["launches"], "ms": round(v["ms"], 2),
