@@ -183,7 +183,9 @@ int rr_stage2_loss(const float *rois, const float *reg, int r, const float *gt, 
  *   from d roi).  k <= min(4096, c*h*w).  No 3x3 peak filter (the reference never
  *   applies one); rr_peak3x3 provides operators/centernet_operator.py:204-210 as an option.
  * rr_group_by_class: stable regrouping of each image's k rows by class (classes ascending =
- *   torch.unique order of models/rrnet.py:59); seg_off [b*num_classes+1] row offsets.
+ *   torch.unique order of models/rrnet.py:59); seg_off [b*num_classes+1] row offsets.  Rows whose class lies
+ *   outside [cls_base, cls_base+num_classes) are dropped and leave a gap at the end of the image's k-row block:
+ *   callers that pad with such rows pass explicit segment lengths (rr_soft_nms_ragged).
  * rr_hard_nms_segments: torchvision.ops.nms as called at models/rrnet.py:69,78; rows of a
  *   segment score-descending, 6 floats per row; kept rows are compacted to the segment front.
  * rr_pack_segments: phase 0 -> out_off [nseg+1] exclusive prefix of n_out (out_off[nseg] = R);

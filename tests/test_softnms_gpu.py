@@ -131,3 +131,49 @@ def test_legacy_hard_nms_family_vs_oracle():
           sd.ctypes.data_as(ctypes.c_void_p), n, 5, 0.5, torch.cuda.current_device())
         assert list(order[keep[:num.value]]) == onms.legacy_nms(d, 0.5)
     assert W.nms(np.zeros((0, 5), np.float32), 0.5) == []
+
+
+def test_ext_nms_batch_and_auto_evaluate(tmp_path):
+    """utils/metrics: the batched per-file / per-class Soft-NMS equals the oracle's ext_nms file by file, bit for
+    bit, and auto_evaluate_results == evaluating those results in memory."""
+    import contextlib
+    import io
+    from oracle import nms as onms
+    from rrnet_amd.utils.metrics import metrics as M
+    rng = np.random.default_rng(12)
+    preds, targets = [], []
+    for n in [80, 0, 1, 300, 45]:
+        xy = rng.uniform(0, 200, (n, 2)); wh = rng.uniform(10, 60, (n, 2))
+        p = np.concatenate([xy, wh, rng.uniform(0.02, 1, (n, 1)), rng.integers(1, 11, (n, 1))], 1).astype(np.float32)
+        preds.append(p[np.argsort(-p[:, 4], kind='stable')])
+        g = max(n // 4, 2)
+        txy = rng.uniform(0, 200, (g, 2)); twh = rng.uniform(10, 60, (g, 2))
+        targets.append(np.concatenate([txy, twh, np.ones((g, 1)), rng.integers(0, 11, (g, 1)), np.zeros((g, 2))], 1)
+                       .astype(np.float32))
+    got = M.ext_nms_batch(preds, 0.1)
+    for p, gk in zip(preds, got):
+        ref = onms.ext_nms(p) if p.shape[0] else p.reshape(0, 6)
+        assert gk.shape == ref.shape
+        np.testing.assert_array_equal(gk.view(np.uint32), ref.view(np.uint32))
+    pd_dir, gt_dir = tmp_path / "pred", tmp_path / "gt"
+    pd_dir.mkdir(); gt_dir.mkdir()
+    for i, (p, t) in enumerate(zip(preds, targets)):
+        if p.shape[0] == 0:
+            continue
+        np.savetxt(pd_dir / ("f%d.txt" % i), np.concatenate([p, -np.ones((p.shape[0], 2))], 1), delimiter=',', fmt='%.6f')
+        np.savetxt(gt_dir / ("f%d.txt" % i), t, delimiter=',', fmt='%d')
+    with contextlib.redirect_stdout(io.StringIO()):
+        ap, rc = M.auto_evaluate_results(str(pd_dir), str(gt_dir), 0.05, 0.1)
+    flags, confs, tc, ic = M._fresh(11, 10)
+    for name in M._names(str(pd_dir)):
+        p = M._read(os.path.join(str(pd_dir), name + ".txt"))
+        p = p[p[:, 4] > 0.05].astype(np.float32)
+        p = p[np.argsort(-p[:, 4], kind='stable')]
+        k = onms.ext_nms(p[:, :6])
+        k = torch.from_numpy(M._snap(k.astype(np.float64))).float()
+        k = k[torch.sort(k[:, 4], descending=True)[1]][:500]
+        t = torch.from_numpy(M._read(os.path.join(str(gt_dir), name + ".txt"))).float()[:500]
+        flags, confs, tc, ic = M.get_tp(k, t, flags, confs, tc, ic, M.THRESHOLDS, 11)
+    ap2, rc2 = M.calculate_ap_rc(flags, confs, tc, ic)
+    np.testing.assert_allclose(ap.numpy(), ap2.numpy(), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(float(rc), float(rc2), rtol=1e-6, atol=1e-7)

@@ -388,9 +388,54 @@ def g9_targets():
     save("targets.npz", d)
 
 
+def _metric_case(rng, m, n, n_ignore, img=400):
+    """Predictions [m,6] xywh,score,cls(1..10) scattered around the targets; targets [n,8] VisDrone rows with
+    `n_ignore` ignored regions (cls 0)."""
+    txy = rng.uniform(0, img - 60, (n, 2)); twh = rng.uniform(8, 60, (n, 2))
+    tcls = rng.integers(1, 11, (n, 1)).astype(np.float64)
+    tcls[:n_ignore] = 0
+    target = np.concatenate([txy, twh, np.ones((n, 1)), tcls, np.zeros((n, 2))], 1).astype(np.float32)
+    src = rng.integers(0, n, m)
+    pxy = txy[src] + rng.normal(0, 4, (m, 2)); pwh = twh[src] * rng.uniform(0.7, 1.3, (m, 2))
+    pcls = np.where(rng.uniform(size=(m, 1)) < 0.8, np.maximum(tcls[src], 1), rng.integers(1, 11, (m, 1)))
+    pred = np.concatenate([pxy, pwh, rng.uniform(0.02, 1, (m, 1)), pcls], 1).astype(np.float32)
+    return torch.from_numpy(pred), torch.from_numpy(target)
+
+
+def g10_metrics():
+    """utils/metrics/metrics.py: bbox_iou :10-49, get_tp :52-131, calculate_ap_rc :134-176, evaluate_once :179-207
+    (evaluate_results / auto_evaluate_results use np.int / np.float, removed in numpy 2: not runnable here)."""
+    import contextlib
+    import io
+    from utils.metrics import metrics as M
+    rng = np.random.default_rng(10)
+    d = {}
+    thresholds = torch.arange(0.5, 1.0, 0.05)
+    cases = [_metric_case(rng, 120, 40, 3), _metric_case(rng, 60, 25, 0), _metric_case(rng, 200, 70, 6),
+             _metric_case(rng, 30, 12, 2)]
+    tc, ic = torch.zeros(10), torch.zeros(10)
+    flags = [torch.zeros(0, 10) for _ in range(10)]
+    confs = [torch.zeros(0) for _ in range(10)]
+    for i, (pred, target) in enumerate(cases):
+        d["c%d/pred" % i], d["c%d/target" % i] = pred, target
+        iou, ov = M.bbox_iou(pred[:, :4], target[:, :4], x1y1x2y2=False, overlap=True)
+        d["c%d/iou" % i], d["c%d/overlap" % i] = iou, ov
+        with contextlib.redirect_stdout(io.StringIO()):
+            ap, rc = M.evaluate_once(pred.clone(), target.clone(), max_det_num=100 if i == 2 else 500)
+        d["c%d/ap" % i], d["c%d/rc" % i] = ap, rc
+        flags, confs, tc, ic = M.get_tp(pred.clone(), target.clone(), flags, confs, tc, ic, thresholds, 11)
+        d["c%d/target_count" % i], d["c%d/in_img_count" % i] = tc.clone(), ic.clone()
+    for c in range(10):
+        d["all/flags%d" % c], d["all/confs%d" % c] = flags[c], confs[c]
+    ap, rc = M.calculate_ap_rc(flags, confs, tc, ic)
+    d["all/ap"], d["all/rc"] = ap, rc
+    save("metrics.npz", d)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     for name, fn in (("g2", g2_decode), ("g3", g3_losses), ("g4", g4_blocks), ("g5", g5_ctnet_tiny),
-                     ("g6", g6_stage2), ("g7", g7_extnms), ("g8", g8_rrnet_tiny), ("g9", g9_targets)):
+                     ("g6", g6_stage2), ("g7", g7_extnms), ("g8", g8_rrnet_tiny), ("g9", g9_targets),
+                     ("g10", g10_metrics)):
         if not only or name in only:
             fn()
