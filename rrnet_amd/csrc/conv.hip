@@ -54,6 +54,7 @@ struct ConvArgs {
     const float *zero; // 16 zero bytes (rr_zero16) for masked gather lanes
     int ksplit;        // > 1: grid.z slices the K loop and the epilogue adds with float atomics (dst pre-zeroed
                        // or holding the running sum); no bias / ReLU / statistics in that mode
+    int parity_order;  // dgrad, stride 2: 4 x 2 bits, parity class handled by blockIdx.y = 0..3 (most taps first)
     int parity;        // dgrad, stride 2: blockIdx.y = output parity class (h%2, w%2); only the taps that
                        // can reach that class are visited (1/2/2/4 of a 3x3) instead of masking 3/4 of the MFMAs
 };
@@ -107,7 +108,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
     int r0 = 0, s0 = 0, tstep = 1, Rc = a.R, Sc = a.S;
     int ph = 0, pw = 0, Hc = a.DH, Wc = a.DW, Mloc = a.M;
     if (MODE == 1 && a.parity) {
-        ph = blockIdx.y >> 1; pw = blockIdx.y & 1;
+        // heaviest parity class first (grid.y is the slow dispatch dimension): no long tail of 4-tap blocks
+        const int pcls = (a.parity_order >> (2 * blockIdx.y)) & 3;
+        ph = pcls >> 1; pw = pcls & 1;
         Hc = (a.DH - ph + 1) / 2; Wc = (a.DW - pw + 1) / 2;
         Mloc = a.N * Hc * Wc;
         if (m0 >= Mloc) return;
@@ -979,10 +982,20 @@ int pick_ksplit(int blocks, int nk)
         const char *e = getenv("RR_CONV_SPLITK");
         enabled = (e && atoi(e) == 0) ? 0 : 1;
     }
-    if (!enabled || blocks >= 256 || nk < 16) return 1;
-    int ks = 512 / blocks;
-    if (ks > nk / 8) ks = nk / 8;
-    return ks < 1 ? 1 : ks;
+    if (!enabled || blocks >= 256 || nk < 16) return 1;   // a full first wave of tiles: splitting costs more than it balances
+    // Occupancy model: 256 CUs, two workgroups resident per CU.  A pair shares the MFMA pipes at ~0.87 of peak, a
+    // lone workgroup reaches ~0.75 (nobody fills its issue gaps); every workgroup pays ~3 K-steps of prologue +
+    // epilogue.  The busiest CU holds ceil(total / 256) workgroups; pick the split with the shortest makespan.
+    int best = 1;
+    float best_t = 0.f;
+    for (int ks = 1; ks <= 8 && ks <= nk / 8; ++ks) {
+        const int total = blocks * ks;
+        const int n = (total + 255) / 256;
+        const float per = (float)((nk + ks - 1) / ks) + 3.0f + (ks > 1 ? 1.0f : 0.0f);   // + atomic epilogue
+        const float t = (float)(n / 2) * (2.0f * per / 0.87f) + (float)(n % 2) * (per / 0.75f);
+        if (best_t == 0.f || t < best_t * 0.95f) { best = ks; best_t = t; }
+    }
+    return best;
 }
 
 // column sums / sums of squares of y -> slab row 0 (the other rows are zeroed by the caller); used when
@@ -1157,6 +1170,15 @@ extern "C" int rr_conv_dgrad(const float *dy, const float *w, float *dx, int n, 
     if (stride == 2 && !scalar) {     // parity-decomposed: 4 classes of ceil(h/2) x ceil(w/2) pixels each
         a.parity = 1;
         gy = 4;
+        int taps[4], ord[4] = {0, 1, 2, 3};
+        for (int cl = 0; cl < 4; ++cl) {
+            const int r0 = ((cl >> 1) + pad_h) & 1, s0 = ((cl & 1) + pad_w) & 1;
+            taps[cl] = (r0 < r ? (r - r0 + 1) / 2 : 0) * (s0 < s ? (s - s0 + 1) / 2 : 0);
+        }
+        for (int i = 0; i < 4; ++i)
+            for (int j = i + 1; j < 4; ++j)
+                if (taps[ord[j]] > taps[ord[i]]) { const int t = ord[i]; ord[i] = ord[j]; ord[j] = t; }
+        a.parity_order = ord[0] | (ord[1] << 2) | (ord[2] << 4) | (ord[3] << 6);
         blocks = rr_cdiv((long)n * ((h + 1) / 2) * ((wd + 1) / 2), BM) * rr_cdiv(c, bn);
         nk = rr_cdiv(k, bk) * ((r + 1) / 2) * ((s + 1) / 2);
     }
