@@ -22,6 +22,8 @@ class RRNetHipError(RuntimeError):
 def lib():
     global _lib
     if _lib is None:
+        global LIB_PATH
+        LIB_PATH = os.environ.get("RRNET_HIP_LIB", LIB_PATH)     # kernel experiments: an alternative build of the library
         if not os.path.exists(LIB_PATH):
             raise RRNetHipError(
                 "librrnet_hip.so not found at %s — build it with `python rrnet_amd/csrc/build.py` "
