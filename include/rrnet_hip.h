@@ -265,6 +265,11 @@ int rr_roi_align_bwd(const float *dout, const float *rois, int r, int b, int h, 
 int rr_dcn_fwd(const float *x, const float *offset, const float *mask, const float *w, const float *bias, float *y,
                int n, int h, int wd, int c, int k, int r, int s, int stride, int pad_h, int pad_w, int dilation,
                int deformable_groups, hipStream_t stream);
+/* Same operation with bf16 matrix operands (samples and weights rounded to bf16 in the kernel, fp32 accumulation on
+ * v_mfma_f32_32x32x16_bf16): inputs and outputs stay fp32 tensors.  BASELINE config 4. */
+int rr_dcn_fwd_bf16(const float *x, const float *offset, const float *mask, const float *w, const float *bias, float *y,
+                    int n, int h, int wd, int c, int k, int r, int s, int stride, int pad_h, int pad_w, int dilation,
+                    int deformable_groups, hipStream_t stream);
 size_t rr_dcn_col_bytes(int n, int h, int wd, int c, int r, int s, int stride, int pad_h, int pad_w, int dilation);
 int rr_dcn_im2col(const float *x, const float *offset, const float *mask, float *col, int n, int h, int wd, int c,
                   int r, int s, int stride, int pad_h, int pad_w, int dilation, int deformable_groups,

@@ -191,6 +191,159 @@ __global__ __launch_bounds__(256) void dcn_fprop_kernel(const DcnArgs a)
     }
 }
 
+// ---- bf16-operand forward (BASELINE config 4) --------------------------------------------------------------------
+// Same gather-GEMM; the blended samples and the weights are rounded to bf16 (round-to-nearest-even) on their way into
+// LDS and multiplied on v_mfma_f32_32x32x16_bf16 (fp32 accumulation): 8 MFMAs per 32-channel K-step instead of 64,
+// which moves the bound from the matrix pipe to the four-corner gather.  LDS tiles are [row][k] with 40 bf16 per
+// row (16-byte aligned rows, one ds_read_b128 = the 8 k values a lane feeds to one MFMA).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+constexpr int LDKH = BK + 8;
+
+__device__ __forceinline__ unsigned short f2bf(float f)
+{
+    unsigned int u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);          // round to nearest even (inputs are finite)
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ u16x4 f2bf4(f32x4 v)
+{
+    u16x4 r;
+    r[0] = f2bf(v[0]); r[1] = f2bf(v[1]); r[2] = f2bf(v[2]); r[3] = f2bf(v[3]);
+    return r;
+}
+
+template <int BN>
+__global__ __launch_bounds__(256) void dcn_fprop_bf16_kernel(const DcnArgs a)
+{
+    constexpr int WN = BN / 64 ? BN / 64 : 1, WM = 4 / WN;
+    constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+    constexpr int A_ELEMS = BM * LDKH, B_ELEMS = BN * LDKH;      // in bf16 elements
+    constexpr int AJ = BM / 32, BJ = BN / 32;
+    extern __shared__ __align__(16) unsigned short ldsh[];
+    unsigned short *As = ldsh, *Bs = ldsh + 2 * A_ELEMS;
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave / WN, wn = wave % WN;
+    const int ntiles = (a.K + BN - 1) / BN;
+    const int n_tile = blockIdx.x % ntiles, m_tile = blockIdx.x / ntiles;
+    const int m0 = m_tile * BM, n0 = n_tile * BN;
+    const int RS = a.R * a.S;
+    const int cpt = (a.C + BK - 1) / BK;
+    const int nk = RS * cpt;
+    const int cpg = a.C / a.dg;
+    const int a_col = (t & 7) * 4, a_row = t >> 3;
+
+    int rn[AJ], rp[AJ], rq[AJ];
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+        const int m = m0 + a_row + 32 * j;
+        if (m < a.M) {
+            const int pq = a.P * a.Q;
+            rn[j] = m / pq;
+            const int rem = m - rn[j] * pq;
+            rp[j] = rem / a.Q;
+            rq[j] = rem - rp[j] * a.Q;
+        } else {
+            rn[j] = -1; rp[j] = 0; rq[j] = 0;
+        }
+    }
+    f32x4 rv[AJ][4], rb[BJ];
+    float rw[AJ][4];
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+
+    auto issue = [&](int kc) {
+        const int tap = kc / cpt, cch = kc - tap * cpt;
+        const int i = tap / a.S, jx = tap - i * a.S;
+        const int c0 = cch * BK;
+        const int g = c0 / cpg;
+        const bool c_ok = c0 + a_col < a.C;
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) {
+            if (rn[j] >= 0 && c_ok) {
+                const long m = (long)m0 + a_row + 32 * j;
+                const float *po = a.offset + m * (2 * a.dg * RS) + g * 2 * RS + 2 * tap;
+                const float mk = a.mask[m * (a.dg * RS) + g * RS + tap];
+                const Tap4 tp = make_tap(a, rn[j], rp[j], rq[j], i, jx, po[0], po[1], mk);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float *src = tp.o[e] >= 0 ? a.x + tp.o[e] + c0 + a_col : a.zero;
+                    rv[j][e] = *reinterpret_cast<const f32x4 *>(src);
+                    rw[j][e] = tp.w[e];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { rv[j][e] = zero; rw[j][e] = 0.f; }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) {
+            const int ko = n0 + a_row + 32 * j;
+            const bool ok = ko < a.K && c0 + a_col < a.C;
+            const float *src = ok ? a.w + ((long)ko * RS + tap) * a.C + c0 + a_col : a.zero;
+            rb[j] = *reinterpret_cast<const f32x4 *>(src);
+        }
+    };
+    auto commit = [&](int buf) {
+        unsigned short *A = As + buf * A_ELEMS, *B = Bs + buf * B_ELEMS;
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) {
+            const f32x4 v = rv[j][0] * rw[j][0] + rv[j][1] * rw[j][1] + rv[j][2] * rw[j][2] + rv[j][3] * rw[j][3];
+            *reinterpret_cast<u16x4 *>(A + (a_row + 32 * j) * LDKH + a_col) = f2bf4(v);
+        }
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) *reinterpret_cast<u16x4 *>(B + (a_row + 32 * j) * LDKH + a_col) = f2bf4(rb[j]);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    const int lr = lane & 31, lh = lane >> 5;
+
+    issue(0);
+    commit(0);
+    __syncthreads();
+    for (int kc = 0; kc < nk; ++kc) {
+        const int buf = kc & 1;
+        if (kc + 1 < nk) issue(kc + 1);
+        const unsigned short *A = As + buf * A_ELEMS, *B = Bs + buf * B_ELEMS;
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            // both operands use the same (lane half, element) -> k map, so the MFMA's own k ordering is immaterial
+            bf16x8 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                fa[i] = *reinterpret_cast<const bf16x8 *>(A + ((wm * TM + i) * 32 + lr) * LDKH + kk * 16 + lh * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                fb[j] = *reinterpret_cast<const bf16x8 *>(B + ((wn * TN + j) * 32 + lr) * LDKH + kk * 16 + lh * 8);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        if (kc + 1 < nk) commit(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int ko = n0 + (wn * TN + j) * 32 + lr;
+        if (ko >= a.K) continue;
+        const float bv = a.bias ? a.bias[ko] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (m < a.M) a.y[(long)m * a.K + ko] = acc[i][j][e] + bv;
+            }
+    }
+}
+
 // columns [M][R*S*C] = mask * bilinear samples (only the backward needs them materialised)
 __global__ __launch_bounds__(256) void dcn_im2col_kernel(const DcnArgs a, float *col)
 {
@@ -320,6 +473,23 @@ extern "C" int rr_dcn_fwd(const float *x, const float *offset, const float *mask
         hipLaunchKernelGGL(dcn_fprop_kernel<32>, dim3(blocks), dim3(256), lds, stream, a);
     }
     RR_CHECK_LAUNCH("rr_dcn_fwd");
+    return RR_OK;
+}
+
+extern "C" int rr_dcn_fwd_bf16(const float *x, const float *offset, const float *mask, const float *w, const float *bias,
+                               float *y, int n, int h, int wd, int c, int k, int r, int s, int stride, int pad_h, int pad_w,
+                               int dilation, int deformable_groups, hipStream_t stream)
+{
+    DcnArgs a{};
+    const int rc = fill_args(a, x, offset, mask, w, n, h, wd, c, k, r, s, stride, pad_h, pad_w, dilation, deformable_groups);
+    if (rc != RR_OK) return rc;
+    a.bias = bias; a.y = y;
+    const int bn = k > 32 ? 128 : 32;
+    const int blocks = rr_cdiv(a.M, BM) * rr_cdiv(k, bn);
+    const size_t lds = sizeof(unsigned short) * 2 * (BM * LDKH + bn * LDKH);
+    if (bn == 128) hipLaunchKernelGGL(dcn_fprop_bf16_kernel<128>, dim3(blocks), dim3(256), lds, stream, a);
+    else hipLaunchKernelGGL(dcn_fprop_bf16_kernel<32>, dim3(blocks), dim3(256), lds, stream, a);
+    RR_CHECK_LAUNCH("rr_dcn_fwd_bf16");
     return RR_OK;
 }
 

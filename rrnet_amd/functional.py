@@ -453,12 +453,12 @@ def differentiable_proposals(wh, offset, rois, roi_pix):
 # ---------------------------------------------------------------------------------------------
 class _DCNv2(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, input, offset, mask, weight, bias, stride, padding, dilation, deformable_groups):
+    def forward(ctx, input, offset, mask, weight, bias, stride, padding, dilation, deformable_groups, bf16=False):
         x, off, m, w = ops.to_nhwc(input), ops.to_nhwc(offset), ops.to_nhwc(mask), ops.to_nhwc(weight)
         ctx.cfg = (int(stride), tuple(padding), int(dilation), int(deformable_groups))
         ctx.save_for_backward(x, off, m, w)
         ctx.params = (weight, bias)
-        return ops.dcn_fwd(x, off, m, w, bias, *ctx.cfg)
+        return ops.dcn_fwd(x, off, m, w, bias, *ctx.cfg, bf16=bf16)
 
     @staticmethod
     def backward(ctx, dy):
@@ -486,12 +486,18 @@ class _DCNv2(torch.autograd.Function):
             tgt = b_t if b_t is not None else torch.zeros_like(bias)
             ops.bias_relu_bwd(dy, None, tgt)
             db = None if b_t is not None else tgt
-        return dx, doff, dmask, (None if w_t is not None else dw), db, None, None, None, None
+        return dx, doff, dmask, (None if w_t is not None else dw), db, None, None, None, None, None
 
 
-def dcn_v2_conv(input, offset, mask, weight, bias, stride, padding, dilation, deformable_groups):
-    """Reference signature (ext/dcn/dcn_v2.py:52).  stride / dilation: int or equal pair; padding: int or pair."""
+DCN_BF16 = os.environ.get("RR_DCN_BF16", "0") == "1"   # BASELINE config 4: bf16 matrix operands in the DCN forward
+
+
+def dcn_v2_conv(input, offset, mask, weight, bias, stride, padding, dilation, deformable_groups, bf16=None):
+    """Reference signature (ext/dcn/dcn_v2.py:52).  stride / dilation: int or equal pair; padding: int or pair.
+    bf16 (extension): round the sampled columns and the weights to bf16 for the forward MFMA (fp32 accumulation,
+    fp32 backward); default from RR_DCN_BF16."""
     st = stride if isinstance(stride, int) else stride[0]
     dl = dilation if isinstance(dilation, int) else dilation[0]
     pd = (padding, padding) if isinstance(padding, int) else tuple(padding)
-    return _DCNv2.apply(input, offset, mask, weight, bias, st, pd, dl, deformable_groups)
+    return _DCNv2.apply(input, offset, mask, weight, bias, st, pd, dl, deformable_groups,
+                        DCN_BF16 if bf16 is None else bool(bf16))

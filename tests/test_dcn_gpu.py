@@ -79,3 +79,34 @@ def test_dcn_module_matches_oracle_and_trains():
     np.testing.assert_allclose(out.detach().cpu().numpy(), ref.numpy(), atol=1e-3, rtol=1e-3)
     out.square().mean().backward()
     assert xd.grad is not None and md.conv_offset_mask.weight.grad.abs().sum().item() > 0
+
+
+@pytest.mark.parametrize("cfg", CASES, ids=lambda c: "n%dc%dh%dw%dk%d_k%ds%dp%dd%dg%d" % c)
+def test_dcn_forward_bf16_operands(cfg):
+    """BASELINE config 4: bf16 matrix operands, fp32 accumulation.  Against the fp32 oracle evaluated on
+    bf16-ROUNDED weights (exact for that operand) the remaining error is the rounding of the sampled columns:
+    2^-9 relative per term, far below 2e-2 of the output scale; the zero-offset identity stays exact."""
+    from oracle import dcn as odcn
+    from rrnet_amd.functional import dcn_v2_conv
+    n, c, h, w, k, ks, stride, pad, dil, dg = cfg
+    g = torch.Generator().manual_seed(sum(cfg) + 1)
+    p = (h + 2 * pad - (dil * (ks - 1) + 1)) // stride + 1
+    q = (w + 2 * pad - (dil * (ks - 1) + 1)) // stride + 1
+    x = torch.randn(n, c, h, w, generator=g)
+    off = torch.randn(n, 2 * dg * ks * ks, p, q, generator=g) * 1.5
+    mask = torch.sigmoid(torch.randn(n, dg * ks * ks, p, q, generator=g))
+    wt = (torch.randn(k, c, ks, ks, generator=g) / np.sqrt(c * ks * ks)).bfloat16().float()
+    b = torch.randn(k, generator=g)
+    ref = odcn.dcn_v2_conv(x, off, mask, wt, b, stride, pad, dil, dg)
+    dev = [t.cuda().contiguous(memory_format=CL) for t in (x, off, mask, wt)]
+    out = dcn_v2_conv(*dev, b.cuda(), stride, pad, dil, dg, bf16=True)
+    err = (out.cpu() - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    assert err <= 2e-2 * scale, (err, scale)
+    # and it really is a different (lower precision) path than the fp32 kernel, not an alias of it
+    out32 = dcn_v2_conv(*dev, b.cuda(), stride, pad, dil, dg, bf16=False)
+    assert (out32.cpu() - ref).abs().max().item() < err or err == 0.0
+    # backward of the bf16 forward is the fp32 backward
+    xg = dev[0].clone().requires_grad_()
+    dcn_v2_conv(xg, dev[1], dev[2], dev[3], b.cuda(), stride, pad, dil, dg, bf16=True).sum().backward()
+    assert torch.isfinite(xg.grad).all()
