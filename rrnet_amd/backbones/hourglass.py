@@ -43,16 +43,14 @@ class ResidualBlock(nn.Module):
 
     def forward(self, x):
         # both consumers of x (conv1 and the skip path) accumulate their input gradients into one buffer
-        xa, xb, acc = RF.fanout_shared(x, 2)
-        out = RF.conv_bn_act(xa, self.conv1, self.bn1, relu=True, x_acc=acc)
+        xa, xb, _ = RF.fanout_shared(x, 2)
+        out = RF.conv_bn_act(xa, self.conv1, self.bn1, relu=True)
         if len(self.skip_connection):
-            skip = RF.conv_bn_act(xb, self.skip_connection[0], self.skip_connection[1], relu=False, x_acc=acc)
-            res_acc = None
+            skip = RF.conv_bn_act(xb, self.skip_connection[0], self.skip_connection[1], relu=False)
         else:
-            skip = xb
-            res_acc = acc
+            skip = xb                                   # identity skip: the raw view, its tag names the accumulator
         # relu(bn2(conv2(out)) + skip): BN apply, residual add and ReLU are one kernel
-        return RF.conv_bn_act(out, self.conv2, self.bn2, relu=True, residual=skip, res_acc=res_acc)
+        return RF.conv_bn_act(out, self.conv2, self.bn2, relu=True, residual=skip)
 
 
 class ConvBNRelu(nn.Module):
@@ -103,7 +101,7 @@ class Hourglass(nn.Module):
     make_upsample_layer = staticmethod(lambda: nn.Upsample(scale_factor=2))
 
     def forward(self, x):
-        xa, xb = RF.fanout(x, 2)
+        xa, xb, _ = RF.fanout_shared(x, 2)              # both branches start with a residual block: one accumulator
         up1 = self.up1(xa)
         low3 = self.low3(self.low2(self.low1(xb)))
         # nearest x2 -> bilinear(align_corners) to up1's size -> add, without the 4x intermediate
@@ -140,7 +138,7 @@ class HourglassNet(nn.Module):
         outs = []
         for i in range(self.num_stacks):
             last = i == self.num_stacks - 1
-            pa, pb = (pre, None) if last else RF.fanout(pre, 2)
+            pa, pb = (pre, None) if last else RF.fanout_shared(pre, 2)[:2]
             feat = self.convs[i](self.hgs[i](pa))
             outs.append(feat)
             if not last:

@@ -138,6 +138,10 @@ class _ConvBnAct(torch.autograd.Function):
 def conv_bn_act(x, conv, bn, relu=True, residual=None, x_acc=None, res_acc=None):
     """conv: nn.Conv2d (bias-free), bn: nn.BatchNorm2d / nn.SyncBatchNorm used as parameter holders.
     x_acc / res_acc: the GradAcc of the fan-out `x` / `residual` came from (see fanout_shared)."""
+    if x_acc is None:
+        x_acc = getattr(x, "_rr_acc", None)
+    if res_acc is None and residual is not None:
+        res_acc = getattr(residual, "_rr_acc", None)     # set only on raw fan-out views (identity skip)
     return _ConvBnAct.apply(x, conv.weight, bn.weight, bn.bias, residual, bn, conv.stride[0], tuple(conv.padding), relu,
                             x_acc, res_acc)
 
@@ -147,7 +151,8 @@ class _ConvBias(torch.autograd.Function):
     (detectors/centernet_detector.py:62,73,85-93; fasterrcnn_detector.py:17)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, stride, pad, relu):
+    def forward(ctx, x, w, b, stride, pad, relu, x_acc=None):
+        ctx.x_acc = x_acc
         x = ops.to_nhwc(x)
         wc = ops.to_nhwc(w)
         y = ops.conv_fprop(x, wc, b, stride, pad, relu)
@@ -171,7 +176,15 @@ class _ConvBias(torch.autograd.Function):
             ret_db = None if b_t is not None else tgt
         elif relu:
             dy = ops.sum_n([dy], y)
-        dx = ops.conv_dgrad(dy, wc, ctx.xshape, stride, pad) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            x_acc = ctx.x_acc
+            if x_acc is not None and x_acc.buf is not None:
+                ops.conv_dgrad(dy, wc, ctx.xshape, stride, pad, out=x_acc.buf, accumulate=True)
+            else:
+                dx = ops.conv_dgrad(dy, wc, ctx.xshape, stride, pad)
+                if x_acc is not None:
+                    x_acc.buf = dx
         w_t = _grad_target(w)
         ret_dw = None
         if w_t is not None:
@@ -180,16 +193,16 @@ class _ConvBias(torch.autograd.Function):
             dw = ops.zeros_nhwc(*w.shape, device=x.device)
             ops.conv_wgrad(x, dy, dw, stride, pad)
             ret_dw = dw
-        return dx, ret_dw, ret_db, None, None, None
+        return dx, ret_dw, ret_db, None, None, None, None
 
 
 def conv_bias(x, conv, relu=False):
-    return _ConvBias.apply(x, conv.weight, conv.bias, conv.stride[0], tuple(conv.padding), relu)
+    return _ConvBias.apply(x, conv.weight, conv.bias, conv.stride[0], tuple(conv.padding), relu, getattr(x, "_rr_acc", None))
 
 
 def conv_weight(x, weight, bias=None, stride=1, pad=(0, 0), relu=False):
     """_ConvBias on a bare weight tensor (e.g. one assembled from several parameters)."""
-    return _ConvBias.apply(x, weight, bias, stride, tuple(pad), relu)
+    return _ConvBias.apply(x, weight, bias, stride, tuple(pad), relu, getattr(x, "_rr_acc", None))
 
 
 class _WHShiftSum(torch.autograd.Function):
@@ -254,7 +267,9 @@ _SHARED_ACC = os.environ.get("RR_SHARED_ACC", "1") != "0"
 class GradAcc:
     """Fan-in target shared by the consumers of one fan-out: the first consumer to run its backward publishes its
     input gradient here, the others add into it (inside their dgrad epilogue) and hand autograd `None`, so the
-    fan-out's backward finds one complete gradient and launches no sum kernel."""
+    fan-out's backward finds one complete gradient and launches no sum kernel.  The views a fan-out returns carry
+    the accumulator as `_rr_acc`; convolution nodes pick it up from their input, and a nested fan-out of such a view
+    (a residual block at the head of an hourglass branch) joins the same accumulator."""
     __slots__ = ("buf",)
 
     def __init__(self):
@@ -262,10 +277,17 @@ class GradAcc:
 
 
 def fanout_shared(x, n):
-    """fanout + the GradAcc its consumers may share (None when x carries no gradient)."""
+    """fanout whose views carry a shared GradAcc -> (view_1, .., view_n, acc); acc is None when x carries no
+    gradient."""
     if n == 1 or not x.requires_grad:
         return (x,) * n + (None,)
-    return _FanOut.apply(x, n) + (GradAcc() if _SHARED_ACC else None,)
+    outs = _FanOut.apply(x, n)
+    if not _SHARED_ACC:
+        return outs + (None,)
+    acc = getattr(x, "_rr_acc", None) or GradAcc()
+    for o in outs:
+        o._rr_acc = acc
+    return outs + (acc,)
 
 
 class _ReLU(torch.autograd.Function):

@@ -81,7 +81,7 @@ class RRNet(nn.Module):
     def forward_stage1(self, feats):
         hms, whs, offsets = [], [], []
         for i in range(self.num_stacks):
-            fa, fb, fc = RF.fanout(RF.relu(feats[i]), 3)
+            fa, fb, fc, _ = RF.fanout_shared(RF.relu(feats[i]), 3)   # three 3x3 head convs: one gradient buffer
             hms.append(self.hm(fa, i))
             whs.append(self.wh(fb, i))
             offsets.append(self.offset_reg(fc, i))
