@@ -70,7 +70,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nb)
 // PIPE: software-pipelined main loop (global loads two K-steps ahead, LDS fragments one 8-deep group
 // ahead, barrier placed between the third and fourth MFMA group) so that a wave's MFMA stream never
 // waits on a barrier or on LDS latency.
-template <int BN, int MODE, bool SCALAR, int BKT, bool PIPE>
+template <int BN, int MODE, bool SCALAR, int BKT, int PIPE>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
 {
     constexpr int WN = BN / 64 ? BN / 64 : 1;   // waves along N
@@ -92,8 +92,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
     constexpr int BJ = B_KN ? BJ_KN : BJ_NK;
 
     extern __shared__ __align__(16) float lds[];
-    float *As = lds;                    // [2][A_ELEMS]
-    float *Bs = lds + 2 * A_ELEMS;      // [2][B_ELEMS]
+    constexpr int NBUF = PIPE == 2 ? 1 : 2;   // PIPE 2: one LDS image per operand, three workgroups per CU
+    float *As = lds;                    // [NBUF][A_ELEMS]
+    float *Bs = lds + NBUF * A_ELEMS;   // [NBUF][B_ELEMS]
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
@@ -335,7 +336,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
 
     const int lr = lane & 31, lh = lane >> 5;
 
-    if constexpr (!PIPE) {
+    if constexpr (PIPE == 0) {
     if (kc_lo < kc_hi) {
         load_tiles(kc_lo);
         store_tiles(0);
@@ -373,7 +374,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
         __syncthreads();
     }
     } else {
-    static_assert(!PIPE || (BKT == 32 && !SCALAR && BN == 128), "pipelined loop: 4 groups of 8 per K-step, vector gather, 128x128 tile");
+    static_assert(PIPE == 0 || (BKT == 32 && !SCALAR && BN == 128), "pipelined loop: 4 groups of 8 per K-step, vector gather, 128x128 tile");
     // Each K-step = 4 groups x 4 sub-groups of 4 MFMAs.  Memory instructions are dealt out between the
     // sub-groups (never clustered): a VMEM / DS issue that would stall this wave's in-order stream then
     // overlaps the 64-cycle MFMAs already in the pipe (probe: clustered ds_write+barrier costs 5 %,
@@ -460,7 +461,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
         if (!B_KN) *reinterpret_cast<f32x4 *>(Bs + buf * B_ELEMS + (a_row + RPP * j) * LDK + a_col) = rb[j];
         else *reinterpret_cast<f32x4 *>(Bs + buf * B_ELEMS + (t / TPR + KRPP * j) * LDB + (t % TPR) * 4) = rb[j];
     };
-    static_assert(!PIPE || (AJ == 4 && BJ == 4), "piece schedule below assumes 4 + 4 float4 per thread");
+    static_assert(PIPE == 0 || (AJ == 4 && BJ == 4), "piece schedule below assumes 4 + 4 float4 per thread");
     if (kc_lo < kc_hi) {
         prep();
 #pragma unroll
@@ -475,6 +476,37 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
     }
     __syncthreads();
     if (kc_lo < kc_hi) read_frags(0, 0, fa0, fb0);
+    if constexpr (PIPE == 2) {
+    // Single LDS image, two barriers per K-step, both inside group 3: after the last fragment reads of tile kc
+    // everybody waits (1), the registers holding tile kc+1 are written over it, everybody waits (2), then the
+    // first fragments of kc+1 and the global loads of kc+2 go out — all under group 3's 16 MFMAs.  Half the LDS
+    // of the double-buffered loop: a third workgroup fits on the CU and covers the barrier waits.
+    for (int kc = kc_lo; kc < kc_hi; ++kc) {
+        p_live = kc + 2 < kc_hi;
+        read_frags(0, 1, fa1, fb1);
+        sub(fa0, fb0, 0); sub(fa0, fb0, 1); sub(fa0, fb0, 2); sub(fa0, fb0, 3);
+        read_frags(0, 2, fa0, fb0);
+        sub(fa1, fb1, 0); sub(fa1, fb1, 1); sub(fa1, fb1, 2); sub(fa1, fb1, 3);
+        read_frags(0, 3, fa1, fb1);
+        sub(fa0, fb0, 0); sub(fa0, fb0, 1); sub(fa0, fb0, 2); sub(fa0, fb0, 3);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        store_a(0, 0); store_a(1, 0); store_a(2, 0); store_a(3, 0);
+        sub(fa1, fb1, 0);
+        store_b(0, 0); store_b(1, 0); store_b(2, 0); store_b(3, 0);
+        sub(fa1, fb1, 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(0, 0, fa0, fb0);
+        prep();
+        load_a(0); load_a(1); load_a(2); load_a(3);
+        sub(fa1, fb1, 2);
+        load_b(0); load_b(1); load_b(2); load_b(3);
+        sub(fa1, fb1, 3);
+    }
+    } else {
     for (int kc = kc_lo; kc < kc_hi; ++kc) {
         const int buf = (kc - kc_lo) & 1;
         // The body is branch-free on purpose: past the end of the K range the loads turn into out-of-range
@@ -514,6 +546,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
         // group 3 (set 1) overlaps the first fragment reads of the next K-step
         read_frags(buf ^ 1, 0, fa0, fb0);
         sub(fa1, fb1, 0); sub(fa1, fb1, 1); sub(fa1, fb1, 2); sub(fa1, fb1, 3);
+    }
     }
     }
 
@@ -952,7 +985,10 @@ int launch(K kern, int blocks, size_t lds, hipStream_t stream, const A &args, co
     return RR_OK;
 }
 
-size_t igemm_lds(int bn, bool b_kn, int bk) { return sizeof(float) * 2 * (BM * (bk + 4) + (b_kn ? bk * bn : bn * (bk + 4))); }
+size_t igemm_lds(int bn, bool b_kn, int bk, int nbuf = 2)
+{
+    return sizeof(float) * nbuf * (BM * (bk + 4) + (b_kn ? bk * bn : bn * (bk + 4)));
+}
 
 int wgrad_aligned()
 {
@@ -1032,7 +1068,7 @@ int conv_pipe()
     static int v = -1;
     if (v < 0) {
         const char *e = getenv("RR_CONV_PIPE");
-        v = (e && atoi(e) == 0) ? 0 : 1;
+        v = e ? atoi(e) : 2;       // 0 plain loop, 1 pipelined (two LDS images), 2 pipelined with one LDS image (default)
     }
     return v;
 }
@@ -1042,17 +1078,20 @@ int launch_igemm(ConvArgs &a, int bn, bool scalar, int blocks, int gy, int gz, h
 {
     const int bk = conv_bk();
     const size_t lds = igemm_lds(bn, MODE == 1, bk);
-#define IG(BNv, SCv, BKv, PIPEv) launch(conv_igemm_kernel<BNv, MODE, SCv, BKv, PIPEv>, blocks, lds, stream, a, name, gy, gz)
+#define IG(BNv, SCv, BKv, PIPEv) launch(conv_igemm_kernel<BNv, MODE, SCv, BKv, PIPEv>, blocks, PIPEv == 2 ? igemm_lds(bn, MODE == 1, bk, 1) : lds, stream, a, name, gy, gz)
     if (bk == 32) {
         // the pipelined kernel addresses both tensors through 32-bit buffer offsets
         const bool small = (long)a.N * a.SH * a.SW * a.SC * 4 < (1l << 31) && (long)a.wK * a.R * a.S * a.wC * 4 < (1l << 31);
-        if (bn == 128) return scalar ? IG(128, true, 32, false)
-                                     : (conv_pipe() && small ? IG(128, false, 32, true) : IG(128, false, 32, false));
-        if (bn == 64) return IG(64, false, 32, false);   // 4 waves along M, 32x64 each: 33..64-column layers
-        return scalar ? IG(32, true, 32, false) : IG(32, false, 32, false);
+        if (bn == 128) {
+            if (scalar) return IG(128, true, 32, 0);
+            if (conv_pipe() == 2 && small) return IG(128, false, 32, 2);
+            return conv_pipe() && small ? IG(128, false, 32, 1) : IG(128, false, 32, 0);
+        }
+        if (bn == 64) return IG(64, false, 32, 0);   // 4 waves along M, 32x64 each: 33..64-column layers
+        return scalar ? IG(32, true, 32, 0) : IG(32, false, 32, 0);
     }
-    if (bn == 128) return scalar ? IG(128, true, 16, false) : IG(128, false, 16, false);
-    return scalar ? IG(32, true, 16, false) : IG(32, false, 16, false);
+    if (bn == 128) return scalar ? IG(128, true, 16, 0) : IG(128, false, 16, 0);
+    return scalar ? IG(32, true, 16, 0) : IG(32, false, 16, 0);
 #undef IG
 }
 
