@@ -633,8 +633,10 @@ struct WgradArgs {
 // PIPE: 0 plain double-buffered loop; 1 software-pipelined; 2 software-pipelined for Q % BK == 0, where the BK pixels
 // of a K-step lie in one output row: the row walk (n, p, q0) is wave-uniform and lives in SGPRs, the tensor offsets go
 // through the buffer instruction's scalar offset, and the per-lane work per load is one add, one compare, one select.
+// PIPE 3 = PIPE 2 with ONE LDS image per operand and two barriers inside the last MFMA group (three workgroups per CU,
+// like conv_igemm_kernel<PIPE 2>).
 template <int BMW, int BN, bool A_SCALAR, bool B_SCALAR, int PIPE>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a)
+__global__ __launch_bounds__(256, PIPE == 3 ? 3 : 1) void conv_wgrad_kernel(const WgradArgs a)
 {
     constexpr int TILES = (BMW / 32) * (BN / 32);
     constexpr int KS = TILES == 1 ? 4 : 1;                       // waves splitting K
@@ -647,7 +649,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a)
     constexpr int TPR_B = BN / 4, RPP_B = 256 / TPR_B, BJ = BN / 32;
 
     extern __shared__ __align__(16) float lds[];
-    float *As = lds, *Bs = lds + 2 * A_ELEMS;
+    constexpr int NBUF = PIPE == 3 ? 1 : 2;
+    float *As = lds, *Bs = lds + NBUF * A_ELEMS;
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wk = KS > 1 ? wave : 0;
@@ -750,7 +753,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a)
 
     const int lr = lane & 31, lh = lane >> 5;
     constexpr bool WPIPE = PIPE != 0 && (BMW == 128 && BN == 128 && !A_SCALAR && !B_SCALAR);
-    constexpr bool ALIGNED = PIPE == 2;
+    constexpr bool ALIGNED = PIPE >= 2;
     if constexpr (!WPIPE) {
     load_tiles(kc_begin);
     store_tiles(0);
@@ -909,6 +912,32 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a)
     for (int j = 0; j < 4; ++j) { load_a(j, kc_begin + 1); load_b(j); adv_b(j); }
     __syncthreads();
     rdg(0, 0, fa0, fb0);
+    if constexpr (PIPE == 3) {
+    for (int kc = kc_begin; kc < kc_end; ++kc) {
+        rdg(0, 1, fa1, fb1);
+        sub(fa0, fb0, 0); sub(fa0, fb0, 1); sub(fa0, fb0, 2); sub(fa0, fb0, 3);
+        rdg(0, 2, fa0, fb0);
+        sub(fa1, fb1, 0); sub(fa1, fb1, 1); sub(fa1, fb1, 2); sub(fa1, fb1, 3);
+        rdg(0, 3, fa1, fb1);
+        sub(fa0, fb0, 0); sub(fa0, fb0, 1); sub(fa0, fb0, 2); sub(fa0, fb0, 3);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        st_a(0, 0); st_a(1, 0); st_a(2, 0); st_a(3, 0);
+        sub(fa1, fb1, 0);
+        st_b(0, 0); st_b(1, 0); st_b(2, 0); st_b(3, 0);
+        sub(fa1, fb1, 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        rdg(0, 0, fa0, fb0);
+        load_a(0, kc + 2); load_a(1, kc + 2); load_a(2, kc + 2); load_a(3, kc + 2);
+        sub(fa1, fb1, 2);
+        load_b(0); load_b(1); load_b(2); load_b(3);
+        adv_b(0); adv_b(1); adv_b(2); adv_b(3);
+        sub(fa1, fb1, 3);
+    }
+    } else {
     for (int kc = kc_begin; kc < kc_end; ++kc) {
         const int buf = (kc - kc_begin) & 1;
         // branch-free body (see conv_igemm_kernel<PIPE>): past the end of this split's K range the loads are
@@ -947,6 +976,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a)
         sub(fa1, fb1, 1);
         sub(fa1, fb1, 2);
         sub(fa1, fb1, 3);
+    }
     }
     }
 #pragma unroll
@@ -995,7 +1025,7 @@ int wgrad_aligned()
     static int v = -1;
     if (v < 0) {
         const char *e = getenv("RR_WGRAD_ALIGNED");
-        v = (e && atoi(e) == 0) ? 0 : 1;
+        v = e ? atoi(e) : 1;       // 0 generic row walk, 1 uniform row walk + one LDS image (default), 2 uniform + two images
     }
     return v;
 }
@@ -1253,25 +1283,27 @@ extern "C" int rr_conv_wgrad(const float *x, const float *dy, float *dw, int n, 
     // Split the pixel (K) dimension so that tiles*splits fills the 512 resident-workgroup slots
     // (256 CUs x 2) exactly once: equal-length workgroups in more than one round pay a whole extra
     // round for any remainder.  Never fewer than 8 K-steps per split.
-    int splits = tiles < 512 ? 512 / tiles : 1;
+    // pipelined 128x128 variants: 32-bit buffer offsets, both tensors below 2 GiB
+    const bool as = (k % 4) != 0, bs = (c % 4) != 0;
+    const bool pipe_ok = bmw == 128 && bn == 128 && !as && !bs && conv_pipe() && M * k * 4 < (1l << 31) &&
+                         (long)n * h * wd * c * 4 < (1l << 31);
+    const int wmode = !pipe_ok ? 0 : (a.Q % BK == 0 && wgrad_aligned() ? (wgrad_aligned() == 2 ? 2 : 3) : 1);
+    const int slots = wmode == 3 ? 768 : 512;       // resident workgroups: 256 CUs x 3 with one LDS image, else x 2
+    int splits = tiles < slots ? slots / tiles : 1;
     if (splits > rr_cdiv(total_chunks, 8)) splits = rr_cdiv(total_chunks, 8);
     if (splits < 1) splits = 1;
     a.chunks_per_split = rr_cdiv(total_chunks, splits);
     splits = rr_cdiv(total_chunks, a.chunks_per_split);
     const int blocks = tiles * splits;
-    const size_t lds = sizeof(float) * 2 * (BK * bmw + BK * bn);
-    const bool as = (k % 4) != 0, bs = (c % 4) != 0;
+    const size_t lds = sizeof(float) * (wmode == 3 ? 1 : 2) * (BK * bmw + BK * bn);
 #define WG(BMv, BNv)                                                                                                  \
     (as ? (bs ? launch(conv_wgrad_kernel<BMv, BNv, true, true, 0>, blocks, lds, stream, a, "rr_conv_wgrad")      \
               : launch(conv_wgrad_kernel<BMv, BNv, true, false, 0>, blocks, lds, stream, a, "rr_conv_wgrad"))    \
         : (bs ? launch(conv_wgrad_kernel<BMv, BNv, false, true, 0>, blocks, lds, stream, a, "rr_conv_wgrad")     \
               : launch(conv_wgrad_kernel<BMv, BNv, false, false, 0>, blocks, lds, stream, a, "rr_conv_wgrad")))
-    // pipelined 128x128 variant: 32-bit buffer offsets, both tensors below 2 GiB
-    if (bmw == 128 && bn == 128 && !as && !bs && conv_pipe() && M * k * 4 < (1l << 31) &&
-        (long)n * h * wd * c * 4 < (1l << 31))
-        return a.Q % BK == 0 && wgrad_aligned()
-                   ? launch(conv_wgrad_kernel<128, 128, false, false, 2>, blocks, lds, stream, a, "rr_conv_wgrad")
-                   : launch(conv_wgrad_kernel<128, 128, false, false, 1>, blocks, lds, stream, a, "rr_conv_wgrad");
+    if (wmode == 3) return launch(conv_wgrad_kernel<128, 128, false, false, 3>, blocks, lds, stream, a, "rr_conv_wgrad");
+    if (wmode == 2) return launch(conv_wgrad_kernel<128, 128, false, false, 2>, blocks, lds, stream, a, "rr_conv_wgrad");
+    if (wmode == 1) return launch(conv_wgrad_kernel<128, 128, false, false, 1>, blocks, lds, stream, a, "rr_conv_wgrad");
     if (bmw == 128) return bn == 128 ? WG(128, 128) : WG(128, 32);
     return bn == 128 ? WG(32, 128) : WG(32, 32);
 #undef WG
