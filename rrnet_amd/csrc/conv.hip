@@ -1030,6 +1030,16 @@ int wgrad_aligned()
     return v;
 }
 
+int small_tiles()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("RR_CONV_SMALL_TILES");
+        v = e ? atoi(e) : 16;      // <= 16 tiles of 128x128 (the 8x8 level): 128x32 tiles give 4x the workgroups
+    }
+    return v;
+}
+
 int conv_bk()
 {
     static int bk = -1;
@@ -1150,7 +1160,8 @@ static int fprop_impl(const float *x, const float *w, const float *bias, float *
     a.M = (int)M; a.Kg = r * s * c; a.wK = k; a.wC = c;
     const bool scalar = (c % 4) != 0 || r * s > 64;   // the vector path keeps a 64-bit tap mask per row
     const int bk = conv_bk();
-    const int bn = k > 64 ? 128 : (k > 32 ? (!scalar && bk == 32 ? 64 : 128) : 32);
+    int bn = k > 64 ? 128 : (k > 32 ? (!scalar && bk == 32 ? 64 : 128) : 32);
+    if (bn == 128 && !scalar && rr_cdiv(M, BM) * rr_cdiv(k, 128) <= small_tiles()) bn = 32;   // tiny layers: 4x the tiles
     const int blocks = rr_cdiv(M, BM) * rr_cdiv(k, bn);
     const int nk = scalar ? rr_cdiv(a.Kg, bk) : rr_cdiv(c, bk) * r * s;
     int ks = (bias == nullptr && !relu && k % 4 == 0 && k <= 1024) ? pick_ksplit(blocks, nk) : 1;
@@ -1232,7 +1243,8 @@ extern "C" int rr_conv_dgrad(const float *dy, const float *w, float *dx, int n, 
     a.M = (int)M; a.Kg = r * s * k; a.wK = k; a.wC = c;
     const bool scalar = (k % 4) != 0 || (c % 4) != 0 || r * s > 64 || stride > 2;
     const int bk = conv_bk();
-    const int bn = c > 64 ? 128 : (c > 32 ? (!scalar && bk == 32 ? 64 : 128) : 32);
+    int bn = c > 64 ? 128 : (c > 32 ? (!scalar && bk == 32 ? 64 : 128) : 32);
+    if (bn == 128 && !scalar && stride == 1 && rr_cdiv(M, BM) * rr_cdiv(c, 128) <= small_tiles()) bn = 32;
     int blocks = rr_cdiv(M, BM) * rr_cdiv(c, bn);
     int gy = 1;
     int nk = scalar ? rr_cdiv(a.Kg, bk) : rr_cdiv(k, bk) * r * s;

@@ -35,7 +35,7 @@ for i, (n, c, h, w, k, r, st) in enumerate(SHAPES):
     dw = torch.zeros((k, r, r, c), device="cuda").permute(0, 3, 1, 2)
     dx = ops.empty_nhwc(n, c, h, w, "cuda")
     flops = 2.0 * n * p * q * k * c * r * r
-    t1 = timeit(lambda: ops.conv_fprop(x, wt, None, st, (pad, pad), False, want_stats=True))
+    t1 = timeit(lambda: ops.conv_fprop(x, wt, None, st, (pad, pad), False, want_stats=os.environ.get("RR_BENCH_NOSTATS") != "1"))
     t2 = timeit(lambda: ops.conv_dgrad(dy, wt, (n, c, h, w), st, (pad, pad), out=dx))
     t3 = timeit(lambda: ops.conv_wgrad(x, dy, dw, st, (pad, pad)))
     print("N%d C%d %dx%d K%d r%d s%d | fprop %.3f ms %.1f TF | dgrad %.3f ms %.1f TF | wgrad %.3f ms %.1f TF" % (
