@@ -169,12 +169,12 @@ def main():
                 tpath = os.path.join(ROOT, "profiles", "r01_traffic_pmc.json")
                 if os.path.exists(tpath) and a.backbone == "hourglass" and a.size == 1024 and a.batch == 8:
                     with open(tpath) as f:
-                        traffic = json.load(f).get("conv_igemm_kernel<128, 0, false, 32, true>", {}).get("traffic_bytes_per_launch")
+                        traffic = json.load(f).get("conv_igemm_kernel<128, 0, false, 32, 2>", {}).get("traffic_bytes_per_launch")
                 out["roofline"] = {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
                                    "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
                                    "traffic": traffic,
                                    "algorithmic_bytes_per_launch": round(timer.bytes.get(dom, 0.0) / d["launches"]),
-                                   "kernel": "conv_igemm_kernel<128, 0, false, 32, true> (implicit-GEMM forward kernel, v_mfma_f32_32x32x2_f32; "
+                                   "kernel": "conv_igemm_kernel<128, 0, false, 32, 2> (implicit-GEMM forward kernel, v_mfma_f32_32x32x2_f32; "
                                              "launched for fprop and for stride-1 dgrad on flipped weights)",
                                    "launches": d["launches"], "avg_launch_ms": round(d["ms"] / d["launches"], 4),
                                    "algorithmic_gflop_per_launch": round(d["flops"] / d["launches"] / 1e9, 3)}

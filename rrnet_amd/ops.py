@@ -62,9 +62,16 @@ def _timed(name, flops, fn, detail=None, nbytes=0.0):
     return TIMER.launch(name, flops, fn, detail, nbytes)
 
 
-def _igemm_name(kind, n_gemm, scalar):
-    """Timer key = the HIP kernel instance that runs (tile width as picked in csrc/conv.hip)."""
+_SMALL_TILES = int(os.environ.get("RR_CONV_SMALL_TILES", "16"))
+
+
+def _igemm_name(kind, n_gemm, scalar, m_rows=1 << 30, stride=1):
+    """Timer key = the HIP kernel instance that runs (tile width as picked in csrc/conv.hip: 128 columns, 64 for
+    33..64-column layers, 32 for narrow ones and for layers with at most RR_CONV_SMALL_TILES 128x128 tiles)."""
     bn = 128 if n_gemm > 64 or (scalar and n_gemm > 32) else (64 if n_gemm > 32 else 32)
+    if bn == 128 and not scalar and (kind == "fprop" or stride == 1):
+        if -(-m_rows // 128) * -(-n_gemm // 128) <= _SMALL_TILES:
+            bn = 32
     return "conv_%s<BN=%d,%s>" % (kind, bn, "scalar" if scalar else "vec4")
 
 
@@ -108,7 +115,7 @@ def conv_fprop(x, w, bias=None, stride=1, pad=(0, 0), relu=False, want_stats=Fal
         slab = torch.empty(nbytes // 8, dtype=torch.float64, device=x.device)
     f = _C.fn("rr_conv_fprop")
     flops = 2.0 * n * p * q * k * c * r * s
-    _C.check(_timed(_igemm_name("fprop", k, c % 4 != 0), flops,
+    _C.check(_timed(_igemm_name("fprop", k, c % 4 != 0, n * p * q), flops,
                     lambda: f(_C.ptr(x), _C.ptr(w), _C.ptr(bias), _C.ptr(y), _C.ptr(slab), n, h, wd, c, k, r, s,
                               stride, pad[0], pad[1], int(relu), _C.stream()),
                     (n, h, wd, c, k, r, s, stride), 4.0 * (x.numel() + y.numel() + w.numel())), "rr_conv_fprop")
@@ -157,13 +164,13 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False)
                  "rr_weight_flip_transpose")
         f1 = _C.fn("rr_conv_dgrad_s1")
         # same HIP kernel instance as a forward convolution: timed under its name
-        _C.check(_timed(_igemm_name("fprop", c, False), flops,
+        _C.check(_timed(_igemm_name("fprop", c, False, n * h * wd), flops,
                         lambda: f1(_C.ptr(dy), _C.ptr(wt), _C.ptr(out), n, h, wd, c, k, r, s, pad[0], pad[1],
                                    int(accumulate), _C.stream()), (n, h, wd, c, k, r, s, stride),
                         4.0 * (dy.numel() + out.numel() * (2 if accumulate else 1) + w.numel())), "rr_conv_dgrad_s1")
         return out
     f = _C.fn("rr_conv_dgrad")
-    _C.check(_timed(_igemm_name("dgrad", c, (k % 4 != 0) or (c % 4 != 0)), flops,
+    _C.check(_timed(_igemm_name("dgrad", c, (k % 4 != 0) or (c % 4 != 0), n * h * wd, stride), flops,
                     lambda: f(_C.ptr(dy), _C.ptr(w), _C.ptr(out), n, h, wd, c, k, r, s, stride, pad[0], pad[1],
                               int(accumulate), _C.stream()), (n, h, wd, c, k, r, s, stride)), "rr_conv_dgrad")
     return out
