@@ -71,14 +71,16 @@ __device__ __forceinline__ int xcd_remap(int bid, int nb)
 // ahead, barrier placed between the third and fourth MFMA group) so that a wave's MFMA stream never
 // waits on a barrier or on LDS latency.
 template <int BN, int MODE, bool SCALAR, int BKT, int PIPE>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
+__global__ __launch_bounds__(256, PIPE == 3 ? 3 : 1) void conv_igemm_kernel(const ConvArgs a)
 {
     constexpr int WN = BN / 64 ? BN / 64 : 1;   // waves along N
     constexpr int WM = 4 / WN;                  // waves along M
     constexpr int TM = BM / (WM * 32);
     constexpr int TN = BN / (WN * 32);
     constexpr bool B_KN = (MODE == 1);          // dgrad reads W as [k][n]
-    constexpr int LDK = BKT + 4;                // [m][k] image row stride: conflict-free ds_read_b128
+    // [m][k] image row stride: padded by 4 floats for conflict-free ds_read_b128; PIPE 3 (LDS-DMA staging) cannot pad
+    // (a wave's 64 x 16 B land contiguously) and XOR-swizzles the 16-byte chunks of a row with (row & 7) instead
+    constexpr int LDK = PIPE == 3 ? BKT : BKT + 4;
     constexpr int LDB = B_KN ? BN : LDK;
     constexpr int A_ELEMS = BM * LDK;
     constexpr int B_ELEMS = B_KN ? BKT * BN : BN * LDK;
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
     constexpr int BJ = B_KN ? BJ_KN : BJ_NK;
 
     extern __shared__ __align__(16) float lds[];
-    constexpr int NBUF = PIPE == 2 ? 1 : 2;   // PIPE 2: one LDS image per operand, three workgroups per CU
+    constexpr int NBUF = PIPE >= 2 ? 1 : 2;   // PIPE 2 / 3: one LDS image per operand, three / four workgroups per CU
     float *As = lds;                    // [NBUF][A_ELEMS]
     float *Bs = lds + NBUF * A_ELEMS;   // [NBUF][B_ELEMS]
 
@@ -132,7 +134,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
     }
 
     // ---- per-thread A rows: destination pixel coordinates
-    const int a_col = (t % CPR) * 4;
+    // PIPE 3: lane (row, slot) fetches chunk slot ^ (row & 7), so that its DMA lands at the swizzled position
+    const int a_col = PIPE == 3 ? (((t % CPR) ^ ((t / CPR) & 7)) * 4) : (t % CPR) * 4;
     const int a_row = t / CPR;
     int a_n[AJ], a_h[AJ], a_w[AJ];
 #pragma unroll
@@ -383,6 +386,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
     auto read_frags = [&](int buf, int kk, f32x4 (&fa)[TM], f32x4 (&fb)[TN]) {
         const float *A = As + buf * A_ELEMS;
         const float *B = Bs + buf * B_ELEMS;
+        if constexpr (PIPE == 3) {
+            const int slot = ((kk * 2 + lh) ^ (lr & 7)) * 4;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                fa[i] = *reinterpret_cast<const f32x4 *>(A + ((wm * TM + i) * 32 + lr) * LDK + slot);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                fb[j] = *reinterpret_cast<const f32x4 *>(B + ((wn * TN + j) * 32 + lr) * LDK + slot);
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
             fa[i] = *reinterpret_cast<const f32x4 *>(A + ((wm * TM + i) * 32 + lr) * LDK + kk * 8 + lh * 4);
@@ -462,6 +475,56 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
         else *reinterpret_cast<f32x4 *>(Bs + buf * B_ELEMS + (t / TPR + KRPP * j) * LDB + (t % TPR) * 4) = rb[j];
     };
     static_assert(PIPE == 0 || (AJ == 4 && BJ == 4), "piece schedule below assumes 4 + 4 float4 per thread");
+    if constexpr (PIPE == 3) {
+    // LDS-DMA staging (buffer_load_dwordx4 ... lds): no staging registers, no ds_write; one unpadded, XOR-swizzled LDS
+    // image.  Per K-step: after the last fragment reads of tile kc everybody waits (1), each wave fires its 8 DMA
+    // loads of tile kc+1 under group 3's MFMAs, waits for its own (vmcnt 0), everybody waits (2); the exposed part of
+    // the load latency is covered by the other workgroups of the CU.
+    // Opt-in (RR_CONV_PIPE=3), measured on MI355X: at three workgroups per CU it ties with PIPE 2 (137-139 TFLOP/s on
+    // the 256x256 layer); a fourth workgroup needs <= 128 registers per lane and spills 17 dwords whose
+    // scratch reloads put s_waitcnt vmcnt(0) between the DMA loads, so PIPE 2 stays the default.
+    static_assert(PIPE != 3 || !B_KN, "DMA staging: [n][k] weight image only (fprop / flipped-weight dgrad)");
+    typedef __attribute__((address_space(3))) void lds_void;
+    auto dma_a = [&](int j) {
+        const unsigned ok = (unsigned)p_cok & (unsigned)((a_mask[j] >> p_tlc) & 1ull) & (unsigned)p_live;
+        const unsigned off = ok ? (unsigned)(a_boff[j] + p_adelta) : 0x80000000u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lds_void *)(As + (wave * 8 + RPP * j) * LDK), 16, off, 0, 0, 0);
+    };
+    auto dma_b = [&](int j) {
+        const unsigned ok = ((unsigned)b_ok[j] & (unsigned)p_wcok) & (unsigned)p_live;
+        const unsigned off = ok ? (unsigned)(b_boff[j] + p_wdelta) : 0x80000000u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void *)(Bs + (wave * 8 + RPP * j) * LDK), 16, off, 0, 0, 0);
+    };
+    if (kc_lo < kc_hi) {
+        prep();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { dma_a(j); dma_b(j); }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kc_lo < kc_hi) read_frags(0, 0, fa0, fb0);
+    for (int kc = kc_lo; kc < kc_hi; ++kc) {
+        p_live = kc + 1 < kc_hi;
+        read_frags(0, 1, fa1, fb1);
+        sub(fa0, fb0, 0); sub(fa0, fb0, 1); sub(fa0, fb0, 2); sub(fa0, fb0, 3);
+        read_frags(0, 2, fa0, fb0);
+        sub(fa1, fb1, 0); sub(fa1, fb1, 1); sub(fa1, fb1, 2); sub(fa1, fb1, 3);
+        prep();
+        read_frags(0, 3, fa1, fb1);
+        sub(fa0, fb0, 0); sub(fa0, fb0, 1); sub(fa0, fb0, 2); sub(fa0, fb0, 3);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        dma_a(0); dma_a(1); dma_a(2); dma_a(3);
+        sub(fa1, fb1, 0);
+        dma_b(0); dma_b(1); dma_b(2); dma_b(3);
+        sub(fa1, fb1, 1); sub(fa1, fb1, 2); sub(fa1, fb1, 3);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(0, 0, fa0, fb0);
+    }
+    } else {
     if (kc_lo < kc_hi) {
         prep();
 #pragma unroll
@@ -546,6 +609,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a)
         // group 3 (set 1) overlaps the first fragment reads of the next K-step
         read_frags(buf ^ 1, 0, fa0, fb0);
         sub(fa1, fb1, 0); sub(fa1, fb1, 1); sub(fa1, fb1, 2); sub(fa1, fb1, 3);
+    }
     }
     }
     }
@@ -1118,13 +1182,18 @@ int launch_igemm(ConvArgs &a, int bn, bool scalar, int blocks, int gy, int gz, h
 {
     const int bk = conv_bk();
     const size_t lds = igemm_lds(bn, MODE == 1, bk);
-#define IG(BNv, SCv, BKv, PIPEv) launch(conv_igemm_kernel<BNv, MODE, SCv, BKv, PIPEv>, blocks, PIPEv == 2 ? igemm_lds(bn, MODE == 1, bk, 1) : lds, stream, a, name, gy, gz)
+#define IG(BNv, SCv, BKv, PIPEv)                                                                                     \
+    launch(conv_igemm_kernel<BNv, MODE, SCv, BKv, PIPEv>, blocks,                                                    \
+           PIPEv == 3 ? sizeof(float) * (BM + bn) * bk : (PIPEv == 2 ? igemm_lds(bn, MODE == 1, bk, 1) : lds), stream, a, name, gy, gz)
     if (bk == 32) {
         // the pipelined kernel addresses both tensors through 32-bit buffer offsets
         const bool small = (long)a.N * a.SH * a.SW * a.SC * 4 < (1l << 31) && (long)a.wK * a.R * a.S * a.wC * 4 < (1l << 31);
         if (bn == 128) {
             if (scalar) return IG(128, true, 32, 0);
-            if (conv_pipe() == 2 && small) return IG(128, false, 32, 2);
+            if constexpr (MODE == 0) {
+                if (conv_pipe() == 3 && small) return IG(128, false, 32, 3);
+            }
+            if (conv_pipe() >= 2 && small) return IG(128, false, 32, 2);
             return conv_pipe() && small ? IG(128, false, 32, 1) : IG(128, false, 32, 0);
         }
         if (bn == 64) return IG(64, false, 32, 0);   // 4 waves along M, 32x64 each: 33..64-column layers
