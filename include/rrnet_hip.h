@@ -135,6 +135,10 @@ int rr_upsample_add_bwd(const float *dout, float *dlow, int n, int h, int w, int
                         hipStream_t stream);
 int rr_avgpool_fwd(const float *x, float *out, long r, int hw, int c, hipStream_t stream);
 int rr_avgpool_bwd(const float *dout, float *dx, long r, int hw, int c, hipStream_t stream);
+/* Inference tail of the stage-2 head (backbones/resnet.py:48-53 + detectors/fasterrcnn_detector.py:15):
+ * out[r,c] = mean over the hw positions of relu(y[r,p,c]*scale[c] + shift[c] + res[r,p,c]); y, res NHWC [r,hw,c]. */
+int rr_bn_res_relu_avgpool(const float *y, const float *scale, const float *shift, const float *res, float *out,
+                           long r, int hw, int c, hipStream_t stream);
 /* WH head, detectors/centernet_detector.py:26-77 (HCov k x 1 and WCov 1 x k to one channel each,
  * interleaved [W,H]): t [n,h,w,ct] (ct >= 2k, a multiple of 4 keeps the vector conv paths) = 1x1
  * convolution of the 256-channel map with the 2k tap vectors (rows 0..k-1 = HCov taps, k..2k-1 = WCov

@@ -378,6 +378,29 @@ __global__ __launch_bounds__(EW_THREADS) void avgpool_fwd_kernel(const float *x,
         out[i] = s * inv;
     }
 }
+// inference tail of the stage-2 head in one pass: mean over the HW positions of relu(y*scale + shift + res)
+// (backbones/resnet.py:48-53 bn3 + residual + relu, then fasterrcnn_detector.py:15 adaptive_avg_pool2d(1)); the
+// activated [R,HW,C] tensor is never written
+__global__ __launch_bounds__(EW_THREADS) void bn_res_relu_avgpool_kernel(const f32x4 *y, const float *scale, const float *shift,
+                                                                         const f32x4 *res, f32x4 *out, long R, int HW, int C4)
+{
+    const long total = R * C4;
+    const float inv = 1.f / (float)HW;
+    for (long i = (long)blockIdx.x * EW_THREADS + threadIdx.x; i < total; i += (long)gridDim.x * EW_THREADS) {
+        const long r = i / C4;
+        const int c4 = (int)(i - r * C4);
+        const f32x4 sc = *reinterpret_cast<const f32x4 *>(scale + c4 * 4), sh = *reinterpret_cast<const f32x4 *>(shift + c4 * 4);
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < HW; ++k) {
+            const long o = (r * HW + k) * C4 + c4;
+            f32x4 v = y[o] * sc + sh + res[o];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+            s += v;
+        }
+        out[i] = s * inv;
+    }
+}
 __global__ __launch_bounds__(EW_THREADS) void avgpool_bwd_kernel(const float *dout, float *dx, long R, int HW, int C)
 {
     const long total = R * HW * C;
@@ -606,6 +629,17 @@ extern "C" int rr_avgpool_fwd(const float *x, float *out, long r, int hw, int c,
 {
     EW_LAUNCH(avgpool_fwd_kernel, r * c, stream, x, out, r, hw, c);
     RR_CHECK_LAUNCH("rr_avgpool_fwd");
+    return RR_OK;
+}
+
+extern "C" int rr_bn_res_relu_avgpool(const float *y, const float *scale, const float *shift, const float *res, float *out,
+                                      long r, int hw, int c, hipStream_t stream)
+{
+    RR_CHECK_ARG(r >= 0 && hw > 0 && c > 0 && c % 4 == 0, "rr_bn_res_relu_avgpool: bad dims (C multiple of 4)");
+    if (r == 0) return RR_OK;
+    EW_LAUNCH(bn_res_relu_avgpool_kernel, r * (c / 4), stream, (const f32x4 *)y, scale, shift, (const f32x4 *)res, (f32x4 *)out, r,
+              hw, c / 4);
+    RR_CHECK_LAUNCH("rr_bn_res_relu_avgpool");
     return RR_OK;
 }
 

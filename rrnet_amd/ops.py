@@ -312,6 +312,16 @@ def avgpool_fwd(x):
     return out
 
 
+def bn_res_relu_avgpool(y, scale, shift, res):
+    """[R,C,h,w] (NHWC) x2 -> [R,C,1,1]: mean_p relu(y*scale + shift + res), one pass (inference)."""
+    assert is_nhwc(y) and is_nhwc(res) and y.shape == res.shape
+    r, c, h, w = y.shape
+    out = empty_nhwc(r, c, 1, 1, y.device)
+    _C.check(_C.fn("rr_bn_res_relu_avgpool")(_C.ptr(y), _C.ptr(scale), _C.ptr(shift), _C.ptr(res), _C.ptr(out), r, h * w, c,
+                                             _C.stream()), "rr_bn_res_relu_avgpool")
+    return out
+
+
 def avgpool_bwd(dout, shape):
     r, c, h, w = shape
     dx = empty_nhwc(r, c, h, w, dout.device)
