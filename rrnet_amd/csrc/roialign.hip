@@ -179,13 +179,140 @@ __global__ __launch_bounds__(256) void roi_align_sep_kernel(const float *feat, c
         }
     }
 }
+// ---- forward, 3x3 bins, whole-footprint form ---------------------------------------------------
+// RRNet's only use (models/rrnet.py:51: output (3,3)).  The three bins of an axis share their border pixels, so the
+// RoI's footprint is walked ONCE: every pixel row is read a single time and scattered into the (at most 2 x 2) bins it
+// belongs to — (3g+1)^2 row reads instead of 9(g+1)^2 (100 vs 144 at a 3x3 sampling grid).  Axis weights per bin over
+// the footprint live in LDS; the bin loops are wave-uniform branches on "weight != 0".
+constexpr int FP_MAX = 3 * (SEP_MAXG + 2);
+
+struct AxisFP {
+    float w[3][FP_MAX];
+    int base, n;
+};
+
+__global__ __launch_bounds__(256) void roi_align_3x3_kernel(const float *feat, const float *rois, float *out, int R, int H, int W,
+                                                            int C, float scale, int sampling)
+{
+    __shared__ AxisFP ay[4], ax[4];
+    __shared__ AxisW ty[4], tx[4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + wave;
+    const bool live = r < R;
+    const float *q = rois + (long)(live ? r : 0) * 5;
+    const int b = (int)q[0];
+    const float x1 = q[1] * scale, y1 = q[2] * scale, x2 = q[3] * scale, y2 = q[4] * scale;
+    const float rw = fmaxf(x2 - x1, 1.f), rh = fmaxf(y2 - y1, 1.f);
+    const float bh = rh / 3.f, bw = rw / 3.f;
+    const int gh = sampling > 0 ? sampling : (int)ceilf(rh / 3.f);
+    const int gw = sampling > 0 ? sampling : (int)ceilf(rw / 3.f);
+    const bool sep = gh <= SEP_MAXG && gw <= SEP_MAXG && bh <= (float)gh && bw <= (float)gw;
+    if (sep) {
+        if (lane < 3) axis_weights(y1 + lane * bh, bh, gh, H, ty[wave].w[lane], &ty[wave].base[lane], &ty[wave].n[lane]);
+        else if (lane < 6) {
+            const int p = lane - 3;
+            axis_weights(x1 + p * bw, bw, gw, W, tx[wave].w[p], &tx[wave].base[p], &tx[wave].n[p]);
+        }
+    }
+    __syncthreads();
+    if (sep && lane < 2) {       // merge the three bins of one axis into footprint-indexed weight rows
+        AxisW &t = lane == 0 ? ty[wave] : tx[wave];
+        AxisFP &f = lane == 0 ? ay[wave] : ax[wave];
+        int lo = 1 << 30, hi = -1;
+        for (int p = 0; p < 3; ++p)
+            if (t.n[p] > 0) { lo = t.base[p] < lo ? t.base[p] : lo; hi = t.base[p] + t.n[p] > hi ? t.base[p] + t.n[p] : hi; }
+        if (hi < 0) { lo = 0; hi = 0; }
+        f.base = lo; f.n = hi - lo;
+        for (int p = 0; p < 3; ++p) {
+            for (int i = 0; i < f.n; ++i) f.w[p][i] = 0.f;
+            for (int i = 0; i < t.n[p]; ++i) f.w[p][t.base[p] - lo + i] = t.w[p][i];
+        }
+    }
+    __syncthreads();
+    if (!live) return;
+    const float count = (float)(gh * gw);
+    const float *img = feat + (long)b * H * W * C;
+    if (!sep) {   // very large RoI: per-sample taps
+        for (int c0 = lane * 4; c0 < C; c0 += 256)
+            for (int bin = 0; bin < 9; ++bin) {
+                const int ph = bin / 3, pw = bin % 3;
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                for (int iy = 0; iy < gh; ++iy) {
+                    const float y = y1 + ph * bh + ((float)iy + 0.5f) * bh / (float)gh;
+                    for (int ix = 0; ix < gw; ++ix) {
+                        const float x = x1 + pw * bw + ((float)ix + 0.5f) * bw / (float)gw;
+                        const Tap t = make_tap(y, x, H, W, C);
+                        if (!t.ok) continue;
+                        const float *f = img + c0;
+                        acc += t.w00 * *reinterpret_cast<const f32x4 *>(f + t.o00) + t.w01 * *reinterpret_cast<const f32x4 *>(f + t.o01) +
+                               t.w10 * *reinterpret_cast<const f32x4 *>(f + t.o10) + t.w11 * *reinterpret_cast<const f32x4 *>(f + t.o11);
+                    }
+                }
+                *reinterpret_cast<f32x4 *>(out + ((long)r * 9 + bin) * C + c0) = acc / count;
+            }
+        return;
+    }
+    const AxisFP &fy = ay[wave], &fx = ax[wave];
+    for (int c0 = lane * 4; c0 < C; c0 += 256) {
+        f32x4 acc[3][3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int rr = 0; rr < fy.n; ++rr) {
+            const float wy0 = fy.w[0][rr], wy1 = fy.w[1][rr], wy2 = fy.w[2][rr];
+            const float *row = img + ((long)(fy.base + rr) * W + fx.base) * C + c0;
+            for (int cc = 0; cc < fx.n; ++cc) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(row + (long)cc * C);
+                const float wx0 = fx.w[0][cc], wx1 = fx.w[1][cc], wx2 = fx.w[2][cc];
+                // wave-uniform: a pixel lies in at most two bins per axis
+                if (wy0 != 0.f) {
+                    if (wx0 != 0.f) acc[0][0] += (wy0 * wx0) * v;
+                    if (wx1 != 0.f) acc[0][1] += (wy0 * wx1) * v;
+                    if (wx2 != 0.f) acc[0][2] += (wy0 * wx2) * v;
+                }
+                if (wy1 != 0.f) {
+                    if (wx0 != 0.f) acc[1][0] += (wy1 * wx0) * v;
+                    if (wx1 != 0.f) acc[1][1] += (wy1 * wx1) * v;
+                    if (wx2 != 0.f) acc[1][2] += (wy1 * wx2) * v;
+                }
+                if (wy2 != 0.f) {
+                    if (wx0 != 0.f) acc[2][0] += (wy2 * wx0) * v;
+                    if (wx1 != 0.f) acc[2][1] += (wy2 * wx1) * v;
+                    if (wx2 != 0.f) acc[2][2] += (wy2 * wx2) * v;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                *reinterpret_cast<f32x4 *>(out + (((long)r * 3 + i) * 3 + j) * C + c0) = acc[i][j] / count;
+    }
+}
 }  // namespace
+
+static int roi3x3_enabled()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("RR_ROI_3X3");
+        v = (e && atoi(e) == 0) ? 0 : 1;
+    }
+    return v;
+}
 
 extern "C" int rr_roi_align_fwd(const float *feat, const float *rois, int r, int h, int w, int c, int ph, int pw,
                                 float spatial_scale, int sampling_ratio, float *out, hipStream_t stream)
 {
     RR_CHECK_ARG(h > 0 && w > 0 && c > 0 && ph > 0 && pw > 0 && r >= 0, "rr_roi_align_fwd: bad dims");
     if (r == 0) return RR_OK;
+    if (c % 4 == 0 && ph == 3 && pw == 3 && roi3x3_enabled()) {
+        hipLaunchKernelGGL(roi_align_3x3_kernel, dim3((r + 3) / 4), dim3(256), 0, stream, feat, rois, out, r, h, w, c,
+                           spatial_scale, sampling_ratio);
+        RR_CHECK_LAUNCH("rr_roi_align_fwd");
+        return RR_OK;
+    }
     if (c % 4 == 0 && ph <= SEP_MAXBINS && pw <= SEP_MAXBINS) {
         hipLaunchKernelGGL(roi_align_sep_kernel, dim3((r + 3) / 4), dim3(256), 0, stream, feat, rois, out, r, h, w, c, ph, pw,
                            spatial_scale, sampling_ratio);
