@@ -133,6 +133,9 @@ int rr_upsample_add_fwd(const float *up1, const float *low, float *out, int n, i
                         int c, hipStream_t stream);
 int rr_upsample_add_bwd(const float *dout, float *dlow, int n, int h, int w, int lh, int lw, int c,
                         hipStream_t stream);
+/* Bilinear resize with align_corners = True (operators/rrnet_operator.py:263, the multi-scale evaluation's
+ * F.interpolate); x NHWC [n,h,w,c] -> out NHWC [n,oh,ow,c]. */
+int rr_resize_bilinear_ac(const float *x, float *out, int n, int h, int w, int oh, int ow, int c, hipStream_t stream);
 int rr_avgpool_fwd(const float *x, float *out, long r, int hw, int c, hipStream_t stream);
 int rr_avgpool_bwd(const float *dout, float *dx, long r, int hw, int c, hipStream_t stream);
 /* Inference tail of the stage-2 head (backbones/resnet.py:48-53 + detectors/fasterrcnn_detector.py:15):

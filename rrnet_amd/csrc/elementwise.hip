@@ -339,6 +339,31 @@ __global__ __launch_bounds__(EW_THREADS) void upsample_bilinear_add_kernel(const
     }
 }
 
+// Stand-alone bilinear resize, align_corners = True (multi-scale evaluation: operators/rrnet_operator.py:263
+// F.interpolate(img, scale_factor=s, mode='bilinear', align_corners=True)); NHWC, any C.
+__global__ __launch_bounds__(EW_THREADS) void resize_bilinear_ac_kernel(const float *x, float *out, int N, int H, int W, int OH,
+                                                                        int OW, int C)
+{
+    const long total = (long)N * OH * OW * C;
+    const float sy = OH > 1 ? (float)(H - 1) / (float)(OH - 1) : 0.f;
+    const float sx = OW > 1 ? (float)(W - 1) / (float)(OW - 1) : 0.f;
+    for (long i = (long)blockIdx.x * EW_THREADS + threadIdx.x; i < total; i += (long)gridDim.x * EW_THREADS) {
+        const int c = (int)(i % C);
+        long p = i / C;
+        const int w = (int)(p % OW); p /= OW;
+        const int h = (int)(p % OH);
+        const int n = (int)(p / OH);
+        const float fy = sy * h, fx = sx * w;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+        const float ly = fy - y0, lx = fx - x0, hy = 1.f - ly, hx = 1.f - lx;
+        const float *b = x + (long)n * H * W * C + c;
+        const float v00 = b[((long)y0 * W + x0) * C], v01 = b[((long)y0 * W + x1) * C];
+        const float v10 = b[((long)y1 * W + x0) * C], v11 = b[((long)y1 * W + x1) * C];
+        out[i] = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+    }
+}
+
 __global__ __launch_bounds__(EW_THREADS) void upsample_bilinear_bwd_kernel(const float *dout, float *dlow, int N, int H, int W,
                                                                            int LH, int LW, int C)
 {
@@ -622,6 +647,14 @@ extern "C" int rr_upsample_add_bwd(const float *dout, float *dlow, int n, int h,
         EW_LAUNCH(upsample_bilinear_bwd_kernel, tot, stream, dout, dlow, n, h, w, lh, lw, c);
     }
     RR_CHECK_LAUNCH("rr_upsample_add_bwd");
+    return RR_OK;
+}
+
+extern "C" int rr_resize_bilinear_ac(const float *x, float *out, int n, int h, int w, int oh, int ow, int c, hipStream_t stream)
+{
+    RR_CHECK_ARG(n > 0 && h > 0 && w > 0 && oh > 0 && ow > 0 && c > 0, "rr_resize_bilinear_ac: bad dims");
+    EW_LAUNCH(resize_bilinear_ac_kernel, (long)n * oh * ow * c, stream, x, out, n, h, w, oh, ow, c);
+    RR_CHECK_LAUNCH("rr_resize_bilinear_ac");
     return RR_OK;
 }
 

@@ -157,7 +157,7 @@ class RRNetOperator(BaseOperator):
         """Multi-scale inference of rrnet_operator.py:256-276 for one image batch (bs=1) -> boxes [n,6]."""
         multi_scale_bboxes = []
         for scale in self.cfg.Val.scales:
-            img = F.interpolate(imgs, scale_factor=scale, mode='bilinear', align_corners=True)
+            img = ops.resize_bilinear_ac(imgs, scale)
             outs = self.model(img)
             _, pred_bbox = self.generate_bbox(outs)
             if not self.cfg.Val.auto_test:

@@ -305,6 +305,18 @@ def upsample_add_bwd(dout, low_shape):
     return dlow
 
 
+def resize_bilinear_ac(x, scale_factor):
+    """F.interpolate(x, scale_factor=s, mode='bilinear', align_corners=True) on an NHWC tensor."""
+    import math
+    x = to_nhwc(x)
+    n, c, h, w = x.shape
+    oh, ow = int(math.floor(h * scale_factor)), int(math.floor(w * scale_factor))
+    out = empty_nhwc(n, c, oh, ow, x.device)
+    _C.check(_C.fn("rr_resize_bilinear_ac")(_C.ptr(x), _C.ptr(out), n, h, w, oh, ow, c, _C.stream()),
+             "rr_resize_bilinear_ac")
+    return out
+
+
 def avgpool_fwd(x):
     r, c, h, w = x.shape
     out = empty_nhwc(r, c, 1, 1, x.device)

@@ -108,3 +108,79 @@ def test_group_by_class_large_matches_stable_sort():
             for c in range(nc):
                 assert so[i * nc + c] == i * k + int((valid[:, 5] < c).sum())
         assert so[-1] == (b - 1) * k + int((boxes[b - 1, :, 5] < nc).sum())
+
+
+def test_multi_scale_evaluate_images_vs_oracle():
+    """the multi-scale evaluation body (operators/rrnet_operator.py:256-279) — bilinear
+    align_corners rescale (rr_resize_bilinear_ac), full model, generate_bbox, score filter, cross-scale concat + sort,
+    per-class Soft-NMS, sort — against the same composition of the CPU oracle on a tiny RRNet."""
+    import types
+    from types import SimpleNamespace
+    import torch.nn.functional as F
+    from oracle import model as om, nms as onms, ops as oo
+    from rrnet_amd import ops
+    from rrnet_amd.models.rrnet import RRNet
+    from rrnet_amd.operators.rrnet_operator import RRNetOperator
+    from tests.helpers import det_fill
+    cfg = SimpleNamespace(num_classes=10, Model=SimpleNamespace(num_stacks=2, backbone="hourglass_tiny", nms_type_for_stage1="nms",
+                          nms_per_class_for_stage1=True), Train=SimpleNamespace(scale_factor=4),
+                          Val=SimpleNamespace(scales=[1, 1.25, 1.5], auto_test=False))
+    model = RRNet(cfg)
+    sd = det_fill({k: tuple(v.shape) for k, v in model.state_dict().items()}, 80)
+    rng = np.random.default_rng(3)
+    for i in range(2):
+        sd["hm.detect_layer.%d.1.bias" % i].fill_(-2.19)
+        sd["wh.detect_H_layer.%d.0.conv.bias" % i].fill_(3.0)
+        sd["wh.detect_W_layer.%d.0.conv.bias" % i].fill_(3.0)
+    sd["head_detector.regressor.weight"] = sd["head_detector.regressor.weight"] * 0.05   # moderate deltas: exp() stays finite
+    img = torch.from_numpy(rng.normal(0, 1, (1, 3, 256, 256)).astype(np.float32))   # 64x64 map: k=1500 <= H*W as the reference needs
+    # eval-mode BN needs running statistics that match the activations (a 60-layer net with unit running variance
+    # saturates every score to 1.0): one training-mode pass of the oracle with momentum 1 stores the batch statistics
+    om.BN_MOMENTUM = 1.0
+    try:
+        with torch.no_grad():
+            pc = om.Params(sd, training=True)
+            om.stage1(pc, om.hourglass_net(pc, img))
+    finally:
+        om.BN_MOMENTUM = 0.1
+    model.load_state_dict(sd)
+    # the resize kernel alone, odd and even target sizes
+    for s in (1.25, 1.5, 0.7):
+        ref = F.interpolate(img, scale_factor=s, mode='bilinear', align_corners=True)
+        got = ops.resize_bilinear_ac(img.cuda(), s)
+        assert tuple(got.shape) == tuple(ref.shape)
+        np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), atol=1e-4, rtol=1e-4)   # source coordinate rounds differently by an ulp
+    # oracle composition
+    P = om.Params({k: v.clone() for k, v in sd.items()}, training=False)
+    per_scale = []
+    with torch.no_grad():
+        for s in cfg.Val.scales:
+            x = F.interpolate(img, scale_factor=s, mode='bilinear', align_corners=True)
+            outs = om.rrnet_forward(P, x, k=1500)
+            _, pred = oo.generate_bbox(outs, 0, 4)
+            pred = pred[pred[:, 4] > 0.01]
+            pred[:, :4] = pred[:, :4] / s
+            per_scale.append(pred)
+    ref = torch.cat(per_scale)
+    ref = ref[torch.sort(ref[:, 4], descending=True, stable=True)[1]]
+    ref = onms.ext_nms(ref.numpy())
+    ref = ref[np.argsort(-ref[:, 4], kind='stable')]
+    # product
+    ns = SimpleNamespace(cfg=cfg, model=model.cuda().to(memory_format=torch.channels_last).eval())
+    ns.generate_bbox = types.MethodType(RRNetOperator.generate_bbox, ns)
+    ns._ext_nms = RRNetOperator._ext_nms
+    with torch.no_grad():
+        got = RRNetOperator.evaluate_images(ns, img.cuda()).numpy()
+    assert abs(got.shape[0] - ref.shape[0]) <= max(2, ref.shape[0] // 200), (got.shape, ref.shape)
+    # rows are score-ordered on both sides; a rare threshold flip inserts / drops a row and near-equal scores may swap,
+    # so every reference row is looked up in a small window of the product's rows
+    used = np.zeros(got.shape[0], bool)
+    hits = 0
+    for i in range(ref.shape[0]):
+        lo, hi = max(0, i - 40), min(got.shape[0], i + 41)
+        cand = np.where(~used[lo:hi] & (np.abs(got[lo:hi, 4] - ref[i, 4]) < 1e-4) & (got[lo:hi, 5] == ref[i, 5]) &
+                        np.all(np.abs(got[lo:hi, :4] - ref[i, :4]) < 5e-2 + 1e-3 * np.abs(ref[i, :4]), axis=1))[0]
+        if cand.size:
+            used[lo + cand[0]] = True
+            hits += 1
+    assert hits >= 0.98 * ref.shape[0], (hits, ref.shape[0])
