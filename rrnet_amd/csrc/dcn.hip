@@ -97,28 +97,38 @@ __global__ __launch_bounds__(256) void dcn_fprop_kernel(const DcnArgs a)
     float rw[AJ][4];
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 
+    // the sample geometry of a (row, tap) pair is shared by the channel chunks of the tap (K-steps run tap outer,
+    // chunk inner): recomputed only when the tap or the deformable group changes — a wave-uniform branch
+    Tap4 tc[AJ];
+    int tc_tap = -1, tc_g = -1;
     auto issue = [&](int kc) {
         const int tap = kc / cpt, cch = kc - tap * cpt;
         const int i = tap / a.S, jx = tap - i * a.S;
         const int c0 = cch * BK;
         const int g = c0 / cpg;
         const bool c_ok = c0 + a_col < a.C;
+        if (tap != tc_tap || g != tc_g) {
+            tc_tap = tap; tc_g = g;
+#pragma unroll
+            for (int j = 0; j < AJ; ++j) {
+                if (rn[j] >= 0) {
+                    const long m = (long)m0 + a_row + 32 * j;
+                    const float *po = a.offset + m * (2 * a.dg * RS) + g * 2 * RS + 2 * tap;
+                    const float mk = a.mask[m * (a.dg * RS) + g * RS + tap];
+                    tc[j] = make_tap(a, rn[j], rp[j], rq[j], i, jx, po[0], po[1], mk);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { tc[j].o[e] = -1; tc[j].w[e] = 0.f; }
+                }
+            }
+        }
 #pragma unroll
         for (int j = 0; j < AJ; ++j) {
-            if (rn[j] >= 0 && c_ok) {
-                const long m = (long)m0 + a_row + 32 * j;
-                const float *po = a.offset + m * (2 * a.dg * RS) + g * 2 * RS + 2 * tap;
-                const float mk = a.mask[m * (a.dg * RS) + g * RS + tap];
-                const Tap4 tp = make_tap(a, rn[j], rp[j], rq[j], i, jx, po[0], po[1], mk);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float *src = tp.o[e] >= 0 ? a.x + tp.o[e] + c0 + a_col : a.zero;
-                    rv[j][e] = *reinterpret_cast<const f32x4 *>(src);
-                    rw[j][e] = tp.w[e];
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { rv[j][e] = zero; rw[j][e] = 0.f; }
+            for (int e = 0; e < 4; ++e) {
+                const float *src = (tc[j].o[e] >= 0 && c_ok) ? a.x + tc[j].o[e] + c0 + a_col : a.zero;
+                rv[j][e] = *reinterpret_cast<const f32x4 *>(src);
+                rw[j][e] = tc[j].w[e];
             }
         }
 #pragma unroll
@@ -251,28 +261,38 @@ __global__ __launch_bounds__(256) void dcn_fprop_bf16_kernel(const DcnArgs a)
     float rw[AJ][4];
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 
+    // the sample geometry of a (row, tap) pair is shared by the channel chunks of the tap (K-steps run tap outer,
+    // chunk inner): recomputed only when the tap or the deformable group changes — a wave-uniform branch
+    Tap4 tc[AJ];
+    int tc_tap = -1, tc_g = -1;
     auto issue = [&](int kc) {
         const int tap = kc / cpt, cch = kc - tap * cpt;
         const int i = tap / a.S, jx = tap - i * a.S;
         const int c0 = cch * BK;
         const int g = c0 / cpg;
         const bool c_ok = c0 + a_col < a.C;
+        if (tap != tc_tap || g != tc_g) {
+            tc_tap = tap; tc_g = g;
+#pragma unroll
+            for (int j = 0; j < AJ; ++j) {
+                if (rn[j] >= 0) {
+                    const long m = (long)m0 + a_row + 32 * j;
+                    const float *po = a.offset + m * (2 * a.dg * RS) + g * 2 * RS + 2 * tap;
+                    const float mk = a.mask[m * (a.dg * RS) + g * RS + tap];
+                    tc[j] = make_tap(a, rn[j], rp[j], rq[j], i, jx, po[0], po[1], mk);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { tc[j].o[e] = -1; tc[j].w[e] = 0.f; }
+                }
+            }
+        }
 #pragma unroll
         for (int j = 0; j < AJ; ++j) {
-            if (rn[j] >= 0 && c_ok) {
-                const long m = (long)m0 + a_row + 32 * j;
-                const float *po = a.offset + m * (2 * a.dg * RS) + g * 2 * RS + 2 * tap;
-                const float mk = a.mask[m * (a.dg * RS) + g * RS + tap];
-                const Tap4 tp = make_tap(a, rn[j], rp[j], rq[j], i, jx, po[0], po[1], mk);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float *src = tp.o[e] >= 0 ? a.x + tp.o[e] + c0 + a_col : a.zero;
-                    rv[j][e] = *reinterpret_cast<const f32x4 *>(src);
-                    rw[j][e] = tp.w[e];
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { rv[j][e] = zero; rw[j][e] = 0.f; }
+            for (int e = 0; e < 4; ++e) {
+                const float *src = (tc[j].o[e] >= 0 && c_ok) ? a.x + tc[j].o[e] + c0 + a_col : a.zero;
+                rv[j][e] = *reinterpret_cast<const f32x4 *>(src);
+                rw[j][e] = tc[j].w[e];
             }
         }
 #pragma unroll
