@@ -12,6 +12,8 @@ their OHWI physical layout), so that
 `module.state_dict()` / `load_state_dict()` keep working: parameters stay nn.Parameters whose
 `.data` are views into the flat buffer.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -19,7 +21,15 @@ from rrnet_amd import ops
 
 
 class FlatParams:
-    def __init__(self, module):
+    """One flat fp32 buffer for the parameters and one for the gradients.  Data-parallel exchange: the gradient
+    buffer is cut into buckets (contiguous parameter ranges); the backward kernels report every parameter whose
+    gradient is complete (`mark_ready`, called by the autograd nodes of rrnet_amd.functional right after their
+    wgrad / bias / BN-affine kernels), and a bucket's all-reduce is launched — asynchronously, on RCCL's stream — the
+    moment its last parameter reports, i.e. while backward is still running on the earlier layers.
+    `all_reduce_grads` (called from the optimizer step) launches whatever is left — buckets holding one of the few
+    parameters whose gradient autograd accumulates itself (the WH head's 17-tap weights) — and waits."""
+
+    def __init__(self, module, bucket_elems=16 * 1024 * 1024):
         params = [p for p in module.parameters() if p.requires_grad]
         assert params, "no trainable parameters"
         dev = params[0].device      # HBM in production; CPU tensors are accepted so that the data-parallel
@@ -45,8 +55,57 @@ class FlatParams:
             p.data = view
             p.grad = gview
             p._rr_grad = gview
+            p._rr_flat = self
+        # buckets: consecutive parameters, closed once they hold >= bucket_elems elements
+        self._bucket_of, self._bucket_range, self._bucket_need = {}, [], []
+        start, need = 0, 0
+        for i, (p, o) in enumerate(zip(params, offs)):
+            self._bucket_of[id(p)] = len(self._bucket_range)
+            need += 1
+            end = offs[i + 1] if i + 1 < len(params) else total
+            if end - start >= bucket_elems or i + 1 == len(params):
+                self._bucket_range.append((start, end))
+                self._bucket_need.append(need)
+                start, need = end, 0
+        self.overlap = os.environ.get("RR_DP_OVERLAP", "1") != "0"
+        self._pg = None
+        self._begin_step()
+
+    def _begin_step(self):
+        nb = len(self._bucket_range)
+        self._ready = [0] * nb
+        self._works = [None] * nb
+        self._marked = set()
+
+    def _distributed(self):
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+    def _group(self):
+        """Own communicator (= own RCCL stream) for the gradient buckets: on the default one a 64 MB bucket would sit in
+        front of the next SyncBN statistics all-reduce and stall the compute stream for its whole duration.  Created at
+        the first use; every rank gets here at the same point of the program."""
+        if self._pg is None:
+            self._pg = dist.new_group()
+        return self._pg
+
+    def mark_ready(self, p):
+        """The gradient of `p` is complete for this step (every kernel that adds into it has been enqueued)."""
+        if not self.overlap or not self._distributed():
+            return
+        key = id(p)
+        if key in self._marked:
+            raise RuntimeError("FlatParams.mark_ready: parameter #%d %s reported its gradient twice in one step "
+                               "(shared weights need RR_DP_OVERLAP=0)"
+                               % ([id(q) for q in self.params].index(key), tuple(p.shape)))
+        self._marked.add(key)
+        b = self._bucket_of[key]
+        self._ready[b] += 1
+        if self._ready[b] == self._bucket_need[b] and self._works[b] is None:
+            o0, o1 = self._bucket_range[b]
+            self._works[b] = dist.all_reduce(self.grad[o0:o1], group=self._group(), async_op=True)
 
     def zero_grad(self):
+        self._begin_step()
         self.grad.zero_()
         for p in self.params:        # keep .grad pointing at the flat views (set_to_none would drop them)
             if p.grad is None or p.grad.data_ptr() != p._rr_grad.data_ptr():
@@ -56,17 +115,19 @@ class FlatParams:
         """Initial parameter broadcast (C2 in SURVEY §2.2): one collective."""
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             dist.broadcast(self.flat, src)
+            self._group()          # the buckets' communicator is set up here, on the main thread, before any backward
 
     def all_reduce_grads(self, chunk_elems=64 * 1024 * 1024):
         """Sum-all-reduce of the flat gradient in a few large slices (C3).  Returns the factor the
         optimizer must scale the gradient with (DDP averages)."""
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        if not self._distributed():
             return 1.0
-        works = []
-        for o in range(0, self.numel, chunk_elems):
-            works.append(dist.all_reduce(self.grad[o:o + chunk_elems], async_op=True))
-        for w in works:
+        for b, (o0, o1) in enumerate(self._bucket_range):      # buckets that were not complete during backward
+            if self._works[b] is None:
+                self._works[b] = dist.all_reduce(self.grad[o0:o1], group=self._group(), async_op=True)
+        for w in self._works:
             w.wait()
+        self._works = [None] * len(self._bucket_range)
         return 1.0 / dist.get_world_size()
 
 

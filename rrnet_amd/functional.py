@@ -22,6 +22,14 @@ def _grad_target(p):
     return getattr(p, "_rr_grad", None)
 
 
+def _mark(*params):
+    """Report finished parameter gradients to the flat buffer's data-parallel bucketing (rrnet_amd.flat)."""
+    for p in params:
+        flat = getattr(p, "_rr_flat", None)
+        if flat is not None and p is not None:
+            flat.mark_ready(p)
+
+
 def _is_sync(bn):
     return isinstance(bn, torch.nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized() \
         and dist.get_world_size() > 1
@@ -119,10 +127,13 @@ class _ConvBnAct(torch.autograd.Function):
         wg = (lambda tgt: ops.stem_wgrad_s2d(x, dy, tgt)) if stem else (lambda tgt: ops.conv_wgrad(x, dy, tgt, stride, pad))
         if w_t is not None:
             wg(w_t)
+            _mark(w)
         else:
             dw = ops.zeros_nhwc(*w.shape, device=x.device)
             wg(dw)
             ret_dw = dw
+        if dg_t is not None and db_t is not None:
+            _mark(gamma_p, beta_p)
         dres = None
         if has_res and ctx.needs_input_grad[4]:
             dres = g if relu else dz
@@ -174,6 +185,8 @@ class _ConvBias(torch.autograd.Function):
             tgt = b_t if b_t is not None else torch.zeros_like(b)
             dy = ops.bias_relu_bwd(dy, y if relu else None, tgt)
             ret_db = None if b_t is not None else tgt
+            if b_t is not None:
+                _mark(b)
         elif relu:
             dy = ops.sum_n([dy], y)
         dx = None
@@ -189,6 +202,7 @@ class _ConvBias(torch.autograd.Function):
         ret_dw = None
         if w_t is not None:
             ops.conv_wgrad(x, dy, w_t, stride, pad)
+            _mark(w)
         else:
             dw = ops.zeros_nhwc(*w.shape, device=x.device)
             ops.conv_wgrad(x, dy, dw, stride, pad)
@@ -228,6 +242,7 @@ class _WHShiftSum(torch.autograd.Function):
             tw.add_(dbw)
             th.add_(dbh)
             dbw = dbh = None
+            _mark(bias_w, bias_h)
         return ops.wh_shift_sum_bwd(dout, ctx.k, ctx.ct), dbw, dbh, None
 
 
@@ -498,6 +513,8 @@ class _DCNv2(torch.autograd.Function):
         dw = w_t if w_t is not None else ops.zeros_nhwc(*weight.shape, device=x.device)
         dw1 = dw.permute(0, 2, 3, 1).reshape(k, 1, 1, r * s * c).permute(0, 3, 1, 2)
         ops.conv_wgrad(col, dy1, dw1, 1, (0, 0))
+        if w_t is not None:
+            _mark(weight)
         del col
         # column gradient, then d input / d offset / d mask
         dcol = ops.conv_dgrad(dy1, w1, (1, r * s * c, mtot, 1), 1, (0, 0))
@@ -508,6 +525,8 @@ class _DCNv2(torch.autograd.Function):
             tgt = b_t if b_t is not None else torch.zeros_like(bias)
             ops.bias_relu_bwd(dy, None, tgt)
             db = None if b_t is not None else tgt
+            if b_t is not None:
+                _mark(bias)
         return dx, doff, dmask, (None if w_t is not None else dw), db, None, None, None, None, None
 
 

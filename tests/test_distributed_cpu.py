@@ -98,3 +98,68 @@ def test_flat_params_views_and_state_dict_cpu():
     assert float(fp.grad.abs().sum()) == 0.0
     net.load_state_dict({k: v + 1 if v.is_floating_point() else v for k, v in sd0.items()})
     assert torch.equal(net[0].weight, sd0["0.weight"] + 1)
+
+
+def _overlap_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from rrnet_amd.flat import FlatParams
+        torch.manual_seed(5)
+        net = nn.Sequential(nn.Conv2d(3, 8, 3, bias=False), nn.BatchNorm2d(8), nn.Conv2d(8, 16, 3), nn.BatchNorm2d(16),
+                            nn.Conv2d(16, 4, 1)).to(memory_format=torch.channels_last)
+        fp = FlatParams(net, bucket_elems=64)              # several buckets
+        params = list(net.parameters())
+        nb = len(fp._bucket_range)
+        out = {"nb": nb}
+        for trial, skip_last in (("all", False), ("partial", True)):
+            fp.zero_grad()
+            for i, p in enumerate(params):
+                p.grad.copy_(torch.full_like(p, float((rank + 1) * (i + 1))))
+            launched = []
+            order = list(reversed(params))                 # backward order
+            if skip_last:
+                order = order[:-2]                         # two parameters never report: the final flush covers them
+            for p in order:
+                fp.mark_ready(p)
+                launched.append(sum(w is not None for w in fp._works))
+            scale = fp.all_reduce_grads()
+            ok = all(torch.allclose(p.grad * scale, torch.full_like(p, 1.5 * (i + 1))) for i, p in enumerate(params))
+            out[trial] = (ok, launched)
+        fp.zero_grad()
+        fp.mark_ready(params[0])
+        try:
+            fp.mark_ready(params[0])
+            out["double"] = False
+        except RuntimeError:
+            out["double"] = True
+        fp.all_reduce_grads()
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bucketed_overlap_bookkeeping_gloo():
+    """FlatParams.mark_ready: buckets are all-reduced as soon as their last parameter reports (backward order),
+    unreported parameters are covered by the final flush, a double report is an error; result = plain all-reduce."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_overlap_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(2):
+        out = res[r]
+        assert out["nb"] >= 3
+        ok, launched = out["all"]
+        assert ok and launched[-1] == out["nb"] and launched[0] <= 1 and launched == sorted(launched)
+        assert any(a < b for a, b in zip(launched, launched[1:]))          # launched progressively, not at the end
+        ok, launched = out["partial"]
+        assert ok and launched[-1] < out["nb"]
+        assert out["double"]

@@ -51,12 +51,15 @@ def _worker(rank, world, port, out):
         from rrnet_amd.flat import FlatAdam, FlatParams
         model = _build().cuda().to(memory_format=torch.channels_last)
         model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model).train()
-        fp = FlatParams(model)
+        fp = FlatParams(model, bucket_elems=4096)      # many buckets: their all-reduces start during backward
         fp.broadcast(0)
         opt = FlatAdam(fp, lr=1e-3)
         x = _data()[rank * 2:(rank + 1) * 2].cuda()
         opt.zero_grad()
         _loss(model, x).backward()
+        launched = sum(w is not None for w in fp._works)
+        # all but the buckets holding an autograd-accumulated parameter (the WH head tap weights) start during backward
+        assert len(fp._bucket_range) > 4 and launched >= len(fp._bucket_range) - 3, (launched, len(fp._bucket_range))
         scale = fp.all_reduce_grads()
         g = (fp.grad * scale).cpu().numpy()
         rm = model.backbone.pre_layer[1].running_mean.cpu().numpy()
