@@ -69,3 +69,28 @@ def test_fused_adam_matches_torch_adam():
         ref_opt.step()
     for rp, p in zip(ref_p, m.parameters()):
         np.testing.assert_allclose(p.detach().cpu().numpy(), rp.detach().numpy(), atol=2e-6, rtol=1e-5)
+
+
+def test_rrnet_tiny_overfits_one_batch():
+    """The whole training loop end to end (operators/rrnet_operator.py:104-186: forward, the four losses, backward,
+    fused Adam, lr schedule, BN statistics) on one fixed synthetic batch: the loss must fall steadily.  A
+    sign / scaling error anywhere in the backward kernels shows up here even when it hides inside a tolerance."""
+    from rrnet_amd.configs.rrnet_config import Config as cfg
+    from rrnet_amd.operators.rrnet_operator import RRNetOperator
+    cfg.Train.batch_size = 2
+    cfg.Train.crop_size = (256, 256)
+    cfg.Model.backbone = "hourglass_tiny"
+    cfg.Distributed.gpu_id, cfg.Distributed.rank, cfg.Distributed.world_size = 0, 0, 1
+    torch.manual_seed(219)
+    op = RRNetOperator(cfg)
+    op.model.train()
+    b = op.training_loader.get_batch()
+    hist = []
+    for step in range(60):
+        _, losses = op.train_step(step, (b[0], b[1].clone()) + tuple(b[2:]))
+        hist.append([float(v.detach()) for v in losses])
+    hist = np.array(hist)
+    assert np.isfinite(hist).all()
+    first, last = hist[:5, 0].mean(), hist[-5:, 0].mean()
+    assert last < 0.6 * first, (first, last)
+    assert hist[-5:, 1].mean() < hist[:5, 1].mean()            # the heat-map focal loss itself goes down
