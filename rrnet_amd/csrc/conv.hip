@@ -377,7 +377,8 @@ __global__ __launch_bounds__(256, PIPE == 3 ? 3 : 1) void conv_igemm_kernel(cons
         __syncthreads();
     }
     } else {
-    static_assert(PIPE == 0 || (BKT == 32 && !SCALAR && BN == 128), "pipelined loop: 4 groups of 8 per K-step, vector gather, 128x128 tile");
+    static_assert(PIPE == 0 || (BKT == 32 && !SCALAR && (BN == 128 || BN == 64)),
+                  "pipelined loop: 4 groups of 8 per K-step, vector gather, 128x128 or 128x64 tile");
     // Each K-step = 4 groups x 4 sub-groups of 4 MFMAs.  Memory instructions are dealt out between the
     // sub-groups (never clustered): a VMEM / DS issue that would stall this wave's in-order stream then
     // overlaps the 64-cycle MFMAs already in the pipe (probe: clustered ds_write+barrier costs 5 %,
@@ -462,6 +463,7 @@ __global__ __launch_bounds__(256, PIPE == 3 ? 3 : 1) void conv_igemm_kernel(cons
         ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_src, off, 0, 0));
     };
     auto load_b = [&](int j) {
+        if (j >= BJ) return;           // 128x64 tile: two weight float4 per thread (j is a literal at every call site)
         const unsigned ok = (B_KN ? ((unsigned)b_ok[j] & (unsigned)(p_c0 + t / TPR + KRPP * j < a.wK))
                                   : ((unsigned)b_ok[j] & (unsigned)p_wcok)) & (unsigned)p_live;
         const unsigned off = ok ? (unsigned)(b_boff[j] + p_wdelta) : OOB;
@@ -471,10 +473,11 @@ __global__ __launch_bounds__(256, PIPE == 3 ? 3 : 1) void conv_igemm_kernel(cons
         *reinterpret_cast<f32x4 *>(As + buf * A_ELEMS + (a_row + RPP * j) * LDK + a_col) = ra[j];
     };
     auto store_b = [&](int j, int buf) {
+        if (j >= BJ) return;
         if (!B_KN) *reinterpret_cast<f32x4 *>(Bs + buf * B_ELEMS + (a_row + RPP * j) * LDK + a_col) = rb[j];
         else *reinterpret_cast<f32x4 *>(Bs + buf * B_ELEMS + (t / TPR + KRPP * j) * LDB + (t % TPR) * 4) = rb[j];
     };
-    static_assert(PIPE == 0 || (AJ == 4 && BJ == 4), "piece schedule below assumes 4 + 4 float4 per thread");
+    static_assert(PIPE == 0 || (AJ == 4 && (BJ == 4 || BJ == 2)), "piece schedule below: 4 + (4 | 2) float4 per thread");
     if constexpr (PIPE == 3) {
     // LDS-DMA staging (buffer_load_dwordx4 ... lds): no staging registers, no ds_write; one unpadded, XOR-swizzled LDS
     // image.  Per K-step: after the last fragment reads of tile kc everybody waits (1), each wave fires its 8 DMA
@@ -1094,6 +1097,16 @@ int wgrad_aligned()
     return v;
 }
 
+int mid_tiles()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("RR_CONV_MID_TILES");
+        v = e ? atoi(e) : 48;      // <= 48 tiles of 128x128 (the 16x16 level): 128x64 tiles; measured worse at 192 (32x32)
+    }
+    return v;
+}
+
 int small_tiles()
 {
     static int v = -1;
@@ -1196,7 +1209,8 @@ int launch_igemm(ConvArgs &a, int bn, bool scalar, int blocks, int gy, int gz, h
             if (conv_pipe() >= 2 && small) return IG(128, false, 32, 2);
             return conv_pipe() && small ? IG(128, false, 32, 1) : IG(128, false, 32, 0);
         }
-        if (bn == 64) return IG(64, false, 32, 0);   // 4 waves along M, 32x64 each: 33..64-column layers
+        if (bn == 64)     // 4 waves along M, 32x64 each: 33..64-column layers and under-filled 384-column levels
+            return conv_pipe() >= 2 && small ? IG(64, false, 32, 2) : IG(64, false, 32, 0);
         return scalar ? IG(32, true, 32, 0) : IG(32, false, 32, 0);
     }
     if (bn == 128) return scalar ? IG(128, true, 16, 0) : IG(128, false, 16, 0);
@@ -1231,6 +1245,7 @@ static int fprop_impl(const float *x, const float *w, const float *bias, float *
     const int bk = conv_bk();
     int bn = k > 64 ? 128 : (k > 32 ? (!scalar && bk == 32 ? 64 : 128) : 32);
     if (bn == 128 && !scalar && rr_cdiv(M, BM) * rr_cdiv(k, 128) <= small_tiles()) bn = 32;   // tiny layers: 4x the tiles
+    else if (bn == 128 && !scalar && bk == 32 && rr_cdiv(M, BM) * rr_cdiv(k, 128) <= mid_tiles()) bn = 64;
     const int blocks = rr_cdiv(M, BM) * rr_cdiv(k, bn);
     const int nk = scalar ? rr_cdiv(a.Kg, bk) : rr_cdiv(c, bk) * r * s;
     int ks = (bias == nullptr && !relu && k % 4 == 0 && k <= 1024) ? pick_ksplit(blocks, nk) : 1;
@@ -1314,6 +1329,7 @@ extern "C" int rr_conv_dgrad(const float *dy, const float *w, float *dx, int n, 
     const int bk = conv_bk();
     int bn = c > 64 ? 128 : (c > 32 ? (!scalar && bk == 32 ? 64 : 128) : 32);
     if (bn == 128 && !scalar && stride == 1 && rr_cdiv(M, BM) * rr_cdiv(c, 128) <= small_tiles()) bn = 32;
+    else if (bn == 128 && !scalar && bk == 32 && stride == 1 && rr_cdiv(M, BM) * rr_cdiv(c, 128) <= mid_tiles()) bn = 64;
     int blocks = rr_cdiv(M, BM) * rr_cdiv(c, bn);
     int gy = 1;
     int nk = scalar ? rr_cdiv(a.Kg, bk) : rr_cdiv(k, bk) * r * s;

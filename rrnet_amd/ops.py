@@ -63,6 +63,7 @@ def _timed(name, flops, fn, detail=None, nbytes=0.0):
 
 
 _SMALL_TILES = int(os.environ.get("RR_CONV_SMALL_TILES", "16"))
+_MID_TILES = int(os.environ.get("RR_CONV_MID_TILES", "48"))
 
 
 def _igemm_name(kind, n_gemm, scalar, m_rows=1 << 30, stride=1):
@@ -70,8 +71,11 @@ def _igemm_name(kind, n_gemm, scalar, m_rows=1 << 30, stride=1):
     33..64-column layers, 32 for narrow ones and for layers with at most RR_CONV_SMALL_TILES 128x128 tiles)."""
     bn = 128 if n_gemm > 64 or (scalar and n_gemm > 32) else (64 if n_gemm > 32 else 32)
     if bn == 128 and not scalar and (kind == "fprop" or stride == 1):
-        if -(-m_rows // 128) * -(-n_gemm // 128) <= _SMALL_TILES:
+        tiles = -(-m_rows // 128) * -(-n_gemm // 128)
+        if tiles <= _SMALL_TILES:
             bn = 32
+        elif tiles <= _MID_TILES:
+            bn = 64
     return "conv_%s<BN=%d,%s>" % (kind, bn, "scalar" if scalar else "vec4")
 
 
