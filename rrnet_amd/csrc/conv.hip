@@ -1136,6 +1136,14 @@ int pick_ksplit(int blocks, int nk)
         enabled = (e && atoi(e) == 0) ? 0 : 1;
     }
     if (!enabled || blocks >= 256 || nk < 16) return 1;   // a full first wave of tiles: splitting costs more than it balances
+    {
+        static int force = -1;
+        if (force < 0) {
+            const char *e = getenv("RR_CONV_FORCE_KS");
+            force = e ? atoi(e) : 0;
+        }
+        if (force > 0) return force <= nk / 4 ? force : 1;
+    }
     // Occupancy model: 256 CUs, two workgroups resident per CU.  A pair shares the MFMA pipes at ~0.87 of peak, a
     // lone workgroup reaches ~0.75 (nobody fills its issue gaps); every workgroup pays ~3 K-steps of prologue +
     // epilogue.  The busiest CU holds ceil(total / 256) workgroups; pick the split with the shortest makespan.
