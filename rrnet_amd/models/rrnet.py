@@ -79,13 +79,8 @@ class RRNet(nn.Module):
         return hms, whs, offsets, stage2_reg, bxyxys, scores, clses
 
     def forward_stage1(self, feats):
-        hms, whs, offsets = [], [], []
-        for i in range(self.num_stacks):
-            fa, fb, fc, _ = RF.fanout_shared(RF.relu(feats[i]), 3)   # three 3x3 head convs: one gradient buffer
-            hms.append(self.hm(fa, i))
-            whs.append(self.wh(fb, i))
-            offsets.append(self.offset_reg(fc, i))
-        return hms, whs, offsets
+        from rrnet_amd.models.centernet import run_stage1_heads
+        return run_stage1_heads(feats, (self.hm, self.wh, self.offset_reg), self.num_stacks)
 
     def forward_stage2(self, feats):
         return self.head_detector(feats)
