@@ -48,6 +48,13 @@ def test_wrapper_reference_contract():
     assert res.shape == (5, 5)
     assert a[0, 4] == np.float32(0.7) and abs(float(a[4, 4]) - 0.030986) < 1e-6
     assert soft_nms(np.zeros((0, 5), np.float32)).shape == (0, 5)
+    # error behaviour of the Cython routine (cdivision=False): sigma == 0 with the gaussian method divides by zero
+    b = np.array([[0, 0, 10, 10, 0.9], [0, 0, 10, 10, 0.8]], dtype=np.float32)
+    with pytest.raises(ZeroDivisionError):
+        soft_nms(b, sigma=0.0, method=2)
+    # degenerate (negative-extent) boxes never overlap under the +1 convention: both survive, no error
+    c = np.array([[0, 0, -1, -1, 0.9], [0, 0, -1, -1, 0.8]], dtype=np.float32)
+    assert soft_nms(c, method=2).shape == (2, 5)
 
 
 @pytest.mark.parametrize("method,Nt,thr", [(2, 0.7, 0.1), (1, 0.3, 0.001), (0, 0.3, 0.001)])
