@@ -26,3 +26,23 @@ for bf in (False, True):
     torch.cuda.synchronize()
     ms = s.elapsed_time(e) / 5
     print("dcn fwd %s operands: %.3f ms  %.1f TFLOP/s" % ("bf16" if bf else "fp32", ms, flops / ms / 1e9))
+
+# backward (fp32): columns materialised + conv GEMM kernels + col2im, as assembled by rrnet_amd.functional._DCNv2
+from rrnet_amd.functional import dcn_v2_conv  # noqa: E402
+xg = x.clone().requires_grad_()
+og = off.clone().requires_grad_()
+mg = mask.clone().requires_grad_()
+wg = wt.clone().requires_grad_()
+y = dcn_v2_conv(xg, og, mg, wg, None, 1, 1, 1, 1)
+gy = torch.randn_like(y)
+y.backward(gy)
+torch.cuda.synchronize()
+for t in (xg, og, mg, wg):
+    t.grad = None
+s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+y = dcn_v2_conv(xg, og, mg, wg, None, 1, 1, 1, 1)
+s.record()
+y.backward(gy)
+e.record()
+torch.cuda.synchronize()
+print("dcn bwd fp32 (im2col + wgrad + dgrad + col2im): %.2f ms" % s.elapsed_time(e))
