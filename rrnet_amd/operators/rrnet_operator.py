@@ -87,7 +87,7 @@ class RRNetOperator(BaseOperator):
         for step in range(self.cfg.Train.iter_num):
             batch = self.training_loader.get_batch()
             outs, losses = self.train_step(step, batch)
-            totals += np.array([float(l) for l in losses])
+            totals += np.array([float(l.detach()) for l in losses])
             pi = self.cfg.Train.print_interval
             if self.main_proc_flag:
                 if step % pi == pi - 1:
