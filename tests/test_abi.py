@@ -66,3 +66,29 @@ def test_cpu_tensors_are_refused():
     from rrnet_amd import _C
     with pytest.raises(_C.RRNetHipError):
         _C.require_cuda(torch.zeros(3))
+
+
+def test_reference_script_imports_resolve_through_aliases():
+    """The import lines of the reference's scripts/RRNet/train.py and eval.py (configs.rrnet_config.Config,
+    operators.distributed_wrapper.DistributedWrapper, operators.rrnet_operator.RRNetOperator,
+    utils.metrics.metrics.evaluate_results, ext.nms.nms_wrapper.soft_nms, models.rrnet.RRNet) resolve to this
+    package after rrnet_amd.install_aliases() — run in a fresh interpreter, no GPU needed for importing."""
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import rrnet_amd; rrnet_amd.install_aliases()\n"
+        "from configs.rrnet_config import Config\n"
+        "from operators.distributed_wrapper import DistributedWrapper\n"
+        "from operators.rrnet_operator import RRNetOperator\n"
+        "from utils.metrics.metrics import evaluate_results, auto_evaluate_results\n"
+        "from ext.nms.nms_wrapper import soft_nms, nms\n"
+        "from models.rrnet import RRNet\n"
+        "from backbones.hourglass import hourglass_net\n"
+        "from detectors.fasterrcnn_detector import FasterRCNNDetector\n"
+        "from modules.loss.focalloss import FocalLossHM\n"
+        "w = DistributedWrapper(Config, RRNetOperator)\n"
+        "import inspect, os\n"
+        "assert os.sep + 'rrnet_amd' + os.sep in inspect.getfile(RRNetOperator) and Config.Model.backbone == 'hourglass'\n"
+        "assert Config.Val.scales == [1, 1.1, 1.2, 1.3, 1.4, 1.5] and Config.Train.lr == 2.5e-4\n"
+        "print('ok')\n" % ROOT)
+    out = subprocess.check_output(["python", "-c", code], text=True, cwd=ROOT, timeout=300)
+    assert out.strip().endswith("ok")
