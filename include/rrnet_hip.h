@@ -187,8 +187,13 @@ int rr_stage2_loss(const float *rois, const float *reg, int r, const float *gt, 
  *   out [b,k,6] = x1,y1,x2,y2,score,cls in feature coordinates, score-descending, ties by the
  *   reference's flat index; pix_out (optional) [b,k] = y*w+x of every row.  rr_roi_provenance maps
  *   packed RoIs back to that pixel; rr_proposal_bwd is the backward of the box assembly (d wh, d off maps
- *   from d roi).  k <= min(4096, c*h*w).  No 3x3 peak filter (the reference never
- *   applies one); rr_peak3x3 provides operators/centernet_operator.py:204-210 as an option.
+ *   from d roi).  k <= min(4096, c*h*w).  peak_filter=1 applies operators/centernet_operator.py:204-210
+ *   (`_ctnet_nms`: keep a score only where it equals its 3x3 window maximum, dead code in the reference, named by
+ *   north_star) INSIDE the scan: only the candidates above the sampled threshold are tested, no extra pass over
+ *   the map; rr_peak3x3 writes the filtered score map itself.  workspace (optional, rr_decode_workspace_bytes(b)
+ *   bytes of device memory): with it, maps of >= 64 K elements are scanned by all CUs (threshold kernel -> streaming
+ *   candidate scan -> one workgroup per frame for sort + box assembly); without it one workgroup per frame does
+ *   everything.  Both give identical rows.
  * rr_group_by_class: stable regrouping of each image's k rows by class (classes ascending =
  *   torch.unique order of models/rrnet.py:59); seg_off [b*num_classes+1] row offsets.  Rows whose class lies
  *   outside [cls_base, cls_base+num_classes) are dropped and leave a gap at the end of the image's k-row block:
@@ -197,8 +202,10 @@ int rr_stage2_loss(const float *rois, const float *reg, int r, const float *gt, 
  *   segment score-descending, 6 floats per row; kept rows are compacted to the segment front.
  * rr_pack_segments: phase 0 -> out_off [nseg+1] exclusive prefix of n_out (out_off[nseg] = R);
  *   phase 1 -> rois [R,5], scores [R], clses [R] (models/rrnet.py:37-49) and/or rows6 [R,6]. */
-int rr_decode_topk(const float *hm, int is_logits, const float *wh, const float *off, int b, int h, int w,
-                   int c, int k, float *out, int *pix_out, hipStream_t stream);
+size_t rr_decode_workspace_bytes(int b);
+int rr_decode_topk(const float *hm, int is_logits, int peak_filter, const float *wh, const float *off, int b,
+                   int h, int w, int c, int k, float *out, int *pix_out, void *workspace, size_t workspace_bytes,
+                   hipStream_t stream);
 int rr_roi_provenance(const float *rois, const float *scores, const float *clses, int r, const float *decoded,
                       const int *pix, int k, int *roi_pix, hipStream_t stream);
 int rr_proposal_bwd(const float *droi, const float *rois, const int *roi_pix, int r, const float *wh, int b, int h,

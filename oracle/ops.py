@@ -169,7 +169,8 @@ def roi_align(feat, rois, output_size, spatial_scale=1.0, sampling_ratio=-1):
     as called at models/rrnet.py:51: spatial_scale 1, sampling_ratio -1 (adaptive
     ceil(roi_size/bins) samples per bin), RoI width/height clamped to >= 1, legacy
     (aligned=False) coordinates.  Differentiable w.r.t. `feat` (sparse-matrix formulation:
-    out[r] = S_r @ feat[b_r] with the bilinear weights in S_r), fp32 throughout."""
+    out[r] = S_r @ feat[b_r] with the bilinear weights in S_r), sample positions and weights in fp32 arithmetic
+    (an fp64 `feat` only widens the final weighted sum: used for the tests' fp64 'truth' runs)."""
     ph, pw = output_size
     n, c, height, width = feat.shape
     rois_np = rois.detach().cpu().numpy().astype(np.float32)
@@ -206,7 +207,7 @@ def roi_align(feat, rois, output_size, spatial_scale=1.0, sampling_ratio=-1):
     if k == 0:
         return feat.new_zeros((0, c, ph, pw))
     S = torch.sparse_coo_tensor(torch.tensor([rows, cols], dtype=torch.long),
-                                torch.tensor(np.array(vals, dtype=np.float32)),
+                                torch.tensor(np.array(vals, dtype=np.float32)).to(feat.dtype),
                                 (k * ph * pw, n * height * width)).coalesce()
     flat = feat.permute(0, 2, 3, 1).reshape(n * height * width, c)
     out = torch.sparse.mm(S, flat)                      # [k*ph*pw, c]

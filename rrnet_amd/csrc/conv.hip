@@ -881,7 +881,14 @@ __global__ __launch_bounds__(256, PIPE == 3 ? 3 : 1) void conv_wgrad_kernel(cons
         return __builtin_amdgcn_make_buffer_rsrc(q, 0, __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
     };
     const __amdgpu_buffer_rsrc_t rs_dy = make_srd(a.dy, (long)a.M * a.K * 4);
-    const __amdgpu_buffer_rsrc_t rs_x = make_srd(a.x, (long)a.N * a.H * a.W * a.C * 4);
+    // Uniform row walk (ALIGNED): the descriptor of x starts pad_w pixels BEFORE the tensor, so that the per-lane
+    // offset (lq*stride + s) * C is never negative.  A negative (wrapped) lane offset is out of range for the
+    // hardware's bounds check even when the scalar offset brings the address back inside the tensor — the left-most
+    // tap column then silently lost the pixel in front of every K-step that does not start a row (Q > 32).  Lanes
+    // whose pixel really lies outside the row are masked by the iw test below and never dereference the shifted base.
+    const long x_shift = ALIGNED ? (long)a.pad_w * a.C * 4 : 0;
+    const __amdgpu_buffer_rsrc_t rs_x = make_srd(reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.x) - x_shift),
+                                                 (long)a.N * a.H * a.W * a.C * 4 + x_shift);
     constexpr unsigned OOB = 0xFFFFFFF0u;
     // A rows: byte offset of row j at K-step 0 of this split is a_off[j]; every K-step adds BK*K*4 (scalar)
     int a_off[AJ], a_m[AJ];
@@ -909,8 +916,8 @@ __global__ __launch_bounds__(256, PIPE == 3 ? 3 : 1) void conv_wgrad_kernel(cons
         for (int j = 0; j < BJ; ++j) {
             const int lq = b_row + RPP_B * j;                     // pixel of this row inside the K-step
             b_iw0[j] = lq * a.stride + ss_off;                    // iw = q0*stride + b_iw0
-            // lanes whose iw is negative get a negative (wrapped) offset here; the iw test masks them
-            b_voff[j] = b_c_ok ? (unsigned)(((lq * a.stride + ss_off) * a.C + c0 + b_col) * 4) : FAR;
+            // relative to the shifted descriptor: (lq*stride + s) pixels, always >= 0
+            b_voff[j] = b_c_ok ? (unsigned)(((lq * a.stride + s) * a.C + c0 + b_col) * 4) : FAR;
         }
     }
     auto load_a = [&](int j, int kc) {

@@ -66,58 +66,101 @@ __device__ void find_bin(const int *hist, int nbins, int need, int *result)
 
 constexpr int DEC_CAP = 8192;      // candidate slots of the fast path (64 KB of LDS)
 constexpr int DEC_SAMPLES = 16384;  // strided sample that places the candidate threshold
+constexpr int SCAN_T = 256;         // threads of a scan workgroup (multi-workgroup path)
+constexpr int SCAN_PER = 32;        // floats per thread of a scan workgroup (8 float4)
 
-// Fast path (all but degenerate maps): the threshold is placed from a strided sample so that ~2K..3K of the
-// n raw values lie above it, ONE scan collects them into LDS, and the exact top-K is taken from the
-// candidates.  Raw values are compared (sigmoid is monotone), so expf runs on the candidates only.  The result is
-// identical to the exact radix path below whenever the K-th score is strictly above the score of the threshold
-// (no outsider can tie with it); otherwise, or when the sample misjudges the count, the exact path runs.
-// Returns the number of candidates left in `keys` (sorted, score-descending) or -1.
-__device__ int decode_fast_path(const float *x, long n, int is_logits, int C, long HW, int K,
-                                unsigned long long *keys, int *hist, int *res, int *cnt)
+// Per-frame scratch of the multi-workgroup path (rr_decode_workspace_bytes): the sampled threshold, the
+// candidate counter and DEC_CAP candidate slots.
+struct DecodeFrameWs {
+    unsigned int thr;    // ordered key of the candidate threshold (0: every element is a candidate)
+    int cnt;             // candidates appended so far (may exceed DEC_CAP: then the exact path runs)
+    int pad[2];
+    unsigned long long cand[DEC_CAP];   // (ordered raw value << 32) | flat NHWC index
+};
+
+// `_ctnet_nms` (operators/centernet_operator.py:204-210): an element survives iff its score equals the maximum of
+// its 3x3 window (same class, window clipped at the border = max_pool2d's -inf padding).  The comparison is on
+// SCORES like the reference's (distinct logits may share one fp32 sigmoid); raw values decide first because the
+// score is monotone in them, expf runs only for a neighbour with a larger raw value.
+__device__ __forceinline__ bool is_peak3x3(const float *x, long i, int C, int H, int W, int is_logits)
+{
+    const long pix = i / C;
+    const int xw = (int)(pix % W), y = (int)(pix / W);
+    const float v = x[i];
+    float sv = 0.f;
+    bool have_sv = false;
+    for (int dy = -1; dy <= 1; ++dy) {
+        const int yy = y + dy;
+        if (yy < 0 || yy >= H) continue;
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int xx = xw + dx;
+            if (xx < 0 || xx >= W || (dx == 0 && dy == 0)) continue;
+            const float u = x[i + ((long)dy * W + dx) * C];
+            if (u > v) {
+                if (!is_logits) return false;
+                if (!have_sv) { sv = score_of(v, 1); have_sv = true; }
+                if (score_of(u, 1) > sv) return false;
+            }
+        }
+    }
+    return true;
+}
+
+// value the top-K ranks element i by: its score, or 0 where the optional peak filter removes it (heat * keep)
+__device__ __forceinline__ float elem_score(const float *x, long i, int is_logits, int peak, int C, int H, int W)
+{
+    if (peak && !is_peak3x3(x, i, C, H, W, is_logits)) return 0.f;
+    return score_of(x[i], is_logits);
+}
+
+// Places the candidate threshold of one frame from a strided sample so that ~2K..3K of the n raw values (of the
+// surviving peaks when the filter is on) lie at or above it.  All threads of the workgroup call it; returns the
+// ordered key (0 = take everything) or 0xffffffff when the fast path cannot be used (K too close to the capacity).
+__device__ unsigned int place_threshold(const float *x, long n, int K, int peak, int is_logits, int C, int H, int W,
+                                        int *hist, int *res)
 {
     const int tid = threadIdx.x;
-    unsigned int t0 = 0;                      // ordered key of the candidate threshold (0: take everything)
-    if (n > DEC_CAP) {
-        const long stride = n / DEC_SAMPLES > 0 ? n / DEC_SAMPLES : 1;
-        const long ns = (n + stride - 1) / stride;
-        long target = 2l * K > K + 1024l ? 2l * K : K + 1024l;
-        if (target > DEC_CAP / 2) target = DEC_CAP / 2;
-        if (target < K) return -1;            // K too close to the candidate capacity
-        int need = (int)((double)target * (double)ns / (double)n);
-        if (need < 8) need = 8;
-        if (need > ns) return -1;
-        unsigned int prefix = 0;
-        for (int pass = 0; pass < 2; ++pass) {
-            const int shift = pass == 0 ? 21 : 10;
-            for (int i = tid; i < 2048; i += DT) hist[i] = 0;
-            __syncthreads();
-            for (long j = tid; j < ns; j += DT) {
-                const unsigned int o = f2ord(x[j * stride]);
-                if (pass == 0 || (o >> 21) == (prefix >> 21)) atomicAdd(&hist[(o >> shift) & 2047], 1);
+    if (n <= DEC_CAP) return 0u;
+    const long stride = n / DEC_SAMPLES > 0 ? n / DEC_SAMPLES : 1;
+    const long ns = (n + stride - 1) / stride;
+    long target = 2l * K > K + 1024l ? 2l * K : K + 1024l;
+    if (target > DEC_CAP / 2) target = DEC_CAP / 2;
+    if (target < K) return 0xffffffffu;
+    int need = (int)((double)target * (double)ns / (double)n);
+    if (need < 8) need = 8;
+    if (need > ns) return 0xffffffffu;
+    unsigned int prefix = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        const int shift = pass == 0 ? 21 : 10;
+        for (int i = tid; i < 2048; i += blockDim.x) hist[i] = 0;
+        if (tid == 0) { res[0] = -1; res[1] = 0; }
+        __syncthreads();
+        for (long j = tid; j < ns; j += blockDim.x) {
+            const long i = j * stride;
+            const unsigned int o = f2ord(x[i]);
+            if (pass == 0 || (o >> 21) == (prefix >> 21)) {
+                if (!peak || is_peak3x3(x, i, C, H, W, is_logits)) atomicAdd(&hist[(o >> shift) & 2047], 1);
             }
-            __syncthreads();
-            find_bin(hist, 2048, need, res);
-            __syncthreads();
-            prefix |= (unsigned int)res[0] << shift;
-            need -= res[1];
-            __syncthreads();
         }
-        t0 = prefix;                          // low 10 bits zero: at or just below the sampled rank
+        __syncthreads();
+        find_bin(hist, 2048, need, res);
+        __syncthreads();
+        const int bin = res[0], above = res[1];
+        __syncthreads();
+        if (bin < 0) return 0u;               // fewer surviving samples than `need`: take every survivor
+        prefix |= (unsigned int)bin << shift;
+        need -= above;
     }
-    if (tid == 0) *cnt = 0;
-    __syncthreads();
-    for (long i = tid; i < n; i += DT) {
-        const unsigned int o = f2ord(x[i]);
-        if (o >= t0) {
-            const int p = atomicAdd(cnt, 1);
-            if (p < DEC_CAP) keys[p] = ((unsigned long long)o << 32) | (unsigned long long)i;
-        }
-    }
-    __syncthreads();
-    const int m = *cnt;
-    if (m < K || m > DEC_CAP) return -1;
-    // candidates -> (score, reference flat index) keys
+    return prefix;                            // low 10 bits zero: at or just below the sampled rank
+}
+
+// m candidates (ordered raw value, flat index) in keys[0..m) -> (score, reference flat index) keys, sorted
+// score-descending; returns m, or -1 when an element outside the candidate set could tie with the K-th score
+// (then the exact path decides).
+__device__ int finish_candidates(unsigned long long *keys, int m, unsigned int t0, int is_logits, int peak, int C, long HW,
+                                 int K)
+{
+    const int tid = threadIdx.x;
     for (int p = tid; p < m; p += DT) {
         const unsigned long long cand = keys[p];
         const long i = (long)(cand & 0xffffffffull);
@@ -141,21 +184,97 @@ __device__ int decode_fast_path(const float *x, long n, int is_logits, int C, lo
             __syncthreads();
         }
     }
+    const unsigned int kth = (unsigned int)(keys[K - 1] >> 32);
     if (t0 != 0) {
-        const unsigned int kth = (unsigned int)(keys[K - 1] >> 32);
         const unsigned int edge = f2ord(score_of(ord2f(t0), is_logits));
-        if (kth <= edge) return -1;           // an outsider could tie with the K-th score: exact path decides
+        if (kth <= edge) return -1;           // an outsider could tie with the K-th score
     }
+    if (peak && kth <= f2ord(0.f)) return -1; // filtered-out elements rank as 0: they could tie / outrank
     return m;
 }
 
-__global__ __launch_bounds__(DT) void decode_topk_kernel(const float *hm, int is_logits, const float *wh, const float *off,
-                                                         int H, int W, int C, int K, int KP, float *out, int *pix_out)
+// Single-workgroup fast path (small maps, or no workspace): threshold, ONE scan into LDS, finish.
+// Raw values are compared (sigmoid is monotone), so expf runs on the candidates only.
+__device__ int decode_fast_path(const float *x, long n, int is_logits, int peak, int C, int H, int W, int K,
+                                unsigned long long *keys, int *hist, int *res, int *cnt)
+{
+    const int tid = threadIdx.x;
+    const unsigned int t0 = place_threshold(x, n, K, peak, is_logits, C, H, W, hist, res);
+    if (t0 == 0xffffffffu) return -1;
+    if (tid == 0) *cnt = 0;
+    __syncthreads();
+    for (long i = tid; i < n; i += DT) {
+        const unsigned int o = f2ord(x[i]);
+        if (o >= t0 && (!peak || is_peak3x3(x, i, C, H, W, is_logits))) {
+            const int p = atomicAdd(cnt, 1);
+            if (p < DEC_CAP) keys[p] = ((unsigned long long)o << 32) | (unsigned long long)i;
+        }
+    }
+    __syncthreads();
+    const int m = *cnt;
+    if (m < K || m > DEC_CAP) return -1;
+    return finish_candidates(keys, m, t0, is_logits, peak, C, (long)H * W, K);
+}
+
+// ---- multi-workgroup path: (1) threshold per frame, (2) all CUs stream the maps and append candidates,
+// ---- (3) one workgroup per frame sorts its candidates and assembles the boxes -------------------------------
+__global__ __launch_bounds__(DT) void decode_threshold_kernel(const float *hm, int is_logits, int peak, int H, int W, int C,
+                                                              int K, DecodeFrameWs *ws)
+{
+    __shared__ int hist[2048];
+    __shared__ int res[2];
+    const long n = (long)H * W * C;
+    const unsigned int t0 = place_threshold(hm + (long)blockIdx.x * n, n, K, peak, is_logits, C, H, W, hist, res);
+    if (threadIdx.x == 0) {
+        ws[blockIdx.x].thr = t0;
+        ws[blockIdx.x].cnt = 0;
+    }
+}
+
+__global__ __launch_bounds__(SCAN_T) void decode_scan_kernel(const float *hm, int is_logits, int peak, int H, int W, int C,
+                                                             DecodeFrameWs *ws)
+{
+    const long n = (long)H * W * C;
+    const float *x = hm + (long)blockIdx.y * n;
+    DecodeFrameWs *f = ws + blockIdx.y;
+    const unsigned int t0 = f->thr;
+    if (t0 == 0xffffffffu) return;
+    const long base = (long)blockIdx.x * (SCAN_T * SCAN_PER);
+    auto push = [&](unsigned int o, long i) {
+        if (peak && !is_peak3x3(x, i, C, H, W, is_logits)) return;
+        const int p = atomicAdd(&f->cnt, 1);
+        if (p < DEC_CAP) f->cand[p] = ((unsigned long long)o << 32) | (unsigned long long)i;
+    };
+    if ((n & 3) == 0 && base + SCAN_T * SCAN_PER <= n) {
+        float4 v[SCAN_PER / 4];
+#pragma unroll
+        for (int r = 0; r < SCAN_PER / 4; ++r)
+            v[r] = *reinterpret_cast<const float4 *>(x + base + ((long)r * SCAN_T + threadIdx.x) * 4);
+#pragma unroll
+        for (int r = 0; r < SCAN_PER / 4; ++r) {
+            const long i0 = base + ((long)r * SCAN_T + threadIdx.x) * 4;
+            const unsigned int o0 = f2ord(v[r].x), o1 = f2ord(v[r].y), o2 = f2ord(v[r].z), o3 = f2ord(v[r].w);
+            if (o0 >= t0) push(o0, i0);
+            if (o1 >= t0) push(o1, i0 + 1);
+            if (o2 >= t0) push(o2, i0 + 2);
+            if (o3 >= t0) push(o3, i0 + 3);
+        }
+    } else {
+        const long end = base + SCAN_T * SCAN_PER < n ? base + SCAN_T * SCAN_PER : n;
+        for (long i = base + threadIdx.x; i < end; i += SCAN_T) {
+            const unsigned int o = f2ord(x[i]);
+            if (o >= t0) push(o, i);
+        }
+    }
+}
+
+__global__ __launch_bounds__(DT) void decode_topk_kernel(const float *hm, int is_logits, int peak, const float *wh,
+                                                         const float *off, int H, int W, int C, int K, int KP, float *out,
+                                                         int *pix_out, const DecodeFrameWs *ws)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned long long *keys = reinterpret_cast<unsigned long long *>(smem);  // [max(KP, DEC_CAP)]
     int *hist = reinterpret_cast<int *>(keys + (KP > DEC_CAP ? KP : DEC_CAP)); // [2048]
-    int *scan = hist + 2048;                                                  // [DT/64 + 1]
     __shared__ int res[2];
     __shared__ int cnt_gt;
 
@@ -164,65 +283,67 @@ __global__ __launch_bounds__(DT) void decode_topk_kernel(const float *hm, int is
     const long n = HW * C;
     const float *x = hm + (long)blockIdx.x * n;
 
-    const int fast = decode_fast_path(x, n, is_logits, C, HW, K, keys, hist, res, &cnt_gt);
+    int fast;
+    if (ws) {                                     // candidates were collected by decode_scan_kernel
+        const DecodeFrameWs *f = ws + blockIdx.x;
+        const int m = f->cnt;
+        const unsigned int t0 = f->thr;
+        fast = -1;
+        if (t0 != 0xffffffffu && m >= K && m <= DEC_CAP) {
+            for (int p = tid; p < m; p += DT) keys[p] = f->cand[p];
+            __syncthreads();
+            fast = finish_candidates(keys, m, t0, is_logits, peak, C, HW, K);
+        }
+    } else {
+        fast = decode_fast_path(x, n, is_logits, peak, C, H, W, K, keys, hist, res, &cnt_gt);
+    }
     __syncthreads();
     if (fast < 0) {
-    // ---- radix select of the K-th largest ordered key
-    unsigned int prefix = 0;   // bits fixed so far (top-aligned)
+    // ---- radix select of the K-th largest 64-bit key (ordered score << 32 | ~reference index): passes 0-2 fix
+    // the score word (11+11+10 bits), passes 3-5 the index word among the elements that tie with the K-th score,
+    // so ties across the K-th rank go to the lowest reference index like everywhere else.  Keys are unique:
+    // exactly K elements are >= the selected key.
+    unsigned int hi_pref = 0, lo_pref = 0;   // bits fixed so far (top-aligned) of the two words
     int need = K;
-    for (int pass = 0; pass < 3; ++pass) {
-        const int shift = pass == 0 ? 21 : (pass == 1 ? 10 : 0);
-        const int nb = pass == 2 ? 1024 : 2048;
+    for (int pass = 0; pass < 6; ++pass) {
+        const int sub = pass % 3;
+        const int shift = sub == 0 ? 21 : (sub == 1 ? 10 : 0);
+        const int nb = sub == 2 ? 1024 : 2048;
         for (int i = tid; i < 2048; i += DT) hist[i] = 0;
         __syncthreads();
         for (long i = tid; i < n; i += DT) {
-            const unsigned int o = f2ord(score_of(x[i], is_logits));
-            const bool in = pass == 0 ? true : (pass == 1 ? (o >> 21) == (prefix >> 21) : (o >> 10) == (prefix >> 10));
-            if (in) atomicAdd(&hist[(o >> shift) & (nb - 1)], 1);
+            const unsigned int o = f2ord(elem_score(x, i, is_logits, peak, C, H, W));
+            unsigned int word, pref;
+            if (pass < 3) {
+                word = o; pref = hi_pref;
+            } else {
+                if (o != hi_pref) continue;
+                word = 0xffffffffu - (unsigned int)((i % C) * HW + i / C); pref = lo_pref;
+            }
+            const bool in = sub == 0 ? true : (sub == 1 ? (word >> 21) == (pref >> 21) : (word >> 10) == (pref >> 10));
+            if (in) atomicAdd(&hist[(word >> shift) & (nb - 1)], 1);
         }
         __syncthreads();
         find_bin(hist, nb, need, res);
         __syncthreads();
-        prefix |= (unsigned int)res[0] << shift;
+        if (pass < 3) hi_pref |= (unsigned int)res[0] << shift; else lo_pref |= (unsigned int)res[0] << shift;
         need -= res[1];
         __syncthreads();
     }
-    const unsigned int thr = prefix;   // ordered key of the K-th largest score
-    const int need_eq = need;          // how many elements equal to thr are taken
-    const int n_gt = K - need_eq;
+    const unsigned long long kth = ((unsigned long long)hi_pref << 32) | (unsigned long long)lo_pref;
 
-    // ---- collect: strictly greater (any order) + the first need_eq equal ones in (thread, round) order
-    int my_eq = 0;
-    for (long i = tid; i < n; i += DT) my_eq += (f2ord(score_of(x[i], is_logits)) == thr) ? 1 : 0;
-    // block exclusive scan of my_eq
-    int incl = my_eq;
-    const int lane = tid & 63, wave = tid >> 6;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int v = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += v;
-    }
-    if (lane == 63) scan[wave] = incl;
+    // ---- collect the K keys >= kth (any order: sorted next)
     if (tid == 0) cnt_gt = 0;
-    __syncthreads();
-    int base_eq = incl - my_eq;
-    for (int w = 0; w < wave; ++w) base_eq += scan[w];
     for (int i = K + tid; i < KP; i += DT) keys[i] = 0ull;
     __syncthreads();
-    int eq_i = 0;
     for (long i = tid; i < n; i += DT) {
-        const unsigned int o = f2ord(score_of(x[i], is_logits));
-        if (o < thr) continue;
-        const int c = (int)(i % C);
-        const long pix = i / C;
-        const unsigned int ref = (unsigned int)(c * HW + pix);
+        const unsigned int o = f2ord(elem_score(x, i, is_logits, peak, C, H, W));
+        if (o < hi_pref) continue;
+        const unsigned int ref = (unsigned int)((i % C) * HW + i / C);
         const unsigned long long key = ((unsigned long long)o << 32) | (unsigned long long)(0xffffffffu - ref);
-        if (o > thr) {
+        if (key >= kth) {
             const int p = atomicAdd(&cnt_gt, 1);
-            keys[p] = key;
-        } else {
-            const int r = base_eq + eq_i++;
-            if (r < need_eq) keys[n_gt + r] = key;
+            if (p < K) keys[p] = key;
         }
     }
     __syncthreads();
@@ -302,26 +423,18 @@ __global__ void proposal_bwd_kernel(const float *droi, const float *rois, const 
     if (wh[o + 1] >= 0.f && hy != 0.f) atomicAdd(dwh + o + 1, hy);
 }
 
-// scores[b,y,x,c] = sigmoid(hm) if it is the maximum of its 3x3 window (same class) else 0
+// scores[b,y,x,c] = sigmoid(hm) if it equals the maximum of its 3x3 window (same class) else 0:
+// operators/centernet_operator.py:204-210 as a stand-alone map (the decode applies the same test to its candidates
+// only, see is_peak3x3).  One expf per element; neighbours are compared on raw values first.
 __global__ void peak3x3_kernel(const float *hm, float *scores, int B, int H, int W, int C)
 {
-    const long total = (long)B * H * W * C;
+    const long per = (long)H * W * C;
+    const long total = (long)B * per;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C);
-        long p = i / C;
-        const int xw = (int)(p % W); p /= W;
-        const int y = (int)(p % H);
-        const long b = p / H;
-        const float v = 1.0f / (1.0f + expf(-hm[i]));
-        float m = v;
-        for (int dy = -1; dy <= 1; ++dy)
-            for (int dx = -1; dx <= 1; ++dx) {
-                const int yy = y + dy, xx = xw + dx;
-                if (yy < 0 || xx < 0 || yy >= H || xx >= W) continue;
-                const float u = 1.0f / (1.0f + expf(-hm[((b * H + yy) * W + xx) * C + c]));
-                m = fmaxf(m, u);
-            }
-        scores[i] = (m == v) ? v : 0.f;
+        const long b = i / per;
+        const long j = i - b * per;
+        const float *x = hm + b * per;
+        scores[i] = is_peak3x3(x, j, C, H, W, 1) ? score_of(x[j], 1) : 0.f;
     }
 }
 
@@ -456,18 +569,34 @@ __global__ void pack_segments_kernel(const float *grouped, const int *seg_off, c
 
 }  // namespace
 
-extern "C" int rr_decode_topk(const float *hm, int is_logits, const float *wh, const float *off, int b, int h, int w,
-                              int c, int k, float *out, int *pix_out, hipStream_t stream)
+extern "C" size_t rr_decode_workspace_bytes(int b) { return b > 0 ? (size_t)b * sizeof(DecodeFrameWs) : 0; }
+
+extern "C" int rr_decode_topk(const float *hm, int is_logits, int peak_filter, const float *wh, const float *off, int b,
+                              int h, int w, int c, int k, float *out, int *pix_out, void *workspace,
+                              size_t workspace_bytes, hipStream_t stream)
 {
     RR_CHECK_ARG(b > 0 && h > 0 && w > 0 && c > 0, "rr_decode_topk: bad dims");
     RR_CHECK_ARG(k > 0 && k <= 4096 && (long)k <= (long)h * w * c, "rr_decode_topk: k=%d out of range (1..min(4096, C*H*W))", k);
     RR_CHECK_ARG((long)h * w * c < (1l << 31), "rr_decode_topk: map too large");
     int kp = 2;
     while (kp < k) kp <<= 1;
+    const long n = (long)h * w * c;
+    // maps worth spreading over the chip: threshold per frame, a streaming scan by all CUs, then one workgroup
+    // per frame; small maps (or no workspace) stay in the single-workgroup kernel
+    DecodeFrameWs *ws = nullptr;
+    if (workspace && n >= 65536) {
+        RR_CHECK_ARG(workspace_bytes >= rr_decode_workspace_bytes(b), "rr_decode_topk: workspace of %zu bytes, need %zu",
+                     workspace_bytes, rr_decode_workspace_bytes(b));
+        ws = static_cast<DecodeFrameWs *>(workspace);
+        hipLaunchKernelGGL(decode_threshold_kernel, dim3(b), dim3(DT), 0, stream, hm, is_logits, peak_filter, h, w, c, k, ws);
+        const int chunks = rr_cdiv(n, SCAN_T * SCAN_PER);
+        hipLaunchKernelGGL(decode_scan_kernel, dim3(chunks, b), dim3(SCAN_T), 0, stream, hm, is_logits, peak_filter, h, w, c, ws);
+    }
     const size_t lds = (size_t)(kp > DEC_CAP ? kp : DEC_CAP) * 8 + 2048 * 4 + (DT / 64 + 1) * 4;
     hipFuncSetAttribute(reinterpret_cast<const void *>(decode_topk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                         (int)lds);
-    hipLaunchKernelGGL(decode_topk_kernel, dim3(b), dim3(DT), lds, stream, hm, is_logits, wh, off, h, w, c, k, kp, out, pix_out);
+    hipLaunchKernelGGL(decode_topk_kernel, dim3(b), dim3(DT), lds, stream, hm, is_logits, peak_filter, wh, off, h, w, c, k, kp,
+                       out, pix_out, ws);
     RR_CHECK_LAUNCH("rr_decode_topk");
     return RR_OK;
 }

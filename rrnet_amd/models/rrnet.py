@@ -25,8 +25,8 @@ def stage1_proposals(hm, wh, offset, k, num_classes, nms_type='nms', nms_per_cla
     every RoI was decoded from (for the backward of the box assembly)."""
     with torch.no_grad():
         hm, wh, offset = ops.to_nhwc(hm.detach()), ops.to_nhwc(wh.detach()), ops.to_nhwc(offset.detach())
-        src = ops.peak3x3(hm) if peak_filter else hm   # optional `_ctnet_nms`; the reference's decode never applies it
-        boxes, pix = ops.decode_topk(src, wh, offset, k, is_logits=not peak_filter, want_pix=True)
+        # peak_filter: optional `_ctnet_nms` (the reference's decode never applies it), tested inside the scan
+        boxes, pix = ops.decode_topk(hm, wh, offset, k, is_logits=True, want_pix=True, peak_filter=peak_filter)
         b = boxes.shape[0]
         if nms_per_class:
             grouped, seg_off = ops.group_by_class(boxes, num_classes)

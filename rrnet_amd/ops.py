@@ -425,13 +425,18 @@ def stage2_loss(rois, reg, gt_xyxy, scale, want_droi=False):
 # ---------------------------------------------------------------------------------------------
 # decode / NMS / RoIAlign
 # ---------------------------------------------------------------------------------------------
-def decode_topk(hm, wh, off, k, is_logits=True, want_pix=False):
+def decode_topk(hm, wh, off, k, is_logits=True, want_pix=False, peak_filter=False, spread=True):
+    """spread=False keeps the whole decode in one workgroup per frame (no workspace): the A/B of the two paths."""
     assert is_nhwc(hm) and is_nhwc(wh) and is_nhwc(off)
     b, c, h, w = hm.shape
     out = torch.empty((b, k, 6), dtype=torch.float32, device=hm.device)
     pix = torch.empty((b, k), dtype=torch.int32, device=hm.device) if want_pix else None
-    _C.check(_C.fn("rr_decode_topk")(_C.ptr(hm), int(is_logits), _C.ptr(wh), _C.ptr(off), b, h, w, c, k, _C.ptr(out),
-                                     _C.ptr(pix), _C.stream()), "rr_decode_topk")
+    ws, ws_bytes = None, 0
+    if spread and h * w * c >= 65536:
+        ws_bytes = _C.fn("rr_decode_workspace_bytes")(b)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=hm.device)
+    _C.check(_C.fn("rr_decode_topk")(_C.ptr(hm), int(is_logits), int(peak_filter), _C.ptr(wh), _C.ptr(off), b, h, w, c, k,
+                                     _C.ptr(out), _C.ptr(pix), _C.ptr(ws), ws_bytes, _C.stream()), "rr_decode_topk")
     return (out, pix) if want_pix else out
 
 

@@ -32,6 +32,20 @@ SHAPES = [
     (2, 16, 7, 9, 24, 3, 3, 2, 1, 1, False, False),         # stride-2 dgrad parity classes, odd H and W
     (1, 64, 11, 11, 128, 3, 3, 2, 1, 1, False, False),
     (3, 40, 5, 7, 40, 1, 1, 2, 0, 0, False, False),
+    # ---- the kernel variants only LARGE layers select (software-pipelined 128x128 tiles, wgrad's uniform row walk
+    # ---- for Q % 32 == 0, stride-1 dgrad through the forward kernel at >= 4096 pixels, mid/small tile choices)
+    (2, 256, 64, 64, 256, 3, 3, 1, 1, 1, False, False),     # dominant layer type at 64x64 (Q = 2 K-steps per row)
+    (1, 256, 96, 96, 256, 3, 3, 1, 1, 1, True, True),       # Q = 96, head conv with bias + ReLU
+    (2, 128, 128, 128, 256, 3, 3, 2, 1, 1, False, False),   # stem ResidualBlock conv1: stride 2, Q = 64
+    (2, 128, 128, 128, 256, 1, 1, 2, 0, 0, False, False),   # its 1x1 stride-2 skip
+    (2, 256, 64, 64, 256, 3, 3, 2, 1, 1, False, False),     # low1 stride-2 3x3, Q = 32
+    (2, 256, 64, 64, 384, 3, 3, 2, 1, 1, False, False),
+    (1, 384, 32, 32, 384, 3, 3, 1, 1, 1, False, False),     # 128x64 / 128x32 tile territory, split-K
+    (1, 384, 16, 16, 512, 3, 3, 2, 1, 1, False, False),
+    (2, 256, 64, 64, 36, 1, 1, 1, 0, 0, False, False),      # WH head's fused 1x1 (36 tap products)
+    (2, 256, 64, 64, 10, 1, 1, 1, 0, 0, True, False),       # hm head 1x1 at 64x64
+    (1, 256, 64, 160, 256, 3, 3, 1, 1, 1, False, False),    # non-square, Q = 160
+    (1, 256, 66, 70, 256, 3, 3, 1, 1, 1, False, False),     # Q % 32 != 0 at a pipelined size
 ]
 
 

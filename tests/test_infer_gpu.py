@@ -28,7 +28,8 @@ def _head_and_params(seed=5):
     return head, P
 
 
-@pytest.mark.parametrize("hf,wf,k,frames", [(32, 48, 200, 3), (68, 120, 1500, 2)])
+# the last case is BASELINE configs[4] at its named size: one 1920x1080 frame = a 270x480 map, K=1500
+@pytest.mark.parametrize("hf,wf,k,frames", [(32, 48, 200, 3), (68, 120, 1500, 2), (270, 480, 1500, 1)])
 def test_refine_frames_matches_oracle(hf, wf, k, frames):
     from oracle import infer as oinfer
     from rrnet_amd import inference
