@@ -228,32 +228,78 @@ def test_config2_hourglass104_train_mode_vs_oracle(size, bs):
         _close(mod.running_mean, r_sd[key + ".running_mean"], atol=1e-4)
         _close(mod.running_var, r_sd[key + ".running_var"], atol=1e-4)
         assert int(mod.num_batches_tracked) == int(r_sd[key + ".num_batches_tracked"]) == 1
-    # gradients under the fp64-derived bound (see test_model_gpu.py::test_centernet_tiny_vs_reference_golden):
-    # truth = fp64 oracle, noise = movement of the fp64 gradient under one fp32 rounding of the input,
-    # e_ref = the fp32 oracle's own distance from truth
-    _, _, truth, _ = _hg104_oracle_train(sd0, batch, torch.float64, keys, k)
-    _, _, moved, _ = _hg104_oracle_train(sd0, batch, torch.float64, keys, k, perturb=6e-8)
+    # gradients under a bound derived from fp64 runs of the oracle (see test_model_gpu.py::
+    # test_centernet_tiny_vs_reference_golden): truth = fp64 oracle; e_ref = the fp32 oracle's own distance from it;
+    # noise = movement of the fp64 gradient when the INPUT is disturbed by one fp32 rounding (6e-8 relative).  A third
+    # term covers ReLU decisions: any fp32 forward lands ~1e-4 away from the fp64 activations after ~100 train-mode
+    # BN layers, so a few hundred pre-activations within that distance of zero fall on the other side ("flips");
+    # each flip changes the gradient discretely without being an error (tests/test_model_gpu.py::
+    # test_stage1_heads_backward_exact_given_masks shows the backward is exact once the masks are given).  Its size
+    # is measured, not guessed: the input disturbance is scaled until the fp64 forward moves as far from the truth
+    # as the HIP forward is (at the last stack's heat-map), and the gradient movement of THAT run (`e_flip`) bounds
+    # what a correct implementation with this forward accuracy can show.
+    t_outs, _, truth, _ = _hg104_oracle_train(sd0, batch, torch.float64, keys, k)
+    p0 = 6e-8
+    m_outs, _, moved, _ = _hg104_oracle_train(sd0, batch, torch.float64, keys, k, perturb=p0)
+    hm_t = t_outs[0][1].detach()
+    d_mine = float((outs[0][1].detach().cpu().double() - hm_t).norm() / hm_t.norm())
+    d_ref = float((r_outs[0][1].detach().double() - hm_t).norm() / hm_t.norm())
+    d_p0 = float((m_outs[0][1].detach() - hm_t).norm() / hm_t.norm())
+    assert d_mine <= 4 * d_ref + 1e-6, (d_mine, d_ref)              # forward accuracy on par with the fp32 oracle
+    p1 = min(p0 * max(d_mine, d_ref) / max(d_p0, 1e-30), 1e-3)
+    _, _, flipped, _ = _hg104_oracle_train(sd0, batch, torch.float64, keys, k, perturb=p1)
     named = dict(model.named_parameters())
     report, bad = [], []
     for kk in keys:
         t = truth[kk]
         scale = max(np.abs(t).max(), 1e-9)
-        noise = np.abs(moved[kk] - t).max()
-        e_ref = np.abs(r_grads[kk] - t).max()
-        g = named[kk].grad.detach().cpu().numpy().astype(np.float64)
-        e_mine = np.abs(g - t).max()
-        # second measure, on the whole tensor: relative L2 deviation from the fp64 gradient
         tn = np.linalg.norm(t)
-        dev_ref = np.linalg.norm(r_grads[kk].ravel() - t.ravel()) / tn
-        dev_mine = np.linalg.norm(g.ravel() - t.ravel()) / tn
-        report.append((kk, e_mine / scale, e_ref / scale, noise / scale, dev_mine, dev_ref))
-        # the floor is 1e-4 of the gradient's scale: the head parameters (short backward path, noise ~1e-6) are
-        # pinned to that; the backbone parameters sit behind ~100 train-mode BN layers of a randomly initialised
-        # net, which amplify one fp32 rounding of the input to ~5e-3 of the gradient's scale (`noise`), and the
-        # fp32 oracle itself is 2e-2..6e-2 away from fp64 there (`e_ref`) — the derived terms take over
-        if not e_mine <= max(8 * e_ref, 16 * noise, 1e-4 * scale):
-            bad.append(("max", kk, e_mine, e_ref, noise, scale))
-        if not dev_mine <= max(4 * dev_ref, 1e-4):
-            bad.append(("l2", kk, dev_mine, dev_ref))
-    print("\n".join("%-58s max: mine %.1e ref %.1e noise %.1e | l2: mine %.1e ref %.1e" % r for r in report))
+        g = named[kk].grad.detach().cpu().numpy().astype(np.float64)
+        e = {n: np.abs(v - t).max() for n, v in (("mine", g), ("ref", r_grads[kk]), ("noise", moved[kk]), ("flip", flipped[kk]))}
+        d = {n: np.linalg.norm(v.ravel() - t.ravel()) / tn for n, v in (("mine", g), ("ref", r_grads[kk]), ("flip", flipped[kk]))}
+        report.append((kk, e["mine"] / scale, e["ref"] / scale, e["noise"] / scale, e["flip"] / scale, d["mine"], d["ref"], d["flip"]))
+        # floor: 1e-4 of the gradient's scale — the head parameters (short backward path) are pinned to that
+        if not e["mine"] <= max(8 * e["ref"], 16 * e["noise"], 4 * e["flip"], 1e-4 * scale):
+            bad.append(("max", kk, e, scale))
+        if not d["mine"] <= max(4 * d["ref"], 4 * d["flip"], 1e-4):      # whole tensor: relative L2 deviation
+            bad.append(("l2", kk, d))
+    print("forward deviation at hm[1]: mine %.1e ref %.1e; input disturbance matched to it: %.1e" % (d_mine, d_ref, p1))
+    print("\n".join("%-56s max: mine %.1e ref %.1e noise %.1e flip %.1e | l2: mine %.1e ref %.1e flip %.1e" % r for r in report))
     assert not bad, bad
+
+
+@pytest.mark.parametrize("h,w,bs", [(256, 256, 2), (192, 320, 1)])
+def test_config2_hourglass104_train_step_every_kernel_call(h, w, bs):
+    """The tight check of the bench path's arithmetic: one full train step (forward, criterion, backward) of RRNet
+    hourglass-104 in train mode with EVERY distinct conv / BatchNorm / elementwise kernel call recomputed on the
+    host in fp64 from the inputs the call actually received (tests/kernel_audit.py) — ~220 distinct (kernel,
+    shape, stride, flags) combinations per size, covering the large-layer variants (pipelined tiles, wgrad's
+    uniform row walk at Q % 32 == 0 and the generic walk at 320/4 = 80, stride-1 dgrad through the forward kernel,
+    accumulate epilogues, split-K, parity-decomposed stride-2 dgrad) in the exact configuration the step selects."""
+    from kernel_audit import audit
+    from rrnet_amd import functional as RF
+    from rrnet_amd.datasets.synthetic import synth_batch
+    from rrnet_amd.models.rrnet import RRNet
+    torch.manual_seed(219)
+    model = RRNet(_cfg("hourglass")).cuda().to(memory_format=CL).train()
+    for i in range(2):
+        model.wh.detect_H_layer[i][0].conv.bias.data.fill_(3.0)
+        model.wh.detect_W_layer[i][0].conv.bias.data.fill_(3.0)
+    imgs, annos, hms, whs, inds, offs, masks, _ = [t.cuda() if torch.is_tensor(t) else t
+                                                   for t in synth_batch(bs, h, w, boxes_per_image=12, seed=219)]
+    with audit() as rec:
+        outs = model(imgs, k=100)
+        hm_l = sum(RF.focal_loss_hm_from_logits(outs[0][i], hms) / 2 for i in range(2))
+        wh_l = sum(RF.reg_l1_loss(outs[1][i], masks, inds, whs) / 2 for i in range(2))
+        off_l = sum(RF.reg_l1_loss(outs[2][i], masks, inds, offs) / 2 for i in range(2))
+        a = annos.clone()
+        a[:, :, 2:4] += a[:, :, 0:2]
+        s2_l = RF.stage2_reg_loss(outs[3], outs[4], a, 4.0)
+        (hm_l + 0.1 * wh_l + off_l + s2_l).backward()
+        torch.cuda.synchronize()
+    kinds = {}
+    for key, err in rec.seen.items():
+        kinds.setdefault(key[0], []).append(err)
+    print("  ".join("%s:%d (max %.1e)" % (kk, len(v), max(v)) for kk, v in sorted(kinds.items())))
+    assert len(rec.seen) > 150 and {"fprop", "dgrad", "wgrad", "bn_apply", "bn_bwd_apply", "bn_bwd_reduce"} <= set(kinds)
+    assert not rec.bad, rec.bad[:10]
