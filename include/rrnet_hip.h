@@ -190,31 +190,35 @@ int rr_stage2_loss(const float *rois, const float *reg, int r, const float *gt, 
  *   from d roi).  k <= min(4096, c*h*w).  peak_filter=1 applies operators/centernet_operator.py:204-210
  *   (`_ctnet_nms`: keep a score only where it equals its 3x3 window maximum, dead code in the reference, named by
  *   north_star) INSIDE the scan: only the candidates above the sampled threshold are tested, no extra pass over
- *   the map; rr_peak3x3 writes the filtered score map itself.  workspace (optional, rr_decode_workspace_bytes(b)
+ *   the map; rr_peak3x3 writes the filtered score map itself (is_logits=0: hm holds
+ *   ready scores, the reference's call form `_ctnet_nms(heat)`).  workspace (optional, rr_decode_workspace_bytes(b)
  *   bytes of device memory): with it, maps of >= 64 K elements are scanned by all CUs (threshold kernel -> streaming
  *   candidate scan -> one workgroup per frame for sort + box assembly); without it one workgroup per frame does
- *   everything.  Both give identical rows.
+ *   everything.  Both give identical rows.  box_mode 0: RRNet rows as above (scale unused); box_mode 1: CenterNet
+ *   rows of operators/centernet_operator.py:152-178 = (x, y, w, h) * scale, score, cls+1, wh NOT clamped.
  * rr_group_by_class: stable regrouping of each image's k rows by class (classes ascending =
  *   torch.unique order of models/rrnet.py:59); seg_off [b*num_classes+1] row offsets.  Rows whose class lies
- *   outside [cls_base, cls_base+num_classes) are dropped and leave a gap at the end of the image's k-row block:
- *   callers that pad with such rows pass explicit segment lengths (rr_soft_nms_ragged).
+ *   outside [cls_base, cls_base+num_classes) are dropped and leave a gap at the end of the image's k-row block, so
+ *   seg_off[s+1]-seg_off[s] over-counts the image's last class by the gap: seg_len (optional, [b*num_classes]) holds
+ *   the exact lengths and is what the NMS entries should be given (rr_hard_nms_segments, rr_soft_nms_ragged).
  * rr_hard_nms_segments: torchvision.ops.nms as called at models/rrnet.py:69,78; rows of a
- *   segment score-descending, 6 floats per row; kept rows are compacted to the segment front.
+ *   segment score-descending, 6 floats per row; kept rows are compacted to the segment front.  seg_len NULL:
+ *   lengths from consecutive offsets.
  * rr_pack_segments: phase 0 -> out_off [nseg+1] exclusive prefix of n_out (out_off[nseg] = R);
  *   phase 1 -> rois [R,5], scores [R], clses [R] (models/rrnet.py:37-49) and/or rows6 [R,6]. */
 size_t rr_decode_workspace_bytes(int b);
 int rr_decode_topk(const float *hm, int is_logits, int peak_filter, const float *wh, const float *off, int b,
-                   int h, int w, int c, int k, float *out, int *pix_out, void *workspace, size_t workspace_bytes,
-                   hipStream_t stream);
+                   int h, int w, int c, int k, int box_mode, float scale, float *out, int *pix_out, void *workspace,
+                   size_t workspace_bytes, hipStream_t stream);
 int rr_roi_provenance(const float *rois, const float *scores, const float *clses, int r, const float *decoded,
                       const int *pix, int k, int *roi_pix, hipStream_t stream);
 int rr_proposal_bwd(const float *droi, const float *rois, const int *roi_pix, int r, const float *wh, int b, int h,
                     int w, float *dwh, float *doff, hipStream_t stream);
-int rr_peak3x3(const float *hm, float *scores, int b, int h, int w, int c, hipStream_t stream);
+int rr_peak3x3(const float *hm, int is_logits, float *scores, int b, int h, int w, int c, hipStream_t stream);
 int rr_group_by_class(const float *boxes, int b, int k, int num_classes, int cls_base, float *grouped,
-                      int *seg_off, hipStream_t stream);
-int rr_hard_nms_segments(float *boxes, const int *seg_off, int nseg, int max_seg_boxes, float thresh,
-                         int *n_out, hipStream_t stream);
+                      int *seg_off, int *seg_len, hipStream_t stream);
+int rr_hard_nms_segments(float *boxes, const int *seg_off, const int *seg_len, int nseg, int max_seg_boxes,
+                         float thresh, int *n_out, hipStream_t stream);
 
 /* ---- the reference's own hard-NMS family: ext/nms/nms/nms_kernel.cu (`_nms`), cpu_nms.pyx:129-176, py_cpu_nms.py,
  * bound by ext/nms/nms_wrapper.py:23-33 `nms(dets, thresh, gpu_id)`.  Legacy "+1" IoU; boxes [n,stride>=4] on the

@@ -107,6 +107,30 @@ def transform_bbox(hm, wh, offset, k):
     return torch.cat([px, py, pw + px, ph + py, scores, clses], dim=2)
 
 
+def ctnet_transform_bbox(hm, wh, offset, k=250, scale_factor=4):
+    """/root/reference/operators/centernet_operator.py:152-178: logits -> rows [x,y,w,h,score,cls+1] of IMAGE 0 in
+    image coordinates (x scale_factor), wh NOT clamped, `offset=None` -> +0.5 centres, rows with score <= 0.01 dropped."""
+    b = hm.size(0)
+    hm = torch.sigmoid(hm)
+    scores, inds, clses, ys, xs = topk_decode(hm, k)
+    if offset is not None:
+        off = _nhwc_gather(offset, inds).view(b, k, 2)
+        xs = xs.view(b, k, 1) + off[:, :, 0:1]
+        ys = ys.view(b, k, 1) + off[:, :, 1:2]
+    else:
+        xs = xs.view(b, k, 1) + 0.5
+        ys = ys.view(b, k, 1) + 0.5
+    whg = _nhwc_gather(wh, inds).view(b, k, 2)
+    clses = clses.view(b, k, 1).float() + 1
+    scores = scores.view(b, k, 1)
+    px = (xs - whg[..., 0:1] / 2) * scale_factor
+    py = (ys - whg[..., 1:2] / 2) * scale_factor
+    pw = whg[..., 0:1] * scale_factor
+    ph = whg[..., 1:2] * scale_factor
+    pred = torch.cat([px[0], py[0], pw[0], ph[0], scores[0], clses[0]], dim=1)
+    return pred[pred[:, 4] > 0.01, :]
+
+
 def ctnet_peak_filter(heat, kernel=3):
     """/root/reference/operators/centernet_operator.py:204-210 (`_ctnet_nms`, dead code in the
     reference; restated because north_star names the 3x3 peak pick)."""

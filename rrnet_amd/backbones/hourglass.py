@@ -152,10 +152,17 @@ class HourglassNet(nn.Module):
 def hourglass_net(num_stacks=2, pretrained_path='./hourglass.pth'):
     """backbones/hourglass.py:202-210.  The reference unconditionally torch.load()s
     './hourglass.pth' (strict=False); that file ships with neither repository, so a missing file
-    leaves the default initialisation in place instead of raising."""
+    leaves the default initialisation in place instead of raising — with a warning, because a training run that
+    expected the pretrained backbone would otherwise silently start from scratch.  `pretrained_path=None` asks for
+    the random initialisation explicitly (tests, the synthetic benchmark)."""
     model = HourglassNet(num_stacks=num_stacks)
-    if pretrained_path and os.path.exists(pretrained_path):
-        model.load_state_dict(torch.load(pretrained_path, map_location='cpu'), strict=False)
+    if pretrained_path:
+        if os.path.exists(pretrained_path):
+            model.load_state_dict(torch.load(pretrained_path, map_location='cpu'), strict=False)
+        else:
+            import warnings
+            warnings.warn("hourglass_net: %r not found — the backbone keeps its random initialisation (the reference "
+                          "raises FileNotFoundError here)" % pretrained_path, RuntimeWarning, stacklevel=2)
     return model
 
 

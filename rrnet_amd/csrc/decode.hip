@@ -234,16 +234,29 @@ __global__ __launch_bounds__(DT) void decode_threshold_kernel(const float *hm, i
 __global__ __launch_bounds__(SCAN_T) void decode_scan_kernel(const float *hm, int is_logits, int peak, int H, int W, int C,
                                                              DecodeFrameWs *ws)
 {
+    // candidates of this workgroup are gathered in LDS (LDS atomics return in ~100 cycles; a returning global atomic
+    // per candidate parked every wave for microseconds) and appended to the frame's list with ONE global atomic
+    constexpr int LCAP = 512;
+    __shared__ unsigned long long lcand[LCAP];
+    __shared__ int lcnt, gbase;
     const long n = (long)H * W * C;
     const float *x = hm + (long)blockIdx.y * n;
     DecodeFrameWs *f = ws + blockIdx.y;
     const unsigned int t0 = f->thr;
     if (t0 == 0xffffffffu) return;
+    if (threadIdx.x == 0) lcnt = 0;
+    __syncthreads();
     const long base = (long)blockIdx.x * (SCAN_T * SCAN_PER);
     auto push = [&](unsigned int o, long i) {
         if (peak && !is_peak3x3(x, i, C, H, W, is_logits)) return;
-        const int p = atomicAdd(&f->cnt, 1);
-        if (p < DEC_CAP) f->cand[p] = ((unsigned long long)o << 32) | (unsigned long long)i;
+        const unsigned long long key = ((unsigned long long)o << 32) | (unsigned long long)i;
+        const int p = atomicAdd(&lcnt, 1);
+        if (p < LCAP) {
+            lcand[p] = key;
+        } else {                                   // a workgroup with > LCAP candidates (t0 == 0, flat maps): direct
+            const int q = atomicAdd(&f->cnt, 1);
+            if (q < DEC_CAP) f->cand[q] = key;
+        }
     };
     if ((n & 3) == 0 && base + SCAN_T * SCAN_PER <= n) {
         float4 v[SCAN_PER / 4];
@@ -266,11 +279,18 @@ __global__ __launch_bounds__(SCAN_T) void decode_scan_kernel(const float *hm, in
             if (o >= t0) push(o, i);
         }
     }
+    __syncthreads();
+    const int m = lcnt < LCAP ? lcnt : LCAP;
+    if (m == 0) return;
+    if (threadIdx.x == 0) gbase = atomicAdd(&f->cnt, m);
+    __syncthreads();
+    for (int p = threadIdx.x; p < m; p += SCAN_T)
+        if (gbase + p < DEC_CAP) f->cand[gbase + p] = lcand[p];
 }
 
 __global__ __launch_bounds__(DT) void decode_topk_kernel(const float *hm, int is_logits, int peak, const float *wh,
                                                          const float *off, int H, int W, int C, int K, int KP, float *out,
-                                                         int *pix_out, const DecodeFrameWs *ws)
+                                                         int *pix_out, const DecodeFrameWs *ws, int box_mode, float scale)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned long long *keys = reinterpret_cast<unsigned long long *>(smem);  // [max(KP, DEC_CAP)]
@@ -374,10 +394,16 @@ __global__ __launch_bounds__(DT) void decode_topk_kernel(const float *hm, int is
         const float *po = off + ((long)blockIdx.x * HW + pix) * 2;
         const float *pw = wh + ((long)blockIdx.x * HW + pix) * 2;
         const float xs = xs0 + po[0], ys = ys0 + po[1];
-        const float w_ = fmaxf(pw[0], 0.f), h_ = fmaxf(pw[1], 0.f);
-        const float px = xs - w_ / 2.f, py = ys - h_ / 2.f;
         float *o = out + ((long)blockIdx.x * K + k) * 6;
-        o[0] = px; o[1] = py; o[2] = w_ + px; o[3] = h_ + py; o[4] = score; o[5] = (float)cls;
+        if (box_mode == 0) {      // RRNet (models/rrnet.py:122-137): wh clamped at 0, x1,y1,x2,y2 in feature coordinates
+            const float w_ = fmaxf(pw[0], 0.f), h_ = fmaxf(pw[1], 0.f);
+            const float px = xs - w_ / 2.f, py = ys - h_ / 2.f;
+            o[0] = px; o[1] = py; o[2] = w_ + px; o[3] = h_ + py; o[4] = score; o[5] = (float)cls;
+        } else {                  // CenterNet (operators/centernet_operator.py:152-178): no clamp, x,y,w,h * scale, cls+1
+            const float w_ = pw[0], h_ = pw[1];
+            o[0] = (xs - w_ / 2.f) * scale; o[1] = (ys - h_ / 2.f) * scale; o[2] = w_ * scale; o[3] = h_ * scale;
+            o[4] = score; o[5] = (float)cls + 1.f;
+        }
         if (pix_out) pix_out[(long)blockIdx.x * K + k] = (int)pix;
     }
 }
@@ -426,7 +452,7 @@ __global__ void proposal_bwd_kernel(const float *droi, const float *rois, const 
 // scores[b,y,x,c] = sigmoid(hm) if it equals the maximum of its 3x3 window (same class) else 0:
 // operators/centernet_operator.py:204-210 as a stand-alone map (the decode applies the same test to its candidates
 // only, see is_peak3x3).  One expf per element; neighbours are compared on raw values first.
-__global__ void peak3x3_kernel(const float *hm, float *scores, int B, int H, int W, int C)
+__global__ void peak3x3_kernel(const float *hm, int is_logits, float *scores, int B, int H, int W, int C)
 {
     const long per = (long)H * W * C;
     const long total = (long)B * per;
@@ -434,7 +460,7 @@ __global__ void peak3x3_kernel(const float *hm, float *scores, int B, int H, int
         const long b = i / per;
         const long j = i - b * per;
         const float *x = hm + b * per;
-        scores[i] = is_peak3x3(x, j, C, H, W, 1) ? score_of(x[j], 1) : 0.f;
+        scores[i] = is_peak3x3(x, j, C, H, W, is_logits) ? score_of(x[j], is_logits) : 0.f;
     }
 }
 
@@ -442,7 +468,7 @@ __global__ void peak3x3_kernel(const float *hm, float *scores, int B, int H, int
 // boxes [B,K,6] -> grouped [B,K,6] with classes ascending, order inside a class preserved;
 // seg_off [B*NC+1] row offsets of every (image, class) segment in the flattened [B*K] row space.
 __global__ __launch_bounds__(256) void group_by_class_kernel(const float *boxes, int K, int NC, int cls_base, int KP,
-                                                             float *grouped, int *seg_off)
+                                                             float *grouped, int *seg_off, int *seg_len)
 {
     extern __shared__ int sm[];   // count[NC], then (LDS sort path) keys[KP]
     int *count = sm;
@@ -465,8 +491,11 @@ __global__ __launch_bounds__(256) void group_by_class_kernel(const float *boxes,
             const int cnt = count[c];
             count[c] = run;                    // becomes the segment's start row
             seg_off[b * NC + c] = b * K + run;
+            if (seg_len) seg_len[b * NC + c] = cnt;
             run += cnt;
         }
+        // rows of classes outside the range are dropped and leave a gap at the end of the image's K-row block:
+        // seg_off[s+1] - seg_off[s] over-counts the image's last class by that gap, seg_len is exact
         if (b == gridDim.x - 1) seg_off[(b + 1) * NC] = b * K + run;
         n_valid = run;
     }
@@ -572,8 +601,8 @@ __global__ void pack_segments_kernel(const float *grouped, const int *seg_off, c
 extern "C" size_t rr_decode_workspace_bytes(int b) { return b > 0 ? (size_t)b * sizeof(DecodeFrameWs) : 0; }
 
 extern "C" int rr_decode_topk(const float *hm, int is_logits, int peak_filter, const float *wh, const float *off, int b,
-                              int h, int w, int c, int k, float *out, int *pix_out, void *workspace,
-                              size_t workspace_bytes, hipStream_t stream)
+                              int h, int w, int c, int k, int box_mode, float scale, float *out, int *pix_out,
+                              void *workspace, size_t workspace_bytes, hipStream_t stream)
 {
     RR_CHECK_ARG(b > 0 && h > 0 && w > 0 && c > 0, "rr_decode_topk: bad dims");
     RR_CHECK_ARG(k > 0 && k <= 4096 && (long)k <= (long)h * w * c, "rr_decode_topk: k=%d out of range (1..min(4096, C*H*W))", k);
@@ -595,8 +624,9 @@ extern "C" int rr_decode_topk(const float *hm, int is_logits, int peak_filter, c
     const size_t lds = (size_t)(kp > DEC_CAP ? kp : DEC_CAP) * 8 + 2048 * 4 + (DT / 64 + 1) * 4;
     hipFuncSetAttribute(reinterpret_cast<const void *>(decode_topk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                         (int)lds);
+    RR_CHECK_ARG(box_mode == 0 || box_mode == 1, "rr_decode_topk: box_mode %d", box_mode);
     hipLaunchKernelGGL(decode_topk_kernel, dim3(b), dim3(DT), lds, stream, hm, is_logits, peak_filter, wh, off, h, w, c, k, kp,
-                       out, pix_out, ws);
+                       out, pix_out, ws, box_mode, scale);
     RR_CHECK_LAUNCH("rr_decode_topk");
     return RR_OK;
 }
@@ -624,18 +654,18 @@ extern "C" int rr_proposal_bwd(const float *droi, const float *rois, const int *
     return RR_OK;
 }
 
-extern "C" int rr_peak3x3(const float *hm, float *scores, int b, int h, int w, int c, hipStream_t stream)
+extern "C" int rr_peak3x3(const float *hm, int is_logits, float *scores, int b, int h, int w, int c, hipStream_t stream)
 {
     const long total = (long)b * h * w * c;
     long blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(peak3x3_kernel, dim3((int)blocks), dim3(256), 0, stream, hm, scores, b, h, w, c);
+    hipLaunchKernelGGL(peak3x3_kernel, dim3((int)blocks), dim3(256), 0, stream, hm, is_logits, scores, b, h, w, c);
     RR_CHECK_LAUNCH("rr_peak3x3");
     return RR_OK;
 }
 
 extern "C" int rr_group_by_class(const float *boxes, int b, int k, int num_classes, int cls_base,
-                                 float *grouped, int *seg_off, hipStream_t stream)
+                                 float *grouped, int *seg_off, int *seg_len, hipStream_t stream)
 {
     RR_CHECK_ARG(b > 0 && k > 0 && num_classes > 0 && num_classes <= 1024, "rr_group_by_class: bad dims");
     int kp = 2;
@@ -646,7 +676,7 @@ extern "C" int rr_group_by_class(const float *boxes, int b, int k, int num_class
         hipFuncSetAttribute(reinterpret_cast<const void *>(group_by_class_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(group_by_class_kernel, dim3(b), dim3(256), lds, stream, boxes, k, num_classes, cls_base, kp,
-                       grouped, seg_off);
+                       grouped, seg_off, seg_len);
     RR_CHECK_LAUNCH("rr_group_by_class");
     return RR_OK;
 }

@@ -14,7 +14,8 @@
 namespace {
 constexpr int NT = 256;
 
-__global__ __launch_bounds__(NT) void hard_nms_kernel(float *boxes, const int *seg_off, float thresh, int cap, int *n_out)
+__global__ __launch_bounds__(NT) void hard_nms_kernel(float *boxes, const int *seg_off, const int *seg_len, float thresh,
+                                                      int cap, int *n_out)
 {
     extern __shared__ __align__(16) float sm[];
     float *bx = sm;                                    // [cap][6]
@@ -22,7 +23,7 @@ __global__ __launch_bounds__(NT) void hard_nms_kernel(float *boxes, const int *s
     __shared__ int wsum[NT / 64];
     const int seg = blockIdx.x, tid = threadIdx.x;
     const int off = seg_off[seg];
-    const int n = seg_off[seg + 1] - off;
+    const int n = seg_len ? seg_len[seg] : seg_off[seg + 1] - off;
     float *g = boxes + (long)off * 6;
     for (int i = tid; i < n * 6; i += NT) bx[i] = g[i];
     for (int i = tid; i < n; i += NT) flag[i] = 0;
@@ -194,8 +195,8 @@ extern "C" void _nms(int *keep_out, int *num_out, const float *boxes_host, int b
     hipFree(keep_dev);
 }
 
-extern "C" int rr_hard_nms_segments(float *boxes, const int *seg_off, int nseg, int max_seg_boxes, float thresh,
-                                    int *n_out, hipStream_t stream)
+extern "C" int rr_hard_nms_segments(float *boxes, const int *seg_off, const int *seg_len, int nseg, int max_seg_boxes,
+                                    float thresh, int *n_out, hipStream_t stream)
 {
     RR_CHECK_ARG(nseg >= 0 && max_seg_boxes >= 0, "rr_hard_nms_segments: negative size");
     RR_CHECK_ARG(max_seg_boxes <= 6000, "rr_hard_nms_segments: segment of %d boxes (limit 6000)", max_seg_boxes);
@@ -204,7 +205,7 @@ extern "C" int rr_hard_nms_segments(float *boxes, const int *seg_off, int nseg, 
     const size_t lds = (size_t)cap * 25 + 16;
     if (lds > 48 * 1024)
         hipFuncSetAttribute(reinterpret_cast<const void *>(hard_nms_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(hard_nms_kernel, dim3(nseg), dim3(NT), lds, stream, boxes, seg_off, thresh, cap, n_out);
+    hipLaunchKernelGGL(hard_nms_kernel, dim3(nseg), dim3(NT), lds, stream, boxes, seg_off, seg_len, thresh, cap, n_out);
     RR_CHECK_LAUNCH("rr_hard_nms_segments");
     return RR_OK;
 }

@@ -76,6 +76,8 @@ class FlatParams:
         self._ready = [0] * nb
         self._works = [None] * nb
         self._marked = set()
+        self._late = set()         # buckets that must wait for the end-of-step exchange (a parameter reported twice)
+        self._reduced = False      # this step's gradient exchange has completed
 
     def _distributed(self):
         return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
@@ -86,21 +88,49 @@ class FlatParams:
         the first use; every rank gets here at the same point of the program."""
         if self._pg is None:
             self._pg = dist.new_group()
+            # RCCL builds a communicator lazily at its first collective: run that first collective HERE, on the main
+            # thread and outside backward, so that the bucket launched from an autograd worker thread in the middle of
+            # backward (interleaved with SyncBN exchanges on the default communicator) finds it ready
+            warm = torch.zeros(1, dtype=torch.float32, device=self.grad.device)
+            dist.all_reduce(warm, group=self._pg)
+            if warm.is_cuda:
+                torch.cuda.current_stream(warm.device).synchronize()
         return self._pg
+
+    def no_sync(self):
+        """Context manager for gradient accumulation (DistributedDataParallel.no_sync): backward passes inside it
+        only accumulate locally; the exchange belongs to the last backward of the step, run outside."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            prev, self._accumulating = getattr(self, "_accumulating", False), True
+            try:
+                yield
+            finally:
+                self._accumulating = prev
+        return ctx()
 
     def mark_ready(self, p):
         """The gradient of `p` is complete for this step (every kernel that adds into it has been enqueued)."""
-        if not self.overlap or not self._distributed():
+        if not self.overlap or not self._distributed() or getattr(self, "_accumulating", False):
             return
         key = id(p)
-        if key in self._marked:
-            raise RuntimeError("FlatParams.mark_ready: parameter #%d %s reported its gradient twice in one step "
-                               "(shared weights need RR_DP_OVERLAP=0)"
-                               % ([id(q) for q in self.params].index(key), tuple(p.shape)))
-        self._marked.add(key)
         b = self._bucket_of[key]
+        if key in self._marked:
+            # a second report in one step (a second backward without no_sync(), shared weights).  If the bucket's
+            # all-reduce has not started it is simply left to the end-of-step exchange; if it has, the bucket holds
+            # the sum over ranks already and adding a local gradient on top cannot be undone
+            if self._works[b] is not None:
+                raise RuntimeError("FlatParams.mark_ready: parameter #%d %s reported its gradient again after its "
+                                   "bucket's all-reduce was launched; wrap all but the last backward of a step in "
+                                   "`with flat.no_sync():` (gradient accumulation) or set RR_DP_OVERLAP=0"
+                                   % ([id(q) for q in self.params].index(key), tuple(p.shape)))
+            self._late.add(b)
+            return
+        self._marked.add(key)
         self._ready[b] += 1
-        if self._ready[b] == self._bucket_need[b] and self._works[b] is None:
+        if self._ready[b] == self._bucket_need[b] and self._works[b] is None and b not in self._late:
             o0, o1 = self._bucket_range[b]
             self._works[b] = dist.all_reduce(self.grad[o0:o1], group=self._group(), async_op=True)
 
@@ -122,12 +152,15 @@ class FlatParams:
         optimizer must scale the gradient with (DDP averages)."""
         if not self._distributed():
             return 1.0
+        if self._reduced:          # idempotent within a step: a second call must not sum the ranks twice
+            return 1.0 / dist.get_world_size()
         for b, (o0, o1) in enumerate(self._bucket_range):      # buckets that were not complete during backward
             if self._works[b] is None:
                 self._works[b] = dist.all_reduce(self.grad[o0:o1], group=self._group(), async_op=True)
         for w in self._works:
             w.wait()
         self._works = [None] * len(self._bucket_range)
+        self._reduced = True
         return 1.0 / dist.get_world_size()
 
 

@@ -29,17 +29,18 @@ def stage1_proposals(hm, wh, offset, k, num_classes, nms_type='nms', nms_per_cla
         boxes, pix = ops.decode_topk(hm, wh, offset, k, is_logits=True, want_pix=True, peak_filter=peak_filter)
         b = boxes.shape[0]
         if nms_per_class:
-            grouped, seg_off = ops.group_by_class(boxes, num_classes)
+            grouped, seg_off, seg_len = ops.group_by_class(boxes, num_classes)
             segs_per_image = num_classes
         else:
             grouped = boxes.clone()
             seg_off = torch.arange(0, (b + 1) * k, k, dtype=torch.int32, device=boxes.device)
+            seg_len = None
             segs_per_image = 1
         rows = grouped.view(-1, 6)
         if nms_type == 'soft_nms':
-            n_out = soft_nms_segments(rows, seg_off, k, sigma=0.5, Nt=0.7, threshold=0.1, method=2)
+            n_out = soft_nms_segments(rows, seg_off, k, sigma=0.5, Nt=0.7, threshold=0.1, method=2, seg_len=seg_len)
         else:
-            n_out = ops.hard_nms_segments(rows, seg_off, k, 0.7)
+            n_out = ops.hard_nms_segments(rows, seg_off, k, 0.7, seg_len)
         rois, scores, clses, _, row_off = ops.pack_segments(rows, seg_off, n_out, segs_per_image, want_offsets=True)
         roi_pix = ops.roi_provenance(rois, scores, clses, boxes, pix) if want_provenance else None
     if want_offsets:   # row offsets of the (image, class) segments inside the packed list
@@ -88,3 +89,52 @@ class RRNet(nn.Module):
     def transform_bbox(self, hm, wh, offset, k=250):
         """models/rrnet.py:117-138 -> [B,k,6] in feature coordinates."""
         return ops.decode_topk(ops.to_nhwc(hm), ops.to_nhwc(wh), ops.to_nhwc(offset), k, is_logits=True)
+
+    # ---- the reference's helper methods (models/rrnet.py:56-115), same signatures and results, on the kernels ----
+    def nms(self, bbox):
+        """models/rrnet.py:56-80 for ONE image: bbox [K,6] (score-descending, as transform_bbox emits) -> kept rows,
+        classes in unique() order, NMS order inside a class.  `forward` runs the batched form (stage1_proposals)."""
+        if bbox.size(0) == 0:
+            return bbox
+        b = bbox.detach().float().contiguous()
+        k = b.size(0)
+        with torch.no_grad():
+            if self.nms_per_class:
+                lo, hi = int(b[:, 5].min()), int(b[:, 5].max())
+                nc = hi - lo + 1
+                grouped, seg_off, seg_len = ops.group_by_class(b.view(1, k, 6), nc, cls_base=lo)
+            else:
+                nc, grouped, seg_len = 1, b.view(1, k, 6).clone(), None
+                seg_off = torch.tensor([0, k], dtype=torch.int32, device=b.device)
+            rows = grouped.view(-1, 6)
+            if self.nms_type == 'soft_nms':
+                n_out = soft_nms_segments(rows, seg_off, k, sigma=0.5, Nt=0.7, threshold=0.1, method=2, seg_len=seg_len)
+            else:
+                n_out = ops.hard_nms_segments(rows, seg_off, k, 0.7, seg_len)
+            return ops.pack_segments(rows, seg_off, n_out, nc, want_rois=False, want_rows=True)[3]
+
+    @staticmethod
+    def _gather_feat(feat, ind, mask=None):
+        """models/rrnet.py:82-91: feat [B,N,D], ind [B,k] -> [B,k,D] (index plumbing, torch)."""
+        dim = feat.size(2)
+        ind = ind.long().unsqueeze(2).expand(ind.size(0), ind.size(1), dim)
+        feat = feat.gather(1, ind)
+        if mask is not None:
+            mask = mask.unsqueeze(2).expand_as(feat)
+            feat = feat[mask].view(-1, dim)
+        return feat
+
+    def _topk(self, scores, k=1500):
+        """models/rrnet.py:93-109: scores [B,C,H,W] (already sigmoid-ed) -> (score [B,k], pixel index [B,k], class
+        [B,k] int, ys [B,k], xs [B,k]).  The reference's two torch.topk calls equal one global top-k per image, which
+        the decode kernel computes (ties: reference flat index ascending)."""
+        b, c, h, w = scores.shape
+        zero = ops.zeros_nhwc(b, 2, h, w, scores.device)
+        rows, pix = ops.decode_topk(ops.to_nhwc(scores.detach().float()), zero, zero, k, is_logits=False, want_pix=True)
+        pix = pix.long()
+        return rows[..., 4], pix, rows[..., 5].int(), (pix // w).float(), (pix % w).float()
+
+    def _transpose_and_gather_feat(self, feat, ind):
+        """models/rrnet.py:111-115: feat [B,D,H,W], ind [B,k] -> [B,k,D]; on NHWC memory the permute is a view."""
+        feat = ops.to_nhwc(feat).permute(0, 2, 3, 1)
+        return self._gather_feat(feat.reshape(feat.size(0), -1, feat.size(3)), ind)

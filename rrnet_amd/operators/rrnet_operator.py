@@ -131,14 +131,20 @@ class RRNetOperator(BaseOperator):
         b[:, 3] = b[:, 1] + b[:, 3]
         n = b.size(0)
         if per_cls:
-            nc = 32                                           # class ids 0..31 (VisDrone uses 1..10)
-            grouped, seg_off = ops.group_by_class(b.view(1, n, 6), nc)
+            # one segment per class id present, like the reference's unique() loop (ids are cls+1, any dataset);
+            # the result lands on the host anyway, so reading the id range costs no extra synchronisation point
+            lo, hi = int(b[:, 5].min()), int(b[:, 5].max())
+            nc = hi - lo + 1
+            if nc > 1023:
+                raise ValueError("_ext_nms: class ids span %d values (limit 1023)" % nc)
+            grouped, seg_off, seg_len = ops.group_by_class(b.view(1, n, 6), nc, cls_base=lo)
         else:
             nc = 1
             grouped = b.view(1, n, 6).clone()
             seg_off = torch.tensor([0, n], dtype=torch.int32, device=dev)
+            seg_len = None
         rows = grouped.view(-1, 6)
-        n_out = soft_nms_segments(rows, seg_off, n, sigma=0.5, Nt=0.7, threshold=0.1, method=2)
+        n_out = soft_nms_segments(rows, seg_off, n, sigma=0.5, Nt=0.7, threshold=0.1, method=2, seg_len=seg_len)
         _, _, _, kept = ops.pack_segments(rows, seg_off, n_out, nc, want_rois=False, want_rows=True)
         kept[:, 2:4] -= kept[:, 0:2]
         return kept.cpu()

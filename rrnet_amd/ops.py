@@ -425,8 +425,10 @@ def stage2_loss(rois, reg, gt_xyxy, scale, want_droi=False):
 # ---------------------------------------------------------------------------------------------
 # decode / NMS / RoIAlign
 # ---------------------------------------------------------------------------------------------
-def decode_topk(hm, wh, off, k, is_logits=True, want_pix=False, peak_filter=False, spread=True):
-    """spread=False keeps the whole decode in one workgroup per frame (no workspace): the A/B of the two paths."""
+def decode_topk(hm, wh, off, k, is_logits=True, want_pix=False, peak_filter=False, spread=True, box_mode=0, scale=1.0):
+    """spread=False keeps the whole decode in one workgroup per frame (no workspace): the A/B of the two paths.
+    box_mode 0: RRNet rows x1,y1,x2,y2,score,cls (feature coordinates, wh clamped at 0); 1: CenterNet rows
+    (x,y,w,h)*scale,score,cls+1 (no clamp)."""
     assert is_nhwc(hm) and is_nhwc(wh) and is_nhwc(off)
     b, c, h, w = hm.shape
     out = torch.empty((b, k, 6), dtype=torch.float32, device=hm.device)
@@ -436,7 +438,8 @@ def decode_topk(hm, wh, off, k, is_logits=True, want_pix=False, peak_filter=Fals
         ws_bytes = _C.fn("rr_decode_workspace_bytes")(b)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=hm.device)
     _C.check(_C.fn("rr_decode_topk")(_C.ptr(hm), int(is_logits), int(peak_filter), _C.ptr(wh), _C.ptr(off), b, h, w, c, k,
-                                     _C.ptr(out), _C.ptr(pix), _C.ptr(ws), ws_bytes, _C.stream()), "rr_decode_topk")
+                                     int(box_mode), float(scale), _C.ptr(out), _C.ptr(pix), _C.ptr(ws), ws_bytes,
+                                     _C.stream()), "rr_decode_topk")
     return (out, pix) if want_pix else out
 
 
@@ -456,28 +459,32 @@ def proposal_bwd(droi, rois, roi_pix, wh):
     return dwh, doff
 
 
-def peak3x3(hm):
+def peak3x3(hm, is_logits=True):
+    """`_ctnet_nms` score map: sigmoid(hm) (or hm itself when is_logits=False) where it equals its 3x3 maximum, else 0."""
     b, c, h, w = hm.shape
     out = empty_nhwc(b, c, h, w, hm.device)
-    _C.check(_C.fn("rr_peak3x3")(_C.ptr(hm), _C.ptr(out), b, h, w, c, _C.stream()), "rr_peak3x3")
+    _C.check(_C.fn("rr_peak3x3")(_C.ptr(hm), int(is_logits), _C.ptr(out), b, h, w, c, _C.stream()), "rr_peak3x3")
     return out
 
 
 def group_by_class(boxes, num_classes, cls_base=0):
-    """boxes [B,K,6] -> grouped [B,K,6], seg_off int32 [B*num_classes+1]."""
+    """boxes [B,K,6] -> grouped [B,K,6], seg_off int32 [B*num_classes+1], seg_len int32 [B*num_classes].
+    Rows whose class lies outside [cls_base, cls_base+num_classes) are dropped (a gap of uninitialised rows at the
+    end of the image's block): hand seg_len, not offset differences, to the NMS entries."""
     b, k, _ = boxes.shape
     grouped = torch.empty_like(boxes)
     seg_off = torch.empty(b * num_classes + 1, dtype=torch.int32, device=boxes.device)
+    seg_len = torch.empty(b * num_classes, dtype=torch.int32, device=boxes.device)
     _C.check(_C.fn("rr_group_by_class")(_C.ptr(boxes), b, k, num_classes, cls_base, _C.ptr(grouped), _C.ptr(seg_off),
-                                        _C.stream()), "rr_group_by_class")
-    return grouped, seg_off
+                                        _C.ptr(seg_len), _C.stream()), "rr_group_by_class")
+    return grouped, seg_off, seg_len
 
 
-def hard_nms_segments(boxes6, seg_off, max_seg, thresh):
+def hard_nms_segments(boxes6, seg_off, max_seg, thresh, seg_len=None):
     nseg = seg_off.numel() - 1
     n_out = torch.zeros(nseg, dtype=torch.int32, device=boxes6.device)
-    _C.check(_C.fn("rr_hard_nms_segments")(_C.ptr(boxes6), _C.ptr(seg_off), nseg, int(max_seg), float(thresh),
-                                           _C.ptr(n_out), _C.stream()), "rr_hard_nms_segments")
+    _C.check(_C.fn("rr_hard_nms_segments")(_C.ptr(boxes6), _C.ptr(seg_off), _C.ptr(seg_len), nseg, int(max_seg),
+                                           float(thresh), _C.ptr(n_out), _C.stream()), "rr_hard_nms_segments")
     return n_out
 
 

@@ -184,20 +184,17 @@ def ext_nms_batch(preds, threshold, max_classes=32):
     if kmax == 0:
         return [np.zeros((0, 6), np.float32) for _ in preds]
     host = np.full((nf, kmax, 6), -1.0, np.float32)          # class -1 rows are padding: grouping drops them
-    seg_len = np.zeros((nf, max_classes), np.int32)          # explicit lengths: padding leaves gaps between segments
     for i, p in enumerate(preds):
         p = p.detach().cpu().numpy() if torch.is_tensor(p) else np.asarray(p)
         host[i, :p.shape[0]] = p[:, :6]
         cls = p[:, 5].astype(np.int64)
         assert cls.size == 0 or (cls.min() >= 0 and cls.max() < max_classes), "class id outside [0, %d)" % max_classes
-        seg_len[i] = np.bincount(cls, minlength=max_classes)
     dev = torch.device("cuda", torch.cuda.current_device())
     b = torch.from_numpy(host).to(dev)
     b[:, :, 2:4] += b[:, :, 0:2]
-    grouped, seg_off = ops.group_by_class(b, max_classes)
+    grouped, seg_off, seg_len = ops.group_by_class(b, max_classes)   # explicit lengths: the padding leaves gaps
     rows = grouped.view(-1, 6)
-    n_out = soft_nms_segments(rows, seg_off, kmax, sigma=0.5, Nt=0.7, threshold=threshold, method=2,
-                              seg_len=torch.from_numpy(seg_len.reshape(-1)).to(dev))
+    n_out = soft_nms_segments(rows, seg_off, kmax, sigma=0.5, Nt=0.7, threshold=threshold, method=2, seg_len=seg_len)
     _, _, _, kept, out_off = ops.pack_segments(rows, seg_off, n_out, max_classes, want_rois=False, want_rows=True,
                                                want_offsets=True)
     kept[:, 2:4] -= kept[:, 0:2]

@@ -92,3 +92,29 @@ def test_reference_script_imports_resolve_through_aliases():
         "print('ok')\n" % ROOT)
     out = subprocess.check_output(["python", "-c", code], text=True, cwd=ROOT, timeout=300)
     assert out.strip().endswith("ok")
+
+
+def test_reference_scripts_run_their_imports_through_shims():
+    """Zero-edit drop-in: with PYTHONPATH=<repo>/shims the import blocks of the reference's scripts/RRNet/{train,eval,
+    auto_eval}.py and scripts/CTNet/*.py resolve to this package — the same module objects as rrnet_amd.* — in a
+    fresh interpreter started OUTSIDE the repository, exactly as `PYTHONPATH=shims python scripts/RRNet/train.py`
+    would (no GPU needed for importing)."""
+    code = (
+        "from configs.rrnet_config import Config\n"
+        "from operators.distributed_wrapper import DistributedWrapper\n"
+        "from operators.rrnet_operator import RRNetOperator\n"
+        "from utils.metrics.metrics import evaluate_results, auto_evaluate_results\n"
+        "from configs.centernet_config import Config as CtConfig\n"
+        "from operators.centernet_operator import CenterNetOperator\n"
+        "import models.rrnet, rrnet_amd.models.rrnet, rrnet_amd.configs.rrnet_config as c2, datasets, ext.nms.nms_wrapper\n"
+        "assert models.rrnet is rrnet_amd.models.rrnet and c2.Config is Config\n"
+        "assert datasets.__name__ == 'rrnet_amd.datasets'\n"
+        "for m in ('nms', '_topk', '_gather_feat', '_transpose_and_gather_feat', 'transform_bbox', 'forward_stage1'):\n"
+        "    assert hasattr(models.rrnet.RRNet, m), m\n"
+        "for m in ('criterion', 'training_process', 'evaluation_process', 'transform_bbox', '_ctnet_nms', '_ext_nms', 'save_result'):\n"
+        "    assert hasattr(CenterNetOperator, m), m\n"
+        "DistributedWrapper(Config, RRNetOperator); DistributedWrapper(CtConfig, CenterNetOperator)\n"
+        "print('ok')\n")
+    env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "shims"))
+    out = subprocess.check_output(["python", "-c", code], text=True, cwd="/tmp", env=env, timeout=300)
+    assert out.strip().endswith("ok")

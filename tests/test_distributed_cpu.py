@@ -128,14 +128,41 @@ def _overlap_worker(rank, world, port, q):
             scale = fp.all_reduce_grads()
             ok = all(torch.allclose(p.grad * scale, torch.full_like(p, 1.5 * (i + 1))) for i, p in enumerate(params))
             out[trial] = (ok, launched)
+        # a parameter that reports twice BEFORE its bucket was launched: the bucket is deferred to the end-of-step
+        # exchange (no error, correct sums); AFTER the launch it is an error (the bucket already holds the rank sum)
         fp.zero_grad()
+        for i, p in enumerate(params):
+            p.grad.copy_(torch.full_like(p, float((rank + 1) * (i + 1))))
+        b0 = fp._bucket_of[id(params[0])]
         fp.mark_ready(params[0])
+        early = fp._works[b0] is not None
         try:
             fp.mark_ready(params[0])
-            out["double"] = False
+            out["double"] = "raised" if early else "deferred"
+            if early:
+                out["double"] = "missed"
         except RuntimeError:
-            out["double"] = True
-        fp.all_reduce_grads()
+            out["double"] = "raised"
+        for p in params[1:]:
+            fp.mark_ready(p)
+        out["deferred_not_launched"] = early or fp._works[b0] is None
+        scale = fp.all_reduce_grads()
+        again = fp.all_reduce_grads()                      # idempotent within a step: no second sum over the ranks
+        out["idempotent"] = (again == scale) and all(
+            torch.allclose(p.grad * scale, torch.full_like(p, 1.5 * (i + 1))) for i, p in enumerate(params))
+        # gradient accumulation: backward passes under no_sync() report nothing
+        fp.zero_grad()
+        with fp.no_sync():
+            for p in params:
+                fp.mark_ready(p)
+        out["no_sync"] = all(w is None for w in fp._works) and not fp._marked
+        for i, p in enumerate(params):
+            p.grad.copy_(torch.full_like(p, float((rank + 1) * (i + 1))))
+        for p in reversed(params):
+            fp.mark_ready(p)
+        scale = fp.all_reduce_grads()
+        out["no_sync"] = out["no_sync"] and all(
+            torch.allclose(p.grad * scale, torch.full_like(p, 1.5 * (i + 1))) for i, p in enumerate(params))
         q.put((rank, out))
     finally:
         dist.destroy_process_group()
@@ -143,7 +170,9 @@ def _overlap_worker(rank, world, port, q):
 
 def test_bucketed_overlap_bookkeeping_gloo():
     """FlatParams.mark_ready: buckets are all-reduced as soon as their last parameter reports (backward order),
-    unreported parameters are covered by the final flush, a double report is an error; result = plain all-reduce."""
+    unreported parameters are covered by the final flush, a double report defers its bucket (or is an error once
+    the bucket was launched), all_reduce_grads is idempotent within a step, no_sync() suppresses the reports;
+    result = plain all-reduce."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -162,4 +191,5 @@ def test_bucketed_overlap_bookkeeping_gloo():
         assert any(a < b for a, b in zip(launched, launched[1:]))          # launched progressively, not at the end
         ok, launched = out["partial"]
         assert ok and launched[-1] < out["nb"]
-        assert out["double"]
+        assert out["double"] in ("deferred", "raised") and out["deferred_not_launched"]
+        assert out["idempotent"] and out["no_sync"]

@@ -100,14 +100,15 @@ def test_group_by_class_large_matches_stable_sort():
         b = 3
         boxes = rng.uniform(0, 100, (b, k, 6)).astype(np.float32)
         boxes[:, :, 5] = rng.integers(0, nc + 2, (b, k))            # two classes out of range: dropped
-        g, so = ops.group_by_class(torch.from_numpy(boxes).cuda(), nc)
-        g, so = g.cpu().numpy(), so.cpu().numpy()
+        g, so, sl = ops.group_by_class(torch.from_numpy(boxes).cuda(), nc)
+        g, so, sl = g.cpu().numpy(), so.cpu().numpy(), sl.cpu().numpy()
         for i in range(b):
             valid = boxes[i][boxes[i, :, 5] < nc]
             order = np.argsort(valid[:, 5], kind='stable')
             np.testing.assert_array_equal(g[i, :valid.shape[0]], valid[order])
             for c in range(nc):
                 assert so[i * nc + c] == i * k + int((valid[:, 5] < c).sum())
+                assert sl[i * nc + c] == int((valid[:, 5] == c).sum())      # exact lengths, also for the last class
         assert so[-1] == (b - 1) * k + int((boxes[b - 1, :, 5] < nc).sum())
 
 

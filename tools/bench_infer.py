@@ -77,46 +77,51 @@ def cpu_baseline(head_sd, pool, n_frames, k):
                                        % (1e3 * t_nms / n_frames)}}
 
 
-def main():
-    a = parse()
+def run(frames=10000, batch=128, pool_frames=128, hf=270, wf=480, k=1500, cpu_frames=3):
+    """-> the result dict (also used by bench.py for its `config5` key)."""
     from rrnet_amd import inference, ops
     from rrnet_amd.datasets.synthetic import synth_head_outputs
     from rrnet_amd.detectors.fasterrcnn_detector import FasterRCNNDetector
-    dev = torch.device("cuda", 0)
-    torch.cuda.set_device(dev)
+    dev = torch.device("cuda", torch.cuda.current_device())
     torch.manual_seed(219)
     head = FasterRCNNDetector().to(dev).eval()
-    head_sd = {k: v.detach().clone() for k, v in head.state_dict().items()}
-    pool = synth_head_outputs(a.pool, a.hf, a.wf, seed=219, device=dev)
+    head_sd = {kk: v.detach().clone() for kk, v in head.state_dict().items()}
+    pool = synth_head_outputs(pool_frames, hf, wf, seed=219, device=dev)
     hm, wh, off, feat = [ops.to_nhwc(t) for t in pool]
-    nb = a.pool // a.batch
+    nb = pool_frames // batch
     assert nb >= 1, "--pool must be >= --batch"
-    batches = [tuple(t[i * a.batch:(i + 1) * a.batch] for t in (hm, wh, off, feat)) for i in range(nb)]
+    batches = [tuple(t[i * batch:(i + 1) * batch] for t in (hm, wh, off, feat)) for i in range(nb)]
 
-    def run(bt):
-        return inference.refine_frames(bt[0], bt[1], bt[2], bt[3], head, k=a.k, relu_feat=False)
+    def step(bt):
+        return inference.refine_frames(bt[0], bt[1], bt[2], bt[3], head, k=k, relu_feat=False)
 
     for i in range(2):
-        out, fo = run(batches[i % nb])
+        out, fo = step(batches[i % nb])
     torch.cuda.synchronize()
-    n_iter = max(a.frames // a.batch, 1)
+    n_iter = max(frames // batch, 1)
     kept = 0
     t0 = time.perf_counter()
     for i in range(n_iter):
-        out, fo = run(batches[i % nb])
+        out, fo = step(batches[i % nb])
         kept += out.shape[0]
     torch.cuda.synchronize()
     t = time.perf_counter() - t0
-    frames = n_iter * a.batch
-    res = {"metric": "boxes/sec (decode + re-regression + Soft-NMS)", "value": round(frames * a.k / t, 1),
+    frames = n_iter * batch
+    res = {"metric": "boxes/sec (decode + re-regression + Soft-NMS)", "value": round(frames * k / t, 1),
            "unit": "boxes/sec", "frames_per_sec": round(frames / t, 1), "frames": frames, "n_gpus": 1,
            "ms_per_batch": round(1e3 * t / n_iter, 3), "output_boxes_per_frame": round(kept / frames, 1),
            "higher_is_better": True, "dtype": "f32", "data": "synthetic", "vs_baseline": None,
            "config": {"workload": "RRNet inference-only post-process, %d frames of 1920x1080 (maps %dx%d), K=%d, "
-                                  "batch %d, pool of %d resident frames" % (frames, a.hf, a.wf, a.k, a.batch, a.pool)}}
-    if a.cpu_frames > 0:
-        res["cpu_baseline"] = cpu_baseline(head_sd, pool, a.cpu_frames, a.k)
-    print(json.dumps(res))
+                                  "batch %d, pool of %d resident frames" % (frames, hf, wf, k, batch, pool_frames)}}
+    if cpu_frames > 0:
+        res["cpu_baseline"] = cpu_baseline(head_sd, pool, cpu_frames, k)
+    return res
+
+
+def main():
+    a = parse()
+    torch.cuda.set_device(0)
+    print(json.dumps(run(a.frames, a.batch, a.pool, a.hf, a.wf, a.k, a.cpu_frames)))
 
 
 if __name__ == "__main__":

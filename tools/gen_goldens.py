@@ -13,6 +13,7 @@ restatement of torchvision 0.3 (not installed here) and are flagged `tv_unpinned
   G6 stage2.npz       FasterRCNNDetector, generate_bbox(_target), criterion stage-2 branch
   G7 extnms.npz       RRNetOperator._ext_nms on a mixed-class set
   G8 rrnet_tiny.npz   RRNet.forward end-to-end on the tiny backbone (tv_unpinned)
+  G11 helpers.npz     CenterNetOperator.transform_bbox / _ctnet_nms / save_result, RRNet._topk / gathers / nms
 """
 import os
 import sys
@@ -432,10 +433,51 @@ def g10_metrics():
     save("metrics.npz", d)
 
 
+def g11_helpers():
+    """CenterNetOperator.transform_bbox :152-178, _ctnet_nms :204-210, save_result :238-249;
+    RRNet._topk / _gather_feat / _transpose_and_gather_feat / nms (models/rrnet.py:56-115, hard-NMS path through the
+    oracle's torchvision restatement -> tv_unpinned)."""
+    import tempfile
+    rng = np.random.default_rng(11)
+    b, c, h, w, k = 2, 10, 24, 40, 60
+    vals = rng.permutation(b * c * h * w).astype(np.float32)          # tie-free
+    hm = torch.from_numpy(((vals / vals.size) * 9 - 6).reshape(b, c, h, w).astype(np.float32))
+    wh = torch.from_numpy(rng.normal(3, 3, (b, 2, h, w)).astype(np.float32))     # some negative: CenterNet keeps them
+    off = torch.from_numpy(rng.uniform(0, 1, (b, 2, h, w)).astype(np.float32))
+    op = CenterNetOperator.__new__(CenterNetOperator)
+    d = dict(hm=hm, wh=wh, offset=off, k=k)
+    d["ct_pred"] = op.transform_bbox(hm, wh, off, k=k, scale_factor=4)
+    d["ct_pred_nooff"] = op.transform_bbox(hm, wh, None, k=k, scale_factor=4)
+    # `_ctnet_nms` on a score map with plateaus and border maxima
+    heat = torch.sigmoid(torch.from_numpy(rng.normal(-2, 2, (2, 4, 19, 23)).astype(np.float32)))
+    heat[0, 1, 5:8, 5:8] = 0.75
+    heat[1, 2, 0, 0:2] = 0.9
+    heat[1, 3] = torch.round(heat[1, 3] * 8) / 8
+    d["heat"], d["heat_nms"] = heat, op._ctnet_nms(heat)
+    with tempfile.TemporaryDirectory() as td:
+        rows = torch.from_numpy(np.concatenate([rng.uniform(-5, 300, (7, 4)), rng.uniform(0, 1, (7, 1)),
+                                                rng.integers(1, 11, (7, 1))], 1).astype(np.float32))
+        op.save_result(os.path.join(td, "r.txt"), rows.clone())
+        d["save_rows"] = rows
+        d["save_text"] = np.frombuffer(open(os.path.join(td, "r.txt"), "rb").read(), dtype=np.uint8)
+    net = RRNet.__new__(RRNet)
+    nn.Module.__init__(net)
+    scores = torch.sigmoid(hm)
+    ts, ti, tc, ty, tx = net._topk(scores, k)
+    d["topk_score"], d["topk_inds"], d["topk_clses"], d["topk_ys"], d["topk_xs"] = ts, ti, tc, ty, tx
+    d["tg_feat"] = net._transpose_and_gather_feat(wh, ti)
+    net.nms_per_class, net.nms_type = True, 'nms'
+    bbox = net.transform_bbox(hm, wh.clamp(min=1.0) * 3, off, k)[0]
+    d["nms_in"], d["nms_out"] = bbox, net.nms(bbox)
+    net.nms_type = 'soft_nms'
+    d["softnms_out"] = net.nms(bbox)
+    save("helpers.npz", d)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     for name, fn in (("g2", g2_decode), ("g3", g3_losses), ("g4", g4_blocks), ("g5", g5_ctnet_tiny),
                      ("g6", g6_stage2), ("g7", g7_extnms), ("g8", g8_rrnet_tiny), ("g9", g9_targets),
-                     ("g10", g10_metrics)):
+                     ("g10", g10_metrics), ("g11", g11_helpers)):
         if not only or name in only:
             fn()
