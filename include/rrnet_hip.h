@@ -296,6 +296,24 @@ int rr_dcn_col2im(const float *x, const float *offset, const float *mask, const 
                   float *doffset, float *dmask, int n, int h, int wd, int c, int r, int s, int stride, int pad_h,
                   int pad_w, int dilation, int deformable_groups, hipStream_t stream);
 
+/* Fused backward (no column buffers): rr_dcn_wgrad adds dY^T x (deformed columns produced in registers) into dw
+ * (float atomics; dw pre-zeroed or holding the running gradient); rr_dcn_dgrad keeps the column gradient in the MFMA
+ * accumulators and writes dx (zeroed inside, float atomics on the bilinear corners), doffset and dmask (plain stores).
+ * Replace ext/dcn/src/cuda/dcn_v2_cuda.cu:206-335 + dcn_v2_im2col_cuda.cu:197-327.  Require k % 4 == 0 and
+ * (dg == 1 or (c/dg) % 128 == 0); the host layer takes the column path above otherwise. */
+int rr_dcn_wgrad(const float *x, const float *offset, const float *mask, const float *dy, float *dw, int n, int h,
+                 int wd, int c, int k, int r, int s, int stride, int pad_h, int pad_w, int dilation,
+                 int deformable_groups, hipStream_t stream);
+int rr_dcn_dgrad(const float *x, const float *offset, const float *mask, const float *w, const float *dy, float *dx,
+                 float *doffset, float *dmask, int n, int h, int wd, int c, int k, int r, int s, int stride, int pad_h,
+                 int pad_w, int dilation, int deformable_groups, hipStream_t stream);
+
+/* DCN module glue (ext/dcn/dcn_v2.py:117-121): om NHWC [m, 3*third] -> offset [m, 2*third] (first two thirds,
+ * unchanged = cat(o1, o2)) and mask [m, third] = sigmoid(last third); backward: dom from doffset, dmask and mask. */
+int rr_dcn_split_fwd(const float *om, long m, int third, float *offset, float *mask, hipStream_t stream);
+int rr_dcn_split_bwd(const float *doffset, const float *dmask, const float *mask, long m, int third, float *dom,
+                     hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

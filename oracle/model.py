@@ -109,15 +109,25 @@ def hourglass_net(P, x, p="backbone"):
     return outs
 
 
+def head_conv3x3(P, key, x):
+    """The heads' first layer: 3x3 conv(+bias), or — builder-defined DCN heads (BASELINE configs[3]) — ext/dcn's
+    `DCN` in its place when the state_dict carries `<key>.conv_offset_mask.*` (oracle/dcn.py:dcn_forward)."""
+    if P.has(key + ".conv_offset_mask.weight"):
+        from oracle import dcn as odcn
+        return odcn.dcn_forward(x, P.sd[key + ".weight"], P.sd[key + ".bias"], P.sd[key + ".conv_offset_mask.weight"],
+                                P.sd[key + ".conv_offset_mask.bias"], 1, 1, 1, 1)
+    return conv(P, key, x, 1, 1)
+
+
 def ctdet_head(P, p, x, i):
     """centernet_detector.py:6-23: 3x3 conv(+bias)+ReLU -> 1x1 conv(+bias)."""
     q = "%s.detect_layer.%d" % (p, i)
-    return conv(P, q + ".1", F.relu(conv(P, q + ".0.conv", x, 1, 1)))
+    return conv(P, q + ".1", F.relu(head_conv3x3(P, q + ".0.conv", x)))
 
 
 def wh_head(P, p, x, i):
     """centernet_detector.py:26-55: 3x3 conv+ReLU -> 17x1 (H) and 1x17 (W) convs, interleaved [W,H]."""
-    c = F.relu(conv(P, "%s.detect_conv_layer.%d.0.conv" % (p, i), x, 1, 1))
+    c = F.relu(head_conv3x3(P, "%s.detect_conv_layer.%d.0.conv" % (p, i), x))
     h = conv(P, "%s.detect_H_layer.%d.0.conv" % (p, i), c, 1, (8, 0))
     w = conv(P, "%s.detect_W_layer.%d.0.conv" % (p, i), c, 1, (0, 8))
     h = h.view(h.size(0), -1, 1, h.size(2), h.size(3))

@@ -447,6 +447,413 @@ __global__ __launch_bounds__(256) void dcn_col2im_kernel(const DcnArgs a, const 
     }
 }
 
+// ---- fused backward ---------------------------------------------------------------------------------------------
+// The reference materialises the columns twice (dcn_v2_cuda.cu:206-335: im2col -> GEMM for dW; GEMM -> column
+// gradient -> col2im / col2im_coord): 2 x 4.8 GB written and read at the config-4 layer.  Here neither buffer exists:
+//   dcn_wgrad_kernel: dW[ko][tap][c] += sum_m dY[m][ko] * col[m][tap,c] with the column tile produced in registers
+//                     from the four bilinear corners on its way into LDS (the forward's A-operand load, as B operand);
+//   dcn_dgrad_kernel: per 128-pixel tile and tap, dcol[m][c] = sum_ko dY[m][ko] W[ko][tap][c] stays in the MFMA
+//                     accumulators, goes through LDS once, and the epilogue turns it into d input (float atomics on
+//                     the four corners), d offset and d mask (reduced over the channels in registers / LDS, stored
+//                     once: no atomics, no memset for those two).
+struct DcnBwdArgs {
+    DcnArgs a;          // a.y unused
+    const float *dy;    // [M][K]
+    float *dw;          // [K][R][S][C], accumulated with float atomics
+    float *dx, *doffset, *dmask;
+    int chunks_per_split, mt, nt;
+    int dbg;            // experiments only (RR_DCN_DBG): 1 no atomics, 2 no corner loads, 3 no epilogue
+};
+
+__device__ __forceinline__ int dcn_xcd_remap(int bid, int nb)
+{
+    const int q = nb >> 3, r = nb & 7, xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+__global__ __launch_bounds__(256, 2) void dcn_wgrad_kernel(const DcnBwdArgs b)
+{
+    const DcnArgs &a = b.a;
+    constexpr int BMW = 128, BN = 128, TM = 2, TN = 2, WN = 2;
+    constexpr int A_ELEMS = BK * BMW, B_ELEMS = BK * BN;
+    extern __shared__ __align__(16) float lds[];
+    float *As = lds, *Bs = lds + 2 * A_ELEMS;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave / WN, wn = wave % WN;
+    const int RS = a.R * a.S;
+    int logical = dcn_xcd_remap(blockIdx.x, gridDim.x);
+    const int tap = logical % RS; logical /= RS;
+    const int n_tile = logical % b.nt; logical /= b.nt;
+    const int m_tile = logical % b.mt;
+    const int split = logical / b.mt;
+    const int ti = tap / a.S, tj = tap - ti * a.S;
+    const int ko0 = m_tile * BMW, c0 = n_tile * BN;
+    const int total_chunks = (a.M + BK - 1) / BK;
+    const int kc_begin = split * b.chunks_per_split;
+    int kc_end = kc_begin + b.chunks_per_split;
+    if (kc_end > total_chunks) kc_end = total_chunks;
+    if (kc_begin >= kc_end) return;
+    const int g = c0 / (a.C / a.dg);                  // one deformable group per channel tile (checked by the host)
+
+    const int row = t >> 5, col4 = (t & 31) * 4;      // 8 pixel rows per pass, 4 passes; 4 ko / 4 channels per thread
+    const bool ko_ok = ko0 + col4 < a.K, c_ok = c0 + col4 < a.C;
+    // Register budget (two workgroups per CU need <= 256 VGPR + AGPR per lane): the column rows of a K-step are
+    // fetched in two halves (rows 0-1 under the first 8 MFMA steps, rows 2-3 under the last 8), so only 2 x 4 corner
+    // vectors are in flight at a time.
+    f32x4 ra[4], rv[2][4];
+    float rw[2][4];
+    float om[4][3];                                   // (dh, dw, mask) of the rows of the K-step after next
+    const int pq = a.P * a.Q;
+
+    auto load_om = [&](int kc) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long m = (long)kc * BK + row + 8 * j;
+            if (kc < kc_end && m < a.M) {
+                const float *po = a.offset + m * (2 * a.dg * RS) + g * 2 * RS + 2 * tap;
+                om[j][0] = po[0]; om[j][1] = po[1];
+                om[j][2] = a.mask[m * (a.dg * RS) + g * RS + tap];
+            } else {
+                om[j][0] = 0.f; om[j][1] = 0.f; om[j][2] = 0.f;
+            }
+        }
+    };
+    auto issue_a = [&](int kc) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long m = (long)kc * BK + row + 8 * j;
+            ra[j] = *reinterpret_cast<const f32x4 *>(m < a.M && ko_ok ? b.dy + m * a.K + ko0 + col4 : a.zero);
+        }
+    };
+    auto issue_b = [&](int kc, int half) {            // the four corners of rows 2*half, 2*half+1
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int j = 2 * half + jj;
+            const long m = (long)kc * BK + row + 8 * j;
+            Tap4 tp;
+            if (m < a.M) {
+                const int n = (int)(m / pq), rem = (int)(m - (long)n * pq), p = rem / a.Q, q = rem - p * a.Q;
+                tp = make_tap(a, n, p, q, ti, tj, om[j][0], om[j][1], om[j][2]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { tp.o[e] = -1; tp.w[e] = 0.f; }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                rv[jj][e] = *reinterpret_cast<const f32x4 *>(tp.o[e] >= 0 && c_ok ? a.x + tp.o[e] + c0 + col4 : a.zero);
+                rw[jj][e] = tp.w[e];
+            }
+        }
+    };
+    auto commit_a = [&](int buf) {
+        float *A = As + buf * A_ELEMS;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4 *>(A + (row + 8 * j) * BMW + col4) = ra[j];
+    };
+    auto commit_b = [&](int buf, int half) {
+        float *B = Bs + buf * B_ELEMS;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const f32x4 v = rv[jj][0] * rw[jj][0] + rv[jj][1] * rw[jj][1] + rv[jj][2] * rw[jj][2] + rv[jj][3] * rw[jj][3];
+            *reinterpret_cast<f32x4 *>(B + (row + 8 * (2 * half + jj)) * BN + col4) = v;
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    const int lr = lane & 31, lh = lane >> 5;
+    auto mma = [&](int buf, int k2lo) {
+        const float *A = As + buf * A_ELEMS, *B = Bs + buf * B_ELEMS;
+#pragma unroll
+        for (int k2 = k2lo; k2 < k2lo + BK / 4; ++k2) {
+            const int kr = 2 * k2 + lh;
+            float fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = A[kr * BMW + (wm * TM + i) * 32 + lr];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = B[kr * BN + (wn * TN + j) * 32 + lr];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    load_om(kc_begin);
+    issue_a(kc_begin);
+    issue_b(kc_begin, 0);
+    commit_b(0, 0);
+    issue_b(kc_begin, 1);
+    commit_b(0, 1);
+    commit_a(0);
+    load_om(kc_begin + 1);
+    __syncthreads();
+    for (int kc = kc_begin; kc < kc_end; ++kc) {
+        const int buf = (kc - kc_begin) & 1;
+        const bool more = kc + 1 < kc_end;
+        if (more) {
+            issue_a(kc + 1);
+            issue_b(kc + 1, 0);                       // geometry from the (dh, dw, mask) fetched one iteration ago
+        }
+        mma(buf, 0);
+        if (more) {
+            commit_b(buf ^ 1, 0);
+            issue_b(kc + 1, 1);
+        }
+        mma(buf, BK / 4);
+        if (more) {
+            commit_b(buf ^ 1, 1);
+            commit_a(buf ^ 1);
+            load_om(kc + 2);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int c = c0 + (wn * TN + j) * 32 + lr;
+        if (c >= a.C) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int ko = ko0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (ko < a.K) unsafeAtomicAdd(b.dw + ((long)ko * RS + tap) * a.C + c, acc[i][j][e]);
+            }
+    }
+}
+
+__global__ __launch_bounds__(256) void dcn_dgrad_kernel(const DcnBwdArgs b)
+{
+    const DcnArgs &a = b.a;
+    constexpr int BN = 128, TM = 2, TN = 2, WN = 2, SST = 132;
+    constexpr int A_ELEMS = BM * LDK, B_ELEMS = BK * BN;
+    extern __shared__ __align__(16) float lds[];
+    float *As = lds, *Bs = lds + 2 * A_ELEMS;
+    float *stage = lds;                                // [BM][SST], aliases the GEMM tiles between two K loops
+    float *geo_w = lds + 2 * A_ELEMS + 2 * B_ELEMS;    // [BM][8]: wt0..3 * 1, lh, lw, mask, unused
+    int *geo_o = reinterpret_cast<int *>(geo_w + BM * 8);   // [BM][4] corner pixel index or -1
+    float *red = reinterpret_cast<float *>(geo_o + BM * 4); // [BM][3] d mask, d offset h, d offset w
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave / WN, wn = wave % WN;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int RS = a.R * a.S;
+    const int m0 = dcn_xcd_remap(blockIdx.x, gridDim.x) * BM;
+    const int a_col = (t & 7) * 4, a_row = t >> 3;     // A: 32 pixel rows per pass x 32 ko
+    const int b_row = t >> 5, b_col = (t & 31) * 4;    // B: 8 ko rows per pass x 128 channels
+    const int nkc = (a.K + BK - 1) / BK;
+    const int nct = (a.C + BN - 1) / BN;
+    const int cpg = a.C / a.dg;
+    const int pq = a.P * a.Q;
+    f32x4 ra[4], rb[4];
+
+    for (int tap = 0; tap < RS; ++tap) {
+        const int ti = tap / a.S, tj = tap - ti * a.S;
+        for (int ct = 0; ct < nct; ++ct) {
+            const int c0 = ct * BN;
+            const int g = c0 / cpg;
+            if (ct == 0 || a.dg > 1) {                 // sample geometry of the tile's pixels for this tap (and group)
+                __syncthreads();
+                if (t < BM) {
+                    const long m = (long)m0 + t;
+                    int o[4] = {-1, -1, -1, -1};
+                    float w4[4] = {0.f, 0.f, 0.f, 0.f}, flh = 0.f, flw = 0.f, mk = 0.f;
+                    if (m < a.M) {
+                        const int n = (int)(m / pq), rem = (int)(m - (long)n * pq), p = rem / a.Q, q = rem - p * a.Q;
+                        const float *po = a.offset + m * (2 * a.dg * RS) + g * 2 * RS + 2 * tap;
+                        mk = a.mask[m * (a.dg * RS) + g * RS + tap];
+                        const float h = (float)(p * a.stride - a.pad_h + ti * a.dil) + po[0];
+                        const float w = (float)(q * a.stride - a.pad_w + tj * a.dil) + po[1];
+                        const bool inside = h > -1.f && w > -1.f && h < (float)a.H && w < (float)a.W;
+                        const float hf = floorf(h), wf = floorf(w);
+                        const int h0 = (int)hf, w0 = (int)wf, h1 = h0 + 1, w1 = w0 + 1;
+                        flh = h - hf; flw = w - wf;
+                        const float hh = 1.f - flh, hw = 1.f - flw;
+                        const int base = n * a.H * a.W;
+                        if (inside && h0 >= 0 && w0 >= 0) { o[0] = base + h0 * a.W + w0; w4[0] = hh * hw; }
+                        if (inside && h0 >= 0 && w1 <= a.W - 1) { o[1] = base + h0 * a.W + w1; w4[1] = hh * flw; }
+                        if (inside && h1 <= a.H - 1 && w0 >= 0) { o[2] = base + h1 * a.W + w0; w4[2] = flh * hw; }
+                        if (inside && h1 <= a.H - 1 && w1 <= a.W - 1) { o[3] = base + h1 * a.W + w1; w4[3] = flh * flw; }
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { geo_o[t * 4 + e] = o[e]; geo_w[t * 8 + e] = w4[e]; }
+                    geo_w[t * 8 + 4] = flh; geo_w[t * 8 + 5] = flw; geo_w[t * 8 + 6] = mk;
+                    if (ct == 0) { red[t * 3] = 0.f; red[t * 3 + 1] = 0.f; red[t * 3 + 2] = 0.f; }
+                }
+                __syncthreads();
+            }
+            // ---- dcol tile = dY[m0.., :] x W[:, tap, c0..]
+            auto issue = [&](int kc) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const long m = (long)m0 + a_row + 32 * j;
+                    const int ko = kc * BK + a_col;
+                    ra[j] = *reinterpret_cast<const f32x4 *>(m < a.M && ko < a.K ? b.dy + m * a.K + ko : a.zero);
+                    const int kb = kc * BK + b_row + 8 * j;
+                    rb[j] = *reinterpret_cast<const f32x4 *>(kb < a.K && c0 + b_col < a.C
+                                                                 ? a.w + ((long)kb * RS + tap) * a.C + c0 + b_col : a.zero);
+                }
+            };
+            auto commit = [&](int buf) {
+                float *A = As + buf * A_ELEMS, *B = Bs + buf * B_ELEMS;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    *reinterpret_cast<f32x4 *>(A + (a_row + 32 * j) * LDK + a_col) = ra[j];
+                    *reinterpret_cast<f32x4 *>(B + (b_row + 8 * j) * BN + b_col) = rb[j];
+                }
+            };
+            f32x16 acc[TM][TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+            issue(0);
+            commit(0);
+            __syncthreads();
+            for (int kc = 0; kc < nkc; ++kc) {
+                const int buf = kc & 1;
+                if (kc + 1 < nkc) issue(kc + 1);
+                const float *A = As + buf * A_ELEMS, *B = Bs + buf * B_ELEMS;
+#pragma unroll
+                for (int kk = 0; kk < BK / 8; ++kk) {
+                    f32x4 fa[TM];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+                        fa[i] = *reinterpret_cast<const f32x4 *>(A + ((wm * TM + i) * 32 + lr) * LDK + kk * 8 + lh * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float fb[TN];
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) fb[j] = B[(kk * 8 + lh * 4 + e) * BN + (wn * TN + j) * 32 + lr];
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int j = 0; j < TN; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j], acc[i][j], 0, 0, 0);
+                    }
+                }
+                if (kc + 1 < nkc) commit(buf ^ 1);
+                __syncthreads();
+            }
+            // ---- epilogue: accumulators -> LDS -> (pixel, channel) threads
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        stage[((wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * SST + (wn * TN + j) * 32 + lr] = acc[i][j][e];
+            __syncthreads();
+            // 16 passes of 8 pixel rows; a thread owns channels l32 + 32 i of its row.  The corner values of pass p+1
+            // are fetched before pass p is processed (the passes are latency-bound gathers otherwise).
+            const int r8 = t >> 5, l32 = t & 31;
+            struct PassRegs { int o[4]; float w[4], flh, flw, mk; float xv[4][4]; };
+            auto fetch = [&](int pass, PassRegs &R) {
+                const int ml = pass * 8 + r8;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { R.o[e] = geo_o[ml * 4 + e]; R.w[e] = geo_w[ml * 8 + e]; }
+                R.flh = geo_w[ml * 8 + 4]; R.flw = geo_w[ml * 8 + 5]; R.mk = geo_w[ml * 8 + 6];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int c = c0 + l32 + 32 * i;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        R.xv[e][i] = (R.o[e] >= 0 && c < a.C && !(b.dbg & 2)) ? a.x[(long)R.o[e] * a.C + c] : 0.f;
+                }
+            };
+            auto process = [&](int pass, const PassRegs &R) {
+                const int ml = pass * 8 + r8;
+                const float hh = 1.f - R.flh, hw = 1.f - R.flw;
+                const float dhw[4] = {-hw, -R.flw, hw, R.flw};      // d weight / d h of the four corners
+                const float dww[4] = {-hh, hh, -R.flh, R.flh};      // d weight / d w
+                float s_m = 0.f, s_h = 0.f, s_w = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int c = c0 + l32 + 32 * i;
+                    const float gcol = stage[ml * SST + l32 + 32 * i];
+                    const float gval = gcol * R.mk;
+                    float val = 0.f, gh = 0.f, gw = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float xv = R.xv[e][i];                // 0 for an invalid corner
+                        val += R.w[e] * xv;
+                        gh += dhw[e] * xv;
+                        gw += dww[e] * xv;
+                        if (R.o[e] >= 0 && c < a.C && !(b.dbg & 1)) unsafeAtomicAdd(b.dx + (long)R.o[e] * a.C + c, gval * R.w[e]);
+                    }
+                    s_m += gcol * val;
+                    s_h += gval * gh;
+                    s_w += gval * gw;
+                }
+#pragma unroll
+                for (int off = 16; off > 0; off >>= 1) {
+                    s_m += __shfl_xor(s_m, off, 64);
+                    s_h += __shfl_xor(s_h, off, 64);
+                    s_w += __shfl_xor(s_w, off, 64);
+                }
+                if (l32 == 0) { red[ml * 3] += s_m; red[ml * 3 + 1] += s_h; red[ml * 3 + 2] += s_w; }
+            };
+            PassRegs R0, R1;
+            fetch(0, R0);
+            for (int pass = 0; pass < ((b.dbg & 4) ? 0 : BM / 8); pass += 2) {
+                fetch(pass + 1, R1);
+                process(pass, R0);
+                if (pass + 2 < BM / 8) fetch(pass + 2, R0);
+                process(pass + 1, R1);
+            }
+            __syncthreads();
+            if ((ct == nct - 1 || a.dg > 1) && t < BM && (long)m0 + t < a.M) {
+                // all channels of the group are in: store (dg > 1: one group per channel tile, cpg == BN multiples)
+                const bool last_of_group = ((c0 + BN) % cpg) == 0 || ct == nct - 1;
+                if (last_of_group) {
+                    const long m = (long)m0 + t;
+                    b.dmask[m * (a.dg * RS) + g * RS + tap] = red[t * 3];
+                    b.doffset[m * (2 * a.dg * RS) + g * 2 * RS + 2 * tap] = red[t * 3 + 1];
+                    b.doffset[m * (2 * a.dg * RS) + g * 2 * RS + 2 * tap + 1] = red[t * 3 + 2];
+                    red[t * 3] = 0.f; red[t * 3 + 1] = 0.f; red[t * 3 + 2] = 0.f;
+                }
+            }
+        }
+    }
+}
+
+// ---- DCN module glue (ext/dcn/dcn_v2.py:117-121): the offset/mask convolution's 3*dg*R*S output channels are
+// chunked in three; offset = cat(o1, o2) = the first two thirds unchanged, mask = sigmoid(last third).  One pass
+// instead of torch.chunk + cat + sigmoid (two copies and an elementwise kernel); backward likewise.
+__global__ void dcn_split_fwd_kernel(const float *om, long M, int third, float *offset, float *mask)
+{
+    const int ch = 3 * third;
+    const long total = M * ch;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long m = i / ch;
+        const int c = (int)(i - m * ch);
+        const float v = om[i];
+        if (c < 2 * third) offset[m * 2 * third + c] = v;
+        else mask[m * third + (c - 2 * third)] = 1.f / (1.f + expf(-v));
+    }
+}
+__global__ void dcn_split_bwd_kernel(const float *doffset, const float *dmask, const float *mask, long M, int third, float *dom)
+{
+    const int ch = 3 * third;
+    const long total = M * ch;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long m = i / ch;
+        const int c = (int)(i - m * ch);
+        if (c < 2 * third) {
+            dom[i] = doffset[m * 2 * third + c];
+        } else {
+            const float s = mask[m * third + (c - 2 * third)];
+            dom[i] = dmask[m * third + (c - 2 * third)] * s * (1.f - s);
+        }
+    }
+}
+
 __device__ float rr_dcn_zero16[4] = {0.f, 0.f, 0.f, 0.f};
 
 int fill_args(DcnArgs &a, const float *x, const float *offset, const float *mask, const float *w, int n, int h, int wd,
@@ -550,5 +957,78 @@ extern "C" int rr_dcn_col2im(const float *x, const float *offset, const float *m
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(dcn_col2im_kernel, dim3((int)blocks), dim3(256), 0, stream, a, dcol, dx, doffset, dmask);
     RR_CHECK_LAUNCH("rr_dcn_col2im");
+    return RR_OK;
+}
+
+// Fused backward, part 1: weight gradient.  dw [K][R][S][C] += dY^T x deformed columns (float atomics; pre-zeroed or
+// holding the running gradient).  Requires K % 4 == 0 and one deformable group per 128-channel tile.
+extern "C" int rr_dcn_wgrad(const float *x, const float *offset, const float *mask, const float *dy, float *dw, int n, int h,
+                            int wd, int c, int k, int r, int s, int stride, int pad_h, int pad_w, int dilation,
+                            int deformable_groups, hipStream_t stream)
+{
+    DcnBwdArgs b{};
+    const int rc = fill_args(b.a, x, offset, mask, nullptr, n, h, wd, c, k, r, s, stride, pad_h, pad_w, dilation, deformable_groups);
+    if (rc != RR_OK) return rc;
+    RR_CHECK_ARG(k % 4 == 0, "rr_dcn_wgrad: K=%d must be a multiple of 4", k);
+    RR_CHECK_ARG(deformable_groups == 1 || (c / deformable_groups) % 128 == 0,
+                 "rr_dcn_wgrad: channels per deformable group (%d) must be a multiple of 128", c / deformable_groups);
+    b.dy = dy; b.dw = dw;
+    b.mt = rr_cdiv(k, 128); b.nt = rr_cdiv(c, 128);
+    const int tiles = b.mt * b.nt * r * s;
+    const int total_chunks = rr_cdiv(b.a.M, BK);
+    int splits = tiles < 512 ? 512 / tiles : 1;
+    if (splits > rr_cdiv(total_chunks, 8)) splits = rr_cdiv(total_chunks, 8);
+    if (splits < 1) splits = 1;
+    b.chunks_per_split = rr_cdiv(total_chunks, splits);
+    splits = rr_cdiv(total_chunks, b.chunks_per_split);
+    const size_t lds = sizeof(float) * 2 * (BK * 128 + BK * 128);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(dcn_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(dcn_wgrad_kernel, dim3(tiles * splits), dim3(256), lds, stream, b);
+    RR_CHECK_LAUNCH("rr_dcn_wgrad");
+    return RR_OK;
+}
+
+// Fused backward, part 2: dx (zeroed here, then float atomics on the bilinear corners), doffset, dmask (plain stores).
+extern "C" int rr_dcn_dgrad(const float *x, const float *offset, const float *mask, const float *w, const float *dy,
+                            float *dx, float *doffset, float *dmask, int n, int h, int wd, int c, int k, int r, int s,
+                            int stride, int pad_h, int pad_w, int dilation, int deformable_groups, hipStream_t stream)
+{
+    DcnBwdArgs b{};
+    const int rc = fill_args(b.a, x, offset, mask, w, n, h, wd, c, k, r, s, stride, pad_h, pad_w, dilation, deformable_groups);
+    if (rc != RR_OK) return rc;
+    RR_CHECK_ARG(k % 4 == 0, "rr_dcn_dgrad: K=%d must be a multiple of 4", k);
+    RR_CHECK_ARG(deformable_groups == 1 || (c / deformable_groups) % 128 == 0,
+                 "rr_dcn_dgrad: channels per deformable group (%d) must be a multiple of 128", c / deformable_groups);
+    RR_CHECK_ARG((long)n * h * wd < (1l << 31), "rr_dcn_dgrad: input too large");
+    b.dy = dy; b.dx = dx; b.doffset = doffset; b.dmask = dmask;
+    { const char *e = getenv("RR_DCN_DBG"); b.dbg = e ? atoi(e) : 0; }
+    hipMemsetAsync(dx, 0, sizeof(float) * (size_t)n * h * wd * c, stream);
+    const size_t lds = sizeof(float) * (2 * (BM * LDK + BK * 128) + BM * 8 + BM * 4 + BM * 3);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(dcn_dgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(dcn_dgrad_kernel, dim3(rr_cdiv(b.a.M, BM)), dim3(256), lds, stream, b);
+    RR_CHECK_LAUNCH("rr_dcn_dgrad");
+    return RR_OK;
+}
+
+extern "C" int rr_dcn_split_fwd(const float *om, long m, int third, float *offset, float *mask, hipStream_t stream)
+{
+    RR_CHECK_ARG(m >= 0 && third > 0, "rr_dcn_split_fwd: bad dims");
+    if (m == 0) return RR_OK;
+    long blocks = (m * 3 * third + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(dcn_split_fwd_kernel, dim3((int)blocks), dim3(256), 0, stream, om, m, third, offset, mask);
+    RR_CHECK_LAUNCH("rr_dcn_split_fwd");
+    return RR_OK;
+}
+
+extern "C" int rr_dcn_split_bwd(const float *doffset, const float *dmask, const float *mask, long m, int third, float *dom,
+                                hipStream_t stream)
+{
+    RR_CHECK_ARG(m >= 0 && third > 0, "rr_dcn_split_bwd: bad dims");
+    if (m == 0) return RR_OK;
+    long blocks = (m * 3 * third + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(dcn_split_bwd_kernel, dim3((int)blocks), dim3(256), 0, stream, doffset, dmask, mask, m, third, dom);
+    RR_CHECK_LAUNCH("rr_dcn_split_bwd");
     return RR_OK;
 }

@@ -21,6 +21,23 @@ class BasicCov(nn.Module):
         return RF.conv_bn_act(x, self.conv, self.bn, relu=True)
 
 
+class DCNCov(nn.Module):
+    """Builder-defined (BASELINE configs[3], "RRNet + ext/dcn deformable-conv heads"; the reference wires DCN into no
+    RRNet head): BasicCov(3, ., ., with_bn=False) with its 3x3 convolution replaced by ext/dcn's `DCN` (modulated
+    deformable conv whose offsets / masks come from a zero-initialised 3x3 conv), then ReLU.  `bf16`: bf16 matrix
+    operands in the deformable conv's forward (fp32 accumulation)."""
+
+    def __init__(self, inp_dim, out_dim, bf16=False):
+        super().__init__()
+        from rrnet_amd.ext.dcn.dcn_v2 import DCN
+        self.conv = DCN(inp_dim, out_dim, 3, stride=1, padding=1)
+        self.conv.bf16 = bool(bf16)
+        self.relu = nn.ReLU(inplace=True)
+
+    def forward(self, x):
+        return RF.relu(self.conv(x))
+
+
 class HCov(nn.Module):
     """k x 1 convolution (a column of k taps)."""
 
@@ -43,13 +60,17 @@ class WCov(nn.Module):
         return RF.conv_bias(x, self.conv)
 
 
+def _head_conv(dcn, bf16):
+    return DCNCov(256, 256, bf16=bf16) if dcn else BasicCov(3, 256, 256, with_bn=False)
+
+
 class CenterNetDetector(nn.Module):
-    def __init__(self, planes, hm=True, num_stacks=2):
+    def __init__(self, planes, hm=True, num_stacks=2, dcn=False, dcn_bf16=False):
         super().__init__()
         self.hm = hm
         self.num_stacks = num_stacks
         self.detect_layer = nn.ModuleList([
-            nn.Sequential(BasicCov(3, 256, 256, with_bn=False), nn.Conv2d(256, planes, (1, 1)))
+            nn.Sequential(_head_conv(dcn, dcn_bf16), nn.Conv2d(256, planes, (1, 1)))
             for _ in range(num_stacks)])
         if self.hm:
             for head in self.detect_layer:
@@ -61,11 +82,11 @@ class CenterNetDetector(nn.Module):
 
 
 class CenterNetWHDetector(nn.Module):
-    def __init__(self, planes, hm=True, num_stacks=2):
+    def __init__(self, planes, hm=True, num_stacks=2, dcn=False, dcn_bf16=False):
         super().__init__()
         self.hm = hm
         self.num_stacks = num_stacks
-        self.detect_conv_layer = nn.ModuleList([nn.Sequential(BasicCov(3, 256, 256, with_bn=False))
+        self.detect_conv_layer = nn.ModuleList([nn.Sequential(_head_conv(dcn, dcn_bf16))
                                                 for _ in range(num_stacks)])
         self.detect_H_layer = nn.ModuleList([nn.Sequential(HCov(17, 256, planes, with_bn=False))
                                              for _ in range(num_stacks)])

@@ -24,6 +24,7 @@ class DCNv2(nn.Module):
         self.padding = _pair(padding)
         self.dilation = _pair(dilation)
         self.deformable_groups = deformable_groups
+        self.bf16 = None      # extension: True/False selects bf16 / fp32 matrix operands; None = RR_DCN_BF16
         self.weight = nn.Parameter(torch.Tensor(out_channels, in_channels, *self.kernel_size))
         self.bias = nn.Parameter(torch.Tensor(out_channels))
         self.reset_parameters()
@@ -40,7 +41,7 @@ class DCNv2(nn.Module):
         assert 2 * self.deformable_groups * self.kernel_size[0] * self.kernel_size[1] == offset.shape[1]
         assert self.deformable_groups * self.kernel_size[0] * self.kernel_size[1] == mask.shape[1]
         return dcn_v2_conv(input, offset, mask, self.weight, self.bias, self.stride, self.padding, self.dilation,
-                           self.deformable_groups)
+                           self.deformable_groups, bf16=self.bf16)
 
 
 class DCN(DCNv2):
@@ -56,9 +57,10 @@ class DCN(DCNv2):
         self.conv_offset_mask.bias.data.zero_()
 
     def forward(self, input):
-        out = RF.conv_bias(input, self.conv_offset_mask)          # the offset / mask conv runs on the MFMA conv kernels
-        o1, o2, mask = torch.chunk(out, 3, dim=1)
-        offset = torch.cat((o1, o2), dim=1)
-        mask = torch.sigmoid(mask)
-        return dcn_v2_conv(input, offset, mask, self.weight, self.bias, self.stride, self.padding, self.dilation,
-                           self.deformable_groups)
+        # `input` has two consumers here (the offset/mask conv and the deformable conv): plain fan-out views, so that a
+        # shared gradient accumulator tagged on `input` by an outer fan-out is not mistaken for a single-consumer tag
+        xa, xb = RF.fanout(input, 2)
+        out = RF.conv_bias(xa, self.conv_offset_mask)             # the offset / mask conv runs on the MFMA conv kernels
+        offset, mask = RF.dcn_offset_mask(out)                    # chunk(3) + cat(o1, o2) + sigmoid(mask): one kernel
+        return dcn_v2_conv(xb, offset, mask, self.weight, self.bias, self.stride, self.padding, self.dilation,
+                           self.deformable_groups, bf16=self.bf16)

@@ -504,21 +504,36 @@ class _DCNv2(torch.autograd.Function):
         weight, bias = ctx.params
         dy = ops.to_nhwc(dy)
         k, c, r, s = w.shape
-        mtot = dy.shape[0] * dy.shape[2] * dy.shape[3]
-        dy1 = dy.permute(0, 2, 3, 1).reshape(1, mtot, 1, k).permute(0, 3, 1, 2)            # [1,k,M,1] view
-        w1 = w.permute(0, 2, 3, 1).reshape(k, 1, 1, r * s * c).permute(0, 3, 1, 2)          # [k, r*s*c, 1, 1] view
-        # weight gradient: columns (materialised, as in the reference) x dy
-        col = ops.dcn_im2col(x, off, m, r, s, stride, pad, dil, dg)
         w_t = _grad_target(weight)
         dw = w_t if w_t is not None else ops.zeros_nhwc(*weight.shape, device=x.device)
-        dw1 = dw.permute(0, 2, 3, 1).reshape(k, 1, 1, r * s * c).permute(0, 3, 1, 2)
-        ops.conv_wgrad(col, dy1, dw1, 1, (0, 0))
+        if DCN_FUSED_BWD and k % 4 == 0 and (dg == 1 or (c // dg) % 128 == 0):
+            # fused: the columns live in registers / LDS inside the two GEMM kernels (csrc/dcn.hip).  The two kernels
+            # are independent and bound by different things (wgrad: corner gather + MFMA; dgrad: the float atomics of
+            # d input at the memory side), so they run concurrently on two HIP streams.
+            cur = torch.cuda.current_stream()
+            side = _side_stream(x.device) if DCN_BWD_STREAMS else None
+            if side is not None:
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    ops.dcn_wgrad(x, off, m, dy, dw, stride, pad, dil, dg)
+            else:
+                ops.dcn_wgrad(x, off, m, dy, dw, stride, pad, dil, dg)
+            dx, doff, dmask = ops.dcn_dgrad(x, off, m, w, dy, stride, pad, dil, dg)
+            if side is not None:
+                cur.wait_stream(side)
+        else:
+            # column path (the reference's structure): columns and their gradient materialised, GEMMs on the conv kernels
+            mtot = dy.shape[0] * dy.shape[2] * dy.shape[3]
+            dy1 = dy.permute(0, 2, 3, 1).reshape(1, mtot, 1, k).permute(0, 3, 1, 2)            # [1,k,M,1] view
+            w1 = w.permute(0, 2, 3, 1).reshape(k, 1, 1, r * s * c).permute(0, 3, 1, 2)          # [k, r*s*c, 1, 1] view
+            col = ops.dcn_im2col(x, off, m, r, s, stride, pad, dil, dg)
+            dw1 = dw.permute(0, 2, 3, 1).reshape(k, 1, 1, r * s * c).permute(0, 3, 1, 2)
+            ops.conv_wgrad(col, dy1, dw1, 1, (0, 0))
+            del col
+            dcol = ops.conv_dgrad(dy1, w1, (1, r * s * c, mtot, 1), 1, (0, 0))
+            dx, doff, dmask = ops.dcn_col2im(x, off, m, dcol, r, s, stride, pad, dil, dg)
         if w_t is not None:
             _mark(weight)
-        del col
-        # column gradient, then d input / d offset / d mask
-        dcol = ops.conv_dgrad(dy1, w1, (1, r * s * c, mtot, 1), 1, (0, 0))
-        dx, doff, dmask = ops.dcn_col2im(x, off, m, dcol, r, s, stride, pad, dil, dg)
         db = None
         if bias is not None:
             b_t = _grad_target(bias)
@@ -530,6 +545,42 @@ class _DCNv2(torch.autograd.Function):
         return dx, doff, dmask, (None if w_t is not None else dw), db, None, None, None, None, None
 
 
+class _DCNSplit(torch.autograd.Function):
+    """ext/dcn/dcn_v2.py:117-121: chunk(3) -> offset = cat(o1, o2), mask = sigmoid(o3), as one pass each way."""
+
+    @staticmethod
+    def forward(ctx, om):
+        offset, mask = ops.dcn_split_fwd(ops.to_nhwc(om))
+        ctx.save_for_backward(mask)
+        return offset, mask
+
+    @staticmethod
+    def backward(ctx, doffset, dmask):
+        (mask,) = ctx.saved_tensors
+        if doffset is None:
+            doffset = torch.zeros((mask.shape[0], 2 * mask.shape[1]) + tuple(mask.shape[2:]), device=mask.device)
+        if dmask is None:
+            dmask = torch.zeros_like(mask)
+        return ops.dcn_split_bwd(ops.to_nhwc(doffset), ops.to_nhwc(dmask), mask)
+
+
+def dcn_offset_mask(om):
+    return _DCNSplit.apply(om)
+
+
+_SIDE = {}
+
+
+def _side_stream(device):
+    """One auxiliary HIP stream per device for work that may overlap the current stream."""
+    key = (device.type, device.index)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=device)
+    return _SIDE[key]
+
+
+DCN_BWD_STREAMS = os.environ.get("RR_DCN_BWD_STREAMS", "1") != "0"   # wgrad and dgrad of the fused backward side by side
+DCN_FUSED_BWD = os.environ.get("RR_DCN_FUSED_BWD", "1") != "0"   # 0: the reference's column-buffer structure (A/B switch)
 DCN_BF16 = os.environ.get("RR_DCN_BF16", "0") == "1"   # BASELINE config 4: bf16 matrix operands in the DCN forward
 
 

@@ -56,9 +56,13 @@ class RRNet(nn.Module):
         self.nms_type = cfg.Model.nms_type_for_stage1
         self.nms_per_class = cfg.Model.nms_per_class_for_stage1
         self.backbone = get_backbone(cfg.Model.backbone, num_stacks=self.num_stacks)
-        self.hm = CenterNetDetector(planes=self.num_classes, num_stacks=self.num_stacks, hm=True)
-        self.wh = CenterNetWHDetector(planes=1, num_stacks=self.num_stacks)
-        self.offset_reg = CenterNetDetector(planes=2, num_stacks=self.num_stacks)
+        # builder-defined option (BASELINE configs[3]): the three heads' 3x3 convolutions as ext/dcn DCN layers,
+        # optionally with bf16 matrix operands in their forward
+        dcn = bool(getattr(cfg.Model, "dcn_heads", False))
+        dcn_bf16 = bool(getattr(cfg.Model, "dcn_bf16", False))
+        self.hm = CenterNetDetector(planes=self.num_classes, num_stacks=self.num_stacks, hm=True, dcn=dcn, dcn_bf16=dcn_bf16)
+        self.wh = CenterNetWHDetector(planes=1, num_stacks=self.num_stacks, dcn=dcn, dcn_bf16=dcn_bf16)
+        self.offset_reg = CenterNetDetector(planes=2, num_stacks=self.num_stacks, dcn=dcn, dcn_bf16=dcn_bf16)
         self.head_detector = FasterRCNNDetector()
 
     def forward(self, x, k=1500):

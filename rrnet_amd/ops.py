@@ -616,3 +616,46 @@ def dcn_col2im(x, offset, mask, dcol, r, s, stride, pad, dilation, dg):
                                     _C.ptr(dmask), n, h, wd, c, r, s, stride, pad[0], pad[1], dilation, dg,
                                     _C.stream()), "rr_dcn_col2im")
     return dx, doff, dmask
+
+
+def dcn_wgrad(x, offset, mask, dy, dw, stride, pad, dilation, dg):
+    """dw [K,C,R,S] (OHWI memory, pre-zeroed or the running gradient) += dY^T x deformed columns; no column buffer."""
+    assert is_nhwc(x) and is_nhwc(offset) and is_nhwc(mask) and is_nhwc(dy) and is_nhwc(dw)
+    n, c, h, wd = x.shape
+    k, _, r, s = dw.shape
+    _C.check(_C.fn("rr_dcn_wgrad")(_C.ptr(x), _C.ptr(offset), _C.ptr(mask), _C.ptr(dy), _C.ptr(dw), n, h, wd, c, k, r, s,
+                                   stride, pad[0], pad[1], dilation, dg, _C.stream()), "rr_dcn_wgrad")
+    return dw
+
+
+def dcn_dgrad(x, offset, mask, w, dy, stride, pad, dilation, dg):
+    """-> dx, doffset, dmask; the column gradient never leaves the MFMA accumulators / LDS."""
+    assert is_nhwc(x) and is_nhwc(offset) and is_nhwc(mask) and is_nhwc(dy) and is_nhwc(w)
+    n, c, h, wd = x.shape
+    k, _, r, s = w.shape
+    dx = empty_nhwc(n, c, h, wd, x.device)
+    doff = torch.empty_like(offset)
+    dmask = torch.empty_like(mask)
+    assert doff.stride() == offset.stride() and dmask.stride() == mask.stride()
+    _C.check(_C.fn("rr_dcn_dgrad")(_C.ptr(x), _C.ptr(offset), _C.ptr(mask), _C.ptr(w), _C.ptr(dy), _C.ptr(dx), _C.ptr(doff),
+                                   _C.ptr(dmask), n, h, wd, c, k, r, s, stride, pad[0], pad[1], dilation, dg, _C.stream()),
+             "rr_dcn_dgrad")
+    return dx, doff, dmask
+
+
+def dcn_split_fwd(om):
+    """om [N, 3t, P, Q] (NHWC memory) -> offset [N, 2t, P, Q], mask [N, t, P, Q] = sigmoid(last third)."""
+    assert is_nhwc(om) and om.shape[1] % 3 == 0
+    n, ch, p, q = om.shape
+    t = ch // 3
+    offset, mask = empty_nhwc(n, 2 * t, p, q, om.device), empty_nhwc(n, t, p, q, om.device)
+    _C.check(_C.fn("rr_dcn_split_fwd")(_C.ptr(om), n * p * q, t, _C.ptr(offset), _C.ptr(mask), _C.stream()), "rr_dcn_split_fwd")
+    return offset, mask
+
+
+def dcn_split_bwd(doffset, dmask, mask):
+    n, t, p, q = mask.shape
+    dom = empty_nhwc(n, 3 * t, p, q, mask.device)
+    _C.check(_C.fn("rr_dcn_split_bwd")(_C.ptr(doffset), _C.ptr(dmask), _C.ptr(mask), n * p * q, t, _C.ptr(dom), _C.stream()),
+             "rr_dcn_split_bwd")
+    return dom

@@ -15,6 +15,9 @@ CASES = [
     (2, 64, 10, 10, 40, 3, 2, 1, 1, 2),        # two deformable groups (32 channels each), stride 2
     (1, 16, 8, 8, 8, 3, 1, 2, 2, 1),           # dilation 2
     (1, 256, 6, 6, 256, 3, 1, 1, 1, 1),
+    (2, 256, 20, 24, 256, 3, 1, 1, 1, 1),      # several pixel tiles x 2 channel tiles x 2 filter tiles (fused backward)
+    (1, 128, 17, 15, 132, 3, 2, 1, 1, 1),      # ragged pixel / filter tiles, stride 2
+    (1, 256, 9, 9, 64, 3, 1, 1, 1, 2),         # two deformable groups of 128 channels: fused backward, per-group geometry
 ]
 
 
@@ -46,6 +49,33 @@ def test_dcn_forward_backward_vs_oracle(cfg):
         ra = r.grad.numpy()
         tol = 1e-3 * max(1.0, np.abs(ra).max())
         np.testing.assert_allclose(a.grad.cpu().numpy(), ra, atol=tol, rtol=1e-3, err_msg=name)
+
+
+def test_dcn_fused_backward_equals_column_path():
+    """The fused backward (columns in registers / LDS inside the two GEMM kernels) against the reference-structured
+    column path (im2col -> GEMM, GEMM -> col2im) of the same library on a multi-tile layer: same gradients up to the
+    summation order."""
+    from rrnet_amd import functional as RF
+    g = torch.Generator().manual_seed(21)
+    n, c, h, w, k = 2, 256, 24, 40, 256
+    x = torch.randn(n, c, h, w, generator=g)
+    off = torch.randn(n, 18, h, w, generator=g) * 2.0
+    mask = torch.sigmoid(torch.randn(n, 9, h, w, generator=g))
+    wt = torch.randn(k, c, 3, 3, generator=g) / 48.0
+    gy = torch.randn(n, k, h, w, generator=g).cuda()
+    grads = {}
+    saved = RF.DCN_FUSED_BWD
+    try:
+        for fused in (True, False):
+            RF.DCN_FUSED_BWD = fused
+            ins = [t.cuda().contiguous(memory_format=CL).requires_grad_() for t in (x, off, mask, wt)]
+            RF.dcn_v2_conv(*ins, None, 1, 1, 1, 1).backward(gy)
+            grads[fused] = [t.grad.cpu() for t in ins]
+    finally:
+        RF.DCN_FUSED_BWD = saved
+    for name, a, b in zip(("dx", "doffset", "dmask", "dw"), grads[True], grads[False]):
+        scale = b.abs().max().item()
+        assert (a - b).abs().max().item() <= 2e-4 * scale, (name, (a - b).abs().max().item(), scale)
 
 
 def test_reference_zero_offset_identity_on_hip():
@@ -110,3 +140,102 @@ def test_dcn_forward_bf16_operands(cfg):
     xg = dev[0].clone().requires_grad_()
     dcn_v2_conv(xg, dev[1], dev[2], dev[3], b.cuda(), stride, pad, dil, dg, bf16=True).sum().backward()
     assert torch.isfinite(xg.grad).all()
+
+
+def _dcn_cfg():
+    from types import SimpleNamespace
+    return SimpleNamespace(num_classes=10, Model=SimpleNamespace(num_stacks=2, backbone="hourglass_tiny",
+                           nms_type_for_stage1="nms", nms_per_class_for_stage1=True, dcn_heads=True, dcn_bf16=False),
+                           Train=SimpleNamespace(scale_factor=4))
+
+
+def test_rrnet_with_dcn_heads_vs_oracle_composition():
+    """BASELINE configs[3] at model level (builder-defined option cfg.Model.dcn_heads): RRNet on the tiny backbone with
+    the three heads' 3x3 convolutions replaced by DCN layers whose offset convolutions are NOT zero (real deformation),
+    train mode: stage-1 maps of both stacks, the three stage-1 losses and the gradients of the DCN parameters against
+    the oracle's composition (oracle/model.py:head_conv3x3 -> oracle/dcn.py)."""
+    from oracle import model as om, ops as oo
+    from rrnet_amd import functional as RF
+    from rrnet_amd.datasets.synthetic import synth_batch
+    from rrnet_amd.models.rrnet import RRNet
+    torch.manual_seed(11)
+    model = RRNet(_dcn_cfg())
+    g = torch.Generator().manual_seed(12)
+    for name, p in model.named_parameters():
+        if "conv_offset_mask.weight" in name:
+            p.data.normal_(0, 0.02, generator=g)
+        if "conv_offset_mask.bias" in name:
+            p.data.normal_(0, 0.3, generator=g)
+    for i in range(2):
+        model.wh.detect_H_layer[i][0].conv.bias.data.fill_(3.0)
+        model.wh.detect_W_layer[i][0].conv.bias.data.fill_(3.0)
+    keys = [k for k, _ in model.named_parameters()
+            if ".0.conv." in k and ("detect_layer." in k or "detect_conv_layer." in k)]      # 6 DCN layers x 4 tensors
+    assert any("conv_offset_mask" in k for k in keys) and len(keys) == 24
+    # The gradient check must not depend on discrete decisions that fp32 rounding can flip (a hidden ReLU whose
+    # pre-activation is within rounding of zero, the sign() of the L1 losses): the DCN biases are raised so that every
+    # hidden unit is active, and the gradients are taken of a dense smooth functional of the head outputs.
+    for name, p in model.named_parameters():
+        if name in keys and name.endswith(".0.conv.bias"):
+            p.data.fill_(5.0)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    for k in keys:
+        sd[k].requires_grad_()
+    imgs, annos, hms, whs, inds, offs, masks, _ = synth_batch(2, 128, 128, boxes_per_image=10, seed=3)
+    proj = [torch.randn(2, c, 32, 32, generator=g) for c in (10, 2, 2)]
+    P = om.Params(sd, True)
+    r_hm, r_wh, r_off = om.stage1(P, om.hourglass_net(P, imgs))
+    r_losses = [sum(oo.hm_loss_from_logits(r_hm[i], hms) / 2 for i in range(2)),
+                sum(oo.reg_l1_loss(r_wh[i], masks, inds, whs) / 2 for i in range(2)),
+                sum(oo.reg_l1_loss(r_off[i], masks, inds, offs) / 2 for i in range(2))]
+    sum((o * w).sum() for i in range(2) for o, w in zip((r_hm[i], r_wh[i], r_off[i]), proj)).backward()
+    model = model.cuda().to(memory_format=CL).train()
+    outs = model(imgs.cuda(), k=50)
+    for i in range(2):
+        for a, b in ((outs[0][i], r_hm[i]), (outs[1][i], r_wh[i]), (outs[2][i], r_off[i])):
+            np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().numpy(), atol=1e-3, rtol=1e-3)
+    gt = [t.cuda() for t in (hms, whs, inds, offs, masks)]
+    losses = [sum(RF.focal_loss_hm_from_logits(outs[0][i], gt[0]) / 2 for i in range(2)),
+              sum(RF.reg_l1_loss(outs[1][i], gt[4], gt[2], gt[1]) / 2 for i in range(2)),
+              sum(RF.reg_l1_loss(outs[2][i], gt[4], gt[2], gt[3]) / 2 for i in range(2))]
+    np.testing.assert_allclose([float(l.detach()) for l in losses], [float(l.detach()) for l in r_losses], rtol=1e-3, atol=1e-3)
+    sum((o * w.cuda()).sum() for i in range(2) for o, w in zip((outs[0][i], outs[1][i], outs[2][i]), proj)).backward()
+    named = dict(model.named_parameters())
+    for k in keys:
+        ref = sd[k].grad.numpy()
+        got = named[k].grad.detach().cpu().numpy()
+        scale = max(np.abs(ref).max(), 1e-8)
+        assert np.abs(got - ref).max() <= 2e-3 * scale + 1e-7, (k, np.abs(got - ref).max(), scale)
+
+
+def test_rrnet_with_dcn_heads_train_step_bf16():
+    """Train-step property check of the config-4 model (DCN heads, bf16 matrix operands in the deformable forward):
+    finite losses, every parameter — the DCN weights and their zero-initialised offset convolutions included —
+    receives a finite gradient and moves."""
+    from rrnet_amd.configs.rrnet_config import Config as cfg
+    from rrnet_amd.operators.rrnet_operator import RRNetOperator
+    saved = dict(cfg.Model)
+    try:
+        cfg.Train.batch_size, cfg.Train.crop_size = 2, (128, 128)
+        cfg.Model.backbone, cfg.Model.dcn_heads, cfg.Model.dcn_bf16 = "hourglass_tiny", True, True
+        cfg.Distributed.gpu_id, cfg.Distributed.rank, cfg.Distributed.world_size = 0, 0, 1
+        torch.manual_seed(cfg.seed)
+        op = RRNetOperator(cfg)
+        op.model.train()
+        flat = op.model.flat
+        before = flat.flat.clone()
+        b = op.training_loader.get_batch()
+        _, losses = op.train_step(2000, (b[0], b[1].clone()) + tuple(b[2:]))
+        assert all(np.isfinite(float(v.detach())) for v in losses)
+        assert torch.isfinite(flat.grad).all() and torch.isfinite(flat.flat).all()
+        names = dict(op.model.module.named_parameters())
+        dcn = op.model.module.hm.detect_layer[1][0].conv
+        assert dcn.bf16 is True
+        for p in (dcn.weight, dcn.conv_offset_mask.weight, dcn.conv_offset_mask.bias):
+            assert p.grad.abs().sum().item() > 0
+        assert (flat.flat != before).float().mean().item() > 0.97
+    finally:
+        for k in list(cfg.Model):
+            if k not in saved:
+                del cfg.Model[k]
+        cfg.Model.update(saved)
