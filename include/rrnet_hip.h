@@ -265,7 +265,11 @@ int rr_finalize_frames(const float *boxes6, const int *seg_off, const int *n_out
  * torchvision.ops.roi_align(feat, rois, (ph,pw)) at models/rrnet.py:51 (spatial_scale 1,
  * sampling_ratio -1, legacy coordinates).  feat NHWC [b,h,w,c]; out NHWC [r,ph,pw,c]. */
 int rr_roi_align_fwd(const float *feat, const float *rois, int r, int h, int w, int c, int ph, int pw,
-                     float spatial_scale, int sampling_ratio, float *out, hipStream_t stream);
+                     float spatial_scale, int sampling_ratio, const int *order, float *out, hipStream_t stream);
+/* order (optional, 3x3 bins): processing position -> RoI index; rr_roi_spatial_order builds it per frame (rois of
+ * frame f = rows [frame_off[f], frame_off[f+1]) of the packed list) by (8-pixel row band, x centre), so that RoIs with
+ * overlapping footprints run back to back on one XCD and share its L2.  Outputs stay in RoI order. */
+int rr_roi_spatial_order(const float *rois, const int *frame_off, int nframes, int *order, hipStream_t stream);
 int rr_roi_align_bwd(const float *dout, const float *rois, int r, int b, int h, int w, int c, int ph, int pw,
                      float spatial_scale, int sampling_ratio, float *dfeat, hipStream_t stream);
 

@@ -561,14 +561,23 @@ def finalize_frames(boxes6, seg_off, n_out, nframes, segs_per_frame, max_frame_b
     return out6, out_off[::segs_per_frame]
 
 
-def roi_align_fwd(feat, rois, out_size, spatial_scale=1.0, sampling_ratio=-1):
+def roi_spatial_order(rois, frame_off):
+    """Per-frame spatial processing order of the packed RoI list (frame_off int32 [B+1], device) -> int32 [R]."""
+    r = rois.shape[0]
+    order = torch.empty(max(r, 1), dtype=torch.int32, device=rois.device)
+    _C.check(_C.fn("rr_roi_spatial_order")(_C.ptr(rois), _C.ptr(frame_off), frame_off.numel() - 1, _C.ptr(order),
+                                           _C.stream()), "rr_roi_spatial_order")
+    return order[:r]
+
+
+def roi_align_fwd(feat, rois, out_size, spatial_scale=1.0, sampling_ratio=-1, order=None):
     assert is_nhwc(feat)
     b, c, h, w = feat.shape
     r = rois.shape[0]
     ph, pw = out_size
     out = empty_nhwc(r, c, ph, pw, feat.device)
     _C.check(_C.fn("rr_roi_align_fwd")(_C.ptr(feat), _C.ptr(rois), r, h, w, c, ph, pw, float(spatial_scale),
-                                       int(sampling_ratio), _C.ptr(out), _C.stream()), "rr_roi_align_fwd")
+                                       int(sampling_ratio), _C.ptr(order), _C.ptr(out), _C.stream()), "rr_roi_align_fwd")
     return out
 
 
