@@ -93,7 +93,7 @@ int rr_conv_wgrad(const float *x, const float *dy, float *dw, int n, int h, int 
  * Training statistics: rr_conv_fprop's slab -> rr_bn_reduce_slab (adds into a zeroed) sums[2][c] (the SyncBN
  * exchange all-reduces exactly this buffer plus the sample count) -> rr_bn_finalize ->
  * mean/invstd (saved for backward), scale/shift (for rr_bn_apply), running stats updated with
- * `momentum` and the unbiased variance.
+ * `momentum` and the unbiased variance, num_batches_tracked (optional int64 counter) incremented.
  * rr_bn_apply: out = relu?(y*scale+shift [+ res | + res*res_scale+res_shift]).
  * rr_bn_bwd_reduce: sums[2][c] = per-channel sum(dy), sum(dy*xhat), dy = dz*(z>0) if z; with z NULL and
  *   mask_scale/mask_shift given the ReLU mask is recomputed as (y*scale+shift > 0) — layers without a
@@ -110,7 +110,7 @@ int rr_conv_wgrad(const float *x, const float *dy, float *dw, int n, int h, int 
 int rr_bn_reduce_slab(const double *slab, int mtiles, int c, double *sums, hipStream_t stream);
 int rr_bn_finalize(const double *sums, double count, const double *count_dev, const float *gamma, const float *beta,
                    float *running_mean, float *running_var, float momentum, float eps, float *mean,
-                   float *invstd, float *scale, float *shift, int c, hipStream_t stream);
+                   float *invstd, float *scale, float *shift, int c, long *num_batches_tracked, hipStream_t stream);
 int rr_bn_eval_coeffs(const float *gamma, const float *beta, const float *running_mean,
                       const float *running_var, float eps, float *scale, float *shift, int c,
                       hipStream_t stream);
@@ -317,6 +317,19 @@ int rr_dcn_dgrad(const float *x, const float *offset, const float *mask, const f
 int rr_dcn_split_fwd(const float *om, long m, int third, float *offset, float *mask, hipStream_t stream);
 int rr_dcn_split_bwd(const float *doffset, const float *dmask, const float *mask, long m, int third, float *dom,
                      hipStream_t stream);
+
+/* ---- deformable PS-RoI pooling (ext/dcn/src/cuda/dcn_v2_psroi_pooling_cuda.cu:59-290; dcn_v2.py:130-300) ------ *
+ * x NHWC [b,h,w,c], c = output_dim * group_size^2; rois [n,5] = (image, x1,y1,x2,y2); trans NCHW
+ * [n, trans_channels = 2*num_classes, part, part] (ignored when no_trans); out / count NHWC [n, pooled, pooled,
+ * output_dim].  Backward: dx (zeroed inside, float atomics) and dtrans (zeroed inside unless no_trans). */
+int rr_dcn_psroi_fwd(const float *x, const float *rois, const float *trans, int n, int h, int w, int c,
+                     int no_trans, float spatial_scale, int output_dim, int group_size, int pooled_size,
+                     int part_size, int sample_per_part, float trans_std, int trans_channels, float *out,
+                     float *count, hipStream_t stream);
+int rr_dcn_psroi_bwd(const float *dout, const float *x, const float *rois, const float *trans, const float *count,
+                     int n, int b, int h, int w, int c, int no_trans, float spatial_scale, int output_dim,
+                     int group_size, int pooled_size, int part_size, int sample_per_part, float trans_std,
+                     int trans_channels, float *dx, float *dtrans, hipStream_t stream);
 
 #ifdef __cplusplus
 }

@@ -21,6 +21,7 @@ PER_FILE = {
     "hardnms.hip": ["-ffp-contract=off"],
     "refine.hip": ["-ffp-contract=off"],
     "targets.hip": ["-ffp-contract=off"],
+    "psroi.hip": ["-ffp-contract=off"],
 }
 
 

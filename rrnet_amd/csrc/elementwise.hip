@@ -49,9 +49,10 @@ __global__ __launch_bounds__(256) void bn_reduce_slab_kernel(const double *slab,
 // with the unbiased variance, as nn.BatchNorm2d does in training mode).
 __global__ void bn_finalize_kernel(const double *sums, double count_h, const double *count_d, const float *gamma, const float *beta,
                                    float *running_mean, float *running_var, float momentum, float eps,
-                                   float *mean, float *invstd, float *scale, float *shift, int C)
+                                   float *mean, float *invstd, float *scale, float *shift, int C, long *num_batches_tracked)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;   // nn.BatchNorm2d's counter, without its own launch
     if (c >= C) return;
     const double count = count_d ? *count_d : count_h;   // device count: SyncBN with ragged per-rank sample counts
     const double m = sums[c] / count;
@@ -526,11 +527,12 @@ extern "C" int rr_bn_reduce_slab(const double *slab, int mtiles, int c, double *
 
 extern "C" int rr_bn_finalize(const double *sums, double count, const double *count_dev, const float *gamma, const float *beta,
                               float *running_mean, float *running_var, float momentum, float eps, float *mean,
-                              float *invstd, float *scale, float *shift, int c, hipStream_t stream)
+                              float *invstd, float *scale, float *shift, int c, long *num_batches_tracked,
+                              hipStream_t stream)
 {
     RR_CHECK_ARG(c > 0 && (count > 0 || count_dev), "rr_bn_finalize: bad dims");
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(rr_cdiv(c, 128)), dim3(128), 0, stream, sums, count, count_dev, gamma, beta,
-                       running_mean, running_var, momentum, eps, mean, invstd, scale, shift, c);
+                       running_mean, running_var, momentum, eps, mean, invstd, scale, shift, c, num_batches_tracked);
     RR_CHECK_LAUNCH("rr_bn_finalize");
     return RR_OK;
 }

@@ -2,7 +2,8 @@
 gather-GEMM (librrnet_hip.so: rr_dcn_fwd / rr_dcn_im2col / rr_dcn_col2im) instead of the `_ext` CUDA
 extension.  Same constructor arguments, parameter names (`weight`, `bias`, `conv_offset_mask.*`) and
 initialisation (uniform(-1/sqrt(n), 1/sqrt(n)) weights, zero bias, zero-initialised offset/mask conv).
-DCNPooling / deformable PS-RoI pooling have no caller anywhere in the reference and are out of scope."""
+`dcn_v2_pooling`, `DCNv2Pooling`, `DCNPooling` (:130-300, deformable PS-RoI pooling; no caller anywhere in the
+reference) on rr_dcn_psroi_fwd / _bwd."""
 import math
 
 import torch
@@ -12,6 +13,7 @@ from torch.nn.modules.utils import _pair
 from rrnet_amd import functional as RF
 
 dcn_v2_conv = RF.dcn_v2_conv
+dcn_v2_pooling = RF.dcn_v2_pooling
 
 
 class DCNv2(nn.Module):
@@ -64,3 +66,59 @@ class DCN(DCNv2):
         offset, mask = RF.dcn_offset_mask(out)                    # chunk(3) + cat(o1, o2) + sigmoid(mask): one kernel
         return dcn_v2_conv(xb, offset, mask, self.weight, self.bias, self.stride, self.padding, self.dilation,
                            self.deformable_groups, bf16=self.bf16)
+
+
+class DCNv2Pooling(nn.Module):
+    """ext/dcn/dcn_v2.py:185-219."""
+
+    def __init__(self, spatial_scale, pooled_size, output_dim, no_trans, group_size=1, part_size=None, sample_per_part=4,
+                 trans_std=.0):
+        super().__init__()
+        self.spatial_scale = spatial_scale
+        self.pooled_size = pooled_size
+        self.output_dim = output_dim
+        self.no_trans = no_trans
+        self.group_size = group_size
+        self.part_size = pooled_size if part_size is None else part_size
+        self.sample_per_part = sample_per_part
+        self.trans_std = trans_std
+
+    def forward(self, input, rois, offset):
+        assert input.shape[1] == self.output_dim
+        if self.no_trans:
+            offset = input.new()
+        return dcn_v2_pooling(input, rois, offset, self.spatial_scale, self.pooled_size, self.output_dim, self.no_trans,
+                              self.group_size, self.part_size, self.sample_per_part, self.trans_std)
+
+
+class DCNPooling(DCNv2Pooling):
+    """ext/dcn/dcn_v2.py:222-300: plain pooling -> fully connected offset / mask predictor (zero-initialised last
+    layer) -> deformable pooling * sigmoid(mask).  The three small Linear layers are library GEMMs (torch), as in the
+    reference."""
+
+    def __init__(self, spatial_scale, pooled_size, output_dim, no_trans, group_size=1, part_size=None, sample_per_part=4,
+                 trans_std=.0, deform_fc_dim=1024):
+        super().__init__(spatial_scale, pooled_size, output_dim, no_trans, group_size, part_size, sample_per_part, trans_std)
+        self.deform_fc_dim = deform_fc_dim
+        if not no_trans:
+            self.offset_mask_fc = nn.Sequential(
+                nn.Linear(self.pooled_size * self.pooled_size * self.output_dim, self.deform_fc_dim), nn.ReLU(inplace=True),
+                nn.Linear(self.deform_fc_dim, self.deform_fc_dim), nn.ReLU(inplace=True),
+                nn.Linear(self.deform_fc_dim, self.pooled_size * self.pooled_size * 3))
+            self.offset_mask_fc[4].weight.data.zero_()
+            self.offset_mask_fc[4].bias.data.zero_()
+
+    def forward(self, input, rois):
+        offset = input.new()
+        args = (self.spatial_scale, self.pooled_size, self.output_dim)
+        tail = (self.group_size, self.part_size, self.sample_per_part, self.trans_std)
+        if not self.no_trans:
+            n = rois.shape[0]
+            roi = dcn_v2_pooling(input, rois, offset, *args, True, *tail)
+            offset_mask = self.offset_mask_fc(roi.reshape(n, -1))       # logical (c, ph, pw) order, as the reference's view
+            offset_mask = offset_mask.view(n, 3, self.pooled_size, self.pooled_size)
+            o1, o2, mask = torch.chunk(offset_mask, 3, dim=1)
+            offset = torch.cat((o1, o2), dim=1)
+            mask = torch.sigmoid(mask)
+            return dcn_v2_pooling(input, rois, offset, *args, self.no_trans, *tail) * mask
+        return dcn_v2_pooling(input, rois, offset, *args, self.no_trans, *tail)

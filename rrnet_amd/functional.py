@@ -56,12 +56,10 @@ class _ConvBnAct(torch.autograd.Function):
             if sync:   # SyncBN exchange: one small all-reduce of [sum, sumsq, count] (C5 in SURVEY §2.2);
                 sums[2 * k] = count          # the global count stays on the device: no host sync per layer
                 dist.all_reduce(sums)
-                cnt_dev = sums[2 * k:]
+                cnt_dev = sums[2 * k:].clone()   # own storage: `sums` is a slice of a shared zero pool (version counter)
             mom = bn.momentum if bn.momentum is not None else 0.1
             mean, invstd, scale, shift = ops.bn_finalize(sums, count, gamma, beta, bn.running_mean, bn.running_var,
-                                                         mom, bn.eps, cnt_dev)
-            if bn.num_batches_tracked is not None:
-                bn.num_batches_tracked += 1
+                                                         mom, bn.eps, cnt_dev, bn.num_batches_tracked)
         else:
             scale, shift = ops.bn_eval_coeffs(gamma, beta, bn.running_mean, bn.running_var, bn.eps)
             mean = invstd = cnt_dev = None
@@ -567,6 +565,33 @@ class _DCNSplit(torch.autograd.Function):
 def dcn_offset_mask(om):
     return _DCNSplit.apply(om)
 
+
+class _DCNv2Pooling(torch.autograd.Function):
+    """ext/dcn/dcn_v2.py:130-182 (`_DCNv2Pooling`): deformable position-sensitive RoI pooling."""
+
+    @staticmethod
+    def forward(ctx, input, rois, offset, spatial_scale, pooled_size, output_dim, no_trans, group_size=1, part_size=None,
+                sample_per_part=4, trans_std=.0):
+        part_size = pooled_size if part_size is None else part_size
+        x = ops.to_nhwc(input)
+        rois = rois.contiguous().float()
+        no_trans = int(no_trans)
+        trans = None if no_trans else offset.contiguous().float()
+        ctx.cfg = (no_trans, float(spatial_scale), int(output_dim), int(group_size), int(pooled_size), int(part_size),
+                   int(sample_per_part), float(trans_std))
+        out, count = ops.dcn_psroi_fwd(x, rois, trans, *ctx.cfg)
+        ctx.save_for_backward(x, rois, trans, count)
+        ctx.has_offset = not no_trans
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        x, rois, trans, count = ctx.saved_tensors
+        dx, dtrans = ops.dcn_psroi_bwd(ops.to_nhwc(grad_output), x, rois, trans, count, *ctx.cfg)
+        return (dx, None, dtrans if ctx.has_offset else None) + (None,) * 8
+
+
+dcn_v2_pooling = _DCNv2Pooling.apply
 
 _SIDE = {}
 

@@ -204,22 +204,51 @@ def _f32(n, device):
     return torch.empty(n, dtype=torch.float32, device=device)
 
 
+class _ZeroPool:
+    """Pre-zeroed float64 scratch handed out in slices: the 163 BatchNorm layers of a step take their statistics
+    accumulators from one zeroed chunk (one fill per ~1 MB) instead of one `torch.zeros` launch each.  A slice is
+    never handed out twice; exhausted chunks stay alive as long as their slices do."""
+
+    CHUNK = 128 * 1024      # doubles
+
+    def __init__(self):
+        self.buf = {}
+
+    def take(self, n, device):
+        n8 = (n + 1) // 2 * 2                      # keep slices 16-byte aligned
+        key = (device.type, device.index)
+        cur = self.buf.get(key)
+        if cur is None or cur[1] + n8 > cur[0].numel():
+            cur = [torch.zeros(max(self.CHUNK, n8), dtype=torch.float64, device=device), 0]
+            self.buf[key] = cur
+        out = cur[0][cur[1]:cur[1] + n]
+        cur[1] += n8
+        return out
+
+
+_ZEROS = _ZeroPool()
+
+
 def bn_reduce_slab(slab, c, extra=0):
     """slab [mtiles,2,c] doubles -> sums [2c (+extra)] doubles (extra slots zeroed: room for the
     sample count in the SyncBN exchange)."""
-    sums = torch.zeros(2 * c + extra, dtype=torch.float64, device=slab.device)
+    sums = _ZEROS.take(2 * c + extra, slab.device)
     mtiles = slab.numel() // (2 * c)
     _C.check(_C.fn("rr_bn_reduce_slab")(_C.ptr(slab), mtiles, c, _C.ptr(sums), _C.stream()), "rr_bn_reduce_slab")
     return sums
 
 
-def bn_finalize(sums, count, gamma, beta, running_mean, running_var, momentum, eps, count_dev=None):
+def bn_finalize(sums, count, gamma, beta, running_mean, running_var, momentum, eps, count_dev=None,
+                num_batches_tracked=None):
     c = gamma.numel()
     dev = gamma.device
-    mean, invstd, scale, shift = _f32(c, dev), _f32(c, dev), _f32(c, dev), _f32(c, dev)
+    buf = _f32(4 * c, dev)                       # mean | invstd | scale | shift: one allocation
+    mean, invstd, scale, shift = buf[0:c], buf[c:2 * c], buf[2 * c:3 * c], buf[3 * c:4 * c]
+    assert num_batches_tracked is None or num_batches_tracked.dtype == torch.int64
     _C.check(_C.fn("rr_bn_finalize")(_C.ptr(sums), float(count), _C.ptr(count_dev), _C.ptr(gamma), _C.ptr(beta), _C.ptr(running_mean),
                                      _C.ptr(running_var), float(momentum), float(eps), _C.ptr(mean), _C.ptr(invstd),
-                                     _C.ptr(scale), _C.ptr(shift), c, _C.stream()), "rr_bn_finalize")
+                                     _C.ptr(scale), _C.ptr(shift), c, _C.ptr(num_batches_tracked), _C.stream()),
+             "rr_bn_finalize")
     return mean, invstd, scale, shift
 
 
@@ -668,3 +697,34 @@ def dcn_split_bwd(doffset, dmask, mask):
     _C.check(_C.fn("rr_dcn_split_bwd")(_C.ptr(doffset), _C.ptr(dmask), _C.ptr(mask), n * p * q, t, _C.ptr(dom), _C.stream()),
              "rr_dcn_split_bwd")
     return dom
+
+
+def dcn_psroi_fwd(x, rois, trans, no_trans, spatial_scale, output_dim, group_size, pooled_size, part_size, sample_per_part,
+                  trans_std):
+    """Deformable PS-RoI pooling.  x NHWC; rois [n,5]; trans [n,2*classes,part,part] (contiguous NCHW) or None.
+    -> out, count: logical [n, output_dim, pooled, pooled], NHWC memory."""
+    assert is_nhwc(x)
+    b, c, h, w = x.shape
+    n = rois.shape[0]
+    out = empty_nhwc(n, output_dim, pooled_size, pooled_size, x.device)
+    count = empty_nhwc(n, output_dim, pooled_size, pooled_size, x.device)
+    tc = 0 if no_trans else trans.shape[1]
+    _C.check(_C.fn("rr_dcn_psroi_fwd")(_C.ptr(x), _C.ptr(rois), _C.ptr(None if no_trans else trans), n, h, w, c, int(no_trans),
+                                       float(spatial_scale), output_dim, group_size, pooled_size, part_size, sample_per_part,
+                                       float(trans_std), tc, _C.ptr(out), _C.ptr(count), _C.stream()), "rr_dcn_psroi_fwd")
+    return out, count
+
+
+def dcn_psroi_bwd(dout, x, rois, trans, count, no_trans, spatial_scale, output_dim, group_size, pooled_size, part_size,
+                  sample_per_part, trans_std):
+    assert is_nhwc(x) and is_nhwc(dout)
+    b, c, h, w = x.shape
+    n = rois.shape[0]
+    dx = empty_nhwc(b, c, h, w, x.device)
+    dtrans = None if no_trans else torch.empty_like(trans)
+    tc = 0 if no_trans else trans.shape[1]
+    _C.check(_C.fn("rr_dcn_psroi_bwd")(_C.ptr(dout), _C.ptr(x), _C.ptr(rois), _C.ptr(None if no_trans else trans), _C.ptr(count),
+                                       n, b, h, w, c, int(no_trans), float(spatial_scale), output_dim, group_size, pooled_size,
+                                       part_size, sample_per_part, float(trans_std), tc, _C.ptr(dx), _C.ptr(dtrans),
+                                       _C.stream()), "rr_dcn_psroi_bwd")
+    return dx, dtrans

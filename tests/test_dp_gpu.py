@@ -84,3 +84,39 @@ def test_two_rank_syncbn_dp_matches_single_rank(tmp_path):
     scale = np.abs(ref).max()
     assert np.abs(z["grad"] - ref).max() <= 2e-3 * scale, (np.abs(z["grad"] - ref).max(), scale)
     np.testing.assert_allclose(z["running_mean"], model.backbone.pre_layer[1].running_mean.cpu().numpy(), atol=1e-5)
+
+
+def _run_bench(extra_env, launcher, port):
+    import json
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
+    args = ["bench.py", "--backbone", "hourglass_tiny", "--size", "512", "--batch", "4", "--steps", "6", "--warmup", "2",
+            "--no-cpu-baseline", "--no-extras", "--no-kernel-timing"]
+    if launcher:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", str(port)] + args + ["--gpus", "2"]
+    else:
+        cmd = [sys.executable] + args
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, out.stdout[-2000:]                    # rank 0 prints exactly one JSON line
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_through_the_launcher():
+    """`bench.py --gpus 2` exactly as the driver launches it (torch.distributed.run, one process per rank, env
+    rendezvous on 127.0.0.1), with both ranks on this box's single GPU and gloo as the transport (RR_SINGLE_DEVICE /
+    RR_DIST_BACKEND — a 1-GPU box cannot host two RCCL ranks).  Checks the contract fields and times the N>1 path:
+    SyncBN exchanges, bucketed gradient all-reduce launched from backward, barrier + max-over-ranks timing.  Two
+    ranks share one GPU, so the aggregate rate can at best equal the single-rank rate; gloo's host round trips
+    (326 small exchanges per step here) take their toll, hence the loose floor."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    one = _run_bench({}, False, port)
+    two = _run_bench({"RR_SINGLE_DEVICE": "1", "RR_DIST_BACKEND": "gloo"}, True, port)
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2
+    assert two["scaling"] == "weak" and two["config"]["global_batch"] == 2 * one["config"]["global_batch"]
+    assert two["config"]["parallelism"] == "dp2" and two["steps"] == 6 and two["warmup"] == 2
+    assert two["value"] > 0 and abs(two["value"] - 8 * 1e3 / two["ms_per_step"]) < 1e-2 * two["value"]
+    print("1 rank: %.1f img/s, 2 ranks on one GPU over gloo: %.1f img/s" % (one["value"], two["value"]))
+    assert two["value"] >= 0.35 * one["value"], (one["value"], two["value"])
