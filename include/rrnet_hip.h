@@ -142,6 +142,11 @@ int rr_avgpool_bwd(const float *dout, float *dx, long r, int hw, int c, hipStrea
  * out[r,c] = mean over the hw positions of relu(y[r,p,c]*scale[c] + shift[c] + res[r,p,c]); y, res NHWC [r,hw,c]. */
 int rr_bn_res_relu_avgpool(const float *y, const float *scale, const float *shift, const float *res, float *out,
                            long r, int hw, int c, hipStream_t stream);
+/* The same tail with the 1x1 convolution in front of it fused in (inference): out [r, n] = mean over the hw rows of a
+ * RoI of relu((h [r*hw, k] x w [n, k]^T) * scale + shift + res [r*hw, n]); the convolution's output never reaches
+ * HBM.  k = 32 or 64, n <= 256 (backbones/resnet.py:46-53 with planes = 64, fasterrcnn_detector.py:15). */
+int rr_conv1x1_bn_res_relu_avgpool(const float *h, const float *w, const float *scale, const float *shift,
+                                   const float *res, float *out, long r, int hw, int k, int n, hipStream_t stream);
 /* WH head, detectors/centernet_detector.py:26-77 (HCov k x 1 and WCov 1 x k to one channel each,
  * interleaved [W,H]): t [n,h,w,ct] (ct >= 2k, a multiple of 4 keeps the vector conv paths) = 1x1
  * convolution of the 256-channel map with the 2k tap vectors (rows 0..k-1 = HCov taps, k..2k-1 = WCov

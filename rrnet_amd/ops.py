@@ -367,6 +367,19 @@ def bn_res_relu_avgpool(y, scale, shift, res):
     return out
 
 
+def conv1x1_bn_res_relu_avgpool(h, w, scale, shift, res):
+    """h [R,K,ph,pw], w [N,K,1,1], res [R,N,ph,pw] (all NHWC) -> [R,N,1,1]: mean_p relu(conv1x1(h)*scale + shift + res),
+    one kernel, the convolution's output stays in LDS (inference)."""
+    assert is_nhwc(h) and is_nhwc(res) and is_nhwc(w)
+    r, k, ph, pw = h.shape
+    n = w.shape[0]
+    assert tuple(w.shape[1:]) == (k, 1, 1) and tuple(res.shape) == (r, n, ph, pw)
+    out = empty_nhwc(r, n, 1, 1, h.device)
+    _C.check(_C.fn("rr_conv1x1_bn_res_relu_avgpool")(_C.ptr(h), _C.ptr(w), _C.ptr(scale), _C.ptr(shift), _C.ptr(res), _C.ptr(out),
+                                                     r, ph * pw, k, n, _C.stream()), "rr_conv1x1_bn_res_relu_avgpool")
+    return out
+
+
 def avgpool_bwd(dout, shape):
     r, c, h, w = shape
     dx = empty_nhwc(r, c, h, w, dout.device)
