@@ -218,12 +218,18 @@ def main():
         timer = ops.KernelTimer(None if a.detail else {"conv_fprop<BN=128,vec4>"})
         ops.TIMER = timer
     sync_all()
+    ops.SYNC_WAIT_S = 0.0
+    host_s = 0.0
     t0 = time.perf_counter()
     for _ in range(a.steps):
+        h0 = time.perf_counter()
         op.train_step(step_no, fresh(batches[step_no % len(batches)]))
+        host_s += time.perf_counter() - h0
         step_no += 1
     sync_all()
     elapsed = time.perf_counter() - t0
+    # host side of a step: time inside train_step() minus the time blocked in its one device->host read (RoI count)
+    host_enqueue_ms = (host_s - ops.SYNC_WAIT_S) / a.steps * 1e3
     ops.TIMER = None
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -281,6 +287,7 @@ def main():
             if a.detail:
                 conv_ms = sum(v["ms"] for v in summ.values())
                 out["conv_time_fraction"] = round(conv_ms / (elapsed * 1e3), 4)
+        out["host_enqueue_ms_per_step"] = round(host_enqueue_ms, 2)
         if a.backbone == "hourglass" and a.size == 1024:
             out["step_mfma_frac"] = round(out["value"] / world * ALGO_TFLOP_PER_IMAGE / FP32_MFMA_PEAK_TFLOPS, 4)
         if world == 1 and not a.no_extras:

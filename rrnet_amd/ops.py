@@ -54,6 +54,7 @@ class KernelTimer:
 
 
 TIMER = None
+SYNC_WAIT_S = 0.0      # host time spent blocked in the RoI-count read (bench.py separates it from the enqueue time)
 
 
 def _timed(name, flops, fn, detail=None, nbytes=0.0):
@@ -546,7 +547,11 @@ def pack_segments(grouped, seg_off, n_out, segs_per_image, want_rois=True, want_
     dev = grouped.device
     f = _C.fn("rr_pack_segments")
     out_off = seg_prefix(n_out)
-    r = int(out_off[-1].item())
+    import time as _time
+    t0 = _time.perf_counter()
+    r = int(out_off[-1].item())              # the step's one device -> host read: the RoI count sizes the head's tensors
+    global SYNC_WAIT_S
+    SYNC_WAIT_S += _time.perf_counter() - t0
     rois = torch.empty((r, 5), dtype=torch.float32, device=dev) if want_rois else None
     scores = torch.empty(r, dtype=torch.float32, device=dev) if want_rois else None
     clses = torch.empty(r, dtype=torch.float32, device=dev) if want_rois else None
