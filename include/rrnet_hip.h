@@ -265,6 +265,9 @@ int rr_refine_boxes(const float *rois, const float *reg, const float *scores, co
                     hipStream_t stream);
 int rr_finalize_frames(const float *boxes6, const int *seg_off, const int *n_out, const int *out_off,
                        int nframes, int segs_per_frame, int max_frame_boxes, float *out6, hipStream_t stream);
+/* rows6 [n,6] -> out6 ordered by score (column 4) descending, ties in input order (operators/rrnet_operator.py:272,
+ * 278: the torch.sort calls around _ext_nms in the multi-scale evaluation); n <= 16384, out6 != rows6. */
+int rr_sort_rows_by_score(const float *rows6, int n, float *out6, hipStream_t stream);
 
 /* ---- RoIAlign --------------------------------------------------------------------------- *
  * torchvision.ops.roi_align(feat, rois, (ph,pw)) at models/rrnet.py:51 (spatial_scale 1,

@@ -114,7 +114,57 @@ __global__ __launch_bounds__(256) void finalize_frames_kernel(const float *boxes
     }
 }
 
+// rows [n,6] -> out [n,6] ordered by score (column 4) descending, equal scores in input order: the two
+// `torch.sort(pred_bbox[:, 4], descending=True)` of operators/rrnet_operator.py:272-279 on the device (one workgroup,
+// LDS bitonic sort of (score, ~position) keys; n <= 16384).
+__global__ __launch_bounds__(1024) void sort_rows_kernel(const float *rows, int n, int KP, float *out)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    unsigned long long *keys = reinterpret_cast<unsigned long long *>(smem);
+    for (int i = threadIdx.x; i < KP; i += 1024) {
+        unsigned long long key = 0ull;
+        if (i < n) {
+            const unsigned int sc = __float_as_uint(rows[(long)i * 6 + 4]);
+            const unsigned int ord = (sc & 0x80000000u) ? ~sc : (sc | 0x80000000u);
+            key = ((unsigned long long)ord << 32) | (unsigned long long)(0xffffffffu - (unsigned int)i);
+        }
+        keys[i] = key;
+    }
+    __syncthreads();
+    for (int k2 = 2; k2 <= KP; k2 <<= 1) {
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < KP / 2; t += 1024) {
+                const int lo = ((t / j) * 2 * j) + (t % j);
+                const int hi = lo + j;
+                const bool desc = ((lo & k2) == 0);
+                const unsigned long long a = keys[lo], b = keys[hi];
+                if ((a < b) == desc) { keys[lo] = b; keys[hi] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    for (int k = threadIdx.x; k < n; k += 1024) {
+        const int pos = (int)(0xffffffffu - (unsigned int)(keys[k] & 0xffffffffull));
+#pragma unroll
+        for (int e = 0; e < 6; ++e) out[(long)k * 6 + e] = rows[(long)pos * 6 + e];
+    }
+}
+
 }  // namespace
+
+extern "C" int rr_sort_rows_by_score(const float *rows6, int n, float *out6, hipStream_t stream)
+{
+    RR_CHECK_ARG(n >= 0 && n <= 16384, "rr_sort_rows_by_score: %d rows (limit 16384)", n);
+    if (n == 0) return RR_OK;
+    int kp = 2;
+    while (kp < n) kp <<= 1;
+    const size_t lds = (size_t)kp * 8;
+    if (lds > 48 * 1024)
+        hipFuncSetAttribute(reinterpret_cast<const void *>(sort_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(sort_rows_kernel, dim3(1), dim3(1024), lds, stream, rows6, n, kp, out6);
+    RR_CHECK_LAUNCH("rr_sort_rows_by_score");
+    return RR_OK;
+}
 
 extern "C" int rr_refine_boxes(const float *rois, const float *reg, const float *scores, const float *clses,
                                const int *seg_off, int nseg, float scale, float score_thr, float *out6, int *seg_len,

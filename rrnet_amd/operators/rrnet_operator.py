@@ -120,19 +120,16 @@ class RRNetOperator(BaseOperator):
         return s1, s2
 
     @staticmethod
-    def _ext_nms(pred_bbox, per_cls=True):
-        """rrnet_operator.py:211-232: per-class gaussian Soft-NMS (Nt 0.7, threshold 0.1) on xywh
-        boxes -> CPU tensor, all classes in one launch."""
-        if pred_bbox.size(0) == 0:
-            return pred_bbox
+    def _ext_nms_device(pred_bbox, per_cls=True):
+        """rrnet_operator.py:211-232 on the device: per-class gaussian Soft-NMS (Nt 0.7, threshold 0.1) on xywh boxes,
+        all classes in one launch; returns a device tensor."""
         dev = pred_bbox.device if pred_bbox.is_cuda else torch.device("cuda", torch.cuda.current_device())
         b = pred_bbox.detach().to(dev, torch.float32).clone()
         b[:, 2] = b[:, 0] + b[:, 2]
         b[:, 3] = b[:, 1] + b[:, 3]
         n = b.size(0)
         if per_cls:
-            # one segment per class id present, like the reference's unique() loop (ids are cls+1, any dataset);
-            # the result lands on the host anyway, so reading the id range costs no extra synchronisation point
+            # one segment per class id present, like the reference's unique() loop (ids are cls+1, any dataset)
             lo, hi = int(b[:, 5].min()), int(b[:, 5].max())
             nc = hi - lo + 1
             if nc > 1023:
@@ -147,7 +144,14 @@ class RRNetOperator(BaseOperator):
         n_out = soft_nms_segments(rows, seg_off, n, sigma=0.5, Nt=0.7, threshold=0.1, method=2, seg_len=seg_len)
         _, _, _, kept = ops.pack_segments(rows, seg_off, n_out, nc, want_rois=False, want_rows=True)
         kept[:, 2:4] -= kept[:, 0:2]
-        return kept.cpu()
+        return kept
+
+    @staticmethod
+    def _ext_nms(pred_bbox, per_cls=True):
+        """rrnet_operator.py:211-232 -> CPU tensor, like the reference."""
+        if pred_bbox.size(0) == 0:
+            return pred_bbox
+        return RRNetOperator._ext_nms_device(pred_bbox, per_cls).cpu()
 
     @staticmethod
     def save_result(file_path, pred_bbox):
@@ -160,7 +164,9 @@ class RRNetOperator(BaseOperator):
                                                         float(bbox[3]), float(bbox[4]), int(bbox[5])))
 
     def evaluate_images(self, imgs):
-        """Multi-scale inference of rrnet_operator.py:256-276 for one image batch (bs=1) -> boxes [n,6]."""
+        """Multi-scale inference of rrnet_operator.py:256-276 for one image batch (bs=1) -> boxes [n,6] on the host.
+        Everything between the resize and the final result stays on the device: per-scale boxes, the cross-scale
+        concatenation, both score sorts (rr_sort_rows_by_score) and the Soft-NMS; one D2H copy at the end."""
         multi_scale_bboxes = []
         for scale in self.cfg.Val.scales:
             img = ops.resize_bilinear_ac(imgs, scale)
@@ -168,16 +174,23 @@ class RRNetOperator(BaseOperator):
             _, pred_bbox = self.generate_bbox(outs)
             if not self.cfg.Val.auto_test:
                 pred_bbox = pred_bbox[pred_bbox[:, 4] > 0.01]
-            pred_bbox = pred_bbox.cpu()
+            pred_bbox = pred_bbox.clone()
             pred_bbox[:, :4] = pred_bbox[:, :4] / scale
             multi_scale_bboxes.append(pred_bbox)
         pred_bbox = torch.cat(multi_scale_bboxes, dim=0)
-        _, idx = torch.sort(pred_bbox[:, 4], descending=True)
-        pred_bbox = pred_bbox[idx]
+        if pred_bbox.size(0) == 0:
+            return pred_bbox.cpu()
+        if pred_bbox.size(0) > 16384:          # beyond the LDS sort (6 scales x 1500 boxes = 9000 in the reference config)
+            pred_bbox = pred_bbox[torch.sort(pred_bbox[:, 4], descending=True, stable=True)[1]]
+        else:
+            pred_bbox = ops.sort_rows_by_score(pred_bbox)
         if not self.cfg.Val.auto_test:
-            pred_bbox = self._ext_nms(pred_bbox)
-        _, idx = torch.sort(pred_bbox[:, 4], descending=True)
-        return pred_bbox[idx]
+            pred_bbox = self._ext_nms_device(pred_bbox)
+        if 0 < pred_bbox.size(0) <= 16384:
+            pred_bbox = ops.sort_rows_by_score(pred_bbox)
+        elif pred_bbox.size(0) > 16384:
+            pred_bbox = pred_bbox[torch.sort(pred_bbox[:, 4], descending=True, stable=True)[1]]
+        return pred_bbox.cpu()
 
     def evaluation_process(self):
         self.model.eval()

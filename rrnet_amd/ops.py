@@ -608,6 +608,14 @@ def finalize_frames(boxes6, seg_off, n_out, nframes, segs_per_frame, max_frame_b
     return out6, out_off[::segs_per_frame]
 
 
+def sort_rows_by_score(rows6):
+    """[n,6] device rows -> a new tensor ordered by score descending (ties keep their input order)."""
+    rows6 = rows6.contiguous()
+    out = torch.empty_like(rows6)
+    _C.check(_C.fn("rr_sort_rows_by_score")(_C.ptr(rows6), rows6.shape[0], _C.ptr(out), _C.stream()), "rr_sort_rows_by_score")
+    return out
+
+
 def roi_spatial_order(rois, frame_off):
     """Per-frame spatial processing order of the packed RoI list (frame_off int32 [B+1], device) -> int32 [R]."""
     r = rois.shape[0]

@@ -171,6 +171,7 @@ def test_multi_scale_evaluate_images_vs_oracle():
     ns = SimpleNamespace(cfg=cfg, model=model.cuda().to(memory_format=torch.channels_last).eval())
     ns.generate_bbox = types.MethodType(RRNetOperator.generate_bbox, ns)
     ns._ext_nms = RRNetOperator._ext_nms
+    ns._ext_nms_device = RRNetOperator._ext_nms_device
     with torch.no_grad():
         got = RRNetOperator.evaluate_images(ns, img.cuda()).numpy()
     assert abs(got.shape[0] - ref.shape[0]) <= max(2, ref.shape[0] // 200), (got.shape, ref.shape)
@@ -186,3 +187,14 @@ def test_multi_scale_evaluate_images_vs_oracle():
             used[lo + cand[0]] = True
             hits += 1
     assert hits >= 0.98 * ref.shape[0], (hits, ref.shape[0])
+
+
+def test_sort_rows_by_score_is_the_stable_descending_sort():
+    from rrnet_amd import ops
+    rng = np.random.default_rng(4)
+    for n in (1, 7, 1500, 9000, 16384):
+        rows = rng.uniform(0, 100, (n, 6)).astype(np.float32)
+        rows[:, 4] = np.round(rng.uniform(0, 1, n) * 50) / 50            # many exact ties
+        got = ops.sort_rows_by_score(torch.from_numpy(rows).cuda()).cpu().numpy()
+        exp = rows[np.argsort(-rows[:, 4], kind="stable")]
+        assert np.array_equal(got, exp), n
