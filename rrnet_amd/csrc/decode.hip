@@ -67,10 +67,12 @@ __device__ void find_bin(const int *hist, int nbins, int need, int *result)
 constexpr int DEC_CAP = 8192;      // candidate slots of the fast path (64 KB of LDS)
 constexpr int DEC_SAMPLES = 16384;  // strided sample that places the candidate threshold
 constexpr int SCAN_T = 256;         // threads of a scan workgroup (multi-workgroup path)
-constexpr int SCAN_PER = 32;        // floats per thread of a scan workgroup (8 float4)
+constexpr int SCAN_PER = 32;        // floats per thread of a scan workgroup (8 float4; decode_scan_kernel is written for 8)
 
 // Per-frame scratch of the multi-workgroup path (rr_decode_workspace_bytes): the sampled threshold, the
 // candidate counter and DEC_CAP candidate slots.
+typedef float4 f32x4s;
+
 struct DecodeFrameWs {
     unsigned int thr;    // ordered key of the candidate threshold (0: every element is a candidate)
     int cnt;             // candidates appended so far (may exceed DEC_CAP: then the exact path runs)
@@ -231,6 +233,22 @@ __global__ __launch_bounds__(DT) void decode_threshold_kernel(const float *hm, i
     }
 }
 
+// rare path of the scan (≈0.2 % of the elements): kept out of line so that the streaming loop stays small, fully
+// unrolled and in registers (inlined 32 times it pushed the loaded float4s into scratch memory and doubled the traffic)
+__device__ __noinline__ void scan_push(const float *x, unsigned int o, long i, int peak, int is_logits, int C, int H, int W,
+                                       unsigned long long *lcand, int *lcnt, int lcap, DecodeFrameWs *f)
+{
+    if (peak && !is_peak3x3(x, i, C, H, W, is_logits)) return;
+    const unsigned long long key = ((unsigned long long)o << 32) | (unsigned long long)i;
+    const int p = atomicAdd(lcnt, 1);
+    if (p < lcap) {
+        lcand[p] = key;
+    } else {                                       // a workgroup with > lcap candidates (t0 == 0, flat maps): direct
+        const int q = atomicAdd(&f->cnt, 1);
+        if (q < DEC_CAP) f->cand[q] = key;
+    }
+}
+
 __global__ __launch_bounds__(SCAN_T) void decode_scan_kernel(const float *hm, int is_logits, int peak, int H, int W, int C,
                                                              DecodeFrameWs *ws)
 {
@@ -242,41 +260,36 @@ __global__ __launch_bounds__(SCAN_T) void decode_scan_kernel(const float *hm, in
     const long n = (long)H * W * C;
     const float *x = hm + (long)blockIdx.y * n;
     DecodeFrameWs *f = ws + blockIdx.y;
+    const long base = (long)blockIdx.x * (SCAN_T * SCAN_PER);
+    const bool full = (n & 3) == 0 && base + SCAN_T * SCAN_PER <= n;
+    f32x4s v0, v1, v2, v3, v4, v5, v6, v7;
+    if (full) {                                    // the streaming loads go out before the threshold is even known
+        const f32x4s *p = reinterpret_cast<const f32x4s *>(x + base) + threadIdx.x;
+        v0 = p[0 * SCAN_T]; v1 = p[1 * SCAN_T]; v2 = p[2 * SCAN_T]; v3 = p[3 * SCAN_T];
+        v4 = p[4 * SCAN_T]; v5 = p[5 * SCAN_T]; v6 = p[6 * SCAN_T]; v7 = p[7 * SCAN_T];
+    }
     const unsigned int t0 = f->thr;
     if (t0 == 0xffffffffu) return;
     if (threadIdx.x == 0) lcnt = 0;
     __syncthreads();
-    const long base = (long)blockIdx.x * (SCAN_T * SCAN_PER);
-    auto push = [&](unsigned int o, long i) {
-        if (peak && !is_peak3x3(x, i, C, H, W, is_logits)) return;
-        const unsigned long long key = ((unsigned long long)o << 32) | (unsigned long long)i;
-        const int p = atomicAdd(&lcnt, 1);
-        if (p < LCAP) {
-            lcand[p] = key;
-        } else {                                   // a workgroup with > LCAP candidates (t0 == 0, flat maps): direct
-            const int q = atomicAdd(&f->cnt, 1);
-            if (q < DEC_CAP) f->cand[q] = key;
+    if (full) {
+#define RR_SCAN4(V, R)                                                                                              \
+        {                                                                                                           \
+            const long i0 = base + ((long)(R) * SCAN_T + threadIdx.x) * 4;                                          \
+            const unsigned int o0 = f2ord(V.x), o1 = f2ord(V.y), o2 = f2ord(V.z), o3 = f2ord(V.w);                  \
+            if (o0 >= t0) scan_push(x, o0, i0, peak, is_logits, C, H, W, lcand, &lcnt, LCAP, f);                    \
+            if (o1 >= t0) scan_push(x, o1, i0 + 1, peak, is_logits, C, H, W, lcand, &lcnt, LCAP, f);                \
+            if (o2 >= t0) scan_push(x, o2, i0 + 2, peak, is_logits, C, H, W, lcand, &lcnt, LCAP, f);                \
+            if (o3 >= t0) scan_push(x, o3, i0 + 3, peak, is_logits, C, H, W, lcand, &lcnt, LCAP, f);                \
         }
-    };
-    if ((n & 3) == 0 && base + SCAN_T * SCAN_PER <= n) {
-        float4 v[SCAN_PER / 4];
-#pragma unroll
-        for (int r = 0; r < SCAN_PER / 4; ++r)
-            v[r] = *reinterpret_cast<const float4 *>(x + base + ((long)r * SCAN_T + threadIdx.x) * 4);
-#pragma unroll
-        for (int r = 0; r < SCAN_PER / 4; ++r) {
-            const long i0 = base + ((long)r * SCAN_T + threadIdx.x) * 4;
-            const unsigned int o0 = f2ord(v[r].x), o1 = f2ord(v[r].y), o2 = f2ord(v[r].z), o3 = f2ord(v[r].w);
-            if (o0 >= t0) push(o0, i0);
-            if (o1 >= t0) push(o1, i0 + 1);
-            if (o2 >= t0) push(o2, i0 + 2);
-            if (o3 >= t0) push(o3, i0 + 3);
-        }
+        RR_SCAN4(v0, 0) RR_SCAN4(v1, 1) RR_SCAN4(v2, 2) RR_SCAN4(v3, 3)
+        RR_SCAN4(v4, 4) RR_SCAN4(v5, 5) RR_SCAN4(v6, 6) RR_SCAN4(v7, 7)
+#undef RR_SCAN4
     } else {
         const long end = base + SCAN_T * SCAN_PER < n ? base + SCAN_T * SCAN_PER : n;
         for (long i = base + threadIdx.x; i < end; i += SCAN_T) {
             const unsigned int o = f2ord(x[i]);
-            if (o >= t0) push(o, i);
+            if (o >= t0) scan_push(x, o, i, peak, is_logits, C, H, W, lcand, &lcnt, LCAP, f);
         }
     }
     __syncthreads();
