@@ -239,6 +239,21 @@ __global__ __launch_bounds__(T) void soft_nms_kernel(float *boxes, const int *se
     __syncthreads();
     __shared__ int outn;
     if (threadIdx.x == 0) outn = n;
+    if (T > 64 && n <= 192) {
+        // The launch is sized for the LONGEST possible segment (the caller's bound, e.g. K = 1500), the typical
+        // (frame, class) segment holds ~150 boxes: those run on the first wave alone — same algorithm, wave
+        // shuffles instead of block barriers in every one of its ~N steps (the barriers were most of the step).
+        __syncthreads();
+        if (threadIdx.x >= 64) return;
+        soft_nms_segment<64>(v, n, sigma, Nt, thr, method, red, &outn, err);
+        const int nn1 = outn;
+        for (int p = threadIdx.x; p < nn1; p += 64) {
+            float *r = b + (size_t)p * stride;
+            r[0] = v.x1[p]; r[1] = v.y1[p]; r[2] = v.x2[p]; r[3] = v.y2[p]; r[4] = v.s[p];
+        }
+        if (threadIdx.x == 0) n_out[seg] = nn1;
+        return;
+    }
     soft_nms_segment<T>(v, n, sigma, Nt, thr, method, red, &outn, err);
     __syncthreads();
     const int nn = outn;
