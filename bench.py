@@ -76,13 +76,13 @@ def _cpu_step(seed, size, k):
         times.append(time.perf_counter() - t0)
         if size >= 1024:                               # the full-size sample is a single run (it takes ~a minute)
             return times[0]
-    return sorted(times[1:])[len(times[1:]) // 2] if len(times) > 2 else times[-1], times
+    return sum(times[1:]) / len(times[1:]), times
 
 
 def cpu_baseline(seed, k=100, budget_s=150.0):
     """The oracle ("port": torch-CPU restatement of the reference graph, oracle/model.py + ops.py) running the
     hourglass-104 RRNet train step INCLUDING the Adam update on this box's host cores.  Measured: 512x512 frame, one
-    warm-up then the median of two timed steps; conv FLOPs scale with the pixel count, so images/sec at 1024^2 =
+    warm-up then the mean of two timed steps; conv FLOPs scale with the pixel count, so images/sec at 1024^2 =
     1 / (t_512 * 4).  If the 512x512 runs leave room in the time budget, one real 1024x1024 step is timed too and
     reported next to the extrapolation (`value` is the measured one when present)."""
     t_start = time.perf_counter()
@@ -92,7 +92,7 @@ def cpu_baseline(seed, k=100, budget_s=150.0):
            "torch_num_threads": threads, "host_cpus": os.cpu_count(),
            "t_512_s": [round(t, 2) for t in all512], "images_per_sec_from_512": round(1.0 / (t512 * 4.0), 5)}
     sample = ("oracle torch-CPU RRNet hourglass-104 train step (fwd+losses+bwd+Adam), 1 frame 512x512, k=%d, %d threads: "
-              "warm-up %.2f s, timed %.2f / %.2f s, median scaled x4 (conv-FLOP ratio) to 1024x1024"
+              "warm-up %.2f s, timed %.2f / %.2f s, their mean scaled x4 (conv-FLOP ratio) to 1024x1024"
               % (k, threads, all512[0], all512[1], all512[2]))
     spent = time.perf_counter() - t_start
     if spent + 6.0 * t512 < budget_s:                  # a cold 1024^2 step costs ~4x a warm 512^2 one + warm-up effects
