@@ -785,7 +785,10 @@ __global__ __launch_bounds__(256) void dcn_dgrad_kernel(const DcnBwdArgs b)
                         val += R.w[e] * xv;
                         gh += dhw[e] * xv;
                         gw += dww[e] * xv;
-                        if (R.o[e] >= 0 && c < a.C && !(b.dbg & 1)) unsafeAtomicAdd(b.dx + (long)R.o[e] * a.C + c, gval * R.w[e]);
+                        // (a corner of weight 0 — integer sample positions, e.g. the zero-initialised offsets of a fresh DCN
+                        // layer — adds nothing: no atomic for it)
+                        if (R.o[e] >= 0 && R.w[e] != 0.f && c < a.C && !(b.dbg & 1))
+                            unsafeAtomicAdd(b.dx + (long)R.o[e] * a.C + c, gval * R.w[e]);
                     }
                     s_m += gcol * val;
                     s_h += gval * gh;
