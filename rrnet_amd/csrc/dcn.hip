@@ -364,6 +364,220 @@ __global__ __launch_bounds__(256) void dcn_fprop_bf16_kernel(const DcnArgs a)
     }
 }
 
+// ---- bf16-operand forward with an LDS-staged input window (round 2) -------------------------------------------------
+// The gather was the bound of dcn_fprop_bf16_kernel: every (pixel, tap) fetched its four corner rows from global
+// memory, 19.4 GB per call through the fabric for a 0.54 GB input (each input row is wanted ~36 times, minutes apart in
+// L2 terms).  Here a workgroup owns a 2-D block of TH x TW = 8 x 16 output pixels, and for every 32-channel chunk the
+// input window that block can reach — the block, the filter's extent and a margin of RW pixels for the offsets — is
+// staged ONCE into LDS (coalesced rows, prefetched into registers under the previous chunk's MFMAs); the 9 taps of
+// the chunk gather their corners from LDS.  Corners that fall outside the window (|offset| beyond the margin) are
+// fetched from global memory by the lanes concerned.  The sample geometry (4 corner indices + 4 mask-weighted bilinear
+// weights per pixel and tap) is computed once per workgroup into LDS tables.  K-steps run chunk outer / tap inner.
+// stride 1 only (the window of a strided layer is not compact); other layers take dcn_fprop_bf16_kernel.
+constexpr int WIN_TH = 8, WIN_TW = 16;
+
+struct DcnWinArgs {
+    DcnArgs a;
+    int RW, WH, WW;        // margin, window height / width in pixels
+    int tiles_y, tiles_x;  // pixel blocks per image
+};
+
+template <int BN>      // 128 or 256 output channels per workgroup: at 256 one gather feeds twice the MFMAs
+__global__ __launch_bounds__(256) void dcn_fprop_win_bf16_kernel(const DcnWinArgs wa)
+{
+    const DcnArgs &a = wa.a;
+    constexpr int WN = 2, WM = 2, TM = 2, TN = BN / 64, BJ = BN / 32;
+    constexpr int A_ELEMS = BM * LDKH, B_ELEMS = BN * LDKH;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int RS = a.R * a.S;
+    const int npx = wa.WH * wa.WW;
+    float *win = reinterpret_cast<float *>(smem);                               // [npx][32]
+    unsigned int *geo_o = reinterpret_cast<unsigned int *>(win + (size_t)npx * BK);   // [BM][RS][4]
+    float *geo_w = reinterpret_cast<float *>(geo_o + BM * RS * 4);              // [BM][RS][4]
+    unsigned short *As = reinterpret_cast<unsigned short *>(geo_w + BM * RS * 4);
+    unsigned short *Bs = As + 2 * A_ELEMS;
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave / WN, wn = wave % WN;
+    const int ntiles = (a.K + BN - 1) / BN;
+    int bid = blockIdx.x;
+    const int n_tile = bid % ntiles; bid /= ntiles;
+    const int txi = bid % wa.tiles_x; bid /= wa.tiles_x;
+    const int tyi = bid % wa.tiles_y;
+    const int n = bid / wa.tiles_y;
+    const int y0 = tyi * WIN_TH, x0 = txi * WIN_TW, n0 = n_tile * BN;
+    const int wy0 = y0 - a.pad_h - wa.RW, wx0 = x0 - a.pad_w - wa.RW;   // image coordinates of window pixel (0, 0)
+    const int cpt = a.C / BK;                                            // channel chunks (C % 32 == 0 on this path)
+    const int cpg = a.C / a.dg;
+    const int a_col = (t & 7) * 4, a_row = t >> 3;
+    const long img = (long)n * a.H * a.W;
+
+    // ---- geometry tables for deformable group g
+    auto build_geo = [&](int g) {
+        for (int it = t; it < BM * RS; it += 256) {
+            const int r = it / RS, tap = it - r * RS;
+            const int p = y0 + r / WIN_TW, q = x0 + r % WIN_TW;
+            unsigned int o[4] = {0u, 0u, 0u, 0u};
+            float w4[4] = {0.f, 0.f, 0.f, 0.f};
+            if (p < a.P && q < a.Q) {
+                const long m = ((long)n * a.P + p) * a.Q + q;
+                const float *po = a.offset + m * (2 * a.dg * RS) + g * 2 * RS + 2 * tap;
+                const float mk = a.mask[m * (a.dg * RS) + g * RS + tap];
+                const int ti = tap / a.S, tj = tap - ti * a.S;
+                const float h = (float)(p - a.pad_h + ti * a.dil) + po[0];
+                const float w = (float)(q - a.pad_w + tj * a.dil) + po[1];
+                const bool inside = h > -1.f && w > -1.f && h < (float)a.H && w < (float)a.W;
+                const float hf = floorf(h), wf = floorf(w);
+                const int h0 = (int)hf, w0 = (int)wf;
+                const float lh = h - hf, lw = w - wf, hh = 1.f - lh, hw = 1.f - lw;
+                const float cw[4] = {hh * hw, hh * lw, lh * hw, lh * lw};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int hy = h0 + (e >> 1), wx = w0 + (e & 1);
+                    if (inside && hy >= 0 && hy <= a.H - 1 && wx >= 0 && wx <= a.W - 1) {
+                        w4[e] = cw[e] * mk;
+                        const int ly = hy - wy0, lx = wx - wx0;
+                        o[e] = (ly >= 0 && ly < wa.WH && lx >= 0 && lx < wa.WW) ? (unsigned int)(ly * wa.WW + lx)
+                                                                               : (0x80000000u | (unsigned int)(hy * a.W + wx));
+                    }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { geo_o[it * 4 + e] = o[e]; geo_w[it * 4 + e] = w4[e]; }
+        }
+    };
+    // ---- window of channel chunk `cch`: global -> registers (prefetch) -> LDS
+    constexpr int WREG = 14;                       // float4 per thread: windows up to 448 pixels
+    f32x4 wreg[WREG];
+    auto fetch_window = [&](int cch) {
+        const int c0 = cch * BK;
+#pragma unroll
+        for (int u = 0; u < WREG; ++u) {
+            const int i = t + u * 256;
+            const int px = i >> 3, c4 = (i & 7) * 4;
+            const int ly = px / wa.WW, lx = px - ly * wa.WW;
+            const int gy = wy0 + ly, gx = wx0 + lx;
+            const bool ok = px < npx && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            wreg[u] = *reinterpret_cast<const f32x4 *>(ok ? a.x + (img + (long)gy * a.W + gx) * a.C + c0 + c4 : a.zero);
+        }
+    };
+    auto store_window = [&]() {
+#pragma unroll
+        for (int u = 0; u < WREG; ++u) {
+            const int i = t + u * 256;
+            if ((i >> 3) < npx) *reinterpret_cast<f32x4 *>(win + (size_t)i * 4) = wreg[u];
+        }
+    };
+    f32x4 rv[4], rb[BJ];
+    auto build_a = [&](int cch, int tap) {          // blended samples of the 4 rows this thread stages
+        const int c0 = cch * BK;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = a_row + 32 * j;
+            const unsigned int *go = geo_o + (r * RS + tap) * 4;
+            const float *gw = geo_w + (r * RS + tap) * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned int o = go[e];
+                const float wgt = gw[e];
+                f32x4 xv;
+                if (o & 0x80000000u) xv = *reinterpret_cast<const f32x4 *>(a.x + (img + (long)(o & 0x7fffffffu)) * a.C + c0 + a_col);
+                else xv = *reinterpret_cast<const f32x4 *>(win + (size_t)o * BK + a_col);
+                v += xv * wgt;
+            }
+            rv[j] = v;
+        }
+    };
+    auto issue_b = [&](int cch, int tap) {
+        const int c0 = cch * BK;
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) {
+            const int ko = n0 + a_row + 32 * j;
+            rb[j] = *reinterpret_cast<const f32x4 *>(ko < a.K ? a.w + ((long)ko * RS + tap) * a.C + c0 + a_col : a.zero);
+        }
+    };
+    auto commit = [&](int buf) {
+        unsigned short *A = As + buf * A_ELEMS, *B = Bs + buf * B_ELEMS;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<u16x4 *>(A + (a_row + 32 * j) * LDKH + a_col) = f2bf4(rv[j]);
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) *reinterpret_cast<u16x4 *>(B + (a_row + 32 * j) * LDKH + a_col) = f2bf4(rb[j]);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    const int lr = lane & 31, lh = lane >> 5;
+
+    int g_cur = 0;
+    build_geo(0);
+    fetch_window(0);
+    store_window();
+    __syncthreads();
+    build_a(0, 0);
+    issue_b(0, 0);
+    commit(0);
+    __syncthreads();
+    const int nk = cpt * RS;
+    for (int kc = 0; kc < nk; ++kc) {
+        const int buf = kc & 1;
+        const int cch = kc / RS, tap = kc - cch * RS;
+        const bool more = kc + 1 < nk;
+        const bool new_chunk = more && tap == RS - 1;           // the next K-step opens chunk cch + 1
+        if (tap == 0 && cch + 1 < cpt) fetch_window(cch + 1);    // lands under this chunk's 9 K-steps
+        if (more && !new_chunk) {
+            issue_b(cch, tap + 1);
+            build_a(cch, tap + 1);
+        }
+        const unsigned short *A = As + buf * A_ELEMS, *B = Bs + buf * B_ELEMS;
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            bf16x8 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                fa[i] = *reinterpret_cast<const bf16x8 *>(A + ((wm * TM + i) * 32 + lr) * LDKH + kk * 16 + lh * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                fb[j] = *reinterpret_cast<const bf16x8 *>(B + ((wn * TN + j) * 32 + lr) * LDKH + kk * 16 + lh * 8);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        if (new_chunk) {
+            // every wave is past its last gather from the old window (it built tap RS-1 one K-step ago)
+            __syncthreads();
+            store_window();
+            const int g = ((cch + 1) * BK) / cpg;
+            if (g != g_cur) { g_cur = g; build_geo(g); }
+            __syncthreads();
+            issue_b(cch + 1, 0);
+            build_a(cch + 1, 0);
+        }
+        if (more) commit(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int ko = n0 + (wn * TN + j) * 32 + lr;
+        if (ko >= a.K) continue;
+        const float bv = a.bias ? a.bias[ko] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int r = (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                const int p = y0 + r / WIN_TW, q = x0 + r % WIN_TW;
+                if (p < a.P && q < a.Q) a.y[(((long)n * a.P + p) * a.Q + q) * a.K + ko] = acc[i][j][e] + bv;
+            }
+    }
+}
+
 // columns [M][R*S*C] = mask * bilinear samples (only the backward needs them materialised)
 __global__ __launch_bounds__(256) void dcn_im2col_kernel(const DcnArgs a, float *col)
 {
@@ -462,7 +676,6 @@ struct DcnBwdArgs {
     float *dw;          // [K][R][S][C], accumulated with float atomics
     float *dx, *doffset, *dmask;
     int chunks_per_split, mt, nt;
-    int dbg;            // experiments only (RR_DCN_DBG): 1 no atomics, 2 no corner loads, 3 no epilogue
 };
 
 __device__ __forceinline__ int dcn_xcd_remap(int bid, int nb)
@@ -764,7 +977,7 @@ __global__ __launch_bounds__(256) void dcn_dgrad_kernel(const DcnBwdArgs b)
                     const int c = c0 + l32 + 32 * i;
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        R.xv[e][i] = (R.o[e] >= 0 && c < a.C && !(b.dbg & 2)) ? a.x[(long)R.o[e] * a.C + c] : 0.f;
+                        R.xv[e][i] = (R.o[e] >= 0 && c < a.C) ? a.x[(long)R.o[e] * a.C + c] : 0.f;
                 }
             };
             auto process = [&](int pass, const PassRegs &R) {
@@ -787,7 +1000,7 @@ __global__ __launch_bounds__(256) void dcn_dgrad_kernel(const DcnBwdArgs b)
                         gw += dww[e] * xv;
                         // (a corner of weight 0 — integer sample positions, e.g. the zero-initialised offsets of a fresh DCN
                         // layer — adds nothing: no atomic for it)
-                        if (R.o[e] >= 0 && R.w[e] != 0.f && c < a.C && !(b.dbg & 1))
+                        if (R.o[e] >= 0 && R.w[e] != 0.f && c < a.C)
                             unsafeAtomicAdd(b.dx + (long)R.o[e] * a.C + c, gval * R.w[e]);
                     }
                     s_m += gcol * val;
@@ -804,7 +1017,7 @@ __global__ __launch_bounds__(256) void dcn_dgrad_kernel(const DcnBwdArgs b)
             };
             PassRegs R0, R1;
             fetch(0, R0);
-            for (int pass = 0; pass < ((b.dbg & 4) ? 0 : BM / 8); pass += 2) {
+            for (int pass = 0; pass < BM / 8; pass += 2) {
                 fetch(pass + 1, R1);
                 process(pass, R0);
                 if (pass + 2 < BM / 8) fetch(pass + 2, R0);
@@ -906,6 +1119,16 @@ extern "C" int rr_dcn_fwd(const float *x, const float *offset, const float *mask
     return RR_OK;
 }
 
+static int dcn_win_margin()
+{
+    static int v = -2;
+    if (v == -2) {
+        const char *e = getenv("RR_DCN_WINDOW");      // margin in pixels around the filter's reach; -1 / 0 disables the window kernel
+        v = e ? atoi(e) : 3;
+    }
+    return v;
+}
+
 extern "C" int rr_dcn_fwd_bf16(const float *x, const float *offset, const float *mask, const float *w, const float *bias,
                                float *y, int n, int h, int wd, int c, int k, int r, int s, int stride, int pad_h, int pad_w,
                                int dilation, int deformable_groups, hipStream_t stream)
@@ -915,6 +1138,32 @@ extern "C" int rr_dcn_fwd_bf16(const float *x, const float *offset, const float 
     if (rc != RR_OK) return rc;
     a.bias = bias; a.y = y;
     const int bn = k > 32 ? 128 : 32;
+    const int rw = dcn_win_margin();
+    if (rw > 0 && stride == 1 && bn == 128 && c % BK == 0 && (long)h * wd < (1l << 30)) {
+        // LDS-window kernel: the input block a pixel tile can reach is staged once per channel chunk
+        DcnWinArgs wa{};
+        wa.a = a;
+        wa.RW = rw;
+        wa.WH = WIN_TH + (r - 1) * dilation + 2 * rw + 1;
+        wa.WW = WIN_TW + (s - 1) * dilation + 2 * rw + 1;
+        wa.tiles_y = rr_cdiv(a.P, WIN_TH);
+        wa.tiles_x = rr_cdiv(a.Q, WIN_TW);
+        const int npx = wa.WH * wa.WW;
+        const int wbn = (k % 256 == 0 || k > 384) ? 256 : 128;
+        const size_t lds = (size_t)npx * BK * 4 + (size_t)BM * r * s * 4 * 8 + sizeof(unsigned short) * 2 * (BM * LDKH + wbn * LDKH);
+        if (npx <= 14 * 32 && lds <= 160 * 1024 - 512) {
+            const int blocks = n * wa.tiles_y * wa.tiles_x * rr_cdiv(k, wbn);
+            if (wbn == 256) {
+                hipFuncSetAttribute(reinterpret_cast<const void *>(dcn_fprop_win_bf16_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipLaunchKernelGGL(dcn_fprop_win_bf16_kernel<256>, dim3(blocks), dim3(256), lds, stream, wa);
+            } else {
+                hipFuncSetAttribute(reinterpret_cast<const void *>(dcn_fprop_win_bf16_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipLaunchKernelGGL(dcn_fprop_win_bf16_kernel<128>, dim3(blocks), dim3(256), lds, stream, wa);
+            }
+            RR_CHECK_LAUNCH("rr_dcn_fwd_bf16");
+            return RR_OK;
+        }
+    }
     const int blocks = rr_cdiv(a.M, BM) * rr_cdiv(k, bn);
     const size_t lds = sizeof(unsigned short) * 2 * (BM * LDKH + bn * LDKH);
     if (bn == 128) hipLaunchKernelGGL(dcn_fprop_bf16_kernel<128>, dim3(blocks), dim3(256), lds, stream, a);
@@ -1004,7 +1253,6 @@ extern "C" int rr_dcn_dgrad(const float *x, const float *offset, const float *ma
                  "rr_dcn_dgrad: channels per deformable group (%d) must be a multiple of 128", c / deformable_groups);
     RR_CHECK_ARG((long)n * h * wd < (1l << 31), "rr_dcn_dgrad: input too large");
     b.dy = dy; b.dx = dx; b.doffset = doffset; b.dmask = dmask;
-    { const char *e = getenv("RR_DCN_DBG"); b.dbg = e ? atoi(e) : 0; }
     hipMemsetAsync(dx, 0, sizeof(float) * (size_t)n * h * wd * c, stream);
     const size_t lds = sizeof(float) * (2 * (BM * LDK + BK * 128) + BM * 8 + BM * 4 + BM * 3);
     hipFuncSetAttribute(reinterpret_cast<const void *>(dcn_dgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
