@@ -67,3 +67,14 @@ def to_heatmap(data, scale_factor=4, cls_num=10):
     for k, cls in enumerate(cls_idx):
         draw_umich_gaussian(hm[cls.long().item()], ct_int[k], radius[k])
     return data[0], data[1], hm, wh, ind, offset, reg_mask
+
+
+def flip_img(data):
+    """datasets/transforms/functional.py:13-19: horizontal flip of a [C,H,W] image tensor."""
+    return data.flip(dims=(2,))
+
+
+def flip_annos(data, w):
+    """datasets/transforms/functional.py:22-29: x -> w - x - width for xywh rows (in place, like the reference)."""
+    data[:, 0] = w - data[:, 0] - data[:, 2]
+    return data

@@ -12,6 +12,7 @@ import torch.optim as optim
 from rrnet_amd import functional as RF
 from rrnet_amd import ops
 from rrnet_amd.datasets import make_dataloader
+from rrnet_amd.datasets.transforms.functional import flip_annos, flip_img
 from rrnet_amd.flat import FlatAdam, FlatParams
 from rrnet_amd.models.centernet import CenterNet
 from rrnet_amd.models.rrnet import RRNet
@@ -19,17 +20,6 @@ from rrnet_amd.modules.loss.focalloss import FocalLossHM
 from rrnet_amd.modules.loss.regl1loss import RegL1Loss
 from .base_operator import BaseOperator
 from .rrnet_operator import RRNetOperator
-
-
-def flip_img(img):
-    """datasets/transforms/functional.py flip_img: horizontal flip of a [C,H,W] image."""
-    return torch.flip(img, dims=[2])
-
-
-def flip_annos(annos, w):
-    """datasets/transforms/functional.py flip_annos: x -> w - x - width for xywh rows (in place, like the reference)."""
-    annos[:, 0] = w - annos[:, 0] - annos[:, 2]
-    return annos
 
 
 class CenterNetOperator(BaseOperator):
