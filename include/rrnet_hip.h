@@ -319,6 +319,12 @@ int rr_dcn_wgrad(const float *x, const float *offset, const float *mask, const f
 int rr_dcn_dgrad(const float *x, const float *offset, const float *mask, const float *w, const float *dy, float *dx,
                  float *doffset, float *dmask, int n, int h, int wd, int c, int k, int r, int s, int stride, int pad_h,
                  int pad_w, int dilation, int deformable_groups, hipStream_t stream);
+/* rr_dcn_dgrad with bf16 matrix operands (dY, W rounded to bf16; fp32 accumulation and scatter) and d input pre-summed
+ * in an LDS window per 8x16 pixel block and 32-channel chunk before it goes out as global atomics (a tenth of the atomic
+ * bytes): the backward of rr_dcn_fwd_bf16.  stride 1, c % 32 == 0; other layers take the rr_dcn_dgrad kernel. */
+int rr_dcn_dgrad_bf16(const float *x, const float *offset, const float *mask, const float *w, const float *dy, float *dx,
+                      float *doffset, float *dmask, int n, int h, int wd, int c, int k, int r, int s, int stride,
+                      int pad_h, int pad_w, int dilation, int deformable_groups, hipStream_t stream);
 
 /* DCN module glue (ext/dcn/dcn_v2.py:117-121): om NHWC [m, 3*third] -> offset [m, 2*third] (first two thirds,
  * unchanged = cat(o1, o2)) and mask [m, third] = sigmoid(last third); backward: dom from doffset, dmask and mask. */

@@ -1070,6 +1070,278 @@ __global__ void dcn_split_bwd_kernel(const float *doffset, const float *dmask, c
     }
 }
 
+// ---- fused backward, data side, with on-chip pre-summation of d input (bf16 matrix operands) -------------------------
+// dcn_dgrad_kernel adds every (pixel, tap, corner, channel) contribution to d input with its own global float atomic:
+// 19.3 GB of atomic bytes at the config-4 layer, i.e. 14.8 ms at the chip's ≈1.3 TB/s atomic rate whatever the schedule.
+// Here a workgroup owns a 2-D block of 8 x 16 output pixels; for each 32-channel chunk it computes the nine taps' column
+// gradients in ONE sweep over K (dcol_tap[128 px][32 ch] = dY[128][K] x W[K][tap][32 ch]: nine accumulator tiles in
+// registers, bf16 operands, fp32 accumulation), scatters the corner contributions into an LDS image of the input window the block
+// can reach (fixed-point ds_add_u32 — ds_add_f32 is 26x slower on this part; pixel stride 33 words against bank
+// conflicts) and flushes that window ONCE per chunk with global atomics: ≈3.3 window pixels per output pixel instead of 36 corner adds, 1.8 GB of atomic bytes instead of 19.3.
+// Corners beyond the window margin go to global memory directly.  d offset / d mask are summed over the chunks in LDS and
+// stored once.  Sample geometry per (pixel, tap) in LDS: (h0, w0) of the first corner, the fractions, the mask.
+struct DcnWinBwdArgs {
+    DcnWinArgs w;
+    const float *dy;
+    float *dx, *doffset, *dmask;
+};
+
+template <int RS>      // taps of the filter (9 for 3x3): one accumulator tile per tap lives in registers through a chunk
+__global__ __launch_bounds__(256) void dcn_dgrad_win_bf16_kernel(const DcnWinBwdArgs wb)
+{
+    const DcnWinArgs &wa = wb.w;
+    const DcnArgs &a = wa.a;
+    constexpr int CW = 32, WSTR = 33, SST = 36;
+    constexpr int A_ELEMS = BM * LDKH, B_ELEMS = RS * CW * LDKH;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int npx = wa.WH * wa.WW;
+    int *dxw = reinterpret_cast<int *>(smem);                                       // [npx][33] fixed point (see below)
+    int *geo_i = dxw + (size_t)((npx * WSTR + 3) & ~3);                             // [BM][RS]: (h0 << 16) | (w0 & 0xffff); 0x7fffffff = no sample
+    float *geo_f = reinterpret_cast<float *>(geo_i + BM * RS);                      // [BM][RS][3]: lh, lw, mask
+    float *red = geo_f + BM * RS * 3;                                               // [BM][RS][3]: d mask, d off h, d off w
+    float *stage = red + BM * RS * 3;                                               // [BM][SST]
+    unsigned short *As = reinterpret_cast<unsigned short *>(stage + BM * SST);      // [BM][LDKH]   (single image: operands
+    unsigned short *Bs = As + A_ELEMS;                                              // [RS][32][LDKH] are prefetched in registers)
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int lr = lane & 31, lh_ = lane >> 5;
+    int bid = dcn_xcd_remap(blockIdx.x, gridDim.x);
+    const int txi = bid % wa.tiles_x; bid /= wa.tiles_x;
+    const int tyi = bid % wa.tiles_y;
+    const int n = bid / wa.tiles_y;
+    const int y0 = tyi * WIN_TH, x0 = txi * WIN_TW;
+    const int wy0 = y0 - a.pad_h - wa.RW, wx0 = x0 - a.pad_w - wa.RW;
+    const int cpt = a.C / CW, cpg = a.C / a.dg;
+    const int nkc = (a.K + BK - 1) / BK;
+    const int a_col = (t & 7) * 4, a_row = t >> 3;
+    const long img = (long)n * a.H * a.W;
+
+    __shared__ float wmax[4];
+    __shared__ int mkmax_bits;       // bits of max |mask| seen by this block (over all groups: a bound is all that is needed)
+    auto build_geo = [&](int g) {
+        for (int it = t; it < BM * RS; it += 256) {
+            const int r = it / RS, tap = it - r * RS;
+            const int p = y0 + r / WIN_TW, q = x0 + r % WIN_TW;
+            int packed = 0x7fffffff;
+            float flh = 0.f, flw = 0.f, mk = 0.f;
+            if (p < a.P && q < a.Q) {
+                const long m = ((long)n * a.P + p) * a.Q + q;
+                const float *po = a.offset + m * (2 * a.dg * RS) + g * 2 * RS + 2 * tap;
+                const int ti = tap / a.S, tj = tap - ti * a.S;
+                const float h = (float)(p - a.pad_h + ti * a.dil) + po[0];
+                const float w = (float)(q - a.pad_w + tj * a.dil) + po[1];
+                if (h > -1.f && w > -1.f && h < (float)a.H && w < (float)a.W) {
+                    const float hf = floorf(h), wf = floorf(w);
+                    packed = ((int)hf << 16) | ((int)wf & 0xffff);
+                    flh = h - hf; flw = w - wf;
+                    mk = a.mask[m * (a.dg * RS) + g * RS + tap];
+                }
+            }
+            geo_i[it] = packed;
+            geo_f[it * 3] = flh; geo_f[it * 3 + 1] = flw; geo_f[it * 3 + 2] = mk;
+            atomicMax(&mkmax_bits, (int)(__float_as_uint(mk) & 0x7fffffffu));      // |mask| bound of the block (non-negative floats order as ints)
+        }
+    };
+    auto store_red = [&](int g) {
+        for (int it = t; it < BM * RS; it += 256) {
+            const int r = it / RS, tap = it - r * RS;
+            const int p = y0 + r / WIN_TW, q = x0 + r % WIN_TW;
+            if (p < a.P && q < a.Q) {
+                const long m = ((long)n * a.P + p) * a.Q + q;
+                wb.dmask[m * (a.dg * RS) + g * RS + tap] = red[it * 3];
+                wb.doffset[m * (2 * a.dg * RS) + g * 2 * RS + 2 * tap] = red[it * 3 + 1];
+                wb.doffset[m * (2 * a.dg * RS) + g * 2 * RS + 2 * tap + 1] = red[it * 3 + 2];
+            }
+            red[it * 3] = 0.f; red[it * 3 + 1] = 0.f; red[it * 3 + 2] = 0.f;
+        }
+    };
+    for (int i = t; i < npx * WSTR; i += 256) dxw[i] = 0;
+    for (int i = t; i < BM * RS * 3; i += 256) red[i] = 0.f;
+    if (t == 0) mkmax_bits = 0;
+    __syncthreads();
+    int g_cur = 0;
+    build_geo(0);
+    __syncthreads();
+
+    f32x4 ra[4], rb[RS];
+    for (int cch = 0; cch < cpt; ++cch) {
+        const int c0 = cch * CW;
+        const int g = c0 / cpg;
+        if (g != g_cur) {                       // (dg > 1) new deformable group: store its predecessor's sums, new geometry
+            __syncthreads();
+            store_red(g_cur);
+            g_cur = g;
+            build_geo(g);
+            __syncthreads();
+        }
+        // ---- the nine column-gradient tiles of this chunk in ONE sweep over K:
+        //      dcol_tap[128 px][32 ch] = dY[128][K] x W[K][tap][c0 .. c0+31]
+        auto issue = [&](int kc) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = a_row + 32 * j;
+                const int p = y0 + r / WIN_TW, q = x0 + r % WIN_TW;
+                const int ko = kc * BK + a_col;
+                ra[j] = *reinterpret_cast<const f32x4 *>((p < a.P && q < a.Q && ko < a.K)
+                                                             ? wb.dy + (((long)n * a.P + p) * a.Q + q) * a.K + ko : a.zero);
+            }
+            const int kb = kc * BK + a_row;          // one ko row per 8 threads, 4 channels each, all taps
+#pragma unroll
+            for (int tap = 0; tap < RS; ++tap)
+                rb[tap] = *reinterpret_cast<const f32x4 *>(kb < a.K ? a.w + ((long)kb * RS + tap) * a.C + c0 + a_col : a.zero);
+        };
+        auto commit = [&]() {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *reinterpret_cast<u16x4 *>(As + (a_row + 32 * j) * LDKH + a_col) = f2bf4(ra[j]);
+#pragma unroll
+            for (int tap = 0; tap < RS; ++tap) {
+                const u16x4 hb = f2bf4(rb[tap]);     // B images are [tap][n = channel][k = ko]: transposed 2-byte stores
+#pragma unroll
+                for (int c = 0; c < 4; ++c) Bs[(tap * CW + a_col + c) * LDKH + a_row] = hb[c];
+            }
+        };
+        f32x16 acc[RS];
+#pragma unroll
+        for (int tap = 0; tap < RS; ++tap)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[tap][e] = 0.f;
+        issue(0);
+        for (int kc = 0; kc < nkc; ++kc) {
+            commit();
+            __syncthreads();
+            if (kc + 1 < nkc) issue(kc + 1);         // lands under this K-step's 18 MFMAs
+#pragma unroll
+            for (int kk = 0; kk < BK / 16; ++kk) {
+                const bf16x8 fa = *reinterpret_cast<const bf16x8 *>(As + (wave * 32 + lr) * LDKH + kk * 16 + lh_ * 8);
+#pragma unroll
+                for (int tap = 0; tap < RS; ++tap) {
+                    const bf16x8 fb = *reinterpret_cast<const bf16x8 *>(Bs + (tap * CW + lr) * LDKH + kk * 16 + lh_ * 8);
+                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[tap], 0, 0, 0);
+                }
+            }
+            __syncthreads();
+        }
+        // ---- the window accumulates in FIXED POINT: ds_add_f32 costs ~190 cycles per wave-instruction on this part
+        //      (3 cycles per lane, serialised across the waves of a CU; measured), ds_add_u32 ~7.  Scale = the power of
+        //      two that keeps 36 contributions of the chunk's largest |dcol| x |mask| below 2^30: absolute rounding
+        //      <= 2^-31 of that bound per add, exact scaling back at the flush.
+        float amax = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < RS; ++tap)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) amax = fmaxf(amax, fabsf(acc[tap][e]));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+        if (lane == 0) wmax[wave] = amax;
+        __syncthreads();
+        const float bound = 36.f * fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3])) * fmaxf(__int_as_float(mkmax_bits), 1e-30f);
+        int ex = 0;
+        frexpf(bound, &ex);
+        const float fx_scale = bound > 0.f ? ldexpf(1.f, 30 - ex) : 0.f, fx_inv = ldexpf(1.f, ex - 30);
+        // ---- epilogue per tap: accumulators -> LDS -> (pixel row, 4 channels) threads
+        for (int tap = 0; tap < RS; ++tap) {            // a real loop: only the accumulator -> LDS copy is per-tap code
+            {
+                float *sp = stage + (wave * 32 + 4 * lh_) * SST + lr;
+#define RR_PUT(T)                                                                                   \
+    case T:                                                                                         \
+        _Pragma("unroll") for (int e = 0; e < 16; ++e) sp[((e & 3) + 8 * (e >> 2)) * SST] = acc[T < RS ? T : 0][e]; \
+        break;
+                switch (tap) {
+                    RR_PUT(0) RR_PUT(1) RR_PUT(2) RR_PUT(3) RR_PUT(4) RR_PUT(5) RR_PUT(6) RR_PUT(7) RR_PUT(8)
+                    default: break;
+                }
+#undef RR_PUT
+            }
+            // corner values of all four row passes go out first: one exposed global latency per tap, not four
+            f32x4 xv[4][4];
+            int gis[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = a_row + 32 * j;
+                const int gi = geo_i[r * RS + tap];
+                gis[j] = gi;
+                const int h0 = gi >> 16, w0 = (int)(short)(gi & 0xffff);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int hy = h0 + (e >> 1), wx = w0 + (e & 1);
+                    const bool ok = gi != 0x7fffffff && hy >= 0 && hy <= a.H - 1 && wx >= 0 && wx <= a.W - 1;
+                    xv[j][e] = *reinterpret_cast<const f32x4 *>(ok ? a.x + (img + (long)hy * a.W + wx) * a.C + c0 + a_col : a.zero);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = a_row + 32 * j;
+                const int gi = gis[j];
+                float s_m = 0.f, s_h = 0.f, s_w = 0.f;
+                if (gi != 0x7fffffff) {
+                    const int h0 = gi >> 16, w0 = (int)(short)(gi & 0xffff);
+                    const float flh = geo_f[(r * RS + tap) * 3], flw = geo_f[(r * RS + tap) * 3 + 1], mk = geo_f[(r * RS + tap) * 3 + 2];
+                    const float hh = 1.f - flh, hw = 1.f - flw;
+                    const float wt[4] = {hh * hw, hh * flw, flh * hw, flh * flw};
+                    const float dhw[4] = {-hw, -flw, hw, flw};
+                    const float dww[4] = {-hh, hh, -flh, flh};
+                    const f32x4 gcol = *reinterpret_cast<const f32x4 *>(stage + r * SST + a_col);
+                    f32x4 val = {0.f, 0.f, 0.f, 0.f}, gh = val, gw = val;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int hy = h0 + (e >> 1), wx = w0 + (e & 1);
+                        if (hy < 0 || hy > a.H - 1 || wx < 0 || wx > a.W - 1) continue;       // corner outside the image
+                        val += xv[j][e] * wt[e];
+                        gh += xv[j][e] * dhw[e];
+                        gw += xv[j][e] * dww[e];
+                        if (wt[e] != 0.f) {
+                            const f32x4 add = gcol * (mk * wt[e]);
+                            const int ly = hy - wy0, lx = wx - wx0;
+                            if (ly >= 0 && ly < wa.WH && lx >= 0 && lx < wa.WW) {
+                                int *d = dxw + (ly * wa.WW + lx) * WSTR + a_col;
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) atomicAdd(d + c, __float2int_rn(add[c] * fx_scale));   // ds_add_u32
+                            } else {
+                                float *d = wb.dx + (img + (long)hy * a.W + wx) * a.C + c0 + a_col;
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) unsafeAtomicAdd(d + c, add[c]);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        s_m += gcol[c] * val[c];
+                        s_h += gcol[c] * mk * gh[c];
+                        s_w += gcol[c] * mk * gw[c];
+                    }
+                }
+#pragma unroll
+                for (int off = 4; off > 0; off >>= 1) {     // the 8 threads of a pixel row
+                    s_m += __shfl_xor(s_m, off, 64);
+                    s_h += __shfl_xor(s_h, off, 64);
+                    s_w += __shfl_xor(s_w, off, 64);
+                }
+                if ((t & 7) == 0) {
+                    float *rd = red + (r * RS + tap) * 3;
+                    rd[0] += s_m; rd[1] += s_h; rd[2] += s_w;
+                }
+            }
+            __syncthreads();        // stage is rewritten by the next tap
+        }
+        // ---- flush this chunk's window: lane <-> channel, 128-byte row segments, one global atomic per touched element
+        {
+            const int c = t & 31;
+            for (int px = t >> 5; px < npx; px += 8) {
+                const int iv = dxw[px * WSTR + c];
+                if (iv != 0) {
+                    const int ly = px / wa.WW, lx = px - ly * wa.WW;
+                    const int gy = wy0 + ly, gx = wx0 + lx;      // inside the image by construction (only valid corners add)
+                    unsafeAtomicAdd(wb.dx + (img + (long)gy * a.W + gx) * a.C + c0 + c, (float)iv * fx_inv);
+                    dxw[px * WSTR + c] = 0;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    store_red(g_cur);
+}
+
 __device__ float rr_dcn_zero16[4] = {0.f, 0.f, 0.f, 0.f};
 
 int fill_args(DcnArgs &a, const float *x, const float *offset, const float *mask, const float *w, int n, int h, int wd,
@@ -1241,9 +1513,9 @@ extern "C" int rr_dcn_wgrad(const float *x, const float *offset, const float *ma
 }
 
 // Fused backward, part 2: dx (zeroed here, then float atomics on the bilinear corners), doffset, dmask (plain stores).
-extern "C" int rr_dcn_dgrad(const float *x, const float *offset, const float *mask, const float *w, const float *dy,
-                            float *dx, float *doffset, float *dmask, int n, int h, int wd, int c, int k, int r, int s,
-                            int stride, int pad_h, int pad_w, int dilation, int deformable_groups, hipStream_t stream)
+static int dcn_dgrad_impl(const float *x, const float *offset, const float *mask, const float *w, const float *dy,
+                          float *dx, float *doffset, float *dmask, int n, int h, int wd, int c, int k, int r, int s,
+                          int stride, int pad_h, int pad_w, int dilation, int deformable_groups, int bf16, hipStream_t stream)
 {
     DcnBwdArgs b{};
     const int rc = fill_args(b.a, x, offset, mask, w, n, h, wd, c, k, r, s, stride, pad_h, pad_w, dilation, deformable_groups);
@@ -1254,11 +1526,50 @@ extern "C" int rr_dcn_dgrad(const float *x, const float *offset, const float *ma
     RR_CHECK_ARG((long)n * h * wd < (1l << 31), "rr_dcn_dgrad: input too large");
     b.dy = dy; b.dx = dx; b.doffset = doffset; b.dmask = dmask;
     hipMemsetAsync(dx, 0, sizeof(float) * (size_t)n * h * wd * c, stream);
+    const int rw = dcn_win_margin();
+    if (bf16 && rw > 0 && stride == 1 && c % 32 == 0 && h < 32768 && wd < 32768 &&
+        (deformable_groups == 1 || (c / deformable_groups) % 32 == 0)) {
+        DcnWinBwdArgs wb{};
+        wb.w.a = b.a;
+        wb.w.RW = rw;
+        wb.w.WH = WIN_TH + (r - 1) * dilation + 2 * rw + 1;
+        wb.w.WW = WIN_TW + (s - 1) * dilation + 2 * rw + 1;
+        wb.w.tiles_y = rr_cdiv(b.a.P, WIN_TH);
+        wb.w.tiles_x = rr_cdiv(b.a.Q, WIN_TW);
+        wb.dy = dy; wb.dx = dx; wb.doffset = doffset; wb.dmask = dmask;
+        const int npx = wb.w.WH * wb.w.WW;
+        const size_t ldsw = sizeof(float) * (size_t)(((npx * 33 + 3) & ~3) + BM * r * s * 7 + BM * 36) +
+                            sizeof(unsigned short) * (BM * LDKH + r * s * 32 * LDKH);
+        if (r * s == 9 && ldsw <= 160 * 1024 - 512) {
+            hipFuncSetAttribute(reinterpret_cast<const void *>(dcn_dgrad_win_bf16_kernel<9>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw);
+            hipLaunchKernelGGL(dcn_dgrad_win_bf16_kernel<9>, dim3(n * wb.w.tiles_y * wb.w.tiles_x), dim3(256), ldsw, stream, wb);
+            RR_CHECK_LAUNCH("rr_dcn_dgrad");
+            return RR_OK;
+        }
+    }
     const size_t lds = sizeof(float) * (2 * (BM * LDK + BK * 128) + BM * 8 + BM * 4 + BM * 3);
     hipFuncSetAttribute(reinterpret_cast<const void *>(dcn_dgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(dcn_dgrad_kernel, dim3(rr_cdiv(b.a.M, BM)), dim3(256), lds, stream, b);
     RR_CHECK_LAUNCH("rr_dcn_dgrad");
     return RR_OK;
+}
+
+extern "C" int rr_dcn_dgrad(const float *x, const float *offset, const float *mask, const float *w, const float *dy,
+                            float *dx, float *doffset, float *dmask, int n, int h, int wd, int c, int k, int r, int s,
+                            int stride, int pad_h, int pad_w, int dilation, int deformable_groups, hipStream_t stream)
+{
+    return dcn_dgrad_impl(x, offset, mask, w, dy, dx, doffset, dmask, n, h, wd, c, k, r, s, stride, pad_h, pad_w, dilation,
+                          deformable_groups, 0, stream);
+}
+
+// The same gradients with bf16 matrix operands (dY and W rounded to bf16 for the column-gradient GEMM, fp32 accumulation,
+// fp32 scatter) and d input pre-summed on chip: the backward of rr_dcn_fwd_bf16 (BASELINE config 4).
+extern "C" int rr_dcn_dgrad_bf16(const float *x, const float *offset, const float *mask, const float *w, const float *dy,
+                                 float *dx, float *doffset, float *dmask, int n, int h, int wd, int c, int k, int r, int s,
+                                 int stride, int pad_h, int pad_w, int dilation, int deformable_groups, hipStream_t stream)
+{
+    return dcn_dgrad_impl(x, offset, mask, w, dy, dx, doffset, dmask, n, h, wd, c, k, r, s, stride, pad_h, pad_w, dilation,
+                          deformable_groups, 1, stream);
 }
 
 extern "C" int rr_dcn_split_fwd(const float *om, long m, int third, float *offset, float *mask, hipStream_t stream)

@@ -493,6 +493,7 @@ class _DCNv2(torch.autograd.Function):
         ctx.cfg = (int(stride), tuple(padding), int(dilation), int(deformable_groups))
         ctx.save_for_backward(x, off, m, w)
         ctx.params = (weight, bias)
+        ctx.bf16 = bool(bf16)
         return ops.dcn_fwd(x, off, m, w, bias, *ctx.cfg, bf16=bf16)
 
     @staticmethod
@@ -516,7 +517,8 @@ class _DCNv2(torch.autograd.Function):
                     ops.dcn_wgrad(x, off, m, dy, dw, stride, pad, dil, dg)
             else:
                 ops.dcn_wgrad(x, off, m, dy, dw, stride, pad, dil, dg)
-            dx, doff, dmask = ops.dcn_dgrad(x, off, m, w, dy, stride, pad, dil, dg)
+            # a bf16 forward takes the bf16-operand data gradient (d input pre-summed on chip); the weight gradient stays fp32
+            dx, doff, dmask = ops.dcn_dgrad(x, off, m, w, dy, stride, pad, dil, dg, bf16=ctx.bf16 and DCN_BF16_BWD)
             if side is not None:
                 cur.wait_stream(side)
         else:
@@ -604,6 +606,7 @@ def _side_stream(device):
     return _SIDE[key]
 
 
+DCN_BF16_BWD = os.environ.get("RR_DCN_BF16_BWD", "1") != "0"         # bf16 forward -> bf16-operand dgrad (0: fp32 dgrad)
 DCN_BWD_STREAMS = os.environ.get("RR_DCN_BWD_STREAMS", "1") != "0"   # wgrad and dgrad of the fused backward side by side
 DCN_FUSED_BWD = os.environ.get("RR_DCN_FUSED_BWD", "1") != "0"   # 0: the reference's column-buffer structure (A/B switch)
 DCN_BF16 = os.environ.get("RR_DCN_BF16", "0") == "1"   # BASELINE config 4: bf16 matrix operands in the DCN forward

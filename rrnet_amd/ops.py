@@ -692,8 +692,9 @@ def dcn_wgrad(x, offset, mask, dy, dw, stride, pad, dilation, dg):
     return dw
 
 
-def dcn_dgrad(x, offset, mask, w, dy, stride, pad, dilation, dg):
-    """-> dx, doffset, dmask; the column gradient never leaves the MFMA accumulators / LDS."""
+def dcn_dgrad(x, offset, mask, w, dy, stride, pad, dilation, dg, bf16=False):
+    """-> dx, doffset, dmask; the column gradient never leaves the MFMA accumulators / LDS.  bf16: bf16 matrix operands
+    (dY, W) and d input pre-summed in an LDS window before the global atomics (rr_dcn_dgrad_bf16)."""
     assert is_nhwc(x) and is_nhwc(offset) and is_nhwc(mask) and is_nhwc(dy) and is_nhwc(w)
     n, c, h, wd = x.shape
     k, _, r, s = w.shape
@@ -701,9 +702,9 @@ def dcn_dgrad(x, offset, mask, w, dy, stride, pad, dilation, dg):
     doff = torch.empty_like(offset)
     dmask = torch.empty_like(mask)
     assert doff.stride() == offset.stride() and dmask.stride() == mask.stride()
-    _C.check(_C.fn("rr_dcn_dgrad")(_C.ptr(x), _C.ptr(offset), _C.ptr(mask), _C.ptr(w), _C.ptr(dy), _C.ptr(dx), _C.ptr(doff),
-                                   _C.ptr(dmask), n, h, wd, c, k, r, s, stride, pad[0], pad[1], dilation, dg, _C.stream()),
-             "rr_dcn_dgrad")
+    name = "rr_dcn_dgrad_bf16" if bf16 else "rr_dcn_dgrad"
+    _C.check(_C.fn(name)(_C.ptr(x), _C.ptr(offset), _C.ptr(mask), _C.ptr(w), _C.ptr(dy), _C.ptr(dx), _C.ptr(doff),
+                         _C.ptr(dmask), n, h, wd, c, k, r, s, stride, pad[0], pad[1], dilation, dg, _C.stream()), name)
     return dx, doff, dmask
 
 

@@ -78,6 +78,56 @@ def test_dcn_fused_backward_equals_column_path():
         assert (a - b).abs().max().item() <= 2e-4 * scale, (name, (a - b).abs().max().item(), scale)
 
 
+@pytest.mark.parametrize("shape", [(2, 256, 24, 40, 256, 1), (1, 64, 19, 21, 96, 1), (1, 256, 16, 16, 64, 2)])
+def test_dcn_bf16_dgrad_equals_fp32_dgrad_on_rounded_operands(shape):
+    """rr_dcn_dgrad_bf16 (bf16 matrix operands, d input pre-summed in an LDS window) computes exactly what the fp32
+    kernel computes when dY and W are rounded to bf16 beforehand: same products, fp32 accumulation — only the summation
+    order differs.  Covers ragged 8x16 pixel blocks, several blocks per image, offsets beyond the window margin
+    (sigma 2.5: a few percent of the corners take the direct global path) and two deformable groups."""
+    from rrnet_amd import ops
+    n, c, h, w, k, dg = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(n, c, h, w, generator=g)
+    off = torch.randn(n, 18 * dg, h, w, generator=g) * 2.5
+    mask = torch.sigmoid(torch.randn(n, 9 * dg, h, w, generator=g))
+    wt = (torch.randn(k, c, 3, 3, generator=g) / 48.0).bfloat16().float()
+    dy = torch.randn(n, k, h, w, generator=g).bfloat16().float()
+    dev = [ops.to_nhwc(t.cuda()) for t in (x, off, mask, wt, dy)]
+    ref = ops.dcn_dgrad(*dev, 1, (1, 1), 1, dg, bf16=False)
+    got = ops.dcn_dgrad(*dev, 1, (1, 1), 1, dg, bf16=True)
+    for name, a, b in zip(("dx", "doffset", "dmask"), got, ref):
+        scale = b.abs().max().item()
+        assert (a - b).abs().max().item() <= 5e-5 * scale, (name, (a - b).abs().max().item(), scale)
+
+
+def test_dcn_bf16_dgrad_fixed_point_window_keeps_local_precision():
+    """The LDS window of rr_dcn_dgrad_bf16 accumulates in fixed point with ONE power-of-two scale per (8x16 pixel block,
+    32-channel chunk), derived from that block's largest |dcol| x |mask|: a block with huge output gradients must not
+    cost precision anywhere else.  dY is 1e6 x larger in the first block of frame 0 than in the rest of the batch;
+    rows far from that block are compared at THEIR scale; masks > 1 (allowed by dcn_v2_conv) enter the bound too."""
+    from rrnet_amd import ops
+    n, c, h, w, k = 2, 64, 48, 48, 64
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(n, c, h, w, generator=g)
+    off = torch.randn(n, 18, h, w, generator=g)
+    mask = torch.rand(n, 9, h, w, generator=g) * 3.0
+    wt = (torch.randn(k, c, 3, 3, generator=g) / 24.0).bfloat16().float()
+    dy = (torch.randn(n, k, h, w, generator=g) * 1e-3)
+    dy[0, :, :8, :16] *= 1e6
+    dy = dy.bfloat16().float()
+    dev = [ops.to_nhwc(t.cuda()) for t in (x, off, mask, wt, dy)]
+    ref = ops.dcn_dgrad(*dev, 1, (1, 1), 1, 1, bf16=False)
+    got = ops.dcn_dgrad(*dev, 1, (1, 1), 1, 1, bf16=True)
+    for name, a, b in zip(("dx", "doffset", "dmask"), got, ref):
+        far_a, far_b = a[1], b[1]                                  # the other frame: untouched by the loud block
+        scale = far_b.abs().max().item()
+        assert 0 < scale < 1.0
+        assert (far_a - far_b).abs().max().item() <= 5e-5 * scale, (name, (far_a - far_b).abs().max().item(), scale)
+        loud = b[0].abs().max().item()
+        assert loud > 100 * scale
+        assert (a[0] - b[0]).abs().max().item() <= 5e-5 * loud, (name, (a[0] - b[0]).abs().max().item(), loud)
+
+
 def test_reference_zero_offset_identity_on_hip():
     from rrnet_amd.ext.dcn.dcn_v2 import DCNv2
     N, C, H, W = 2, 8, 6, 6
