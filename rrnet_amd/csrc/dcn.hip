@@ -1080,6 +1080,16 @@ __global__ void dcn_split_bwd_kernel(const float *doffset, const float *dmask, c
 // conflicts) and flushes that window ONCE per chunk with global atomics: ≈3.3 window pixels per output pixel instead of 36 corner adds, 1.8 GB of atomic bytes instead of 19.3.
 // Corners beyond the window margin go to global memory directly.  d offset / d mask are summed over the chunks in LDS and
 // stored once.  Sample geometry per (pixel, tap) in LDS: (h0, w0) of the first corner, the fractions, the mask.
+// Sum over the 8 lanes of an aligned lane group, on the VALU (DPP row_half_mirror, then the two quad permutes): every
+// lane ends with the total.  __shfl_xor compiles to ds_bpermute — LDS traffic the epilogue below cannot afford.
+__device__ __forceinline__ float dpp_sum8(float v)
+{
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, false));   // lane i <- lane 7 - i
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
+    return v;
+}
+
 struct DcnWinBwdArgs {
     DcnWinArgs w;
     const float *dy;
@@ -1087,24 +1097,29 @@ struct DcnWinBwdArgs {
 };
 
 template <int RS>      // taps of the filter (9 for 3x3): one accumulator tile per tap lives in registers through a chunk
-__global__ __launch_bounds__(256) void dcn_dgrad_win_bf16_kernel(const DcnWinBwdArgs wb)
+__global__ __launch_bounds__(512) void dcn_dgrad_win_bf16_kernel(const DcnWinBwdArgs wb)
 {
+    // 512 threads = 8 waves, two per SIMD: the window leaves room for ONE workgroup per CU, and the epilogue is a chain
+    // of dependent LDS / L2 round trips that a single wave per SIMD cannot hide.  Wave w computes pixel rows
+    // 32 (w & 3) .. +31 of the block for taps 5 (w >> 2) .. +4 (five accumulator tiles; the ninth..tenth slot idles).
     const DcnWinArgs &wa = wb.w;
     const DcnArgs &a = wa.a;
-    constexpr int CW = 32, WSTR = 33, SST = 36;
-    constexpr int A_ELEMS = BM * LDKH, B_ELEMS = RS * CW * LDKH;
+    constexpr int CW = 32, WSTR = 33, SST = 36, NT = 512, TG = 5, GEO_SLOW = 1 << 20;
+    constexpr int A_ELEMS = BM * LDKH;
     extern __shared__ __align__(16) unsigned char smem[];
     const int npx = wa.WH * wa.WW;
     int *dxw = reinterpret_cast<int *>(smem);                                       // [npx][33] fixed point (see below)
-    int *geo_i = dxw + (size_t)((npx * WSTR + 3) & ~3);                             // [BM][RS]: (h0 << 16) | (w0 & 0xffff); 0x7fffffff = no sample
+    int *geo_i = dxw + (size_t)((npx * WSTR + 3) & ~3);                             // [BM][RS]: window pixel of corner 0 | corner-valid bits << 16 | SLOW
     float *geo_f = reinterpret_cast<float *>(geo_i + BM * RS);                      // [BM][RS][3]: lh, lw, mask
     float *red = geo_f + BM * RS * 3;                                               // [BM][RS][3]: d mask, d off h, d off w
-    float *stage = red + BM * RS * 3;                                               // [BM][SST]
-    unsigned short *As = reinterpret_cast<unsigned short *>(stage + BM * SST);      // [BM][LDKH]   (single image: operands
+    float *xw = red + BM * RS * 3;                                                  // [npx][32]: the input window of this chunk
+    unsigned short *As = reinterpret_cast<unsigned short *>(xw + (size_t)npx * CW); // [BM][LDKH]   (single image: operands
     unsigned short *Bs = As + A_ELEMS;                                              // [RS][32][LDKH] are prefetched in registers)
+    float *stage = reinterpret_cast<float *>(As);                                   // [BM][SST]: epilogue only, over the idle operand images
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int lr = lane & 31, lh_ = lane >> 5;
+    const int wpx = wave & 3, wtg = wave >> 2;
     int bid = dcn_xcd_remap(blockIdx.x, gridDim.x);
     const int txi = bid % wa.tiles_x; bid /= wa.tiles_x;
     const int tyi = bid % wa.tiles_y;
@@ -1113,16 +1128,17 @@ __global__ __launch_bounds__(256) void dcn_dgrad_win_bf16_kernel(const DcnWinBwd
     const int wy0 = y0 - a.pad_h - wa.RW, wx0 = x0 - a.pad_w - wa.RW;
     const int cpt = a.C / CW, cpg = a.C / a.dg;
     const int nkc = (a.K + BK - 1) / BK;
-    const int a_col = (t & 7) * 4, a_row = t >> 3;
+    const int a_col = (t & 7) * 4, a_row = t >> 3;          // a_row 0..63
+    const int b_row = a_row & 31, b_tg = a_row >> 5;        // weight rows: ko row b_row, taps 5 b_tg .. +4
     const long img = (long)n * a.H * a.W;
 
-    __shared__ float wmax[4];
+    __shared__ float wmax[8];
     __shared__ int mkmax_bits;       // bits of max |mask| seen by this block (over all groups: a bound is all that is needed)
     auto build_geo = [&](int g) {
-        for (int it = t; it < BM * RS; it += 256) {
+        for (int it = t; it < BM * RS; it += NT) {
             const int r = it / RS, tap = it - r * RS;
             const int p = y0 + r / WIN_TW, q = x0 + r % WIN_TW;
-            int packed = 0x7fffffff;
+            int packed = 0;                       // no valid corner: nothing to add, zero gradients
             float flh = 0.f, flw = 0.f, mk = 0.f;
             if (p < a.P && q < a.Q) {
                 const long m = ((long)n * a.P + p) * a.Q + q;
@@ -1132,7 +1148,18 @@ __global__ __launch_bounds__(256) void dcn_dgrad_win_bf16_kernel(const DcnWinBwd
                 const float w = (float)(q - a.pad_w + tj * a.dil) + po[1];
                 if (h > -1.f && w > -1.f && h < (float)a.H && w < (float)a.W) {
                     const float hf = floorf(h), wf = floorf(w);
-                    packed = ((int)hf << 16) | ((int)wf & 0xffff);
+                    const int h0 = (int)hf, w0 = (int)wf;
+                    int valid = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int hy = h0 + (e >> 1), wx = w0 + (e & 1);
+                        if (hy >= 0 && hy <= a.H - 1 && wx >= 0 && wx <= a.W - 1) valid |= 1 << e;
+                    }
+                    // fast samples have their whole 2x2 footprint inside the window: corner e is window pixel
+                    // base + (e >> 1) * WW + (e & 1); the others recompute their position and go corner by corner
+                    const int ly = h0 - wy0, lx = w0 - wx0;
+                    const bool fast = ly >= 0 && ly + 1 < wa.WH && lx >= 0 && lx + 1 < wa.WW;
+                    packed = (valid << 16) | (fast ? (ly * wa.WW + lx) : GEO_SLOW);
                     flh = h - hf; flw = w - wf;
                     mk = a.mask[m * (a.dg * RS) + g * RS + tap];
                 }
@@ -1143,7 +1170,7 @@ __global__ __launch_bounds__(256) void dcn_dgrad_win_bf16_kernel(const DcnWinBwd
         }
     };
     auto store_red = [&](int g) {
-        for (int it = t; it < BM * RS; it += 256) {
+        for (int it = t; it < BM * RS; it += NT) {
             const int r = it / RS, tap = it - r * RS;
             const int p = y0 + r / WIN_TW, q = x0 + r % WIN_TW;
             if (p < a.P && q < a.Q) {
@@ -1155,15 +1182,15 @@ __global__ __launch_bounds__(256) void dcn_dgrad_win_bf16_kernel(const DcnWinBwd
             red[it * 3] = 0.f; red[it * 3 + 1] = 0.f; red[it * 3 + 2] = 0.f;
         }
     };
-    for (int i = t; i < npx * WSTR; i += 256) dxw[i] = 0;
-    for (int i = t; i < BM * RS * 3; i += 256) red[i] = 0.f;
+    for (int i = t; i < npx * WSTR; i += NT) dxw[i] = 0;
+    for (int i = t; i < BM * RS * 3; i += NT) red[i] = 0.f;
     if (t == 0) mkmax_bits = 0;
     __syncthreads();
     int g_cur = 0;
     build_geo(0);
     __syncthreads();
 
-    f32x4 ra[4], rb[RS];
+    f32x4 ra[2], rb[TG];
     for (int cch = 0; cch < cpt; ++cch) {
         const int c0 = cch * CW;
         const int g = c0 / cpg;
@@ -1174,49 +1201,67 @@ __global__ __launch_bounds__(256) void dcn_dgrad_win_bf16_kernel(const DcnWinBwd
             build_geo(g);
             __syncthreads();
         }
+        // ---- this chunk's input window (d offset / d mask re-read the four corners of every sample: from L2 that is
+        //      19 GB per call, the same gather the windowed forward removed)
+        for (int i = t; i < npx * 8; i += NT) {
+            const int px = i >> 3, c4 = (i & 7) * 4;
+            const int ly = px / wa.WW, lx = px - ly * wa.WW;
+            const int gy = wy0 + ly, gx = wx0 + lx;
+            const bool ok = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            *reinterpret_cast<f32x4 *>(xw + (size_t)i * 4) =
+                *reinterpret_cast<const f32x4 *>(ok ? a.x + (img + (long)gy * a.W + gx) * a.C + c0 + c4 : a.zero);
+        }
         // ---- the nine column-gradient tiles of this chunk in ONE sweep over K:
         //      dcol_tap[128 px][32 ch] = dY[128][K] x W[K][tap][c0 .. c0+31]
         auto issue = [&](int kc) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int r = a_row + 32 * j;
+            for (int j = 0; j < 2; ++j) {
+                const int r = a_row + 64 * j;
                 const int p = y0 + r / WIN_TW, q = x0 + r % WIN_TW;
                 const int ko = kc * BK + a_col;
                 ra[j] = *reinterpret_cast<const f32x4 *>((p < a.P && q < a.Q && ko < a.K)
                                                              ? wb.dy + (((long)n * a.P + p) * a.Q + q) * a.K + ko : a.zero);
             }
-            const int kb = kc * BK + a_row;          // one ko row per 8 threads, 4 channels each, all taps
+            const int kb = kc * BK + b_row;          // one ko row per 8 threads, 4 channels each, five taps
 #pragma unroll
-            for (int tap = 0; tap < RS; ++tap)
-                rb[tap] = *reinterpret_cast<const f32x4 *>(kb < a.K ? a.w + ((long)kb * RS + tap) * a.C + c0 + a_col : a.zero);
+            for (int i = 0; i < TG; ++i) {
+                const int tap = b_tg * TG + i;
+                rb[i] = *reinterpret_cast<const f32x4 *>((kb < a.K && tap < RS) ? a.w + ((long)kb * RS + tap) * a.C + c0 + a_col : a.zero);
+            }
         };
         auto commit = [&]() {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) *reinterpret_cast<u16x4 *>(As + (a_row + 32 * j) * LDKH + a_col) = f2bf4(ra[j]);
+            for (int j = 0; j < 2; ++j) *reinterpret_cast<u16x4 *>(As + (a_row + 64 * j) * LDKH + a_col) = f2bf4(ra[j]);
 #pragma unroll
-            for (int tap = 0; tap < RS; ++tap) {
-                const u16x4 hb = f2bf4(rb[tap]);     // B images are [tap][n = channel][k = ko]: transposed 2-byte stores
+            for (int i = 0; i < TG; ++i) {
+                const int tap = b_tg * TG + i;
+                if (tap < RS) {
+                    const u16x4 hb = f2bf4(rb[i]);   // B images are [tap][n = channel][k = ko]: transposed 2-byte stores
 #pragma unroll
-                for (int c = 0; c < 4; ++c) Bs[(tap * CW + a_col + c) * LDKH + a_row] = hb[c];
+                    for (int c = 0; c < 4; ++c) Bs[(tap * CW + a_col + c) * LDKH + b_row] = hb[c];
+                }
             }
         };
-        f32x16 acc[RS];
+        f32x16 acc[TG];
 #pragma unroll
-        for (int tap = 0; tap < RS; ++tap)
+        for (int i = 0; i < TG; ++i)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[tap][e] = 0.f;
+            for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
         issue(0);
         for (int kc = 0; kc < nkc; ++kc) {
             commit();
             __syncthreads();
-            if (kc + 1 < nkc) issue(kc + 1);         // lands under this K-step's 18 MFMAs
+            if (kc + 1 < nkc) issue(kc + 1);         // lands under this K-step's MFMAs
 #pragma unroll
             for (int kk = 0; kk < BK / 16; ++kk) {
-                const bf16x8 fa = *reinterpret_cast<const bf16x8 *>(As + (wave * 32 + lr) * LDKH + kk * 16 + lh_ * 8);
+                const bf16x8 fa = *reinterpret_cast<const bf16x8 *>(As + (wpx * 32 + lr) * LDKH + kk * 16 + lh_ * 8);
 #pragma unroll
-                for (int tap = 0; tap < RS; ++tap) {
-                    const bf16x8 fb = *reinterpret_cast<const bf16x8 *>(Bs + (tap * CW + lr) * LDKH + kk * 16 + lh_ * 8);
-                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[tap], 0, 0, 0);
+                for (int i = 0; i < TG; ++i) {
+                    const int tap = wtg * TG + i;
+                    if (tap < RS) {                   // wave-uniform
+                        const bf16x8 fb = *reinterpret_cast<const bf16x8 *>(Bs + (tap * CW + lr) * LDKH + kk * 16 + lh_ * 8);
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[i], 0, 0, 0);
+                    }
                 }
             }
             __syncthreads();
@@ -1227,96 +1272,100 @@ __global__ __launch_bounds__(256) void dcn_dgrad_win_bf16_kernel(const DcnWinBwd
         //      <= 2^-31 of that bound per add, exact scaling back at the flush.
         float amax = 0.f;
 #pragma unroll
-        for (int tap = 0; tap < RS; ++tap)
+        for (int i = 0; i < TG; ++i)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) amax = fmaxf(amax, fabsf(acc[tap][e]));
+            for (int e = 0; e < 16; ++e) amax = fmaxf(amax, fabsf(acc[i][e]));
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
         if (lane == 0) wmax[wave] = amax;
         __syncthreads();
-        const float bound = 36.f * fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3])) * fmaxf(__int_as_float(mkmax_bits), 1e-30f);
+        float bmax = wmax[0];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) bmax = fmaxf(bmax, wmax[i]);
+        const float bound = 36.f * bmax * fmaxf(__int_as_float(mkmax_bits), 1e-30f);
         int ex = 0;
         frexpf(bound, &ex);
         const float fx_scale = bound > 0.f ? ldexpf(1.f, 30 - ex) : 0.f, fx_inv = ldexpf(1.f, ex - 30);
         // ---- epilogue per tap: accumulators -> LDS -> (pixel row, 4 channels) threads
         for (int tap = 0; tap < RS; ++tap) {            // a real loop: only the accumulator -> LDS copy is per-tap code
-            {
-                float *sp = stage + (wave * 32 + 4 * lh_) * SST + lr;
+            if (tap / TG == wtg) {                      // the four waves that hold this tap's tiles
+                float *sp = stage + (wpx * 32 + 4 * lh_) * SST + lr;
 #define RR_PUT(T)                                                                                   \
     case T:                                                                                         \
-        _Pragma("unroll") for (int e = 0; e < 16; ++e) sp[((e & 3) + 8 * (e >> 2)) * SST] = acc[T < RS ? T : 0][e]; \
+        _Pragma("unroll") for (int e = 0; e < 16; ++e) sp[((e & 3) + 8 * (e >> 2)) * SST] = acc[T][e]; \
         break;
-                switch (tap) {
-                    RR_PUT(0) RR_PUT(1) RR_PUT(2) RR_PUT(3) RR_PUT(4) RR_PUT(5) RR_PUT(6) RR_PUT(7) RR_PUT(8)
+                switch (tap - wtg * TG) {
+                    RR_PUT(0) RR_PUT(1) RR_PUT(2) RR_PUT(3) RR_PUT(4)
                     default: break;
                 }
 #undef RR_PUT
             }
-            // corner values of all four row passes go out first: one exposed global latency per tap, not four
-            f32x4 xv[4][4];
-            int gis[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int r = a_row + 32 * j;
-                const int gi = geo_i[r * RS + tap];
-                gis[j] = gi;
-                const int h0 = gi >> 16, w0 = (int)(short)(gi & 0xffff);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int hy = h0 + (e >> 1), wx = w0 + (e & 1);
-                    const bool ok = gi != 0x7fffffff && hy >= 0 && hy <= a.H - 1 && wx >= 0 && wx <= a.W - 1;
-                    xv[j][e] = *reinterpret_cast<const f32x4 *>(ok ? a.x + (img + (long)hy * a.W + wx) * a.C + c0 + a_col : a.zero);
-                }
-            }
             __syncthreads();
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int r = a_row + 32 * j;
-                const int gi = gis[j];
+            for (int j = 0; j < 2; ++j) {
+                const int r = a_row + 64 * j;
+                const int gi = geo_i[r * RS + tap];
+                const int valid = (gi >> 16) & 15;
                 float s_m = 0.f, s_h = 0.f, s_w = 0.f;
-                if (gi != 0x7fffffff) {
-                    const int h0 = gi >> 16, w0 = (int)(short)(gi & 0xffff);
+                if (valid) {
                     const float flh = geo_f[(r * RS + tap) * 3], flw = geo_f[(r * RS + tap) * 3 + 1], mk = geo_f[(r * RS + tap) * 3 + 2];
                     const float hh = 1.f - flh, hw = 1.f - flw;
                     const float wt[4] = {hh * hw, hh * flw, flh * hw, flh * flw};
                     const float dhw[4] = {-hw, -flw, hw, flw};
                     const float dww[4] = {-hh, hh, -flh, flh};
                     const f32x4 gcol = *reinterpret_cast<const f32x4 *>(stage + r * SST + a_col);
-                    f32x4 val = {0.f, 0.f, 0.f, 0.f}, gh = val, gw = val;
+                    const float mks = mk * fx_scale;
+                    // d mask = sum_e wt_e <gcol, x_e>, d offset = mask * sum_e dwt_e <gcol, x_e>: one dot product per corner
+                    if (!(gi & GEO_SLOW)) {
+                        const float *xb = xw + (size_t)(gi & 0xffff) * CW + a_col;
+                        int *db = dxw + (gi & 0xffff) * WSTR + a_col;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int hy = h0 + (e >> 1), wx = w0 + (e & 1);
-                        if (hy < 0 || hy > a.H - 1 || wx < 0 || wx > a.W - 1) continue;       // corner outside the image
-                        val += xv[j][e] * wt[e];
-                        gh += xv[j][e] * dhw[e];
-                        gw += xv[j][e] * dww[e];
-                        if (wt[e] != 0.f) {
-                            const f32x4 add = gcol * (mk * wt[e]);
+                        for (int e = 0; e < 4; ++e) {
+                            if (!((valid >> e) & 1)) continue;                                   // corner outside the image
+                            const int po = (e >> 1) * wa.WW + (e & 1);
+                            const f32x4 xv = *reinterpret_cast<const f32x4 *>(xb + po * CW);
+                            const float d = gcol[0] * xv[0] + gcol[1] * xv[1] + gcol[2] * xv[2] + gcol[3] * xv[3];
+                            s_m += wt[e] * d; s_h += dhw[e] * d; s_w += dww[e] * d;
+                            const float f = mks * wt[e];
+                            if (f != 0.f) {
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) atomicAdd(db + po * WSTR + c, __float2int_rn(gcol[c] * f));   // ds_add_u32
+                            }
+                        }
+                    } else {
+                        // footprint not inside the window (offset beyond the margin): position again from the offsets
+                        const int p = y0 + r / WIN_TW, q = x0 + r % WIN_TW;
+                        const float *po = a.offset + (((long)n * a.P + p) * a.Q + q) * (2 * a.dg * RS) + g_cur * 2 * RS + 2 * tap;
+                        const int ti = tap / a.S, tj = tap - ti * a.S;
+                        const int h0 = (int)floorf((float)(p - a.pad_h + ti * a.dil) + po[0]);
+                        const int w0 = (int)floorf((float)(q - a.pad_w + tj * a.dil) + po[1]);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if (!((valid >> e) & 1)) continue;
+                            const int hy = h0 + (e >> 1), wx = w0 + (e & 1);
                             const int ly = hy - wy0, lx = wx - wx0;
-                            if (ly >= 0 && ly < wa.WH && lx >= 0 && lx < wa.WW) {
-                                int *d = dxw + (ly * wa.WW + lx) * WSTR + a_col;
+                            const bool inwin = ly >= 0 && ly < wa.WH && lx >= 0 && lx < wa.WW;
+                            f32x4 xv;
+                            if (inwin) xv = *reinterpret_cast<const f32x4 *>(xw + (size_t)(ly * wa.WW + lx) * CW + a_col);
+                            else xv = *reinterpret_cast<const f32x4 *>(a.x + (img + (long)hy * a.W + wx) * a.C + c0 + a_col);
+                            const float d = gcol[0] * xv[0] + gcol[1] * xv[1] + gcol[2] * xv[2] + gcol[3] * xv[3];
+                            s_m += wt[e] * d; s_h += dhw[e] * d; s_w += dww[e] * d;
+                            if (wt[e] != 0.f) {
+                                if (inwin) {
+                                    int *d4 = dxw + (ly * wa.WW + lx) * WSTR + a_col;
 #pragma unroll
-                                for (int c = 0; c < 4; ++c) atomicAdd(d + c, __float2int_rn(add[c] * fx_scale));   // ds_add_u32
-                            } else {
-                                float *d = wb.dx + (img + (long)hy * a.W + wx) * a.C + c0 + a_col;
+                                    for (int c = 0; c < 4; ++c) atomicAdd(d4 + c, __float2int_rn(gcol[c] * (mks * wt[e])));
+                                } else {
+                                    float *d4 = wb.dx + (img + (long)hy * a.W + wx) * a.C + c0 + a_col;
 #pragma unroll
-                                for (int c = 0; c < 4; ++c) unsafeAtomicAdd(d + c, add[c]);
+                                    for (int c = 0; c < 4; ++c) unsafeAtomicAdd(d4 + c, gcol[c] * (mk * wt[e]));
+                                }
                             }
                         }
                     }
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        s_m += gcol[c] * val[c];
-                        s_h += gcol[c] * mk * gh[c];
-                        s_w += gcol[c] * mk * gw[c];
-                    }
+                    s_h *= mk; s_w *= mk;
                 }
-#pragma unroll
-                for (int off = 4; off > 0; off >>= 1) {     // the 8 threads of a pixel row
-                    s_m += __shfl_xor(s_m, off, 64);
-                    s_h += __shfl_xor(s_h, off, 64);
-                    s_w += __shfl_xor(s_w, off, 64);
-                }
+                s_m = dpp_sum8(s_m); s_h = dpp_sum8(s_h); s_w = dpp_sum8(s_w);      // the 8 threads of a pixel row
                 if ((t & 7) == 0) {
                     float *rd = red + (r * RS + tap) * 3;
                     rd[0] += s_m; rd[1] += s_h; rd[2] += s_w;
@@ -1327,7 +1376,7 @@ __global__ __launch_bounds__(256) void dcn_dgrad_win_bf16_kernel(const DcnWinBwd
         // ---- flush this chunk's window: lane <-> channel, 128-byte row segments, one global atomic per touched element
         {
             const int c = t & 31;
-            for (int px = t >> 5; px < npx; px += 8) {
+            for (int px = t >> 5; px < npx; px += NT / 32) {
                 const int iv = dxw[px * WSTR + c];
                 if (iv != 0) {
                     const int ly = px / wa.WW, lx = px - ly * wa.WW;
@@ -1531,18 +1580,24 @@ static int dcn_dgrad_impl(const float *x, const float *offset, const float *mask
         (deformable_groups == 1 || (c / deformable_groups) % 32 == 0)) {
         DcnWinBwdArgs wb{};
         wb.w.a = b.a;
-        wb.w.RW = rw;
-        wb.w.WH = WIN_TH + (r - 1) * dilation + 2 * rw + 1;
-        wb.w.WW = WIN_TW + (s - 1) * dilation + 2 * rw + 1;
         wb.w.tiles_y = rr_cdiv(b.a.P, WIN_TH);
         wb.w.tiles_x = rr_cdiv(b.a.Q, WIN_TW);
         wb.dy = dy; wb.dx = dx; wb.doffset = doffset; wb.dmask = dmask;
-        const int npx = wb.w.WH * wb.w.WW;
-        const size_t ldsw = sizeof(float) * (size_t)(((npx * 33 + 3) & ~3) + BM * r * s * 7 + BM * 36) +
-                            sizeof(unsigned short) * (BM * LDKH + r * s * 32 * LDKH);
+        // two windows live in LDS here (d input in fixed point, input values): the margin is the largest <= the
+        // requested one that fits (2 pixels for a 3x3 filter with dilation 1)
+        size_t ldsw = 0;
+        for (int m = rw; m >= 1; --m) {
+            wb.w.RW = m;
+            wb.w.WH = WIN_TH + (r - 1) * dilation + 2 * m + 1;
+            wb.w.WW = WIN_TW + (s - 1) * dilation + 2 * m + 1;
+            const int npx = wb.w.WH * wb.w.WW;
+            ldsw = sizeof(float) * (size_t)(((npx * 33 + 3) & ~3) + BM * r * s * 7 + npx * 32) +
+                   sizeof(unsigned short) * (BM * LDKH + r * s * 32 * LDKH);
+            if (ldsw <= 160 * 1024 - 512) break;
+        }
         if (r * s == 9 && ldsw <= 160 * 1024 - 512) {
             hipFuncSetAttribute(reinterpret_cast<const void *>(dcn_dgrad_win_bf16_kernel<9>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw);
-            hipLaunchKernelGGL(dcn_dgrad_win_bf16_kernel<9>, dim3(n * wb.w.tiles_y * wb.w.tiles_x), dim3(256), ldsw, stream, wb);
+            hipLaunchKernelGGL(dcn_dgrad_win_bf16_kernel<9>, dim3(n * wb.w.tiles_y * wb.w.tiles_x), dim3(512), ldsw, stream, wb);
             RR_CHECK_LAUNCH("rr_dcn_dgrad");
             return RR_OK;
         }
