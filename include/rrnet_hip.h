@@ -326,6 +326,14 @@ int rr_dcn_dgrad_bf16(const float *x, const float *offset, const float *mask, co
                       float *doffset, float *dmask, int n, int h, int wd, int c, int k, int r, int s, int stride,
                       int pad_h, int pad_w, int dilation, int deformable_groups, hipStream_t stream);
 
+/* rr_dcn_wgrad with bf16 matrix operands (dY and the masked bilinear samples rounded to bf16; fp32 accumulation): a
+ * workgroup keeps the [256 filters][9 taps x 32 channels] block of dW in its accumulators and walks over 8x16 pixel
+ * blocks whose input window is staged in LDS as in rr_dcn_fwd_bf16.  3x3, stride 1, c % 32 == 0; other layers take the
+ * rr_dcn_wgrad kernel. */
+int rr_dcn_wgrad_bf16(const float *x, const float *offset, const float *mask, const float *dy, float *dw, int n, int h,
+                      int wd, int c, int k, int r, int s, int stride, int pad_h, int pad_w, int dilation,
+                      int deformable_groups, hipStream_t stream);
+
 /* DCN module glue (ext/dcn/dcn_v2.py:117-121): om NHWC [m, 3*third] -> offset [m, 2*third] (first two thirds,
  * unchanged = cat(o1, o2)) and mask [m, third] = sigmoid(last third); backward: dom from doffset, dmask and mask. */
 int rr_dcn_split_fwd(const float *om, long m, int third, float *offset, float *mask, hipStream_t stream);

@@ -1391,6 +1391,191 @@ __global__ __launch_bounds__(512) void dcn_dgrad_win_bf16_kernel(const DcnWinBwd
     store_red(g_cur);
 }
 
+// ---- fused backward, weight side, bf16 matrix operands and the forward's LDS window ---------------------------------
+// dW[ko][tap][c] = sum_px dY[px][ko] * col[px][tap, c].  A workgroup owns ONE 32-channel chunk and 256 filters — the
+// whole [256 filters][9 taps x 32 channels] block of dW in its accumulators (8 waves x 9 tiles of 32x32) — and walks
+// over its share of the 8x16 pixel blocks: per block the input window of the chunk goes to LDS once (as in the
+// forward), per half block (64 pixels) dY is rounded to bf16 and written TRANSPOSED ([filter][pixel]: the pixel is the
+// reduction index, 8 consecutive pixels = one MFMA operand register pair) and the masked bilinear samples likewise
+// ([tap][channel][pixel]).  36 MFMAs per wave and half block; the blocks of a split are shared by the C/32 chunk
+// workgroups, which sit on one XCD so that dY is read from HBM once.  dW leaves with one float atomic per element and
+// workgroup (75 MB per call at the config-4 layer).
+struct DcnWinWgradArgs {
+    DcnWinArgs w;
+    const float *dy;
+    float *dw;
+    int splits, ktiles;
+};
+
+template <int RS>
+__global__ __launch_bounds__(512) void dcn_wgrad_win_bf16_kernel(const DcnWinWgradArgs wb)
+{
+    const DcnWinArgs &wa = wb.w;
+    const DcnArgs &a = wa.a;
+    constexpr int CW = 32, NT = 512, HP = 64, LDP = HP + 8, GEO_SLOW = 1 << 20, KT = 256;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int npx = wa.WH * wa.WW;
+    float *xw = reinterpret_cast<float *>(smem);                                    // [npx][32]
+    int *geo_i = reinterpret_cast<int *>(xw + (size_t)npx * CW);                    // [BM][RS]: as in dcn_dgrad_win_bf16_kernel
+    float *geo_f = reinterpret_cast<float *>(geo_i + BM * RS);                      // [BM][RS][3]: lh, lw, mask
+    unsigned short *dyT = reinterpret_cast<unsigned short *>(geo_f + BM * RS * 3);  // [256 filters][LDP pixels]
+    unsigned short *colT = dyT + KT * LDP;                                          // [RS][32 channels][LDP pixels]
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int lr = lane & 31, lh_ = lane >> 5;
+    const int cpt = a.C / CW, cpg = a.C / a.dg;
+    // blockIdx -> (split, chunk, filter tile): the chunk workgroups of one split share an XCD (blockIdx & 7)
+    int split, rest;
+    if ((wb.splits & 7) == 0) { split = (blockIdx.x & 7) + 8 * ((blockIdx.x >> 3) / (cpt * wb.ktiles)); rest = (blockIdx.x >> 3) % (cpt * wb.ktiles); }
+    else { split = blockIdx.x / (cpt * wb.ktiles); rest = blockIdx.x % (cpt * wb.ktiles); }
+    const int cch = rest % cpt, kt = rest / cpt;
+    const int c0 = cch * CW, g = c0 / cpg, k0 = kt * KT;
+    const int a_col = (t & 7) * 4, a_row = t >> 3;          // sample builder: pixel a_row of the half block, 4 channels
+    const int fq = t & 63, pg = t >> 6;                     // dY stager: filters 4 fq .. +3, pixels 8 pg .. +7 of the half block
+    const int ntiles = a.N * wa.tiles_y * wa.tiles_x;
+
+    f32x16 acc[RS];
+#pragma unroll
+    for (int tap = 0; tap < RS; ++tap)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[tap][e] = 0.f;
+
+    f32x4 rdy[8];
+    auto issue_dy = [&](int tile, int half) {                // 8 pixels x 4 filters, a 1 KB row segment per wave and pixel
+        int bid = tile;
+        const int txi = bid % wa.tiles_x; bid /= wa.tiles_x;
+        const int tyi = bid % wa.tiles_y;
+        const int n = bid / wa.tiles_y;
+        const int r0 = half * HP + 8 * pg;
+        const int p = tyi * WIN_TH + r0 / WIN_TW, q0 = txi * WIN_TW + r0 % WIN_TW;
+        const int f = k0 + 4 * fq;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            rdy[i] = *reinterpret_cast<const f32x4 *>((p < a.P && q0 + i < a.Q && f < a.K)
+                                                          ? wb.dy + (((long)n * a.P + p) * a.Q + q0 + i) * a.K + f : a.zero);
+    };
+    auto commit_dy = [&]() {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            u16x4 lo, hi;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { lo[i] = f2bf(rdy[i][j]); hi[i] = f2bf(rdy[4 + i][j]); }
+            unsigned short *d = dyT + (4 * fq + j) * LDP + 8 * pg;
+            *reinterpret_cast<u16x4 *>(d) = lo;
+            *reinterpret_cast<u16x4 *>(d + 4) = hi;
+        }
+    };
+
+    int tile = split;
+    if (tile < ntiles) issue_dy(tile, 0);
+    for (; tile < ntiles; tile += wb.splits) {
+        int bid = tile;
+        const int txi = bid % wa.tiles_x; bid /= wa.tiles_x;
+        const int tyi = bid % wa.tiles_y;
+        const int n = bid / wa.tiles_y;
+        const int y0 = tyi * WIN_TH, x0 = txi * WIN_TW;
+        const int wy0 = y0 - a.pad_h - wa.RW, wx0 = x0 - a.pad_w - wa.RW;
+        const long img = (long)n * a.H * a.W;
+        __syncthreads();                                     // the previous block's last samples / MFMA reads are done
+        // ---- input window of this block and chunk, sample geometry of deformable group g
+        for (int i = t; i < npx * 8; i += NT) {
+            const int px = i >> 3, c4 = (i & 7) * 4;
+            const int ly = px / wa.WW, lx = px - ly * wa.WW;
+            const int gy = wy0 + ly, gx = wx0 + lx;
+            const bool ok = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            *reinterpret_cast<f32x4 *>(xw + (size_t)i * 4) =
+                *reinterpret_cast<const f32x4 *>(ok ? a.x + (img + (long)gy * a.W + gx) * a.C + c0 + c4 : a.zero);
+        }
+        for (int it = t; it < BM * RS; it += NT) {
+            const int r = it / RS, tap = it - r * RS;
+            const int p = y0 + r / WIN_TW, q = x0 + r % WIN_TW;
+            int packed = 0;
+            float flh = 0.f, flw = 0.f, mk = 0.f;
+            if (p < a.P && q < a.Q) {
+                const long m = ((long)n * a.P + p) * a.Q + q;
+                const float *po = a.offset + m * (2 * a.dg * RS) + g * 2 * RS + 2 * tap;
+                const int ti = tap / a.S, tj = tap - ti * a.S;
+                const float h = (float)(p - a.pad_h + ti * a.dil) + po[0];
+                const float w = (float)(q - a.pad_w + tj * a.dil) + po[1];
+                if (h > -1.f && w > -1.f && h < (float)a.H && w < (float)a.W) {
+                    const float hf = floorf(h), wf = floorf(w);
+                    const int h0 = (int)hf, w0 = (int)wf;
+                    int valid = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int hy = h0 + (e >> 1), wx = w0 + (e & 1);
+                        if (hy >= 0 && hy <= a.H - 1 && wx >= 0 && wx <= a.W - 1) valid |= 1 << e;
+                    }
+                    const int ly = h0 - wy0, lx = w0 - wx0;
+                    const bool fast = ly >= 0 && ly + 1 < wa.WH && lx >= 0 && lx + 1 < wa.WW;
+                    packed = (valid << 16) | (fast ? (ly * wa.WW + lx) : GEO_SLOW);
+                    flh = h - hf; flw = w - wf;
+                    mk = a.mask[m * (a.dg * RS) + g * RS + tap];
+                }
+            }
+            geo_i[it] = packed;
+            geo_f[it * 3] = flh; geo_f[it * 3 + 1] = flw; geo_f[it * 3 + 2] = mk;
+        }
+        for (int half = 0; half < 2; ++half) {
+            __syncthreads();                                 // window + geometry visible; dyT / colT free again
+            commit_dy();
+            // ---- masked bilinear samples of 64 pixels x 9 taps x 32 channels, bf16, pixel-minor
+            const int r = half * HP + a_row;
+#pragma unroll 3
+            for (int tap = 0; tap < RS; ++tap) {
+                const int gi = geo_i[r * RS + tap];
+                const int valid = (gi >> 16) & 15;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (valid) {
+                    const float flh = geo_f[(r * RS + tap) * 3], flw = geo_f[(r * RS + tap) * 3 + 1], mk = geo_f[(r * RS + tap) * 3 + 2];
+                    const float hh = 1.f - flh, hw = 1.f - flw;
+                    const float wt[4] = {hh * hw * mk, hh * flw * mk, flh * hw * mk, flh * flw * mk};     // as make_tap: the forward's samples exactly
+                    if (!(gi & GEO_SLOW)) {
+                        const float *xb = xw + (size_t)(gi & 0xffff) * CW + a_col;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if ((valid >> e) & 1) v += *reinterpret_cast<const f32x4 *>(xb + ((e >> 1) * wa.WW + (e & 1)) * CW) * wt[e];
+                    } else {
+                        const int p = y0 + r / WIN_TW, q = x0 + r % WIN_TW;
+                        const float *po = a.offset + (((long)n * a.P + p) * a.Q + q) * (2 * a.dg * RS) + g * 2 * RS + 2 * tap;
+                        const int ti = tap / a.S, tj = tap - ti * a.S;
+                        const int h0 = (int)floorf((float)(p - a.pad_h + ti * a.dil) + po[0]);
+                        const int w0 = (int)floorf((float)(q - a.pad_w + tj * a.dil) + po[1]);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if ((valid >> e) & 1)
+                                v += *reinterpret_cast<const f32x4 *>(a.x + (img + (long)(h0 + (e >> 1)) * a.W + w0 + (e & 1)) * a.C + c0 + a_col) * wt[e];
+                    }
+                }
+                const u16x4 hb = f2bf4(v);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) colT[(tap * CW + a_col + c) * LDP + a_row] = hb[c];
+            }
+            __syncthreads();
+            // next half block's dY lands under the MFMAs
+            if (half == 0) issue_dy(tile, 1);
+            else if (tile + wb.splits < ntiles) issue_dy(tile + wb.splits, 0);
+#pragma unroll
+            for (int kk = 0; kk < HP / 16; ++kk) {
+                const bf16x8 fa = *reinterpret_cast<const bf16x8 *>(dyT + (wave * 32 + lr) * LDP + kk * 16 + lh_ * 8);
+#pragma unroll
+                for (int tap = 0; tap < RS; ++tap) {
+                    const bf16x8 fb = *reinterpret_cast<const bf16x8 *>(colT + (tap * CW + lr) * LDP + kk * 16 + lh_ * 8);
+                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[tap], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // ---- dW += this workgroup's partial sums: lane <-> channel, 128-byte row segments
+#pragma unroll
+    for (int tap = 0; tap < RS; ++tap)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int f = k0 + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh_;
+            if (f < a.K && acc[tap][e] != 0.f) unsafeAtomicAdd(wb.dw + ((long)f * RS + tap) * a.C + c0 + lr, acc[tap][e]);
+        }
+}
+
 __device__ float rr_dcn_zero16[4] = {0.f, 0.f, 0.f, 0.f};
 
 int fill_args(DcnArgs &a, const float *x, const float *offset, const float *mask, const float *w, int n, int h, int wd,
@@ -1559,6 +1744,45 @@ extern "C" int rr_dcn_wgrad(const float *x, const float *offset, const float *ma
     hipLaunchKernelGGL(dcn_wgrad_kernel, dim3(tiles * splits), dim3(256), lds, stream, b);
     RR_CHECK_LAUNCH("rr_dcn_wgrad");
     return RR_OK;
+}
+
+extern "C" int rr_dcn_wgrad_bf16(const float *x, const float *offset, const float *mask, const float *dy, float *dw, int n, int h,
+                                 int wd, int c, int k, int r, int s, int stride, int pad_h, int pad_w, int dilation,
+                                 int deformable_groups, hipStream_t stream)
+{
+    const int rw = dcn_win_margin();
+    if (rw > 0 && stride == 1 && r * s == 9 && c % 32 == 0 && k % 4 == 0 && h < 32768 && wd < 32768 &&
+        (deformable_groups == 1 || (c / deformable_groups) % 32 == 0)) {
+        DcnWinWgradArgs wb{};
+        const int rc = fill_args(wb.w.a, x, offset, mask, nullptr, n, h, wd, c, k, r, s, stride, pad_h, pad_w, dilation, deformable_groups);
+        if (rc != RR_OK) return rc;
+        wb.w.tiles_y = rr_cdiv(wb.w.a.P, WIN_TH);
+        wb.w.tiles_x = rr_cdiv(wb.w.a.Q, WIN_TW);
+        wb.dy = dy; wb.dw = dw;
+        size_t ldsw = 0;
+        for (int m = rw; m >= 1; --m) {
+            wb.w.RW = m;
+            wb.w.WH = WIN_TH + (r - 1) * dilation + 2 * m + 1;
+            wb.w.WW = WIN_TW + (s - 1) * dilation + 2 * m + 1;
+            const int npx = wb.w.WH * wb.w.WW;
+            ldsw = sizeof(float) * (size_t)(npx * 32 + BM * r * s * 4) + sizeof(unsigned short) * (size_t)((256 + r * s * 32) * 72);
+            if (ldsw <= 160 * 1024 - 512) break;
+        }
+        if (ldsw <= 160 * 1024 - 512) {
+            const int ntiles = n * wb.w.tiles_y * wb.w.tiles_x;
+            wb.ktiles = rr_cdiv(k, 256);
+            const int per_split = (c / 32) * wb.ktiles;
+            int splits = rr_cdiv(256, per_split);          // one workgroup per CU (the window leaves room for one)
+            if (splits > 8) splits = splits / 8 * 8;
+            if (splits > ntiles) splits = ntiles;
+            wb.splits = splits;
+            hipFuncSetAttribute(reinterpret_cast<const void *>(dcn_wgrad_win_bf16_kernel<9>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw);
+            hipLaunchKernelGGL(dcn_wgrad_win_bf16_kernel<9>, dim3(splits * per_split), dim3(512), ldsw, stream, wb);
+            RR_CHECK_LAUNCH("rr_dcn_wgrad_bf16");
+            return RR_OK;
+        }
+    }
+    return rr_dcn_wgrad(x, offset, mask, dy, dw, n, h, wd, c, k, r, s, stride, pad_h, pad_w, dilation, deformable_groups, stream);
 }
 
 // Fused backward, part 2: dx (zeroed here, then float atomics on the bilinear corners), doffset, dmask (plain stores).

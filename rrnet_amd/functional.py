@@ -511,14 +511,15 @@ class _DCNv2(torch.autograd.Function):
             # d input at the memory side), so they run concurrently on two HIP streams.
             cur = torch.cuda.current_stream()
             side = _side_stream(x.device) if DCN_BWD_STREAMS else None
+            # a bf16 forward takes the bf16-operand gradients (input window in LDS, d input pre-summed on chip)
+            bf = bool(ctx.bf16 and DCN_BF16_BWD)
             if side is not None:
                 side.wait_stream(cur)
                 with torch.cuda.stream(side):
-                    ops.dcn_wgrad(x, off, m, dy, dw, stride, pad, dil, dg)
+                    ops.dcn_wgrad(x, off, m, dy, dw, stride, pad, dil, dg, bf16=bf)
             else:
-                ops.dcn_wgrad(x, off, m, dy, dw, stride, pad, dil, dg)
-            # a bf16 forward takes the bf16-operand data gradient (d input pre-summed on chip); the weight gradient stays fp32
-            dx, doff, dmask = ops.dcn_dgrad(x, off, m, w, dy, stride, pad, dil, dg, bf16=ctx.bf16 and DCN_BF16_BWD)
+                ops.dcn_wgrad(x, off, m, dy, dw, stride, pad, dil, dg, bf16=bf)
+            dx, doff, dmask = ops.dcn_dgrad(x, off, m, w, dy, stride, pad, dil, dg, bf16=bf)
             if side is not None:
                 cur.wait_stream(side)
         else:
@@ -606,7 +607,7 @@ def _side_stream(device):
     return _SIDE[key]
 
 
-DCN_BF16_BWD = os.environ.get("RR_DCN_BF16_BWD", "1") != "0"         # bf16 forward -> bf16-operand dgrad (0: fp32 dgrad)
+DCN_BF16_BWD = os.environ.get("RR_DCN_BF16_BWD", "1") != "0"         # bf16 forward -> bf16-operand wgrad / dgrad (0: fp32 kernels)
 DCN_BWD_STREAMS = os.environ.get("RR_DCN_BWD_STREAMS", "1") != "0"   # wgrad and dgrad of the fused backward side by side
 DCN_FUSED_BWD = os.environ.get("RR_DCN_FUSED_BWD", "1") != "0"   # 0: the reference's column-buffer structure (A/B switch)
 DCN_BF16 = os.environ.get("RR_DCN_BF16", "0") == "1"   # BASELINE config 4: bf16 matrix operands in the DCN forward

@@ -682,13 +682,15 @@ def dcn_col2im(x, offset, mask, dcol, r, s, stride, pad, dilation, dg):
     return dx, doff, dmask
 
 
-def dcn_wgrad(x, offset, mask, dy, dw, stride, pad, dilation, dg):
-    """dw [K,C,R,S] (OHWI memory, pre-zeroed or the running gradient) += dY^T x deformed columns; no column buffer."""
+def dcn_wgrad(x, offset, mask, dy, dw, stride, pad, dilation, dg, bf16=False):
+    """dw [K,C,R,S] (OHWI memory, pre-zeroed or the running gradient) += dY^T x deformed columns; no column buffer.
+    bf16: bf16 matrix operands (dY, samples), input window in LDS (rr_dcn_wgrad_bf16)."""
     assert is_nhwc(x) and is_nhwc(offset) and is_nhwc(mask) and is_nhwc(dy) and is_nhwc(dw)
     n, c, h, wd = x.shape
     k, _, r, s = dw.shape
-    _C.check(_C.fn("rr_dcn_wgrad")(_C.ptr(x), _C.ptr(offset), _C.ptr(mask), _C.ptr(dy), _C.ptr(dw), n, h, wd, c, k, r, s,
-                                   stride, pad[0], pad[1], dilation, dg, _C.stream()), "rr_dcn_wgrad")
+    name = "rr_dcn_wgrad_bf16" if bf16 else "rr_dcn_wgrad"
+    _C.check(_C.fn(name)(_C.ptr(x), _C.ptr(offset), _C.ptr(mask), _C.ptr(dy), _C.ptr(dw), n, h, wd, c, k, r, s,
+                         stride, pad[0], pad[1], dilation, dg, _C.stream()), name)
     return dw
 
 

@@ -100,6 +100,37 @@ def test_dcn_bf16_dgrad_equals_fp32_dgrad_on_rounded_operands(shape):
         assert (a - b).abs().max().item() <= 5e-5 * scale, (name, (a - b).abs().max().item(), scale)
 
 
+@pytest.mark.parametrize("shape", [(2, 256, 24, 40, 256, 1, 1.0), (1, 64, 19, 21, 96, 1, 2.5), (1, 256, 16, 16, 64, 2, 2.5),
+                                   (1, 32, 40, 33, 260, 1, 1.0)])
+def test_dcn_bf16_wgrad_equals_gemm_of_rounded_operands(shape):
+    """rr_dcn_wgrad_bf16 = dY^T x columns with BOTH operands rounded to bf16 (the columns after the fp32 bilinear blend and
+    mask, as in rr_dcn_fwd_bf16) and fp32 accumulation: checked against a float64 matmul of the rounded operands (columns
+    from rr_dcn_im2col).  Covers ragged pixel blocks, several splits, offsets beyond the window margin, two deformable
+    groups, K not a multiple of 32 / above one 256-filter tile, accumulation into a non-zero dw."""
+    from rrnet_amd import ops
+    n, c, h, w, k, dg, sigma = shape
+    g = torch.Generator().manual_seed(sum(int(v) for v in shape))
+    x = torch.randn(n, c, h, w, generator=g)
+    off = torch.randn(n, 18 * dg, h, w, generator=g) * sigma
+    mask = torch.sigmoid(torch.randn(n, 9 * dg, h, w, generator=g))
+    dy = torch.randn(n, k, h, w, generator=g)
+    xd, od, md, dyd = [ops.to_nhwc(t.cuda()) for t in (x, off, mask, dy)]
+    col = ops.dcn_im2col(xd, od, md, 3, 3, 1, (1, 1), 1, dg)                     # [1, 9c, M, 1] logical, (tap, c) minor
+    colr = col.permute(0, 2, 3, 1).reshape(-1, 9 * c).bfloat16().double()
+    dyr = dyd.permute(0, 2, 3, 1).reshape(-1, k).bfloat16().double()
+    ref = (dyr.t() @ colr).reshape(k, 3, 3, c).permute(0, 3, 1, 2)               # logical [K, C, R, S]
+    base = torch.randn(k, c, 3, 3, generator=g) * 0.1
+    dw = ops.to_nhwc(base.cuda())
+    ops.dcn_wgrad(xd, od, md, dyd, dw, 1, (1, 1), 1, dg, bf16=True)
+    got = dw.double() - base.cuda().double()
+    scale = ref.abs().max().item()
+    assert (got - ref).abs().max().item() <= 3e-5 * scale, ((got - ref).abs().max().item(), scale)
+    # and it is the fp32 kernel's result up to the operand rounding
+    dw32 = ops.zeros_nhwc(k, c, 3, 3, device="cuda")
+    ops.dcn_wgrad(xd, od, md, dyd, dw32, 1, (1, 1), 1, dg)
+    assert (got - dw32.double()).abs().max().item() <= 2e-2 * scale
+
+
 def test_dcn_bf16_dgrad_fixed_point_window_keeps_local_precision():
     """The LDS window of rr_dcn_dgrad_bf16 accumulates in fixed point with ONE power-of-two scale per (8x16 pixel block,
     32-channel chunk), derived from that block's largest |dcol| x |mask|: a block with huge output gradients must not
