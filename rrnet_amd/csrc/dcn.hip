@@ -383,10 +383,11 @@ struct DcnWinArgs {
 };
 
 template <int BN>      // 128 or 256 output channels per workgroup: at 256 one gather feeds twice the MFMAs
-__global__ __launch_bounds__(256) void dcn_fprop_win_bf16_kernel(const DcnWinArgs wa)
+__global__ __launch_bounds__(512) void dcn_fprop_win_bf16_kernel(const DcnWinArgs wa)
 {
     const DcnArgs &a = wa.a;
-    constexpr int WN = 2, WM = 2, TM = 2, TN = BN / 64, BJ = BN / 32;
+    // 512 threads: the window leaves room for one workgroup per CU, and two waves per SIMD hide the gather's LDS latency
+    constexpr int NT = 512, WN = 4, WM = 2, TM = 2, TN = BN / 128, BJ = BN / 64;
     constexpr int A_ELEMS = BM * LDKH, B_ELEMS = BN * LDKH;
     extern __shared__ __align__(16) unsigned char smem[];
     const int RS = a.R * a.S;
@@ -413,7 +414,7 @@ __global__ __launch_bounds__(256) void dcn_fprop_win_bf16_kernel(const DcnWinArg
 
     // ---- geometry tables for deformable group g
     auto build_geo = [&](int g) {
-        for (int it = t; it < BM * RS; it += 256) {
+        for (int it = t; it < BM * RS; it += NT) {
             const int r = it / RS, tap = it - r * RS;
             const int p = y0 + r / WIN_TW, q = x0 + r % WIN_TW;
             unsigned int o[4] = {0u, 0u, 0u, 0u};
@@ -446,13 +447,13 @@ __global__ __launch_bounds__(256) void dcn_fprop_win_bf16_kernel(const DcnWinArg
         }
     };
     // ---- window of channel chunk `cch`: global -> registers (prefetch) -> LDS
-    constexpr int WREG = 14;                       // float4 per thread: windows up to 448 pixels
+    constexpr int WREG = 7;                        // float4 per thread: windows up to 448 pixels
     f32x4 wreg[WREG];
     auto fetch_window = [&](int cch) {
         const int c0 = cch * BK;
 #pragma unroll
         for (int u = 0; u < WREG; ++u) {
-            const int i = t + u * 256;
+            const int i = t + u * NT;
             const int px = i >> 3, c4 = (i & 7) * 4;
             const int ly = px / wa.WW, lx = px - ly * wa.WW;
             const int gy = wy0 + ly, gx = wx0 + lx;
@@ -463,16 +464,16 @@ __global__ __launch_bounds__(256) void dcn_fprop_win_bf16_kernel(const DcnWinArg
     auto store_window = [&]() {
 #pragma unroll
         for (int u = 0; u < WREG; ++u) {
-            const int i = t + u * 256;
+            const int i = t + u * NT;
             if ((i >> 3) < npx) *reinterpret_cast<f32x4 *>(win + (size_t)i * 4) = wreg[u];
         }
     };
-    f32x4 rv[4], rb[BJ];
+    f32x4 rv[2], rb[BJ];
     auto build_a = [&](int cch, int tap) {          // blended samples of the 4 rows this thread stages
         const int c0 = cch * BK;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int r = a_row + 32 * j;
+        for (int j = 0; j < 2; ++j) {
+            const int r = a_row + 64 * j;
             const unsigned int *go = geo_o + (r * RS + tap) * 4;
             const float *gw = geo_w + (r * RS + tap) * 4;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -492,16 +493,16 @@ __global__ __launch_bounds__(256) void dcn_fprop_win_bf16_kernel(const DcnWinArg
         const int c0 = cch * BK;
 #pragma unroll
         for (int j = 0; j < BJ; ++j) {
-            const int ko = n0 + a_row + 32 * j;
+            const int ko = n0 + a_row + 64 * j;
             rb[j] = *reinterpret_cast<const f32x4 *>(ko < a.K ? a.w + ((long)ko * RS + tap) * a.C + c0 + a_col : a.zero);
         }
     };
     auto commit = [&](int buf) {
         unsigned short *A = As + buf * A_ELEMS, *B = Bs + buf * B_ELEMS;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) *reinterpret_cast<u16x4 *>(A + (a_row + 32 * j) * LDKH + a_col) = f2bf4(rv[j]);
+        for (int j = 0; j < 2; ++j) *reinterpret_cast<u16x4 *>(A + (a_row + 64 * j) * LDKH + a_col) = f2bf4(rv[j]);
 #pragma unroll
-        for (int j = 0; j < BJ; ++j) *reinterpret_cast<u16x4 *>(B + (a_row + 32 * j) * LDKH + a_col) = f2bf4(rb[j]);
+        for (int j = 0; j < BJ; ++j) *reinterpret_cast<u16x4 *>(B + (a_row + 64 * j) * LDKH + a_col) = f2bf4(rb[j]);
     };
 
     f32x16 acc[TM][TN];
@@ -1661,10 +1662,10 @@ extern "C" int rr_dcn_fwd_bf16(const float *x, const float *offset, const float 
             const int blocks = n * wa.tiles_y * wa.tiles_x * rr_cdiv(k, wbn);
             if (wbn == 256) {
                 hipFuncSetAttribute(reinterpret_cast<const void *>(dcn_fprop_win_bf16_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                hipLaunchKernelGGL(dcn_fprop_win_bf16_kernel<256>, dim3(blocks), dim3(256), lds, stream, wa);
+                hipLaunchKernelGGL(dcn_fprop_win_bf16_kernel<256>, dim3(blocks), dim3(512), lds, stream, wa);
             } else {
                 hipFuncSetAttribute(reinterpret_cast<const void *>(dcn_fprop_win_bf16_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                hipLaunchKernelGGL(dcn_fprop_win_bf16_kernel<128>, dim3(blocks), dim3(256), lds, stream, wa);
+                hipLaunchKernelGGL(dcn_fprop_win_bf16_kernel<128>, dim3(blocks), dim3(512), lds, stream, wa);
             }
             RR_CHECK_LAUNCH("rr_dcn_fwd_bf16");
             return RR_OK;
