@@ -130,35 +130,10 @@ def extras(a):
 
 
 def config4_train_step(a, steps=2):
-    """BASELINE configs[3] at model level: the headline train step with the three heads' 3x3 convolutions replaced by
-    DCN layers (cfg.Model.dcn_heads, bf16 matrix operands in the deformable forward), same batch, same loop."""
-    from rrnet_amd.configs.rrnet_config import Config as cfg
-    from rrnet_amd.operators.rrnet_operator import RRNetOperator
-    cfg.Model.dcn_heads, cfg.Model.dcn_bf16 = True, True
-    try:
-        torch.manual_seed(cfg.seed)
-        op = RRNetOperator(cfg)                          # the synthetic pool is cached: no host-side regeneration
-        op.model.train()
-        batches = [op.training_loader.get_batch() for _ in range(len(op.training_loader))]
-        step_no = 2000                                   # past the stage-2 warm-up: all four losses on
-
-        def one():
-            nonlocal step_no
-            b = batches[step_no % len(batches)]
-            op.train_step(step_no, (b[0], b[1].clone()) + tuple(b[2:]))
-            step_no += 1
-        one()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            one()
-        torch.cuda.synchronize()
-        t = (time.perf_counter() - t0) / steps
-        return {"value": round(a.batch / t, 4), "unit": "images/sec", "ms_per_step": round(t * 1e3, 2), "steps": steps,
-                "workload": "RRNet hourglass-104 + 6 DCN head layers (bf16 forward operands) train step, B=%d, %dx%d"
-                            % (a.batch, a.size, a.size)}
-    finally:
-        cfg.Model.dcn_heads, cfg.Model.dcn_bf16 = False, False
+    """BASELINE configs[3] at model level (tools/bench_config4.py): the headline train step with the three heads' 3x3
+    convolutions replaced by DCN layers (bf16 matrix operands, non-degenerate offsets), same batch, same loop."""
+    import bench_config4
+    return bench_config4.run(a.batch, a.size, steps, True, a.backbone)
 
 
 def main():

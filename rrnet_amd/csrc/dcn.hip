@@ -1097,8 +1097,10 @@ struct DcnWinBwdArgs {
     float *dx, *doffset, *dmask;
 };
 
-template <int RS>      // taps of the filter (9 for 3x3): one accumulator tile per tap lives in registers through a chunk
-__global__ __launch_bounds__(512) void dcn_dgrad_win_bf16_kernel(const DcnWinBwdArgs wb)
+// F32: the matrix operands stay fp32 (v_mfma_f32_32x32x2_f32, K-steps of 16 filters: the same LDS bytes as 32 in bf16);
+// everything after the GEMM sweep is shared.
+template <int RS, bool F32>      // RS taps (9 for 3x3): one accumulator tile per tap lives in registers through a chunk
+__global__ __launch_bounds__(512) void dcn_dgrad_win_kernel(const DcnWinBwdArgs wb)
 {
     // 512 threads = 8 waves, two per SIMD: the window leaves room for ONE workgroup per CU, and the epilogue is a chain
     // of dependent LDS / L2 round trips that a single wave per SIMD cannot hide.  Wave w computes pixel rows
@@ -1106,7 +1108,10 @@ __global__ __launch_bounds__(512) void dcn_dgrad_win_bf16_kernel(const DcnWinBwd
     const DcnWinArgs &wa = wb.w;
     const DcnArgs &a = wa.a;
     constexpr int CW = 32, WSTR = 33, SST = 36, NT = 512, TG = 5, GEO_SLOW = 1 << 20;
-    constexpr int A_ELEMS = BM * LDKH;
+    constexpr int BKW = F32 ? 16 : 32;                        // filters per K-step
+    constexpr int LDF = 20;                                   // fp32 operand rows: 16 + 4 floats (80 B: aligned, conflict-free b128 reads)
+    constexpr int A_ELEMS = BM * LDKH;                        // in 2-byte units for both precisions (BM * LDF * 2 == BM * LDKH)
+    static_assert(LDF * 2 == LDKH, "fp32 and bf16 operand images have the same size");
     extern __shared__ __align__(16) unsigned char smem[];
     const int npx = wa.WH * wa.WW;
     int *dxw = reinterpret_cast<int *>(smem);                                       // [npx][33] fixed point (see below)
@@ -1117,6 +1122,7 @@ __global__ __launch_bounds__(512) void dcn_dgrad_win_bf16_kernel(const DcnWinBwd
     unsigned short *As = reinterpret_cast<unsigned short *>(xw + (size_t)npx * CW); // [BM][LDKH]   (single image: operands
     unsigned short *Bs = As + A_ELEMS;                                              // [RS][32][LDKH] are prefetched in registers)
     float *stage = reinterpret_cast<float *>(As);                                   // [BM][SST]: epilogue only, over the idle operand images
+    float *Af = reinterpret_cast<float *>(As), *Bf = reinterpret_cast<float *>(Bs);  // F32: [BM][LDF], [RS][32][LDF]
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int lr = lane & 31, lh_ = lane >> 5;
@@ -1128,9 +1134,11 @@ __global__ __launch_bounds__(512) void dcn_dgrad_win_bf16_kernel(const DcnWinBwd
     const int y0 = tyi * WIN_TH, x0 = txi * WIN_TW;
     const int wy0 = y0 - a.pad_h - wa.RW, wx0 = x0 - a.pad_w - wa.RW;
     const int cpt = a.C / CW, cpg = a.C / a.dg;
-    const int nkc = (a.K + BK - 1) / BK;
+    const int nkc = (a.K + BKW - 1) / BKW;
     const int a_col = (t & 7) * 4, a_row = t >> 3;          // a_row 0..63
     const int b_row = a_row & 31, b_tg = a_row >> 5;        // weight rows: ko row b_row, taps 5 b_tg .. +4
+    // F32 staging: dY 128 px x 16 ko = one float4 per thread; W 16 ko x 9 taps x 32 ch: ko row (t >> 3) & 15, taps 3 (t >> 7) .. +2
+    const int fa_row = t >> 2, fa_col = (t & 3) * 4, fb_row = (t >> 3) & 15, fb_tg = t >> 7;
     const long img = (long)n * a.H * a.W;
 
     __shared__ float wmax[8];
@@ -1215,31 +1223,56 @@ __global__ __launch_bounds__(512) void dcn_dgrad_win_bf16_kernel(const DcnWinBwd
         // ---- the nine column-gradient tiles of this chunk in ONE sweep over K:
         //      dcol_tap[128 px][32 ch] = dY[128][K] x W[K][tap][c0 .. c0+31]
         auto issue = [&](int kc) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int r = a_row + 64 * j;
-                const int p = y0 + r / WIN_TW, q = x0 + r % WIN_TW;
-                const int ko = kc * BK + a_col;
-                ra[j] = *reinterpret_cast<const f32x4 *>((p < a.P && q < a.Q && ko < a.K)
+            if constexpr (F32) {
+                const int p = y0 + fa_row / WIN_TW, q = x0 + fa_row % WIN_TW;
+                const int ko = kc * BKW + fa_col;
+                ra[0] = *reinterpret_cast<const f32x4 *>((p < a.P && q < a.Q && ko < a.K)
                                                              ? wb.dy + (((long)n * a.P + p) * a.Q + q) * a.K + ko : a.zero);
-            }
-            const int kb = kc * BK + b_row;          // one ko row per 8 threads, 4 channels each, five taps
+                const int kb = kc * BKW + fb_row;
 #pragma unroll
-            for (int i = 0; i < TG; ++i) {
-                const int tap = b_tg * TG + i;
-                rb[i] = *reinterpret_cast<const f32x4 *>((kb < a.K && tap < RS) ? a.w + ((long)kb * RS + tap) * a.C + c0 + a_col : a.zero);
+                for (int i = 0; i < 3; ++i) {
+                    const int tap = fb_tg * 3 + i;
+                    rb[i] = *reinterpret_cast<const f32x4 *>((kb < a.K && tap < RS) ? a.w + ((long)kb * RS + tap) * a.C + c0 + a_col : a.zero);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int r = a_row + 64 * j;
+                    const int p = y0 + r / WIN_TW, q = x0 + r % WIN_TW;
+                    const int ko = kc * BKW + a_col;
+                    ra[j] = *reinterpret_cast<const f32x4 *>((p < a.P && q < a.Q && ko < a.K)
+                                                                 ? wb.dy + (((long)n * a.P + p) * a.Q + q) * a.K + ko : a.zero);
+                }
+                const int kb = kc * BKW + b_row;         // one ko row per 8 threads, 4 channels each, five taps
+#pragma unroll
+                for (int i = 0; i < TG; ++i) {
+                    const int tap = b_tg * TG + i;
+                    rb[i] = *reinterpret_cast<const f32x4 *>((kb < a.K && tap < RS) ? a.w + ((long)kb * RS + tap) * a.C + c0 + a_col : a.zero);
+                }
             }
         };
         auto commit = [&]() {
+            if constexpr (F32) {
+                *reinterpret_cast<f32x4 *>(Af + fa_row * LDF + fa_col) = ra[0];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) *reinterpret_cast<u16x4 *>(As + (a_row + 64 * j) * LDKH + a_col) = f2bf4(ra[j]);
+                for (int i = 0; i < 3; ++i) {
+                    const int tap = fb_tg * 3 + i;
+                    if (tap < RS) {                  // B images are [tap][n = channel][k = ko]: transposed 4-byte stores
 #pragma unroll
-            for (int i = 0; i < TG; ++i) {
-                const int tap = b_tg * TG + i;
-                if (tap < RS) {
-                    const u16x4 hb = f2bf4(rb[i]);   // B images are [tap][n = channel][k = ko]: transposed 2-byte stores
+                        for (int c = 0; c < 4; ++c) Bf[(tap * CW + a_col + c) * LDF + fb_row] = rb[i][c];
+                    }
+                }
+            } else {
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) Bs[(tap * CW + a_col + c) * LDKH + b_row] = hb[c];
+                for (int j = 0; j < 2; ++j) *reinterpret_cast<u16x4 *>(As + (a_row + 64 * j) * LDKH + a_col) = f2bf4(ra[j]);
+#pragma unroll
+                for (int i = 0; i < TG; ++i) {
+                    const int tap = b_tg * TG + i;
+                    if (tap < RS) {
+                        const u16x4 hb = f2bf4(rb[i]);   // B images are [tap][n = channel][k = ko]: transposed 2-byte stores
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) Bs[(tap * CW + a_col + c) * LDKH + b_row] = hb[c];
+                    }
                 }
             }
         };
@@ -1253,15 +1286,34 @@ __global__ __launch_bounds__(512) void dcn_dgrad_win_bf16_kernel(const DcnWinBwd
             commit();
             __syncthreads();
             if (kc + 1 < nkc) issue(kc + 1);         // lands under this K-step's MFMAs
-#pragma unroll
-            for (int kk = 0; kk < BK / 16; ++kk) {
-                const bf16x8 fa = *reinterpret_cast<const bf16x8 *>(As + (wpx * 32 + lr) * LDKH + kk * 16 + lh_ * 8);
+            if constexpr (F32) {
+                // lane half lh_ takes ko 8 lh_ .. 8 lh_ + 7 of the step (any pairing of ko values across the halves is a
+                // valid 32x32x2 product as long as A and B agree): two ds_read_b128 per operand
+                const f32x4 fa0 = *reinterpret_cast<const f32x4 *>(Af + (wpx * 32 + lr) * LDF + 8 * lh_);
+                const f32x4 fa1 = *reinterpret_cast<const f32x4 *>(Af + (wpx * 32 + lr) * LDF + 8 * lh_ + 4);
 #pragma unroll
                 for (int i = 0; i < TG; ++i) {
                     const int tap = wtg * TG + i;
                     if (tap < RS) {                   // wave-uniform
-                        const bf16x8 fb = *reinterpret_cast<const bf16x8 *>(Bs + (tap * CW + lr) * LDKH + kk * 16 + lh_ * 8);
-                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[i], 0, 0, 0);
+                        const f32x4 fb0 = *reinterpret_cast<const f32x4 *>(Bf + (tap * CW + lr) * LDF + 8 * lh_);
+                        const f32x4 fb1 = *reinterpret_cast<const f32x4 *>(Bf + (tap * CW + lr) * LDF + 8 * lh_ + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[e], fb0[e], acc[i], 0, 0, 0);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[e], fb1[e], acc[i], 0, 0, 0);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < BK / 16; ++kk) {
+                    const bf16x8 fa = *reinterpret_cast<const bf16x8 *>(As + (wpx * 32 + lr) * LDKH + kk * 16 + lh_ * 8);
+#pragma unroll
+                    for (int i = 0; i < TG; ++i) {
+                        const int tap = wtg * TG + i;
+                        if (tap < RS) {                   // wave-uniform
+                            const bf16x8 fb = *reinterpret_cast<const bf16x8 *>(Bs + (tap * CW + lr) * LDKH + kk * 16 + lh_ * 8);
+                            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[i], 0, 0, 0);
+                        }
                     }
                 }
             }
@@ -1801,7 +1853,7 @@ static int dcn_dgrad_impl(const float *x, const float *offset, const float *mask
     b.dy = dy; b.dx = dx; b.doffset = doffset; b.dmask = dmask;
     hipMemsetAsync(dx, 0, sizeof(float) * (size_t)n * h * wd * c, stream);
     const int rw = dcn_win_margin();
-    if (bf16 && rw > 0 && stride == 1 && c % 32 == 0 && h < 32768 && wd < 32768 &&
+    if (rw > 0 && stride == 1 && c % 32 == 0 && h < 32768 && wd < 32768 &&
         (deformable_groups == 1 || (c / deformable_groups) % 32 == 0)) {
         DcnWinBwdArgs wb{};
         wb.w.a = b.a;
@@ -1821,8 +1873,14 @@ static int dcn_dgrad_impl(const float *x, const float *offset, const float *mask
             if (ldsw <= 160 * 1024 - 512) break;
         }
         if (r * s == 9 && ldsw <= 160 * 1024 - 512) {
-            hipFuncSetAttribute(reinterpret_cast<const void *>(dcn_dgrad_win_bf16_kernel<9>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw);
-            hipLaunchKernelGGL(dcn_dgrad_win_bf16_kernel<9>, dim3(n * wb.w.tiles_y * wb.w.tiles_x), dim3(512), ldsw, stream, wb);
+            const dim3 grid(n * wb.w.tiles_y * wb.w.tiles_x);
+            if (bf16) {
+                hipFuncSetAttribute(reinterpret_cast<const void *>(dcn_dgrad_win_kernel<9, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw);
+                hipLaunchKernelGGL((dcn_dgrad_win_kernel<9, false>), grid, dim3(512), ldsw, stream, wb);
+            } else {
+                hipFuncSetAttribute(reinterpret_cast<const void *>(dcn_dgrad_win_kernel<9, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw);
+                hipLaunchKernelGGL((dcn_dgrad_win_kernel<9, true>), grid, dim3(512), ldsw, stream, wb);
+            }
             RR_CHECK_LAUNCH("rr_dcn_dgrad");
             return RR_OK;
         }

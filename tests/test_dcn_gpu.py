@@ -157,6 +157,19 @@ def test_dcn_bf16_dgrad_fixed_point_window_keeps_local_precision():
         loud = b[0].abs().max().item()
         assert loud > 100 * scale
         assert (a[0] - b[0]).abs().max().item() <= 5e-5 * loud, (name, (a[0] - b[0]).abs().max().item(), loud)
+    # the fp32 kernel keeps d input in the same fixed-point window: pin it against the column path (im2col-free GEMM +
+    # rr_dcn_col2im, plain float atomics) of the library on the quiet frame, at the quiet frame's scale
+    from rrnet_amd import functional as RF
+    saved = RF.DCN_FUSED_BWD
+    try:
+        RF.DCN_FUSED_BWD = False
+        ins = [t.clone().requires_grad_() for t in dev[:4]]
+        RF.dcn_v2_conv(*ins, None, 1, 1, 1, 1).backward(dev[4])
+    finally:
+        RF.DCN_FUSED_BWD = saved
+    for name, a, b in zip(("dx", "doffset", "dmask"), ref, [t.grad for t in ins[:3]]):
+        scale = b[1].abs().max().item()
+        assert (a[1] - b[1]).abs().max().item() <= 5e-5 * scale, (name, (a[1] - b[1]).abs().max().item(), scale)
 
 
 def test_reference_zero_offset_identity_on_hip():
