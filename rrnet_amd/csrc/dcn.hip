@@ -1460,19 +1460,24 @@ struct DcnWinWgradArgs {
     int splits, ktiles;
 };
 
-template <int RS>
-__global__ __launch_bounds__(512) void dcn_wgrad_win_bf16_kernel(const DcnWinWgradArgs wb)
+// F32: fp32 operands (v_mfma_f32_32x32x2_f32) in sub-blocks of 32 pixels — the same LDS bytes as 64 pixels of bf16.
+template <int RS, bool F32>
+__global__ __launch_bounds__(512) void dcn_wgrad_win_kernel(const DcnWinWgradArgs wb)
 {
     const DcnWinArgs &wa = wb.w;
     const DcnArgs &a = wa.a;
-    constexpr int CW = 32, NT = 512, HP = 64, LDP = HP + 8, GEO_SLOW = 1 << 20, KT = 256;
+    constexpr int CW = 32, NT = 512, GEO_SLOW = 1 << 20, KT = 256;
+    constexpr int HP = F32 ? 32 : 64;                          // pixels per sub-block
+    constexpr int LDP = F32 ? HP + 4 : HP + 8;                 // operand row length in elements (144 B rows either way)
+    constexpr int NSUB = BM / HP;
     extern __shared__ __align__(16) unsigned char smem[];
     const int npx = wa.WH * wa.WW;
     float *xw = reinterpret_cast<float *>(smem);                                    // [npx][32]
     int *geo_i = reinterpret_cast<int *>(xw + (size_t)npx * CW);                    // [BM][RS]: as in dcn_dgrad_win_bf16_kernel
     float *geo_f = reinterpret_cast<float *>(geo_i + BM * RS);                      // [BM][RS][3]: lh, lw, mask
     unsigned short *dyT = reinterpret_cast<unsigned short *>(geo_f + BM * RS * 3);  // [256 filters][LDP pixels]
-    unsigned short *colT = dyT + KT * LDP;                                          // [RS][32 channels][LDP pixels]
+    unsigned short *colT = dyT + KT * 72;                                           // [RS][32 channels][LDP pixels]
+    float *dyF = reinterpret_cast<float *>(dyT), *colF = reinterpret_cast<float *>(colT);   // F32 images, same bytes
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int lr = lane & 31, lh_ = lane >> 5;
@@ -1483,8 +1488,10 @@ __global__ __launch_bounds__(512) void dcn_wgrad_win_bf16_kernel(const DcnWinWgr
     else { split = blockIdx.x / (cpt * wb.ktiles); rest = blockIdx.x % (cpt * wb.ktiles); }
     const int cch = rest % cpt, kt = rest / cpt;
     const int c0 = cch * CW, g = c0 / cpg, k0 = kt * KT;
-    const int a_col = (t & 7) * 4, a_row = t >> 3;          // sample builder: pixel a_row of the half block, 4 channels
-    const int fq = t & 63, pg = t >> 6;                     // dY stager: filters 4 fq .. +3, pixels 8 pg .. +7 of the half block
+    // sample builder: pixel a_row of the sub-block, 4 channels; bf16: all 9 taps, F32: taps 5 (t >> 8) .. +4
+    const int a_col = (t & 7) * 4, a_row = F32 ? (t >> 3) & 31 : t >> 3, tap0 = F32 ? 5 * (t >> 8) : 0;
+    constexpr int NTAP = F32 ? 5 : RS, PG = F32 ? 4 : 8;
+    const int fq = t & 63, pg = t >> 6;                     // dY stager: filters 4 fq .. +3, pixels PG pg .. +PG-1 of the sub-block
     const int ntiles = a.N * wa.tiles_y * wa.tiles_x;
 
     f32x16 acc[RS];
@@ -1493,29 +1500,34 @@ __global__ __launch_bounds__(512) void dcn_wgrad_win_bf16_kernel(const DcnWinWgr
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[tap][e] = 0.f;
 
-    f32x4 rdy[8];
-    auto issue_dy = [&](int tile, int half) {                // 8 pixels x 4 filters, a 1 KB row segment per wave and pixel
+    f32x4 rdy[PG];
+    auto issue_dy = [&](int tile, int sub) {                 // PG pixels x 4 filters, a 1 KB row segment per wave and pixel
         int bid = tile;
         const int txi = bid % wa.tiles_x; bid /= wa.tiles_x;
         const int tyi = bid % wa.tiles_y;
         const int n = bid / wa.tiles_y;
-        const int r0 = half * HP + 8 * pg;
+        const int r0 = sub * HP + PG * pg;
         const int p = tyi * WIN_TH + r0 / WIN_TW, q0 = txi * WIN_TW + r0 % WIN_TW;
         const int f = k0 + 4 * fq;
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < PG; ++i)
             rdy[i] = *reinterpret_cast<const f32x4 *>((p < a.P && q0 + i < a.Q && f < a.K)
                                                           ? wb.dy + (((long)n * a.P + p) * a.Q + q0 + i) * a.K + f : a.zero);
     };
     auto commit_dy = [&]() {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            u16x4 lo, hi;
+            if constexpr (F32) {
+                const f32x4 v = {rdy[0][j], rdy[1][j], rdy[2][j], rdy[3][j]};
+                *reinterpret_cast<f32x4 *>(dyF + (4 * fq + j) * LDP + 4 * pg) = v;
+            } else {
+                u16x4 lo, hi;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { lo[i] = f2bf(rdy[i][j]); hi[i] = f2bf(rdy[4 + i][j]); }
-            unsigned short *d = dyT + (4 * fq + j) * LDP + 8 * pg;
-            *reinterpret_cast<u16x4 *>(d) = lo;
-            *reinterpret_cast<u16x4 *>(d + 4) = hi;
+                for (int i = 0; i < 4; ++i) { lo[i] = f2bf(rdy[i][j]); hi[i] = f2bf(rdy[4 + i][j]); }
+                unsigned short *d = dyT + (4 * fq + j) * LDP + 8 * pg;
+                *reinterpret_cast<u16x4 *>(d) = lo;
+                *reinterpret_cast<u16x4 *>(d + 4) = hi;
+            }
         }
     };
 
@@ -1569,13 +1581,15 @@ __global__ __launch_bounds__(512) void dcn_wgrad_win_bf16_kernel(const DcnWinWgr
             geo_i[it] = packed;
             geo_f[it * 3] = flh; geo_f[it * 3 + 1] = flw; geo_f[it * 3 + 2] = mk;
         }
-        for (int half = 0; half < 2; ++half) {
+        for (int half = 0; half < NSUB; ++half) {
             __syncthreads();                                 // window + geometry visible; dyT / colT free again
             commit_dy();
             // ---- masked bilinear samples of 64 pixels x 9 taps x 32 channels, bf16, pixel-minor
             const int r = half * HP + a_row;
 #pragma unroll 3
-            for (int tap = 0; tap < RS; ++tap) {
+            for (int ti_ = 0; ti_ < NTAP; ++ti_) {
+                const int tap = tap0 + ti_;
+                if (tap >= RS) break;
                 const int gi = geo_i[r * RS + tap];
                 const int valid = (gi >> 16) & 15;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -1600,21 +1614,41 @@ __global__ __launch_bounds__(512) void dcn_wgrad_win_bf16_kernel(const DcnWinWgr
                                 v += *reinterpret_cast<const f32x4 *>(a.x + (img + (long)(h0 + (e >> 1)) * a.W + w0 + (e & 1)) * a.C + c0 + a_col) * wt[e];
                     }
                 }
-                const u16x4 hb = f2bf4(v);
+                if constexpr (F32) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) colT[(tap * CW + a_col + c) * LDP + a_row] = hb[c];
+                    for (int c = 0; c < 4; ++c) colF[(tap * CW + a_col + c) * LDP + a_row] = v[c];
+                } else {
+                    const u16x4 hb = f2bf4(v);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) colT[(tap * CW + a_col + c) * LDP + a_row] = hb[c];
+                }
             }
             __syncthreads();
             // next half block's dY lands under the MFMAs
-            if (half == 0) issue_dy(tile, 1);
+            if (half + 1 < NSUB) issue_dy(tile, half + 1);
             else if (tile + wb.splits < ntiles) issue_dy(tile + wb.splits, 0);
 #pragma unroll
             for (int kk = 0; kk < HP / 16; ++kk) {
-                const bf16x8 fa = *reinterpret_cast<const bf16x8 *>(dyT + (wave * 32 + lr) * LDP + kk * 16 + lh_ * 8);
+                if constexpr (F32) {
+                    // lane half lh_ takes pixels 8 lh_ .. +7 of the 16-pixel step (A and B agree on the pairing)
+                    const f32x4 fa0 = *reinterpret_cast<const f32x4 *>(dyF + (wave * 32 + lr) * LDP + kk * 16 + 8 * lh_);
+                    const f32x4 fa1 = *reinterpret_cast<const f32x4 *>(dyF + (wave * 32 + lr) * LDP + kk * 16 + 8 * lh_ + 4);
 #pragma unroll
-                for (int tap = 0; tap < RS; ++tap) {
-                    const bf16x8 fb = *reinterpret_cast<const bf16x8 *>(colT + (tap * CW + lr) * LDP + kk * 16 + lh_ * 8);
-                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[tap], 0, 0, 0);
+                    for (int tap = 0; tap < RS; ++tap) {
+                        const f32x4 fb0 = *reinterpret_cast<const f32x4 *>(colF + (tap * CW + lr) * LDP + kk * 16 + 8 * lh_);
+                        const f32x4 fb1 = *reinterpret_cast<const f32x4 *>(colF + (tap * CW + lr) * LDP + kk * 16 + 8 * lh_ + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[e], fb0[e], acc[tap], 0, 0, 0);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[e], fb1[e], acc[tap], 0, 0, 0);
+                    }
+                } else {
+                    const bf16x8 fa = *reinterpret_cast<const bf16x8 *>(dyT + (wave * 32 + lr) * LDP + kk * 16 + lh_ * 8);
+#pragma unroll
+                    for (int tap = 0; tap < RS; ++tap) {
+                        const bf16x8 fb = *reinterpret_cast<const bf16x8 *>(colT + (tap * CW + lr) * LDP + kk * 16 + lh_ * 8);
+                        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[tap], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -1773,9 +1807,9 @@ extern "C" int rr_dcn_col2im(const float *x, const float *offset, const float *m
 
 // Fused backward, part 1: weight gradient.  dw [K][R][S][C] += dY^T x deformed columns (float atomics; pre-zeroed or
 // holding the running gradient).  Requires K % 4 == 0 and one deformable group per 128-channel tile.
-extern "C" int rr_dcn_wgrad(const float *x, const float *offset, const float *mask, const float *dy, float *dw, int n, int h,
-                            int wd, int c, int k, int r, int s, int stride, int pad_h, int pad_w, int dilation,
-                            int deformable_groups, hipStream_t stream)
+static int dcn_wgrad_plain(const float *x, const float *offset, const float *mask, const float *dy, float *dw, int n, int h,
+                           int wd, int c, int k, int r, int s, int stride, int pad_h, int pad_w, int dilation,
+                           int deformable_groups, hipStream_t stream)
 {
     DcnBwdArgs b{};
     const int rc = fill_args(b.a, x, offset, mask, nullptr, n, h, wd, c, k, r, s, stride, pad_h, pad_w, dilation, deformable_groups);
@@ -1799,9 +1833,10 @@ extern "C" int rr_dcn_wgrad(const float *x, const float *offset, const float *ma
     return RR_OK;
 }
 
-extern "C" int rr_dcn_wgrad_bf16(const float *x, const float *offset, const float *mask, const float *dy, float *dw, int n, int h,
-                                 int wd, int c, int k, int r, int s, int stride, int pad_h, int pad_w, int dilation,
-                                 int deformable_groups, hipStream_t stream)
+// Window kernel for either operand precision; returns -1 when the layer does not qualify (caller takes dcn_wgrad_kernel).
+static int dcn_wgrad_win(const float *x, const float *offset, const float *mask, const float *dy, float *dw, int n, int h,
+                         int wd, int c, int k, int r, int s, int stride, int pad_h, int pad_w, int dilation,
+                         int deformable_groups, int bf16, hipStream_t stream)
 {
     const int rw = dcn_win_margin();
     if (rw > 0 && stride == 1 && r * s == 9 && c % 32 == 0 && k % 4 == 0 && h < 32768 && wd < 32768 &&
@@ -1829,13 +1864,40 @@ extern "C" int rr_dcn_wgrad_bf16(const float *x, const float *offset, const floa
             if (splits > 8) splits = splits / 8 * 8;
             if (splits > ntiles) splits = ntiles;
             wb.splits = splits;
-            hipFuncSetAttribute(reinterpret_cast<const void *>(dcn_wgrad_win_bf16_kernel<9>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw);
-            hipLaunchKernelGGL(dcn_wgrad_win_bf16_kernel<9>, dim3(splits * per_split), dim3(512), ldsw, stream, wb);
-            RR_CHECK_LAUNCH("rr_dcn_wgrad_bf16");
+            if (bf16) {
+                hipFuncSetAttribute(reinterpret_cast<const void *>(dcn_wgrad_win_kernel<9, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw);
+                hipLaunchKernelGGL((dcn_wgrad_win_kernel<9, false>), dim3(splits * per_split), dim3(512), ldsw, stream, wb);
+            } else {
+                hipFuncSetAttribute(reinterpret_cast<const void *>(dcn_wgrad_win_kernel<9, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw);
+                hipLaunchKernelGGL((dcn_wgrad_win_kernel<9, true>), dim3(splits * per_split), dim3(512), ldsw, stream, wb);
+            }
+            RR_CHECK_LAUNCH("rr_dcn_wgrad");
             return RR_OK;
         }
     }
-    return rr_dcn_wgrad(x, offset, mask, dy, dw, n, h, wd, c, k, r, s, stride, pad_h, pad_w, dilation, deformable_groups, stream);
+    return -1;
+}
+
+static int dcn_wgrad_plain(const float *x, const float *offset, const float *mask, const float *dy, float *dw, int n, int h,
+                           int wd, int c, int k, int r, int s, int stride, int pad_h, int pad_w, int dilation,
+                           int deformable_groups, hipStream_t stream);
+
+extern "C" int rr_dcn_wgrad_bf16(const float *x, const float *offset, const float *mask, const float *dy, float *dw, int n, int h,
+                                 int wd, int c, int k, int r, int s, int stride, int pad_h, int pad_w, int dilation,
+                                 int deformable_groups, hipStream_t stream)
+{
+    const int rc = dcn_wgrad_win(x, offset, mask, dy, dw, n, h, wd, c, k, r, s, stride, pad_h, pad_w, dilation, deformable_groups, 1, stream);
+    if (rc != -1) return rc;
+    return dcn_wgrad_plain(x, offset, mask, dy, dw, n, h, wd, c, k, r, s, stride, pad_h, pad_w, dilation, deformable_groups, stream);
+}
+
+extern "C" int rr_dcn_wgrad(const float *x, const float *offset, const float *mask, const float *dy, float *dw, int n, int h,
+                            int wd, int c, int k, int r, int s, int stride, int pad_h, int pad_w, int dilation,
+                            int deformable_groups, hipStream_t stream)
+{
+    const int rc = dcn_wgrad_win(x, offset, mask, dy, dw, n, h, wd, c, k, r, s, stride, pad_h, pad_w, dilation, deformable_groups, 0, stream);
+    if (rc != -1) return rc;
+    return dcn_wgrad_plain(x, offset, mask, dy, dw, n, h, wd, c, k, r, s, stride, pad_h, pad_w, dilation, deformable_groups, stream);
 }
 
 // Fused backward, part 2: dx (zeroed here, then float atomics on the bilinear corners), doffset, dmask (plain stores).
