@@ -382,13 +382,16 @@ struct DcnWinArgs {
     int tiles_y, tiles_x;  // pixel blocks per image
 };
 
-template <int BN>      // 128 or 256 output channels per workgroup: at 256 one gather feeds twice the MFMAs
-__global__ __launch_bounds__(512) void dcn_fprop_win_bf16_kernel(const DcnWinArgs wa)
+// F32: fp32 matrix operands (v_mfma_f32_32x32x2_f32); a K-step is then HALF a window chunk (16 channels of one tap),
+// which keeps the operand images at the bf16 kernel's bytes.
+template <int BN, bool F32>      // 128 or 256 output channels per workgroup: at 256 one gather feeds twice the MFMAs
+__global__ __launch_bounds__(512) void dcn_fprop_win_kernel(const DcnWinArgs wa)
 {
     const DcnArgs &a = wa.a;
     // 512 threads: the window leaves room for one workgroup per CU, and two waves per SIMD hide the gather's LDS latency
     constexpr int NT = 512, WN = 4, WM = 2, TM = 2, TN = BN / 128, BJ = BN / 64;
-    constexpr int A_ELEMS = BM * LDKH, B_ELEMS = BN * LDKH;
+    constexpr int A_ELEMS = BM * LDKH, B_ELEMS = BN * LDKH;      // 2-byte units (an fp32 row is 20 floats = 40 units)
+    constexpr int H = F32 ? 2 : 1, LDF = 20, BJF = BN / 128;
     extern __shared__ __align__(16) unsigned char smem[];
     const int RS = a.R * a.S;
     const int npx = wa.WH * wa.WW;
@@ -410,6 +413,7 @@ __global__ __launch_bounds__(512) void dcn_fprop_win_bf16_kernel(const DcnWinArg
     const int cpt = a.C / BK;                                            // channel chunks (C % 32 == 0 on this path)
     const int cpg = a.C / a.dg;
     const int a_col = (t & 7) * 4, a_row = t >> 3;
+    const int fa_col = (t & 3) * 4, fa_row = t >> 2;                     // F32 staging: one 16-channel row quarter per thread
     const long img = (long)n * a.H * a.W;
 
     // ---- geometry tables for deformable group g
@@ -469,40 +473,70 @@ __global__ __launch_bounds__(512) void dcn_fprop_win_bf16_kernel(const DcnWinArg
         }
     };
     f32x4 rv[2], rb[BJ];
-    auto build_a = [&](int cch, int tap) {          // blended samples of the 4 rows this thread stages
+    auto build_a = [&](int cch, int tap, int half) {          // blended samples of the rows this thread stages
         const int c0 = cch * BK;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int r = a_row + 64 * j;
-            const unsigned int *go = geo_o + (r * RS + tap) * 4;
-            const float *gw = geo_w + (r * RS + tap) * 4;
+        if constexpr (F32) {
+            const unsigned int *go = geo_o + (fa_row * RS + tap) * 4;
+            const float *gw = geo_w + (fa_row * RS + tap) * 4;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const unsigned int o = go[e];
                 const float wgt = gw[e];
                 f32x4 xv;
-                if (o & 0x80000000u) xv = *reinterpret_cast<const f32x4 *>(a.x + (img + (long)(o & 0x7fffffffu)) * a.C + c0 + a_col);
-                else xv = *reinterpret_cast<const f32x4 *>(win + (size_t)o * BK + a_col);
+                if (o & 0x80000000u) xv = *reinterpret_cast<const f32x4 *>(a.x + (img + (long)(o & 0x7fffffffu)) * a.C + c0 + half * 16 + fa_col);
+                else xv = *reinterpret_cast<const f32x4 *>(win + (size_t)o * BK + half * 16 + fa_col);
                 v += xv * wgt;
             }
-            rv[j] = v;
+            rv[0] = v;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int r = a_row + 64 * j;
+                const unsigned int *go = geo_o + (r * RS + tap) * 4;
+                const float *gw = geo_w + (r * RS + tap) * 4;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned int o = go[e];
+                    const float wgt = gw[e];
+                    f32x4 xv;
+                    if (o & 0x80000000u) xv = *reinterpret_cast<const f32x4 *>(a.x + (img + (long)(o & 0x7fffffffu)) * a.C + c0 + a_col);
+                    else xv = *reinterpret_cast<const f32x4 *>(win + (size_t)o * BK + a_col);
+                    v += xv * wgt;
+                }
+                rv[j] = v;
+            }
         }
     };
-    auto issue_b = [&](int cch, int tap) {
+    auto issue_b = [&](int cch, int tap, int half) {
         const int c0 = cch * BK;
+        if constexpr (F32) {
 #pragma unroll
-        for (int j = 0; j < BJ; ++j) {
-            const int ko = n0 + a_row + 64 * j;
-            rb[j] = *reinterpret_cast<const f32x4 *>(ko < a.K ? a.w + ((long)ko * RS + tap) * a.C + c0 + a_col : a.zero);
+            for (int j = 0; j < BJF; ++j) {
+                const int ko = n0 + fa_row + 128 * j;
+                rb[j] = *reinterpret_cast<const f32x4 *>(ko < a.K ? a.w + ((long)ko * RS + tap) * a.C + c0 + half * 16 + fa_col : a.zero);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < BJ; ++j) {
+                const int ko = n0 + a_row + 64 * j;
+                rb[j] = *reinterpret_cast<const f32x4 *>(ko < a.K ? a.w + ((long)ko * RS + tap) * a.C + c0 + a_col : a.zero);
+            }
         }
     };
     auto commit = [&](int buf) {
         unsigned short *A = As + buf * A_ELEMS, *B = Bs + buf * B_ELEMS;
+        if constexpr (F32) {
+            *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(A) + fa_row * LDF + fa_col) = rv[0];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) *reinterpret_cast<u16x4 *>(A + (a_row + 64 * j) * LDKH + a_col) = f2bf4(rv[j]);
+            for (int j = 0; j < BJF; ++j) *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(B) + (fa_row + 128 * j) * LDF + fa_col) = rb[j];
+        } else {
 #pragma unroll
-        for (int j = 0; j < BJ; ++j) *reinterpret_cast<u16x4 *>(B + (a_row + 64 * j) * LDKH + a_col) = f2bf4(rb[j]);
+            for (int j = 0; j < 2; ++j) *reinterpret_cast<u16x4 *>(A + (a_row + 64 * j) * LDKH + a_col) = f2bf4(rv[j]);
+#pragma unroll
+            for (int j = 0; j < BJ; ++j) *reinterpret_cast<u16x4 *>(B + (a_row + 64 * j) * LDKH + a_col) = f2bf4(rb[j]);
+        }
     };
 
     f32x16 acc[TM][TN];
@@ -519,46 +553,72 @@ __global__ __launch_bounds__(512) void dcn_fprop_win_bf16_kernel(const DcnWinArg
     fetch_window(0);
     store_window();
     __syncthreads();
-    build_a(0, 0);
-    issue_b(0, 0);
+    build_a(0, 0, 0);
+    issue_b(0, 0, 0);
     commit(0);
     __syncthreads();
-    const int nk = cpt * RS;
+    const int spc = RS * H;                                      // K-steps per window chunk: (tap, half) pairs
+    const int nk = cpt * spc;
     for (int kc = 0; kc < nk; ++kc) {
         const int buf = kc & 1;
-        const int cch = kc / RS, tap = kc - cch * RS;
+        const int cch = kc / spc, rem = kc - cch * spc;
         const bool more = kc + 1 < nk;
-        const bool new_chunk = more && tap == RS - 1;           // the next K-step opens chunk cch + 1
-        if (tap == 0 && cch + 1 < cpt) fetch_window(cch + 1);    // lands under this chunk's 9 K-steps
+        const bool new_chunk = more && rem == spc - 1;           // the next K-step opens chunk cch + 1
+        if (rem == 0 && cch + 1 < cpt) fetch_window(cch + 1);    // lands under this chunk's K-steps
         if (more && !new_chunk) {
-            issue_b(cch, tap + 1);
-            build_a(cch, tap + 1);
+            issue_b(cch, (rem + 1) / H, (rem + 1) % H);
+            build_a(cch, (rem + 1) / H, (rem + 1) % H);
         }
         const unsigned short *A = As + buf * A_ELEMS, *B = Bs + buf * B_ELEMS;
-#pragma unroll
-        for (int kk = 0; kk < BK / 16; ++kk) {
-            bf16x8 fa[TM], fb[TN];
+        if constexpr (F32) {
+            const float *Af = reinterpret_cast<const float *>(A), *Bf = reinterpret_cast<const float *>(B);
+            // lane half lh takes channels 8 lh .. +7 of the 16-channel step (A and B agree on the pairing)
+            f32x4 fa[TM][2], fb[TN][2];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-                fa[i] = *reinterpret_cast<const bf16x8 *>(A + ((wm * TM + i) * 32 + lr) * LDKH + kk * 16 + lh * 8);
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    fa[i][u] = *reinterpret_cast<const f32x4 *>(Af + ((wm * TM + i) * 32 + lr) * LDF + 8 * lh + 4 * u);
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                fb[j] = *reinterpret_cast<const bf16x8 *>(B + ((wn * TN + j) * 32 + lr) * LDKH + kk * 16 + lh * 8);
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int u = 0; u < 2; ++u)
+                    fb[j][u] = *reinterpret_cast<const f32x4 *>(Bf + ((wn * TN + j) * 32 + lr) * LDF + 8 * lh + 4 * u);
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][u][e], fb[j][u][e], acc[i][j], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < BK / 16; ++kk) {
+                bf16x8 fa[TM], fb[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    fa[i] = *reinterpret_cast<const bf16x8 *>(A + ((wm * TM + i) * 32 + lr) * LDKH + kk * 16 + lh * 8);
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                    fb[j] = *reinterpret_cast<const bf16x8 *>(B + ((wn * TN + j) * 32 + lr) * LDKH + kk * 16 + lh * 8);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            }
         }
         if (new_chunk) {
-            // every wave is past its last gather from the old window (it built tap RS-1 one K-step ago)
+            // every wave is past its last gather from the old window (it built the chunk's last step one K-step ago)
             __syncthreads();
             store_window();
             const int g = ((cch + 1) * BK) / cpg;
             if (g != g_cur) { g_cur = g; build_geo(g); }
             __syncthreads();
-            issue_b(cch + 1, 0);
-            build_a(cch + 1, 0);
+            issue_b(cch + 1, 0, 0);
+            build_a(cch + 1, 0, 0);
         }
         if (more) commit(buf ^ 1);
         __syncthreads();
@@ -1691,6 +1751,48 @@ int fill_args(DcnArgs &a, const float *x, const float *offset, const float *mask
 
 }  // namespace
 
+static int dcn_win_margin()
+{
+    static int v = -2;
+    if (v == -2) {
+        const char *e = getenv("RR_DCN_WINDOW");      // margin in pixels around the filter's reach; -1 / 0 disables the window kernel
+        v = e ? atoi(e) : 3;
+    }
+    return v;
+}
+
+// LDS-window forward for either operand precision; -1 when the layer does not qualify.
+static int dcn_fwd_win(const DcnArgs &a, int n, int k, int r, int s, int stride, int dilation, int c, int h, int wd, int bf16,
+                       hipStream_t stream, const char *name)
+{
+    const int rw = dcn_win_margin();
+    if (!(rw > 0 && stride == 1 && k > 32 && c % BK == 0 && (long)h * wd < (1l << 30))) return -1;
+    // the input block a pixel tile can reach is staged once per channel chunk
+    DcnWinArgs wa{};
+    wa.a = a;
+    wa.RW = rw;
+    wa.WH = WIN_TH + (r - 1) * dilation + 2 * rw + 1;
+    wa.WW = WIN_TW + (s - 1) * dilation + 2 * rw + 1;
+    wa.tiles_y = rr_cdiv(a.P, WIN_TH);
+    wa.tiles_x = rr_cdiv(a.Q, WIN_TW);
+    const int npx = wa.WH * wa.WW;
+    const int wbn = (k % 256 == 0 || k > 384) ? 256 : 128;
+    const size_t lds = (size_t)npx * BK * 4 + (size_t)BM * r * s * 4 * 8 + sizeof(unsigned short) * 2 * (BM * LDKH + wbn * LDKH);
+    if (!(npx <= 14 * 32 && lds <= 160 * 1024 - 512)) return -1;
+    const int blocks = n * wa.tiles_y * wa.tiles_x * rr_cdiv(k, wbn);
+#define RR_WIN_LAUNCH(BNV, F32V)                                                                                          \
+    do {                                                                                                                  \
+        hipFuncSetAttribute(reinterpret_cast<const void *>(dcn_fprop_win_kernel<BNV, F32V>),                              \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                        \
+        hipLaunchKernelGGL((dcn_fprop_win_kernel<BNV, F32V>), dim3(blocks), dim3(512), lds, stream, wa);                  \
+    } while (0)
+    if (wbn == 256) { if (bf16) RR_WIN_LAUNCH(256, false); else RR_WIN_LAUNCH(256, true); }
+    else { if (bf16) RR_WIN_LAUNCH(128, false); else RR_WIN_LAUNCH(128, true); }
+#undef RR_WIN_LAUNCH
+    RR_CHECK_LAUNCH(name);
+    return RR_OK;
+}
+
 extern "C" int rr_dcn_fwd(const float *x, const float *offset, const float *mask, const float *w, const float *bias,
                           float *y, int n, int h, int wd, int c, int k, int r, int s, int stride, int pad_h, int pad_w,
                           int dilation, int deformable_groups, hipStream_t stream)
@@ -1699,6 +1801,8 @@ extern "C" int rr_dcn_fwd(const float *x, const float *offset, const float *mask
     const int rc = fill_args(a, x, offset, mask, w, n, h, wd, c, k, r, s, stride, pad_h, pad_w, dilation, deformable_groups);
     if (rc != RR_OK) return rc;
     a.bias = bias; a.y = y;
+    const int wrc = dcn_fwd_win(a, n, k, r, s, stride, dilation, c, h, wd, 0, stream, "rr_dcn_fwd");
+    if (wrc != -1) return wrc;
     const int bn = k > 32 ? 128 : 32;
     const int blocks = rr_cdiv(a.M, BM) * rr_cdiv(k, bn);
     const size_t lds = sizeof(float) * 2 * (BM * LDK + bn * LDK);
@@ -1712,15 +1816,6 @@ extern "C" int rr_dcn_fwd(const float *x, const float *offset, const float *mask
     return RR_OK;
 }
 
-static int dcn_win_margin()
-{
-    static int v = -2;
-    if (v == -2) {
-        const char *e = getenv("RR_DCN_WINDOW");      // margin in pixels around the filter's reach; -1 / 0 disables the window kernel
-        v = e ? atoi(e) : 3;
-    }
-    return v;
-}
 
 extern "C" int rr_dcn_fwd_bf16(const float *x, const float *offset, const float *mask, const float *w, const float *bias,
                                float *y, int n, int h, int wd, int c, int k, int r, int s, int stride, int pad_h, int pad_w,
@@ -1731,32 +1826,8 @@ extern "C" int rr_dcn_fwd_bf16(const float *x, const float *offset, const float 
     if (rc != RR_OK) return rc;
     a.bias = bias; a.y = y;
     const int bn = k > 32 ? 128 : 32;
-    const int rw = dcn_win_margin();
-    if (rw > 0 && stride == 1 && bn == 128 && c % BK == 0 && (long)h * wd < (1l << 30)) {
-        // LDS-window kernel: the input block a pixel tile can reach is staged once per channel chunk
-        DcnWinArgs wa{};
-        wa.a = a;
-        wa.RW = rw;
-        wa.WH = WIN_TH + (r - 1) * dilation + 2 * rw + 1;
-        wa.WW = WIN_TW + (s - 1) * dilation + 2 * rw + 1;
-        wa.tiles_y = rr_cdiv(a.P, WIN_TH);
-        wa.tiles_x = rr_cdiv(a.Q, WIN_TW);
-        const int npx = wa.WH * wa.WW;
-        const int wbn = (k % 256 == 0 || k > 384) ? 256 : 128;
-        const size_t lds = (size_t)npx * BK * 4 + (size_t)BM * r * s * 4 * 8 + sizeof(unsigned short) * 2 * (BM * LDKH + wbn * LDKH);
-        if (npx <= 14 * 32 && lds <= 160 * 1024 - 512) {
-            const int blocks = n * wa.tiles_y * wa.tiles_x * rr_cdiv(k, wbn);
-            if (wbn == 256) {
-                hipFuncSetAttribute(reinterpret_cast<const void *>(dcn_fprop_win_bf16_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                hipLaunchKernelGGL(dcn_fprop_win_bf16_kernel<256>, dim3(blocks), dim3(512), lds, stream, wa);
-            } else {
-                hipFuncSetAttribute(reinterpret_cast<const void *>(dcn_fprop_win_bf16_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                hipLaunchKernelGGL(dcn_fprop_win_bf16_kernel<128>, dim3(blocks), dim3(512), lds, stream, wa);
-            }
-            RR_CHECK_LAUNCH("rr_dcn_fwd_bf16");
-            return RR_OK;
-        }
-    }
+    const int wrc = dcn_fwd_win(a, n, k, r, s, stride, dilation, c, h, wd, 1, stream, "rr_dcn_fwd_bf16");
+    if (wrc != -1) return wrc;
     const int blocks = rr_cdiv(a.M, BM) * rr_cdiv(k, bn);
     const size_t lds = sizeof(unsigned short) * 2 * (BM * LDKH + bn * LDKH);
     if (bn == 128) hipLaunchKernelGGL(dcn_fprop_bf16_kernel<128>, dim3(blocks), dim3(256), lds, stream, a);
