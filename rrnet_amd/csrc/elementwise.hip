@@ -279,6 +279,47 @@ __global__ __launch_bounds__(EW_THREADS) void colsum_kernel(const float *dy, con
     }
 }
 
+// 16 bytes per lane for the wide heads (C % 4 == 0 and C/4 divides 256): thread = channel quad, the block's 256 / (C/4)
+// pixel lanes walk the pixels with two rows in flight; same sums as colsum_kernel up to the summation order.
+__global__ __launch_bounds__(EW_THREADS) void colsum4_kernel(const f32x4 *dy, const f32x4 *z, f32x4 *dy_masked, float *dbias,
+                                                             long npix, int C4)
+{
+    __shared__ f32x4 red[EW_THREADS];
+    const int t = threadIdx.x;
+    const int c4 = t % C4, pl = t / C4, lanes = EW_THREADS / C4;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+    const long step = (long)gridDim.x * lanes;
+    long p = (long)blockIdx.x * lanes + pl;
+    for (; p + step < npix; p += 2 * step) {
+        f32x4 g0 = dy[p * C4 + c4], g1 = dy[(p + step) * C4 + c4];
+        if (z) {
+            const f32x4 z0 = z[p * C4 + c4], z1 = z[(p + step) * C4 + c4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { g0[i] = z0[i] > 0.f ? g0[i] : 0.f; g1[i] = z1[i] > 0.f ? g1[i] : 0.f; }
+            if (dy_masked) { dy_masked[p * C4 + c4] = g0; dy_masked[(p + step) * C4 + c4] = g1; }
+        }
+        s0 += g0; s1 += g1;
+    }
+    if (p < npix) {
+        f32x4 g0 = dy[p * C4 + c4];
+        if (z) {
+            const f32x4 z0 = z[p * C4 + c4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) g0[i] = z0[i] > 0.f ? g0[i] : 0.f;
+            if (dy_masked) dy_masked[p * C4 + c4] = g0;
+        }
+        s0 += g0;
+    }
+    red[t] = s0 + s1;
+    __syncthreads();
+    if (t < C4 && dbias) {
+        f32x4 tot = {0.f, 0.f, 0.f, 0.f};
+        for (int l = 0; l < lanes; ++l) tot += red[l * C4 + t];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) unsafeAtomicAdd(dbias + 4 * t + i, tot[i]);
+    }
+}
+
 // ---- hourglass up path ---------------------------------------------------------------------
 // out[n,h,w,:] = up1[n,h,w,:] + low[n,h/2,w/2,:]     (nn.Upsample(scale_factor=2), nearest; the
 // bilinear align_corners resize that follows in the reference is the identity at equal sizes)
@@ -614,6 +655,15 @@ extern "C" int rr_bias_relu_bwd(const float *dy, const float *z, float *dy_maske
 {
     RR_CHECK_ARG(c > 0 && npix >= 0, "rr_bias_relu_bwd: bad dims");
     if (npix == 0) return RR_OK;
+    if (c % 4 == 0 && c / 4 <= EW_THREADS && EW_THREADS % (c / 4) == 0) {
+        const int lanes4 = EW_THREADS / (c / 4);
+        long blocks4 = (npix + lanes4 * 8 - 1) / (lanes4 * 8);
+        if (blocks4 > 2048) blocks4 = 2048;
+        hipLaunchKernelGGL(colsum4_kernel, dim3((int)blocks4), dim3(EW_THREADS), 0, stream, (const f32x4 *)dy, (const f32x4 *)z,
+                           (f32x4 *)dy_masked, dbias, npix, c / 4);
+        RR_CHECK_LAUNCH("rr_bias_relu_bwd");
+        return RR_OK;
+    }
     const int cpb = c < EW_THREADS ? c : EW_THREADS;
     const int lanes = EW_THREADS / cpb;
     long blocks = (npix + lanes * 16 - 1) / (lanes * 16);

@@ -126,3 +126,23 @@ def test_conv_linearity_large():
     rows = slice(100, 104)
     ref = F.conv2d(x1[:, :, 99:105, :].cpu(), w.cpu(), None, 1, (0, 1))
     np.testing.assert_allclose(y1[:, :, rows, :].cpu().numpy(), ref.numpy(), atol=1e-3, rtol=1e-3)
+
+
+@pytest.mark.parametrize("npix,c,relu", [(70001, 256, True), (4097, 64, True), (513, 4, False), (1000, 10, True),
+                                         (333, 12, True), (65536, 256, False), (7, 256, True)])
+def test_bias_relu_bwd_column_sums(npix, c, relu):
+    """rr_bias_relu_bwd (head convs: conv + bias [+ ReLU]): dy * (z > 0) bit-exact, column sums added to dbias within
+    fp32 summation noise of a float64 sum.  Wide heads (C % 4 == 0, C/4 | 256) take the 16-byte kernel, the rest the
+    scalar one; ragged pixel counts exercise both tails."""
+    from rrnet_amd import ops
+    g = torch.Generator().manual_seed(npix + c)
+    dy = torch.randn(npix, c, generator=g).cuda()
+    z = torch.randn(npix, c, generator=g).cuda() if relu else None
+    db0 = torch.randn(c, generator=g).cuda()
+    db = db0.clone()
+    out = ops.bias_relu_bwd(dy, z, db)
+    want = dy * (z > 0) if relu else dy
+    assert torch.equal(out, want)
+    ref = want.double().sum(0) + db0.double()
+    tol = 1e-6 * want.abs().double().sum(0).max().item() + 1e-6
+    assert (db.double() - ref).abs().max().item() <= tol
