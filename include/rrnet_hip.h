@@ -291,7 +291,10 @@ int rr_roi_align_bwd(const float *dout, const float *rois, int r, int b, int h, 
  *   dw  += rr_conv_wgrad(col as [1,M,1,r*s*c], dy as [1,M,1,k])              (1x1 layer)
  *   dcol = rr_conv_dgrad(dy, w as [k, r*s*c, 1, 1])
  *   rr_dcn_col2im(x, offset, mask, dcol) -> dx (zeroed + float atomics), doffset, dmask
- * Requires c % 4 == 0, c % dg == 0 and (dg == 1 or (c/dg) % 32 == 0). */
+ * Requires c % 4 == 0, c % dg == 0 and (dg == 1 or (c/dg) % 32 == 0).
+ * Layers with stride 1, c % 32 == 0 and k > 32 (3x3 for the two gradients) run on kernels that stage the input block an
+ * 8x16 pixel tile can reach in LDS (margin RR_DCN_WINDOW, default 3 pixels; offsets beyond it go to global memory);
+ * the others on the kernels that gather the bilinear corners from L2.  Same results either way. */
 int rr_dcn_fwd(const float *x, const float *offset, const float *mask, const float *w, const float *bias, float *y,
                int n, int h, int wd, int c, int k, int r, int s, int stride, int pad_h, int pad_w, int dilation,
                int deformable_groups, hipStream_t stream);
@@ -310,7 +313,9 @@ int rr_dcn_col2im(const float *x, const float *offset, const float *mask, const 
 
 /* Fused backward (no column buffers): rr_dcn_wgrad adds dY^T x (deformed columns produced in registers) into dw
  * (float atomics; dw pre-zeroed or holding the running gradient); rr_dcn_dgrad keeps the column gradient in the MFMA
- * accumulators and writes dx (zeroed inside, float atomics on the bilinear corners), doffset and dmask (plain stores).
+ * accumulators and writes dx (zeroed inside; window kernels: contributions pre-summed per pixel block in an LDS image
+ * in fixed point, one power-of-two scale per block and 32-channel chunk, then one global float atomic per window element;
+ * otherwise float atomics on the bilinear corners), doffset and dmask (plain stores).
  * Replace ext/dcn/src/cuda/dcn_v2_cuda.cu:206-335 + dcn_v2_im2col_cuda.cu:197-327.  Require k % 4 == 0 and
  * (dg == 1 or (c/dg) % 128 == 0); the host layer takes the column path above otherwise. */
 int rr_dcn_wgrad(const float *x, const float *offset, const float *mask, const float *dy, float *dw, int n, int h,
@@ -319,9 +324,8 @@ int rr_dcn_wgrad(const float *x, const float *offset, const float *mask, const f
 int rr_dcn_dgrad(const float *x, const float *offset, const float *mask, const float *w, const float *dy, float *dx,
                  float *doffset, float *dmask, int n, int h, int wd, int c, int k, int r, int s, int stride, int pad_h,
                  int pad_w, int dilation, int deformable_groups, hipStream_t stream);
-/* rr_dcn_dgrad with bf16 matrix operands (dY, W rounded to bf16; fp32 accumulation and scatter) and d input pre-summed
- * in an LDS window per 8x16 pixel block and 32-channel chunk before it goes out as global atomics (a tenth of the atomic
- * bytes): the backward of rr_dcn_fwd_bf16.  stride 1, c % 32 == 0; other layers take the rr_dcn_dgrad kernel. */
+/* rr_dcn_dgrad with bf16 matrix operands (dY, W rounded to bf16; fp32 accumulation and scatter): the backward of
+ * rr_dcn_fwd_bf16.  Layers the window kernel does not take run rr_dcn_dgrad's fp32 kernel. */
 int rr_dcn_dgrad_bf16(const float *x, const float *offset, const float *mask, const float *w, const float *dy, float *dx,
                       float *doffset, float *dmask, int n, int h, int wd, int c, int k, int r, int s, int stride,
                       int pad_h, int pad_w, int dilation, int deformable_groups, hipStream_t stream);
