@@ -1770,15 +1770,20 @@ static int dcn_fwd_win(const DcnArgs &a, int n, int k, int r, int s, int stride,
     // the input block a pixel tile can reach is staged once per channel chunk
     DcnWinArgs wa{};
     wa.a = a;
-    wa.RW = rw;
-    wa.WH = WIN_TH + (r - 1) * dilation + 2 * rw + 1;
-    wa.WW = WIN_TW + (s - 1) * dilation + 2 * rw + 1;
     wa.tiles_y = rr_cdiv(a.P, WIN_TH);
     wa.tiles_x = rr_cdiv(a.Q, WIN_TW);
-    const int npx = wa.WH * wa.WW;
     const int wbn = (k % 256 == 0 || k > 384) ? 256 : 128;
-    const size_t lds = (size_t)npx * BK * 4 + (size_t)BM * r * s * 4 * 8 + sizeof(unsigned short) * 2 * (BM * LDKH + wbn * LDKH);
-    if (!(npx <= 14 * 32 && lds <= 160 * 1024 - 512)) return -1;
+    size_t lds = 0;
+    bool fits = false;
+    for (int m = rw; m >= 1 && !fits; --m) {          // the largest margin <= the requested one that fits
+        wa.RW = m;
+        wa.WH = WIN_TH + (r - 1) * dilation + 2 * m + 1;
+        wa.WW = WIN_TW + (s - 1) * dilation + 2 * m + 1;
+        const int npx = wa.WH * wa.WW;
+        lds = (size_t)npx * BK * 4 + (size_t)BM * r * s * 4 * 8 + sizeof(unsigned short) * 2 * (BM * LDKH + wbn * LDKH);
+        fits = npx <= 14 * 32 && lds <= 160 * 1024 - 512;
+    }
+    if (!fits) return -1;
     const int blocks = n * wa.tiles_y * wa.tiles_x * rr_cdiv(k, wbn);
 #define RR_WIN_LAUNCH(BNV, F32V)                                                                                          \
     do {                                                                                                                  \

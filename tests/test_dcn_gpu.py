@@ -107,7 +107,10 @@ def test_dcn_bf16_wgrad_equals_gemm_of_rounded_operands(shape):
     mask, as in rr_dcn_fwd_bf16) and fp32 accumulation: checked against a float64 matmul of the rounded operands (columns
     from rr_dcn_im2col).  Covers ragged pixel blocks, several splits, offsets beyond the window margin, two deformable
     groups, K not a multiple of 32 / above one 256-filter tile, accumulation into a non-zero dw."""
+    import os
     from rrnet_amd import ops
+    if int(os.environ.get("RR_DCN_WINDOW", "3")) <= 0:
+        pytest.skip("without the LDS window rr_dcn_wgrad_bf16 runs the fp32-operand kernel")
     n, c, h, w, k, dg, sigma = shape
     g = torch.Generator().manual_seed(sum(int(v) for v in shape))
     x = torch.randn(n, c, h, w, generator=g)

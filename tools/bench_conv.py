@@ -22,6 +22,11 @@ SHAPES = [  # N, C, H, W, K, R, stride
     (8, 512, 8, 8, 512, 3, 1),
     (8, 256, 256, 256, 256, 1, 1),
     (8, 128, 512, 512, 256, 3, 2),
+    (8, 256, 256, 256, 256, 3, 2),
+    (8, 256, 128, 128, 384, 3, 2),
+    (8, 384, 64, 64, 384, 3, 2),
+    (8, 128, 512, 512, 256, 1, 2),
+    (8, 256, 256, 256, 256, 1, 2),
     (8, 3, 1024, 1024, 128, 7, 2),
 ]
 only = [int(a) for a in sys.argv[1:]]
