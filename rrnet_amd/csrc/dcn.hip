@@ -1141,6 +1141,24 @@ __global__ void dcn_split_bwd_kernel(const float *doffset, const float *dmask, c
 // conflicts) and flushes that window ONCE per chunk with global atomics: ≈3.3 window pixels per output pixel instead of 36 corner adds, 1.8 GB of atomic bytes instead of 19.3.
 // Corners beyond the window margin go to global memory directly.  d offset / d mask are summed over the chunks in LDS and
 // stored once.  Sample geometry per (pixel, tap) in LDS: (h0, w0) of the first corner, the fractions, the mask.
+// MFMA 32x32x16 bf16 operand fragment (8 consecutive reduction indices k = k0 + 8 (lane / 32) .. +7 of column
+// lane % 32) out of a ROW-MAJOR [k][32 columns] bf16 LDS image with 64-byte rows, through the hardware transpose read
+// ds_read_b64_tr_b16 (checked lane by lane on the device: tools/tr_probe.hip): per 16-lane group a 4 x 16 block, lane
+// 4q + p supplies the address of row q, columns 4p .. 4p+3, lane i receives column i.  Operands that arrive k-major from
+// memory (weights [ko][c], pixels [px][c]) are stored with plain 8-byte writes instead of transposed 2-byte ones.  All
+// 64 lanes must be active.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 lds_tr_frag(const unsigned short *img, int k0, int lane)
+{
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    const unsigned short *a = img + (k0 + 8 * (g >> 1) + q) * 32 + 16 * (g & 1) + 4 * p;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)a);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(a + 4 * 32));
+    union { s16x4 h[2]; bf16x8 v; } u;
+    u.h[0] = lo; u.h[1] = hi;
+    return u.v;
+}
+
 // Sum over the 8 lanes of an aligned lane group, on the VALU (DPP row_half_mirror, then the two quad permutes): every
 // lane ends with the total.  __shfl_xor compiles to ds_bpermute — LDS traffic the epilogue below cannot afford.
 __device__ __forceinline__ float dpp_sum8(float v)
@@ -1180,7 +1198,7 @@ __global__ __launch_bounds__(512) void dcn_dgrad_win_kernel(const DcnWinBwdArgs 
     float *red = geo_f + BM * RS * 3;                                               // [BM][RS][3]: d mask, d off h, d off w
     float *xw = red + BM * RS * 3;                                                  // [npx][32]: the input window of this chunk
     unsigned short *As = reinterpret_cast<unsigned short *>(xw + (size_t)npx * CW); // [BM][LDKH]   (single image: operands
-    unsigned short *Bs = As + A_ELEMS;                                              // [RS][32][LDKH] are prefetched in registers)
+    unsigned short *Bs = As + A_ELEMS;                                              // bf16: [RS][32 ko][32 ch]; fp32: [RS][32 ch][LDF] (prefetched in registers)
     float *stage = reinterpret_cast<float *>(As);                                   // [BM][SST]: epilogue only, over the idle operand images
     float *Af = reinterpret_cast<float *>(As), *Bf = reinterpret_cast<float *>(Bs);  // F32: [BM][LDF], [RS][32][LDF]
 
@@ -1329,9 +1347,9 @@ __global__ __launch_bounds__(512) void dcn_dgrad_win_kernel(const DcnWinBwdArgs 
                 for (int i = 0; i < TG; ++i) {
                     const int tap = b_tg * TG + i;
                     if (tap < RS) {
-                        const u16x4 hb = f2bf4(rb[i]);   // B images are [tap][n = channel][k = ko]: transposed 2-byte stores
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) Bs[(tap * CW + a_col + c) * LDKH + b_row] = hb[c];
+                        // B images are [tap][k = ko][n = channel], as the weights lie in memory: the MFMA fragment
+                        // comes out of the transpose read
+                        *reinterpret_cast<u16x4 *>(Bs + (tap * 32 + b_row) * CW + a_col) = f2bf4(rb[i]);
                     }
                 }
             }
@@ -1371,7 +1389,7 @@ __global__ __launch_bounds__(512) void dcn_dgrad_win_kernel(const DcnWinBwdArgs 
                     for (int i = 0; i < TG; ++i) {
                         const int tap = wtg * TG + i;
                         if (tap < RS) {                   // wave-uniform
-                            const bf16x8 fb = *reinterpret_cast<const bf16x8 *>(Bs + (tap * CW + lr) * LDKH + kk * 16 + lh_ * 8);
+                            const bf16x8 fb = lds_tr_frag(Bs + tap * 32 * CW, kk * 16, lane);
                             acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[i], 0, 0, 0);
                         }
                     }
@@ -1580,14 +1598,14 @@ __global__ __launch_bounds__(512) void dcn_wgrad_win_kernel(const DcnWinWgradArg
             if constexpr (F32) {
                 const f32x4 v = {rdy[0][j], rdy[1][j], rdy[2][j], rdy[3][j]};
                 *reinterpret_cast<f32x4 *>(dyF + (4 * fq + j) * LDP + 4 * pg) = v;
-            } else {
-                u16x4 lo, hi;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { lo[i] = f2bf(rdy[i][j]); hi[i] = f2bf(rdy[4 + i][j]); }
-                unsigned short *d = dyT + (4 * fq + j) * LDP + 8 * pg;
-                *reinterpret_cast<u16x4 *>(d) = lo;
-                *reinterpret_cast<u16x4 *>(d + 4) = hi;
             }
+        }
+        if constexpr (!F32) {
+            // bf16: [filter slab of 32][pixel][32 filters], as dY lies in memory; the MFMA fragment (8 consecutive
+            // pixels of one filter) comes out of the transpose read
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                *reinterpret_cast<u16x4 *>(dyT + ((fq >> 3) * HP + 8 * pg + i) * 32 + 4 * (fq & 7)) = f2bf4(rdy[i]);
         }
     };
 
@@ -1678,9 +1696,7 @@ __global__ __launch_bounds__(512) void dcn_wgrad_win_kernel(const DcnWinWgradArg
 #pragma unroll
                     for (int c = 0; c < 4; ++c) colF[(tap * CW + a_col + c) * LDP + a_row] = v[c];
                 } else {
-                    const u16x4 hb = f2bf4(v);
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) colT[(tap * CW + a_col + c) * LDP + a_row] = hb[c];
+                    *reinterpret_cast<u16x4 *>(colT + (tap * HP + a_row) * CW + a_col) = f2bf4(v);   // [tap][pixel][channel]
                 }
             }
             __syncthreads();
@@ -1703,10 +1719,10 @@ __global__ __launch_bounds__(512) void dcn_wgrad_win_kernel(const DcnWinWgradArg
                         for (int e = 0; e < 4; ++e) acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[e], fb1[e], acc[tap], 0, 0, 0);
                     }
                 } else {
-                    const bf16x8 fa = *reinterpret_cast<const bf16x8 *>(dyT + (wave * 32 + lr) * LDP + kk * 16 + lh_ * 8);
+                    const bf16x8 fa = lds_tr_frag(dyT + wave * HP * 32, kk * 16, lane);
 #pragma unroll
                     for (int tap = 0; tap < RS; ++tap) {
-                        const bf16x8 fb = *reinterpret_cast<const bf16x8 *>(colT + (tap * CW + lr) * LDP + kk * 16 + lh_ * 8);
+                        const bf16x8 fb = lds_tr_frag(colT + tap * HP * CW, kk * 16, lane);
                         acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[tap], 0, 0, 0);
                     }
                 }
