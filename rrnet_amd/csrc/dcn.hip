@@ -3,13 +3,17 @@
 // Replaces ext/dcn of the reference: `dcn_v2_cuda_forward/backward` (src/cuda/dcn_v2_cuda.cu:42-172,
 // 206-335) and kernels K2-K5 (src/cuda/dcn_v2_im2col_cuda.cu:125-327), bound by ext/dcn/dcn_v2.py:16-52.
 //   out[n,o,p] = b_o + sum_{c,i,j} W[o,c,i,j] * m[n,g,ij,p] * bilinear(x[n,c], p*s - pad + ij*dil + d[n,g,ij,p])
-// Forward = ONE gather-GEMM: the reference's im2col kernel + column buffer (9x the input) + batched
-// cuBLAS GEMM become the A-operand load of an implicit GEMM on v_mfma_f32_32x32x2_f32 — per (pixel, tap)
-// four NHWC corner rows are fetched as float4s along C and blended with the bilinear x mask weights on
-// their way into LDS.  MFMA-bound like a 3x3 convolution (2*M*K*R*S*C FLOPs) with 4x its activation reads.
-// Backward (this round): columns / column gradients are materialised like the reference does
-// ([M, R*S*C] each), the two GEMMs run on the conv kernels (rr_conv_dgrad / rr_conv_wgrad as 1x1 layers),
-// and one wave per (pixel, tap) turns the column gradient into d input (float atomics), d offset, d mask.
+// All three GEMMs of the layer are gather-GEMMs on MFMA: the reference's im2col kernel + column buffer (9x the
+// input) + batched cuBLAS GEMM become the operand load of an implicit GEMM — per (pixel, tap) four NHWC corner rows are
+// read as float4s along C and blended with the bilinear x mask weights on their way into LDS.
+//   * window kernels (dcn_fprop_win_kernel, dcn_wgrad_win_kernel, dcn_dgrad_win_kernel; stride 1, C % 32 == 0): a
+//     workgroup owns an 8x16 block of output pixels and stages the input block it can reach in LDS once per 32-channel
+//     chunk; templates over the operand precision (bf16 on v_mfma_f32_32x32x16_bf16, fp32 on v_mfma_f32_32x32x2_f32);
+//     d input is pre-summed in a fixed-point LDS image before it goes out as global atomics;
+//   * L2-gather kernels (dcn_fprop_kernel, dcn_fprop_bf16_kernel, dcn_wgrad_kernel, dcn_dgrad_kernel): the same GEMMs
+//     with the corners fetched from global memory per K-step — every other layer shape, and RR_DCN_WINDOW=0;
+//   * column path (dcn_im2col_kernel / dcn_col2im_kernel): the reference's structure ([M, R*S*C] columns materialised,
+//     GEMMs on the conv kernels), kept as the A/B reference of the fused backward and for the layouts it does not take.
 // Layouts: x NHWC; offset NHWC [N,P,Q,2*dg*R*S] (per group: interleaved (dh,dw) per tap, as the
 // reference's channel order); mask NHWC [N,P,Q,dg*R*S]; weight OHWI.
 #include "common.h"
@@ -364,7 +368,7 @@ __global__ __launch_bounds__(256) void dcn_fprop_bf16_kernel(const DcnArgs a)
     }
 }
 
-// ---- bf16-operand forward with an LDS-staged input window (round 2) -------------------------------------------------
+// ---- forward with an LDS-staged input window (round 2; bf16 or fp32 operands) -------------------------------------------------
 // The gather was the bound of dcn_fprop_bf16_kernel: every (pixel, tap) fetched its four corner rows from global
 // memory, 19.4 GB per call through the fabric for a 0.54 GB input (each input row is wanted ~36 times, minutes apart in
 // L2 terms).  Here a workgroup owns a 2-D block of TH x TW = 8 x 16 output pixels, and for every 32-channel chunk the
@@ -1131,7 +1135,7 @@ __global__ void dcn_split_bwd_kernel(const float *doffset, const float *dmask, c
     }
 }
 
-// ---- fused backward, data side, with on-chip pre-summation of d input (bf16 matrix operands) -------------------------
+// ---- fused backward, data side, with on-chip pre-summation of d input (bf16 or fp32 operands) -------------------------
 // dcn_dgrad_kernel adds every (pixel, tap, corner, channel) contribution to d input with its own global float atomic:
 // 19.3 GB of atomic bytes at the config-4 layer, i.e. 14.8 ms at the chip's ≈1.3 TB/s atomic rate whatever the schedule.
 // Here a workgroup owns a 2-D block of 8 x 16 output pixels; for each 32-channel chunk it computes the nine taps' column
@@ -1522,7 +1526,7 @@ __global__ __launch_bounds__(512) void dcn_dgrad_win_kernel(const DcnWinBwdArgs 
     store_red(g_cur);
 }
 
-// ---- fused backward, weight side, bf16 matrix operands and the forward's LDS window ---------------------------------
+// ---- fused backward, weight side, on the forward's LDS window (bf16 or fp32 operands) ---------------------------------
 // dW[ko][tap][c] = sum_px dY[px][ko] * col[px][tap, c].  A workgroup owns ONE 32-channel chunk and 256 filters — the
 // whole [256 filters][9 taps x 32 channels] block of dW in its accumulators (8 waves x 9 tiles of 32x32) — and walks
 // over its share of the 8x16 pixel blocks: per block the input window of the chunk goes to LDS once (as in the
