@@ -18,6 +18,9 @@ CASES = [
     (2, 256, 20, 24, 256, 3, 1, 1, 1, 1),      # several pixel tiles x 2 channel tiles x 2 filter tiles (fused backward)
     (1, 128, 17, 15, 132, 3, 2, 1, 1, 1),      # ragged pixel / filter tiles, stride 2
     (1, 256, 9, 9, 64, 3, 1, 1, 1, 2),         # two deformable groups of 128 channels: fused backward, per-group geometry
+    (1, 32, 12, 20, 64, 3, 1, 2, 2, 1),        # window kernels with dilation 2 (wider window, smaller margin fits)
+    (1, 64, 11, 9, 64, 5, 1, 2, 1, 1),         # 5x5: forward on the window kernel, gradients on the L2-gather kernels
+    (2, 32, 17, 33, 36, 3, 1, 1, 1, 1),        # ragged 8x16 blocks, K = 36 (one partial 32-filter slab)
 ]
 
 
@@ -233,7 +236,15 @@ def test_dcn_forward_bf16_operands(cfg):
     # and it really is a different (lower precision) path than the fp32 kernel, not an alias of it
     out32 = dcn_v2_conv(*dev, b.cuda(), stride, pad, dil, dg, bf16=False)
     assert (out32.cpu() - ref).abs().max().item() < err or err == 0.0
-    # backward of the bf16 forward is the fp32 backward
+    # tight: the kernel IS the GEMM of the bf16-rounded columns (blended and masked in fp32, as rr_dcn_im2col writes them)
+    # with the bf16 weights, accumulated in fp32 — against a float64 matmul of those rounded operands
+    from rrnet_amd import ops
+    col = ops.dcn_im2col(dev[0], dev[1], dev[2], ks, ks, stride, (pad, pad), dil, dg)
+    colr = col.permute(0, 2, 3, 1).reshape(-1, ks * ks * c).bfloat16().double()
+    wr = dev[3].permute(0, 2, 3, 1).reshape(k, -1).double()                     # OHWI rows, already bf16 values
+    tight = (colr @ wr.t() + b.cuda().double()).reshape(n, p, q, k).permute(0, 3, 1, 2)
+    assert (out.double() - tight).abs().max().item() <= 3e-5 * scale, ((out.double() - tight).abs().max().item(), scale)
+    # the backward of a bf16 forward runs the bf16-operand gradient kernels where the window kernels take the layer
     xg = dev[0].clone().requires_grad_()
     dcn_v2_conv(xg, dev[1], dev[2], dev[3], b.cuda(), stride, pad, dil, dg, bf16=True).sum().backward()
     assert torch.isfinite(xg.grad).all()
