@@ -43,5 +43,8 @@ for i, (n, c, h, w, k, r, st) in enumerate(SHAPES):
     t1 = timeit(lambda: ops.conv_fprop(x, wt, None, st, (pad, pad), False, want_stats=os.environ.get("RR_BENCH_NOSTATS") != "1"))
     t2 = timeit(lambda: ops.conv_dgrad(dy, wt, (n, c, h, w), st, (pad, pad), out=dx))
     t3 = timeit(lambda: ops.conv_wgrad(x, dy, dw, st, (pad, pad)))
+    if st == 2:
+        t4 = timeit(lambda: ops.conv_dgrad(dy, wt, (n, c, h, w), st, (pad, pad), out=dx, accumulate=True))
+        print("   dgrad accumulating into dx: %.3f ms %.1f TF" % (t4, flops / t4 / 1e9), flush=True)
     print("N%d C%d %dx%d K%d r%d s%d | fprop %.3f ms %.1f TF | dgrad %.3f ms %.1f TF | wgrad %.3f ms %.1f TF" % (
         n, c, h, w, k, r, st, t1, flops / t1 / 1e9, t2, flops / t2 / 1e9, t3, flops / t3 / 1e9), flush=True)
