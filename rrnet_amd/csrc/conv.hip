@@ -1362,13 +1362,12 @@ extern "C" int rr_conv_dgrad(const float *dy, const float *w, float *dx, int n, 
         a.parity_order = ord[0] | (ord[1] << 2) | (ord[2] << 4) | (ord[3] << 6);
         // classes without any tap (1x1 stride 2: three of four) produce zeros: one memset instead of workgroups
         // that run an empty K loop and store zeros element by element
-        if (!accumulate) {
-            int live = 4;
-            while (live > 1 && taps[ord[live - 1]] == 0) --live;
-            if (live < 4) {
-                hipMemsetAsync(dx, 0, sizeof(float) * (size_t)M * c, stream);
-                gy = live;
-            }
+        // (when accumulating they add nothing: no workgroups at all)
+        int live = 4;
+        while (live > 1 && taps[ord[live - 1]] == 0) --live;
+        if (live < 4) {
+            if (!accumulate) hipMemsetAsync(dx, 0, sizeof(float) * (size_t)M * c, stream);
+            gy = live;
         }
         blocks = rr_cdiv((long)n * ((h + 1) / 2) * ((wd + 1) / 2), BM) * rr_cdiv(c, bn);
         nk = rr_cdiv(k, bk) * ((r + 1) / 2) * ((s + 1) / 2);
