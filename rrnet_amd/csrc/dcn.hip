@@ -1223,7 +1223,7 @@ __global__ __launch_bounds__(512) void dcn_dgrad_win_kernel(const DcnWinBwdArgs 
     const int fa_row = t >> 2, fa_col = (t & 3) * 4, fb_row = (t >> 3) & 15, fb_tg = t >> 7;
     const long img = (long)n * a.H * a.W;
 
-    __shared__ float wmax[8];
+    __shared__ int wmax[8];          // bits of max |dcol| per wave
     __shared__ int mkmax_bits;       // bits of max |mask| seen by this block (over all groups: a bound is all that is needed)
     auto build_geo = [&](int g) {
         for (int it = t; it < BM * RS; it += NT) {
@@ -1405,22 +1405,27 @@ __global__ __launch_bounds__(512) void dcn_dgrad_win_kernel(const DcnWinBwdArgs 
         //      (3 cycles per lane, serialised across the waves of a CU; measured), ds_add_u32 ~7.  Scale = the power of
         //      two that keeps 36 contributions of the chunk's largest |dcol| x |mask| below 2^30: absolute rounding
         //      <= 2^-31 of that bound per add, exact scaling back at the flush.
-        float amax = 0.f;
+        // max |dcol| on the BIT patterns (non-negative floats order as integers, and NaN > inf > finite: fmaxf would
+        // drop a NaN silently)
+        int amax = 0;
 #pragma unroll
         for (int i = 0; i < TG; ++i)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) amax = fmaxf(amax, fabsf(acc[i][e]));
+            for (int e = 0; e < 16; ++e) amax = max(amax, (int)(__float_as_uint(acc[i][e]) & 0x7fffffffu));
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+        for (int o = 32; o > 0; o >>= 1) amax = max(amax, __shfl_xor(amax, o, 64));
         if (lane == 0) wmax[wave] = amax;
         __syncthreads();
-        float bmax = wmax[0];
+        int bbits = wmax[0];
 #pragma unroll
-        for (int i = 1; i < 8; ++i) bmax = fmaxf(bmax, wmax[i]);
-        const float bound = 36.f * bmax * fmaxf(__int_as_float(mkmax_bits), 1e-30f);
+        for (int i = 1; i < 8; ++i) bbits = max(bbits, wmax[i]);
+        const float bound = 36.f * __int_as_float(bbits) * fmaxf(__int_as_float(mkmax_bits), 1e-30f);
+        const bool nonfinite = bbits > 0x7f7fffff || mkmax_bits > 0x7f7fffff || !(bound <= 3.0e38f);   // incl. an overflowing bound
         int ex = 0;
         frexpf(bound, &ex);
-        const float fx_scale = bound > 0.f ? ldexpf(1.f, 30 - ex) : 0.f, fx_inv = ldexpf(1.f, ex - 30);
+        // a non-finite column gradient or mask (diverged training) must stay visible: fixed point cannot carry it, so the
+        // block's whole window receives NaN at the flush
+        const float fx_scale = (bound > 0.f && !nonfinite) ? ldexpf(1.f, 30 - ex) : 0.f, fx_inv = ldexpf(1.f, ex - 30);
         // ---- epilogue per tap: accumulators -> LDS -> (pixel row, 4 channels) threads
         for (int tap = 0; tap < RS; ++tap) {            // a real loop: only the accumulator -> LDS copy is per-tap code
             if (tap / TG == wtg) {                      // the four waves that hold this tap's tiles
@@ -1513,11 +1518,13 @@ __global__ __launch_bounds__(512) void dcn_dgrad_win_kernel(const DcnWinBwdArgs 
             const int c = t & 31;
             for (int px = t >> 5; px < npx; px += NT / 32) {
                 const int iv = dxw[px * WSTR + c];
-                if (iv != 0) {
-                    const int ly = px / wa.WW, lx = px - ly * wa.WW;
-                    const int gy = wy0 + ly, gx = wx0 + lx;      // inside the image by construction (only valid corners add)
+                const int ly = px / wa.WW, lx = px - ly * wa.WW;
+                const int gy = wy0 + ly, gx = wx0 + lx;
+                if (iv != 0) {                                   // inside the image by construction (only valid corners add)
                     unsafeAtomicAdd(wb.dx + (img + (long)gy * a.W + gx) * a.C + c0 + c, (float)iv * fx_inv);
                     dxw[px * WSTR + c] = 0;
+                } else if (nonfinite && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+                    unsafeAtomicAdd(wb.dx + (img + (long)gy * a.W + gx) * a.C + c0 + c, __int_as_float(0x7fc00000));
                 }
             }
         }

@@ -178,6 +178,28 @@ def test_dcn_bf16_dgrad_fixed_point_window_keeps_local_precision():
         assert (a[1] - b[1]).abs().max().item() <= 5e-5 * scale, (name, (a[1] - b[1]).abs().max().item(), scale)
 
 
+@pytest.mark.parametrize("bf16", [False, True])
+def test_dcn_dgrad_nonfinite_gradients_stay_visible(bf16):
+    """A NaN / inf in dY (diverged training) must not be laundered into finite numbers by the fixed-point window: the
+    input gradient around the affected block comes out NaN, d offset / d mask carry it too, and blocks that do not
+    see the bad value stay finite."""
+    from rrnet_amd import ops
+    n, c, h, w, k = 1, 64, 40, 48, 64
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(n, c, h, w, generator=g)
+    off = torch.randn(n, 18, h, w, generator=g) * 0.5
+    mask = torch.sigmoid(torch.randn(n, 9, h, w, generator=g))
+    wt = torch.randn(k, c, 3, 3, generator=g) / 24.0
+    for bad in (float("nan"), float("inf")):
+        dy = torch.randn(n, k, h, w, generator=g)
+        dy[0, 5, 3, 4] = bad
+        dev = [ops.to_nhwc(t.cuda()) for t in (x, off, mask, wt, dy)]
+        dx, doff, dmask = ops.dcn_dgrad(*dev, 1, (1, 1), 1, 1, bf16=bf16)
+        assert not torch.isfinite(dx[0, :, 3, 4]).all()
+        assert not torch.isfinite(dmask[0, :, 3, 4]).all()
+        assert torch.isfinite(dx[0, :, 24:, 32:]).all() and torch.isfinite(dmask[0, :, 24:, 32:]).all()
+
+
 def test_reference_zero_offset_identity_on_hip():
     from rrnet_amd.ext.dcn.dcn_v2 import DCNv2
     N, C, H, W = 2, 8, 6, 6
