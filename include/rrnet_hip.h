@@ -316,8 +316,11 @@ int rr_dcn_col2im(const float *x, const float *offset, const float *mask, const 
  * accumulators and writes dx (zeroed inside; window kernels: contributions pre-summed per pixel block in an LDS image
  * in fixed point, one power-of-two scale per block and 32-channel chunk, then one global float atomic per window element;
  * otherwise float atomics on the bilinear corners), doffset and dmask (plain stores).
- * Replace ext/dcn/src/cuda/dcn_v2_cuda.cu:206-335 + dcn_v2_im2col_cuda.cu:197-327.  Require k % 4 == 0 and
- * (dg == 1 or (c/dg) % 128 == 0); the host layer takes the column path above otherwise. */
+ * Replace ext/dcn/src/cuda/dcn_v2_cuda.cu:206-335 + dcn_v2_im2col_cuda.cu:197-327.  Layers they do not take
+ * (rr_dcn_fused_bwd_supported == 0) go through the column path above. */
+/* 1 when rr_dcn_wgrad / rr_dcn_dgrad (and their _bf16 forms) take a layer of this shape, 0 when the host layer has to
+ * run the column path (rr_dcn_im2col / rr_dcn_col2im + the conv GEMMs). */
+int rr_dcn_fused_bwd_supported(int c, int k, int r, int s, int stride, int deformable_groups);
 int rr_dcn_wgrad(const float *x, const float *offset, const float *mask, const float *dy, float *dw, int n, int h,
                  int wd, int c, int k, int r, int s, int stride, int pad_h, int pad_w, int dilation,
                  int deformable_groups, hipStream_t stream);

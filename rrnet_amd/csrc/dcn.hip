@@ -1985,6 +1985,17 @@ static int dcn_wgrad_plain(const float *x, const float *offset, const float *mas
                            int wd, int c, int k, int r, int s, int stride, int pad_h, int pad_w, int dilation,
                            int deformable_groups, hipStream_t stream);
 
+// 1 when rr_dcn_wgrad / rr_dcn_dgrad take this layer (the host layer runs the column path otherwise): K % 4 == 0 and
+// the deformable groups either span whole 128-channel tiles (L2-gather kernels) or the window kernels apply (3x3,
+// stride 1, C % 32 == 0, groups of a multiple of 32 channels).
+extern "C" int rr_dcn_fused_bwd_supported(int c, int k, int r, int s, int stride, int deformable_groups)
+{
+    if (c <= 0 || k <= 0 || deformable_groups <= 0 || c % deformable_groups != 0 || k % 4 != 0 || c % 4 != 0) return 0;
+    const int cpg = c / deformable_groups;
+    if (deformable_groups == 1 || cpg % 128 == 0) return 1;
+    return dcn_win_margin() > 0 && stride == 1 && r * s == 9 && c % 32 == 0 && cpg % 32 == 0;
+}
+
 extern "C" int rr_dcn_wgrad_bf16(const float *x, const float *offset, const float *mask, const float *dy, float *dw, int n, int h,
                                  int wd, int c, int k, int r, int s, int stride, int pad_h, int pad_w, int dilation,
                                  int deformable_groups, hipStream_t stream)
@@ -2012,8 +2023,6 @@ static int dcn_dgrad_impl(const float *x, const float *offset, const float *mask
     const int rc = fill_args(b.a, x, offset, mask, w, n, h, wd, c, k, r, s, stride, pad_h, pad_w, dilation, deformable_groups);
     if (rc != RR_OK) return rc;
     RR_CHECK_ARG(k % 4 == 0, "rr_dcn_dgrad: K=%d must be a multiple of 4", k);
-    RR_CHECK_ARG(deformable_groups == 1 || (c / deformable_groups) % 128 == 0,
-                 "rr_dcn_dgrad: channels per deformable group (%d) must be a multiple of 128", c / deformable_groups);
     RR_CHECK_ARG((long)n * h * wd < (1l << 31), "rr_dcn_dgrad: input too large");
     b.dy = dy; b.dx = dx; b.doffset = doffset; b.dmask = dmask;
     hipMemsetAsync(dx, 0, sizeof(float) * (size_t)n * h * wd * c, stream);
@@ -2050,6 +2059,8 @@ static int dcn_dgrad_impl(const float *x, const float *offset, const float *mask
             return RR_OK;
         }
     }
+    RR_CHECK_ARG(deformable_groups == 1 || (c / deformable_groups) % 128 == 0,
+                 "rr_dcn_dgrad: channels per deformable group (%d) must be a multiple of 128 on the L2-gather kernel", c / deformable_groups);
     const size_t lds = sizeof(float) * (2 * (BM * LDK + BK * 128) + BM * 8 + BM * 4 + BM * 3);
     hipFuncSetAttribute(reinterpret_cast<const void *>(dcn_dgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(dcn_dgrad_kernel, dim3(rr_cdiv(b.a.M, BM)), dim3(256), lds, stream, b);

@@ -505,7 +505,7 @@ class _DCNv2(torch.autograd.Function):
         k, c, r, s = w.shape
         w_t = _grad_target(weight)
         dw = w_t if w_t is not None else ops.zeros_nhwc(*weight.shape, device=x.device)
-        if DCN_FUSED_BWD and k % 4 == 0 and (dg == 1 or (c // dg) % 128 == 0):
+        if DCN_FUSED_BWD and ops.dcn_fused_bwd_supported(c, k, r, s, stride, dg):
             # fused: the columns live in registers / LDS inside the two GEMM kernels (csrc/dcn.hip).  The two kernels
             # are independent and bound by different things (wgrad: corner gather + MFMA; dgrad: the float atomics of
             # d input at the memory side), so they run concurrently on two HIP streams.

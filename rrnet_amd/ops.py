@@ -682,6 +682,11 @@ def dcn_col2im(x, offset, mask, dcol, r, s, stride, pad, dilation, dg):
     return dx, doff, dmask
 
 
+def dcn_fused_bwd_supported(c, k, r, s, stride, dg):
+    """Whether rr_dcn_wgrad / rr_dcn_dgrad take a layer of this shape (else: the column path)."""
+    return bool(_C.fn("rr_dcn_fused_bwd_supported")(c, k, r, s, stride, dg))
+
+
 def dcn_wgrad(x, offset, mask, dy, dw, stride, pad, dilation, dg, bf16=False):
     """dw [K,C,R,S] (OHWI memory, pre-zeroed or the running gradient) += dY^T x deformed columns; no column buffer.
     bf16: bf16 matrix operands (dY, samples), input window in LDS (rr_dcn_wgrad_bf16)."""

@@ -21,6 +21,8 @@ CASES = [
     (1, 32, 12, 20, 64, 3, 1, 2, 2, 1),        # window kernels with dilation 2 (wider window, smaller margin fits)
     (1, 64, 11, 9, 64, 5, 1, 2, 1, 1),         # 5x5: forward on the window kernel, gradients on the L2-gather kernels
     (2, 32, 17, 33, 36, 3, 1, 1, 1, 1),        # ragged 8x16 blocks, K = 36 (one partial 32-filter slab)
+    (1, 64, 10, 18, 48, 3, 1, 1, 1, 2),        # two deformable groups of 32 channels: window kernels only (fused backward)
+    (1, 128, 9, 17, 32, 3, 1, 1, 1, 4),        # four groups of 32 channels
 ]
 
 
