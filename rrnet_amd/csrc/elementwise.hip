@@ -602,14 +602,17 @@ extern "C" int rr_bn_apply(const float *y, const float *scale, const float *shif
 
 extern "C" int rr_bn_bwd_reduce(const float *dz, const float *z, const float *y, const float *mean,
                                 const float *invstd, const float *mask_scale, const float *mask_shift, double *sums,
-                                long npix, int c, hipStream_t stream)
+                                long npix, int c, int sums_zeroed, hipStream_t stream)
 {
     RR_CHECK_ARG(c % 4 == 0 && c <= 1024, "rr_bn_bwd_reduce: C=%d must be a multiple of 4 and <= 1024", c);
-    hipMemsetAsync(sums, 0, sizeof(double) * 2 * c, stream);
+    if (!sums_zeroed) hipMemsetAsync(sums, 0, sizeof(double) * 2 * c, stream);
     const int c4 = c / 4;
     const int lanes = EW_THREADS / c4 > 0 ? EW_THREADS / c4 : 1;
     long blocks = (npix + lanes * 8 - 1) / (lanes * 8);
-    if (blocks > 2048) blocks = 2048;
+    // every workgroup ends with 2C double atomics on the same 2C addresses: beyond ~1000 workgroups that tail, not the
+    // HBM stream, sets the time of the mid-sized layers (measured: 128x128x256 69 -> 48 us, 64x64x384 56 -> 29 us)
+    const long cap = npix >= 400000 ? 1024 : (npix >= 16384 ? 512 : 256);
+    if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((int)blocks), dim3(EW_THREADS), 0, stream, dz, z, y, mean, invstd, mask_scale,
                        mask_shift, sums, npix, c);
@@ -658,7 +661,7 @@ extern "C" int rr_bias_relu_bwd(const float *dy, const float *z, float *dy_maske
     if (c % 4 == 0 && c / 4 <= EW_THREADS && EW_THREADS % (c / 4) == 0) {
         const int lanes4 = EW_THREADS / (c / 4);
         long blocks4 = (npix + lanes4 * 8 - 1) / (lanes4 * 8);
-        if (blocks4 > 2048) blocks4 = 2048;
+        if (blocks4 > 1024) blocks4 = 1024;      // every workgroup ends with C float atomics on the same C addresses
         hipLaunchKernelGGL(colsum4_kernel, dim3((int)blocks4), dim3(EW_THREADS), 0, stream, (const f32x4 *)dy, (const f32x4 *)z,
                            (f32x4 *)dy_masked, dbias, npix, c / 4);
         RR_CHECK_LAUNCH("rr_bias_relu_bwd");

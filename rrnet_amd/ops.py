@@ -272,12 +272,10 @@ def bn_apply(y, scale, shift, residual=None, relu=False, res_scale=None, res_shi
 
 def bn_bwd_reduce(dz, z, y, mean, invstd, extra=0, mask_scale=None, mask_shift=None):
     n, c, h, w = y.shape
-    sums = torch.empty(2 * c + extra, dtype=torch.float64, device=y.device)
-    if extra:
-        sums[2 * c:].zero_()
+    sums = _ZEROS.take(2 * c + extra, y.device)            # pre-zeroed pool slice: no memset launch per layer
     _C.check(_C.fn("rr_bn_bwd_reduce")(_C.ptr(dz), _C.ptr(z), _C.ptr(y), _C.ptr(mean), _C.ptr(invstd),
                                        _C.ptr(mask_scale), _C.ptr(mask_shift), _C.ptr(sums),
-                                       n * h * w, c, _C.stream()), "rr_bn_bwd_reduce")
+                                       n * h * w, c, 1, _C.stream()), "rr_bn_bwd_reduce")
     return sums
 
 
