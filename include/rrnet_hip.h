@@ -112,6 +112,12 @@ int rr_bn_reduce_slab(const double *slab, int mtiles, int c, double *sums, hipSt
 int rr_bn_finalize(const double *sums, double count, const double *count_dev, const float *gamma, const float *beta,
                    float *running_mean, float *running_var, float momentum, float eps, float *mean,
                    float *invstd, float *scale, float *shift, int c, long *num_batches_tracked, hipStream_t stream);
+/* rr_bn_reduce_slab + rr_bn_finalize in one launch, for the single-process case (no SyncBN exchange of the sums in
+ * between); fixed summation order (no atomics). */
+int rr_bn_stats_finalize(const double *slab, int mtiles, double count, const float *gamma, const float *beta,
+                         float *running_mean, float *running_var, float momentum, float eps, float *mean,
+                         float *invstd, float *scale, float *shift, int c, long *num_batches_tracked,
+                         hipStream_t stream);
 int rr_bn_eval_coeffs(const float *gamma, const float *beta, const float *running_mean,
                       const float *running_var, float eps, float *scale, float *shift, int c,
                       hipStream_t stream);

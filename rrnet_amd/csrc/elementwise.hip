@@ -72,6 +72,48 @@ __global__ void bn_finalize_kernel(const double *sums, double count_h, const dou
     }
 }
 
+// Single-process training (no SyncBN exchange between the two): slab -> sums -> finalize in ONE launch.  A workgroup of
+// 32 channels x 32 row lanes reduces both statistics of its channels over the mtiles rows in a fixed order (no atomics:
+// bit-reproducible, unlike bn_reduce_slab_kernel) and finalizes them.  163 launches per step less.
+__global__ __launch_bounds__(1024) void bn_stats_finalize_kernel(const double *slab, int mtiles, double count, const float *gamma,
+                                                                 const float *beta, float *running_mean, float *running_var,
+                                                                 float momentum, float eps, float *mean, float *invstd,
+                                                                 float *scale, float *shift, int C, long *num_batches_tracked)
+{
+    __shared__ double red[2][32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + tx;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C)
+        for (int m = ty; m < mtiles; m += 32) {
+            s1 += slab[(long)m * 2 * C + c];
+            s2 += slab[(long)m * 2 * C + C + c];
+        }
+    red[0][ty][tx] = s1;
+    red[1][ty][tx] = s2;
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x == 0 && num_batches_tracked) *num_batches_tracked += 1;
+    if (ty != 0 || c >= C) return;
+    double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) { t1 += red[0][k][tx]; t2 += red[1][k][tx]; }
+    const double m = t1 / count;
+    double var = t2 / count - m * m;
+    if (var < 0.0) var = 0.0;
+    const float istd = (float)(1.0 / sqrt(var + (double)eps));
+    mean[c] = (float)m;
+    invstd[c] = istd;
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    const float sc = g * istd;
+    scale[c] = sc;
+    shift[c] = b - (float)m * sc;
+    if (running_mean) {
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+}
+
 // eval mode: scale/shift from the running statistics
 __global__ void bn_eval_coeffs_kernel(const float *gamma, const float *beta, const float *running_mean,
                                       const float *running_var, float eps, float *scale, float *shift, int C)
@@ -575,6 +617,18 @@ extern "C" int rr_bn_finalize(const double *sums, double count, const double *co
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(rr_cdiv(c, 128)), dim3(128), 0, stream, sums, count, count_dev, gamma, beta,
                        running_mean, running_var, momentum, eps, mean, invstd, scale, shift, c, num_batches_tracked);
     RR_CHECK_LAUNCH("rr_bn_finalize");
+    return RR_OK;
+}
+
+extern "C" int rr_bn_stats_finalize(const double *slab, int mtiles, double count, const float *gamma, const float *beta,
+                                    float *running_mean, float *running_var, float momentum, float eps, float *mean,
+                                    float *invstd, float *scale, float *shift, int c, long *num_batches_tracked,
+                                    hipStream_t stream)
+{
+    RR_CHECK_ARG(c > 0 && count > 0 && mtiles > 0, "rr_bn_stats_finalize: bad dims");
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(rr_cdiv(c, 32)), dim3(1024), 0, stream, slab, mtiles, count, gamma, beta,
+                       running_mean, running_var, momentum, eps, mean, invstd, scale, shift, c, num_batches_tracked);
+    RR_CHECK_LAUNCH("rr_bn_stats_finalize");
     return RR_OK;
 }
 

@@ -30,6 +30,9 @@ def _mark(*params):
             flat.mark_ready(p)
 
 
+BN_FUSED_STATS = os.environ.get("RR_BN_FUSED_STATS", "1") != "0"    # single process: slab -> statistics -> coefficients in one launch
+
+
 def _is_sync(bn):
     return isinstance(bn, torch.nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized() \
         and dist.get_world_size() > 1
@@ -51,15 +54,20 @@ class _ConvBnAct(torch.autograd.Function):
         if bn.training:
             y, slab = ops.conv_fprop(x, wc, None, stride, pad, False, want_stats=True)
             count = float(y.numel() // k)
-            sums = ops.bn_reduce_slab(slab, k, extra=1 if sync else 0)
             cnt_dev = None
-            if sync:   # SyncBN exchange: one small all-reduce of [sum, sumsq, count] (C5 in SURVEY §2.2);
-                sums[2 * k] = count          # the global count stays on the device: no host sync per layer
-                dist.all_reduce(sums)
-                cnt_dev = sums[2 * k:].clone()   # own storage: `sums` is a slice of a shared zero pool (version counter)
             mom = bn.momentum if bn.momentum is not None else 0.1
-            mean, invstd, scale, shift = ops.bn_finalize(sums, count, gamma, beta, bn.running_mean, bn.running_var,
-                                                         mom, bn.eps, cnt_dev, bn.num_batches_tracked)
+            # (layers of more than 512 pixel tiles keep the two-kernel form: the fused kernel runs C/32 workgroups only)
+            if sync or not BN_FUSED_STATS or slab.numel() > 512 * 2 * k:   # SyncBN exchange: one small all-reduce of [sum, sumsq, count] (C5 in SURVEY §2.2);
+                sums = ops.bn_reduce_slab(slab, k, extra=1)
+                if sync:
+                    sums[2 * k] = count          # the global count stays on the device: no host sync per layer
+                    dist.all_reduce(sums)
+                    cnt_dev = sums[2 * k:].clone()   # own storage: `sums` is a slice of a shared zero pool (version counter)
+                mean, invstd, scale, shift = ops.bn_finalize(sums, count, gamma, beta, bn.running_mean, bn.running_var,
+                                                             mom, bn.eps, cnt_dev, bn.num_batches_tracked)
+            else:      # nothing to exchange: slab -> statistics -> coefficients in one launch
+                mean, invstd, scale, shift = ops.bn_stats_finalize(slab, count, gamma, beta, bn.running_mean,
+                                                                   bn.running_var, mom, bn.eps, bn.num_batches_tracked)
         else:
             scale, shift = ops.bn_eval_coeffs(gamma, beta, bn.running_mean, bn.running_var, bn.eps)
             mean = invstd = cnt_dev = None

@@ -253,6 +253,20 @@ def bn_finalize(sums, count, gamma, beta, running_mean, running_var, momentum, e
     return mean, invstd, scale, shift
 
 
+def bn_stats_finalize(slab, count, gamma, beta, running_mean, running_var, momentum, eps, num_batches_tracked=None):
+    """bn_reduce_slab + bn_finalize in one launch (single process: nothing to exchange in between)."""
+    c = gamma.numel()
+    buf = _f32(4 * c, gamma.device)
+    mean, invstd, scale, shift = buf[0:c], buf[c:2 * c], buf[2 * c:3 * c], buf[3 * c:4 * c]
+    mtiles = slab.numel() // (2 * c)
+    assert num_batches_tracked is None or num_batches_tracked.dtype == torch.int64
+    _C.check(_C.fn("rr_bn_stats_finalize")(_C.ptr(slab), mtiles, float(count), _C.ptr(gamma), _C.ptr(beta),
+                                           _C.ptr(running_mean), _C.ptr(running_var), float(momentum), float(eps),
+                                           _C.ptr(mean), _C.ptr(invstd), _C.ptr(scale), _C.ptr(shift), c,
+                                           _C.ptr(num_batches_tracked), _C.stream()), "rr_bn_stats_finalize")
+    return mean, invstd, scale, shift
+
+
 def bn_eval_coeffs(gamma, beta, running_mean, running_var, eps):
     c = gamma.numel()
     scale, shift = _f32(c, gamma.device), _f32(c, gamma.device)
