@@ -321,7 +321,7 @@ int rr_dcn_col2im(const float *x, const float *offset, const float *mask, const 
 /* Fused backward (no column buffers): rr_dcn_wgrad adds dY^T x (deformed columns produced in registers) into dw
  * (float atomics; dw pre-zeroed or holding the running gradient); rr_dcn_dgrad keeps the column gradient in the MFMA
  * accumulators and writes dx (zeroed inside; window kernels: contributions pre-summed per pixel block in an LDS image
- * in fixed point, one power-of-two scale per block and 32-channel chunk, then one global float atomic per window element;
+ * in fixed point, one power-of-two scale per block and channel, then one global float atomic per window element;
  * otherwise float atomics on the bilinear corners), doffset and dmask (plain stores).
  * Replace ext/dcn/src/cuda/dcn_v2_cuda.cu:206-335 + dcn_v2_im2col_cuda.cu:197-327.  Layers they do not take
  * (rr_dcn_fused_bwd_supported == 0) go through the column path above. */

@@ -1223,7 +1223,8 @@ __global__ __launch_bounds__(512) void dcn_dgrad_win_kernel(const DcnWinBwdArgs 
     const int fa_row = t >> 2, fa_col = (t & 3) * 4, fb_row = (t >> 3) & 15, fb_tg = t >> 7;
     const long img = (long)n * a.H * a.W;
 
-    __shared__ int wmax[8];          // bits of max |dcol| per wave
+    __shared__ int wmaxc[8][32];     // bits of max |dcol| per wave and channel
+    __shared__ __align__(16) float fxs[32], fxi[32];   // fixed-point scale of the chunk's channels and its inverse (NaN: non-finite)
     __shared__ int mkmax_bits;       // bits of max |mask| seen by this block (over all groups: a bound is all that is needed)
     auto build_geo = [&](int g) {
         for (int it = t; it < BM * RS; it += NT) {
@@ -1402,9 +1403,11 @@ __global__ __launch_bounds__(512) void dcn_dgrad_win_kernel(const DcnWinBwdArgs 
             __syncthreads();
         }
         // ---- the window accumulates in FIXED POINT: ds_add_f32 costs ~190 cycles per wave-instruction on this part
-        //      (3 cycles per lane, serialised across the waves of a CU; measured), ds_add_u32 ~7.  Scale = the power of
-        //      two that keeps 36 contributions of the chunk's largest |dcol| x |mask| below 2^30: absolute rounding
-        //      <= 2^-31 of that bound per add, exact scaling back at the flush.
+        //      (3 cycles per lane, serialised across the waves of a CU; measured), ds_add_u32 ~7.  Scale (per channel) =
+        //      the power of two that keeps 36 contributions of the block's largest |dcol| x |mask| of that channel below
+        //      2^30: absolute rounding <= 2^-31 of that bound per add, exact scaling back at the flush.
+        // One scale PER CHANNEL (a lane of the accumulator tiles is one channel): a channel with small gradients keeps its
+        // own 25 bits next to a loud one in the same chunk, as it would with float atomics.
         // max |dcol| on the BIT patterns (non-negative floats order as integers, and NaN > inf > finite: fmaxf would
         // drop a NaN silently)
         int amax = 0;
@@ -1412,20 +1415,25 @@ __global__ __launch_bounds__(512) void dcn_dgrad_win_kernel(const DcnWinBwdArgs 
         for (int i = 0; i < TG; ++i)
 #pragma unroll
             for (int e = 0; e < 16; ++e) amax = max(amax, (int)(__float_as_uint(acc[i][e]) & 0x7fffffffu));
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) amax = max(amax, __shfl_xor(amax, o, 64));
-        if (lane == 0) wmax[wave] = amax;
+        amax = max(amax, __shfl_xor(amax, 32, 64));          // the two lane halves hold the same channel
+        if (lh_ == 0) wmaxc[wave][lr] = amax;
         __syncthreads();
-        int bbits = wmax[0];
+        if (t < CW) {
+            int bbits = wmaxc[0][t];
 #pragma unroll
-        for (int i = 1; i < 8; ++i) bbits = max(bbits, wmax[i]);
-        const float bound = 36.f * __int_as_float(bbits) * fmaxf(__int_as_float(mkmax_bits), 1e-30f);
-        const bool nonfinite = bbits > 0x7f7fffff || mkmax_bits > 0x7f7fffff || !(bound <= 3.0e38f);   // incl. an overflowing bound
-        int ex = 0;
-        frexpf(bound, &ex);
-        // a non-finite column gradient or mask (diverged training) must stay visible: fixed point cannot carry it, so the
-        // block's whole window receives NaN at the flush
-        const float fx_scale = (bound > 0.f && !nonfinite) ? ldexpf(1.f, 30 - ex) : 0.f, fx_inv = ldexpf(1.f, ex - 30);
+            for (int i = 1; i < 8; ++i) bbits = max(bbits, wmaxc[i][t]);
+            const float bound = 36.f * __int_as_float(bbits) * fmaxf(__int_as_float(mkmax_bits), 1e-30f);
+            // a non-finite column gradient or mask (diverged training) must stay visible: fixed point cannot carry it,
+            // so the channel's whole window receives NaN at the flush (inverse scale = NaN marks it); incl. an
+            // overflowing bound
+            const bool nonfinite = bbits > 0x7f7fffff || mkmax_bits > 0x7f7fffff || !(bound <= 3.0e38f);
+            int ex = 0;
+            frexpf(bound, &ex);
+            fxs[t] = (bound > 0.f && !nonfinite) ? ldexpf(1.f, 30 - ex) : 0.f;
+            fxi[t] = nonfinite ? __int_as_float(0x7fc00000) : ldexpf(1.f, ex - 30);
+        }
+        __syncthreads();
+        const f32x4 fx4 = *reinterpret_cast<const f32x4 *>(fxs + a_col);      // this thread's four channels
         // ---- epilogue per tap: accumulators -> LDS -> (pixel row, 4 channels) threads
         for (int tap = 0; tap < RS; ++tap) {            // a real loop: only the accumulator -> LDS copy is per-tap code
             if (tap / TG == wtg) {                      // the four waves that hold this tap's tiles
@@ -1454,7 +1462,7 @@ __global__ __launch_bounds__(512) void dcn_dgrad_win_kernel(const DcnWinBwdArgs 
                     const float dhw[4] = {-hw, -flw, hw, flw};
                     const float dww[4] = {-hh, hh, -flh, flh};
                     const f32x4 gcol = *reinterpret_cast<const f32x4 *>(stage + r * SST + a_col);
-                    const float mks = mk * fx_scale;
+                    const f32x4 gs = gcol * fx4;                           // column gradient in each channel's fixed-point unit
                     // d mask = sum_e wt_e <gcol, x_e>, d offset = mask * sum_e dwt_e <gcol, x_e>: one dot product per corner
                     if (!(gi & GEO_SLOW)) {
                         const float *xb = xw + (size_t)(gi & 0xffff) * CW + a_col;
@@ -1466,10 +1474,10 @@ __global__ __launch_bounds__(512) void dcn_dgrad_win_kernel(const DcnWinBwdArgs 
                             const f32x4 xv = *reinterpret_cast<const f32x4 *>(xb + po * CW);
                             const float d = gcol[0] * xv[0] + gcol[1] * xv[1] + gcol[2] * xv[2] + gcol[3] * xv[3];
                             s_m += wt[e] * d; s_h += dhw[e] * d; s_w += dww[e] * d;
-                            const float f = mks * wt[e];
+                            const float f = mk * wt[e];
                             if (f != 0.f) {
 #pragma unroll
-                                for (int c = 0; c < 4; ++c) atomicAdd(db + po * WSTR + c, __float2int_rn(gcol[c] * f));   // ds_add_u32
+                                for (int c = 0; c < 4; ++c) atomicAdd(db + po * WSTR + c, __float2int_rn(gs[c] * f));   // ds_add_u32
                             }
                         }
                     } else {
@@ -1494,7 +1502,7 @@ __global__ __launch_bounds__(512) void dcn_dgrad_win_kernel(const DcnWinBwdArgs 
                                 if (inwin) {
                                     int *d4 = dxw + (ly * wa.WW + lx) * WSTR + a_col;
 #pragma unroll
-                                    for (int c = 0; c < 4; ++c) atomicAdd(d4 + c, __float2int_rn(gcol[c] * (mks * wt[e])));
+                                    for (int c = 0; c < 4; ++c) atomicAdd(d4 + c, __float2int_rn(gs[c] * (mk * wt[e])));
                                 } else {
                                     float *d4 = wb.dx + (img + (long)hy * a.W + wx) * a.C + c0 + a_col;
 #pragma unroll
@@ -1516,6 +1524,8 @@ __global__ __launch_bounds__(512) void dcn_dgrad_win_kernel(const DcnWinBwdArgs 
         // ---- flush this chunk's window: lane <-> channel, 128-byte row segments, one global atomic per touched element
         {
             const int c = t & 31;
+            const float fx_inv = fxi[c];
+            const bool nonfinite = fx_inv != fx_inv;
             for (int px = t >> 5; px < npx; px += NT / 32) {
                 const int iv = dxw[px * WSTR + c];
                 const int ly = px / wa.WW, lx = px - ly * wa.WW;

@@ -181,6 +181,40 @@ def test_dcn_bf16_dgrad_fixed_point_window_keeps_local_precision():
 
 
 @pytest.mark.parametrize("bf16", [False, True])
+def test_dcn_dgrad_fixed_point_scale_is_per_channel(bf16):
+    """One input channel with 1e7 x larger weights (hence column gradients) must not cost its neighbours in the same
+    32-channel chunk any precision: the window's fixed-point scale is per channel.  Reference = the column path
+    (float atomics, every channel with its own exponent), on bf16-rounded operands for the bf16 kernel."""
+    from rrnet_amd import functional as RF
+    from rrnet_amd import ops
+    n, c, h, w, k = 1, 64, 24, 32, 64
+    g = torch.Generator().manual_seed(123)
+    x = torch.randn(n, c, h, w, generator=g)
+    off = torch.randn(n, 18, h, w, generator=g)
+    mask = torch.sigmoid(torch.randn(n, 9, h, w, generator=g))
+    wt = torch.randn(k, c, 3, 3, generator=g) / 24.0
+    wt[:, 5] *= 1e7                                              # channel 5 is loud, channels 0..31 share its chunk
+    dy = torch.randn(n, k, h, w, generator=g)
+    if bf16:
+        wt, dy = wt.bfloat16().float(), dy.bfloat16().float()
+    dev = [ops.to_nhwc(t.cuda()) for t in (x, off, mask, wt, dy)]
+    dx = ops.dcn_dgrad(*dev, 1, (1, 1), 1, 1, bf16=bf16)[0]
+    saved = RF.DCN_FUSED_BWD
+    try:
+        RF.DCN_FUSED_BWD = False
+        xin = dev[0].clone().requires_grad_()
+        RF.dcn_v2_conv(xin, dev[1], dev[2], dev[3], None, 1, 1, 1, 1).backward(dev[4])
+    finally:
+        RF.DCN_FUSED_BWD = saved
+    ref = xin.grad
+    quiet = [i for i in range(32) if i != 5]
+    scale_q = ref[:, quiet].abs().max().item()
+    assert ref[:, 5].abs().max().item() > 1e5 * scale_q
+    assert (dx[:, quiet] - ref[:, quiet]).abs().max().item() <= 5e-5 * scale_q
+    assert (dx[:, 5] - ref[:, 5]).abs().max().item() <= 5e-5 * ref[:, 5].abs().max().item()
+
+
+@pytest.mark.parametrize("bf16", [False, True])
 def test_dcn_dgrad_nonfinite_gradients_stay_visible(bf16):
     """A NaN / inf in dY (diverged training) must not be laundered into finite numbers by the fixed-point window: the
     input gradient around the affected block comes out NaN, d offset / d mask carry it too, and blocks that do not
