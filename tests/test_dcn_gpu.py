@@ -140,8 +140,8 @@ def test_dcn_bf16_wgrad_equals_gemm_of_rounded_operands(shape):
 
 
 def test_dcn_bf16_dgrad_fixed_point_window_keeps_local_precision():
-    """The LDS window of rr_dcn_dgrad_bf16 accumulates in fixed point with ONE power-of-two scale per (8x16 pixel block,
-    32-channel chunk), derived from that block's largest |dcol| x |mask|: a block with huge output gradients must not
+    """The LDS window of rr_dcn_dgrad_bf16 accumulates in fixed point with one power-of-two scale per (8x16 pixel block,
+    channel), derived from that block's largest |dcol| x |mask| of the channel: a block with huge output gradients must not
     cost precision anywhere else.  dY is 1e6 x larger in the first block of frame 0 than in the rest of the batch;
     rows far from that block are compared at THEIR scale; masks > 1 (allowed by dcn_v2_conv) enter the bound too."""
     from rrnet_amd import ops
