@@ -1226,7 +1226,15 @@ __global__ __launch_bounds__(512) void dcn_dgrad_win_kernel(const DcnWinBwdArgs 
     __shared__ int wmaxc[8][32];     // bits of max |dcol| per wave and channel
     __shared__ __align__(16) float fxs[32], fxi[32];   // fixed-point scale of the chunk's channels and its inverse (NaN: non-finite)
     __shared__ int mkmax_bits;       // bits of max |mask| seen by this block (over all groups: a bound is all that is needed)
+    __shared__ int maxhits;          // most corner contributions any window pixel can receive from this block's samples
+    // build_geo(g): sample geometry of deformable group g.  Also COUNTS, per window pixel, the corners that land on it
+    // (in the window's unused pad word, column 32 of the 33-word pixel rows): the fixed-point scale below must hold
+    // however many samples the offsets pile onto one input pixel (up to 128 x 9 x 4 in principle, ~36 for small offsets).
+    // Called by all threads, between barriers of the caller; contains two barriers of its own.
     auto build_geo = [&](int g) {
+        for (int px = t; px < npx; px += NT) dxw[px * WSTR + CW] = 0;
+        if (t == 0) maxhits = 1;
+        __syncthreads();
         for (int it = t; it < BM * RS; it += NT) {
             const int r = it / RS, tap = it - r * RS;
             const int p = y0 + r / WIN_TW, q = x0 + r % WIN_TW;
@@ -1254,12 +1262,22 @@ __global__ __launch_bounds__(512) void dcn_dgrad_win_kernel(const DcnWinBwdArgs 
                     packed = (valid << 16) | (fast ? (ly * wa.WW + lx) : GEO_SLOW);
                     flh = h - hf; flw = w - wf;
                     mk = a.mask[m * (a.dg * RS) + g * RS + tap];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int cy = ly + (e >> 1), cx = lx + (e & 1);
+                        if (((valid >> e) & 1) && cy >= 0 && cy < wa.WH && cx >= 0 && cx < wa.WW)
+                            atomicAdd(dxw + (cy * wa.WW + cx) * WSTR + CW, 1);
+                    }
                 }
             }
             geo_i[it] = packed;
             geo_f[it * 3] = flh; geo_f[it * 3 + 1] = flw; geo_f[it * 3 + 2] = mk;
             atomicMax(&mkmax_bits, (int)(__float_as_uint(mk) & 0x7fffffffu));      // |mask| bound of the block (non-negative floats order as ints)
         }
+        __syncthreads();
+        int hits = 0;
+        for (int px = t; px < npx; px += NT) hits = max(hits, dxw[px * WSTR + CW]);
+        if (hits > 1) atomicMax(&maxhits, hits);
     };
     auto store_red = [&](int g) {
         for (int it = t; it < BM * RS; it += NT) {
@@ -1404,8 +1422,8 @@ __global__ __launch_bounds__(512) void dcn_dgrad_win_kernel(const DcnWinBwdArgs 
         }
         // ---- the window accumulates in FIXED POINT: ds_add_f32 costs ~190 cycles per wave-instruction on this part
         //      (3 cycles per lane, serialised across the waves of a CU; measured), ds_add_u32 ~7.  Scale (per channel) =
-        //      the power of two that keeps 36 contributions of the block's largest |dcol| x |mask| of that channel below
-        //      2^30: absolute rounding <= 2^-31 of that bound per add, exact scaling back at the flush.
+        //      the power of two that keeps `maxhits` contributions (the most any window pixel receives, counted in
+        //      build_geo) of the block's largest |dcol| x |mask| of that channel below 2^30: absolute rounding <= 2^-31 of that bound per add, exact scaling back at the flush.
         // One scale PER CHANNEL (a lane of the accumulator tiles is one channel): a channel with small gradients keeps its
         // own 25 bits next to a loud one in the same chunk, as it would with float atomics.
         // max |dcol| on the BIT patterns (non-negative floats order as integers, and NaN > inf > finite: fmaxf would
@@ -1422,7 +1440,7 @@ __global__ __launch_bounds__(512) void dcn_dgrad_win_kernel(const DcnWinBwdArgs 
             int bbits = wmaxc[0][t];
 #pragma unroll
             for (int i = 1; i < 8; ++i) bbits = max(bbits, wmaxc[i][t]);
-            const float bound = 36.f * __int_as_float(bbits) * fmaxf(__int_as_float(mkmax_bits), 1e-30f);
+            const float bound = (float)maxhits * __int_as_float(bbits) * fmaxf(__int_as_float(mkmax_bits), 1e-30f);
             // a non-finite column gradient or mask (diverged training) must stay visible: fixed point cannot carry it,
             // so the channel's whole window receives NaN at the flush (inverse scale = NaN marks it); incl. an
             // overflowing bound

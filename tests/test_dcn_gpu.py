@@ -215,6 +215,44 @@ def test_dcn_dgrad_fixed_point_scale_is_per_channel(bf16):
 
 
 @pytest.mark.parametrize("bf16", [False, True])
+def test_dcn_dgrad_all_samples_on_one_pixel(bf16):
+    """Offsets that send EVERY sample of the image to the same fractional position pile 128 x 9 contributions per block
+    onto four input pixels, all with the same sign (dY > 0, W > 0): the fixed-point window must size its scale by the
+    number of hits it counted, not by the ~36 of well-behaved offsets (an int32 would wrap around otherwise)."""
+    from rrnet_amd import functional as RF
+    from rrnet_amd import ops
+    n, c, h, w, k = 1, 32, 16, 32, 32
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(n, c, h, w, generator=g)
+    ty, tx = 7.3, 9.6
+    off = torch.zeros(n, 18, h, w)
+    for tap in range(9):
+        ti, tj = tap // 3, tap % 3
+        pp = torch.arange(h).view(h, 1).float() - 1 + ti
+        qq = torch.arange(w).view(1, w).float() - 1 + tj
+        off[0, 2 * tap] = ty - pp
+        off[0, 2 * tap + 1] = tx - qq
+    mask = torch.rand(n, 9, h, w, generator=g) * 0.5 + 0.5
+    wt = torch.rand(k, c, 3, 3, generator=g) + 0.5
+    dy = torch.rand(n, k, h, w, generator=g) + 0.5
+    if bf16:
+        wt, dy = wt.bfloat16().float(), dy.bfloat16().float()
+    dev = [ops.to_nhwc(t.cuda()) for t in (x, off, mask, wt, dy)]
+    dx, doff, dmask = ops.dcn_dgrad(*dev, 1, (1, 1), 1, 1, bf16=bf16)
+    saved = RF.DCN_FUSED_BWD
+    try:
+        RF.DCN_FUSED_BWD = False
+        ins = [t.clone().requires_grad_() for t in dev[:3]]
+        RF.dcn_v2_conv(*ins, dev[3], None, 1, 1, 1, 1).backward(dev[4])
+    finally:
+        RF.DCN_FUSED_BWD = saved
+    for name, a, b in zip(("dx", "doffset", "dmask"), (dx, doff, dmask), [t.grad for t in ins]):
+        scale = b.abs().max().item()
+        assert (a - b).abs().max().item() <= 1e-4 * scale, (name, (a - b).abs().max().item(), scale)
+    assert dx[0, :, 7, 9].min().item() > 0 and (dx[0, :, :5] == 0).all()      # everything landed on rows 7..8, cols 9..10
+
+
+@pytest.mark.parametrize("bf16", [False, True])
 def test_dcn_dgrad_nonfinite_gradients_stay_visible(bf16):
     """A NaN / inf in dY (diverged training) must not be laundered into finite numbers by the fixed-point window: the
     input gradient around the affected block comes out NaN, d offset / d mask carry it too, and blocks that do not
