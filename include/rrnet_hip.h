@@ -151,7 +151,8 @@ int rr_bn_res_relu_avgpool(const float *y, const float *scale, const float *shif
                            long r, int hw, int c, hipStream_t stream);
 /* The same tail with the 1x1 convolution in front of it fused in (inference): out [r, n] = mean over the hw rows of a
  * RoI of relu((h [r*hw, k] x w [n, k]^T) * scale + shift + res [r*hw, n]); the convolution's output never reaches
- * HBM.  k = 32 or 64, n <= 256 (backbones/resnet.py:46-53 with planes = 64, fasterrcnn_detector.py:15). */
+ * HBM.  k = 32 or 64, n a multiple of 4 and <= 256 (backbones/resnet.py:46-53 with planes = 64,
+ * fasterrcnn_detector.py:15). */
 int rr_conv1x1_bn_res_relu_avgpool(const float *h, const float *w, const float *scale, const float *shift,
                                    const float *res, float *out, long r, int hw, int k, int n, hipStream_t stream);
 /* WH head, detectors/centernet_detector.py:26-77 (HCov k x 1 and WCov 1 x k to one channel each,

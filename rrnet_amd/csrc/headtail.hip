@@ -121,7 +121,8 @@ extern "C" int rr_conv1x1_bn_res_relu_avgpool(const float *h, const float *w, co
                                               hipStream_t stream)
 {
     RR_CHECK_ARG(r >= 0 && hw > 0 && k > 0 && n > 0, "rr_conv1x1_bn_res_relu_avgpool: bad dims");
-    RR_CHECK_ARG((k == 32 || k == 64) && n <= HT_NMAX, "rr_conv1x1_bn_res_relu_avgpool: K=%d (32 or 64), N=%d (<= %d)", k, n, HT_NMAX);
+    RR_CHECK_ARG((k == 32 || k == 64) && n <= HT_NMAX && n % 4 == 0,
+                 "rr_conv1x1_bn_res_relu_avgpool: K=%d (32 or 64), N=%d (multiple of 4, <= %d)", k, n, HT_NMAX);
     if (r == 0) return RR_OK;
     const unsigned blocks = (unsigned)((r + HT_ROIS - 1) / HT_ROIS);
     if (k == 64) hipLaunchKernelGGL(head_tail_kernel<8>, dim3(blocks), dim3(256), 0, stream, h, w, scale, shift, res, out, r, n, hw);

@@ -27,7 +27,7 @@ class FasterRCNNDetector(nn.Module):
             out = RF.conv_bn_act(out, b.conv2, b.bn2, relu=True)
             scale, shift = ops.bn_eval_coeffs(b.bn3.weight, b.bn3.bias, b.bn3.running_mean, b.bn3.running_var, b.bn3.eps)
             k3 = b.conv3.in_channels
-            if FUSED_TAIL and k3 in (32, 64) and b.conv3.out_channels <= 256:
+            if FUSED_TAIL and k3 in (32, 64) and b.conv3.out_channels <= 256 and b.conv3.out_channels % 4 == 0:
                 # conv3 + bn3 + residual + ReLU + average pool: conv3's [R*9, 256] output never reaches HBM
                 feat = ops.conv1x1_bn_res_relu_avgpool(out, ops.to_nhwc(b.conv3.weight), scale, shift, x)
             else:
