@@ -50,7 +50,8 @@ def _cpu_step(seed, size, k):
     """One oracle train step (forward, criterion, backward, Adam update) on ONE size x size frame -> seconds."""
     from types import SimpleNamespace
     from oracle import model as om, ops as oo
-    from rrnet_amd.datasets.synthetic import synth_batch
+    from oracle.targets import host_batch
+    from rrnet_amd.datasets.synthetic import synth_frames
     from rrnet_amd.models.rrnet import RRNet
     cfg = SimpleNamespace(num_classes=10, Model=SimpleNamespace(num_stacks=2, backbone="hourglass",
                           nms_type_for_stage1="nms", nms_per_class_for_stage1=True))
@@ -63,7 +64,7 @@ def _cpu_step(seed, size, k):
         params.append(sd[kk])
     del net
     opt = torch.optim.Adam(params, lr=2.5e-4)
-    imgs, annos, hms, whs, inds, offs, masks, _ = synth_batch(1, size, size, boxes_per_image=100, seed=seed)
+    imgs, annos, hms, whs, inds, offs, masks, _ = host_batch(*synth_frames(1, size, size, boxes_per_image=100, seed=seed))
     P = om.Params(sd, training=True)
     times = []
     for it in range(3):                                # one warm-up (allocator, oneDNN primitive cache) + two timed

@@ -1,7 +1,7 @@
 // CenterNet training targets on the device for gfx950.
 //
 // Replaces datasets/transforms/functional.py:177-262 of the reference (gaussian_radius, gaussian2d,
-// draw_umich_gaussian, to_heatmap: a Python loop over the boxes of every image on the host) and the padding of
+// draw_umich_gaussian and the heat-map transform :230-262: a Python loop over the boxes of every image on the host) and the padding of
 // datasets/drones_det.py:70-94 (collate_fn_ctnet) for a whole batch in one launch: one 64-lane workgroup per
 // (image, box) computes the box's regression targets and splats its Gaussian into the class plane with an integer
 // atomicMax on the float bit patterns (all values are >= 0, so the orders agree; max is order-independent, the

@@ -2,13 +2,13 @@
 
 Recipe of SURVEY §8(d): seed 219 + rank; uint8-uniform frames normalised with the ImageNet
 mean/std of configs/rrnet_config.py:36-37; `boxes_per_image` annotations with log-uniform sizes in
-[5,166] px and classes 1..10; targets through to_heatmap + the collate_fn_ctnet contract
-(datasets/drones_det.py:70-94): imgs [B,3,H,W], annos [B,M,8], hm [B,10,H/4,W/4], wh/offset
-[B,M,2], ind/reg_mask [B,M,1]."""
+[5,166] px and classes 1..10.  The training targets of the collate_fn_ctnet contract
+(datasets/drones_det.py:70-94: imgs [B,3,H,W], annos [B,M,8], hm [B,10,H/4,W/4], wh/offset
+[B,M,2], ind/reg_mask [B,M,1]) are built ON THE DEVICE by rr_ctnet_targets (csrc/targets.hip) — one launch
+per batch instead of the reference's host loop over boxes (datasets/transforms/functional.py:230-262).
+The host restatement of that loop lives in oracle/targets.py (checker only)."""
 import numpy as np
 import torch
-
-from .transforms.functional import to_heatmap
 
 MEAN = (0.485, 0.456, 0.406)
 STD = (0.229, 0.224, 0.225)
@@ -22,20 +22,6 @@ def synth_annotations(rng, n, height, width, min_wh=5.0, max_wh=166.0):
     y = rng.uniform(0, height - h)
     cls = rng.integers(1, 11, n)
     return np.stack([x, y, w, h, np.ones(n), cls, np.zeros(n), np.zeros(n)], 1).astype(np.float32)
-
-
-def collate_ctnet(samples):
-    """datasets/drones_det.py:70-94."""
-    bs = len(samples)
-    m = max(s[1].size(0) for s in samples)
-    annos = torch.zeros(bs, m, 8); whs = torch.zeros(bs, m, 2); offs = torch.zeros(bs, m, 2)
-    inds = torch.zeros(bs, m, 1); masks = torch.zeros(bs, m, 1)
-    imgs, hms, names = [], [], []
-    for i, (img, a, hm, wh, ind, off, mask, name) in enumerate(samples):
-        n = a.size(0)
-        imgs.append(img.unsqueeze(0)); hms.append(hm.unsqueeze(0)); names.append(name)
-        annos[i, :n] = a[:, :8]; whs[i, :n] = wh; inds[i, :n] = ind; offs[i, :n] = off; masks[i, :n] = mask
-    return torch.cat(imgs), annos, torch.cat(hms), whs, inds, offs, masks, names
 
 
 def collate_ctnet_device(annos_list, height, width, scale_factor=4, num_classes=10, device="cuda"):
@@ -53,18 +39,28 @@ def collate_ctnet_device(annos_list, height, width, scale_factor=4, num_classes=
     return annos_d, hm, wh, ind, off, mask
 
 
-def synth_batch(batch_size, height, width, boxes_per_image=100, seed=219, rank=0, scale_factor=4, num_classes=10):
+def synth_frames(batch_size, height, width, boxes_per_image=100, seed=219, rank=0):
+    """Host side of the recipe (what a real loader would hand over): normalised frames [B,3,H,W] float32 (CPU) and
+    the per-image annotation tensors [n,8]."""
     rng = np.random.default_rng(seed + rank)
     mean = torch.tensor(MEAN).view(3, 1, 1)
     std = torch.tensor(STD).view(3, 1, 1)
-    samples = []
-    for i in range(batch_size):
+    imgs, annos_list = [], []
+    for _ in range(batch_size):
         frame = torch.from_numpy(rng.integers(0, 256, (height, width, 3), dtype=np.uint8))
-        img = (frame.permute(2, 0, 1).float() / 255. - mean) / std
-        annos = torch.from_numpy(synth_annotations(rng, boxes_per_image, height, width))
-        _, a, hm, wh, ind, off, mask = to_heatmap((img, annos), scale_factor, num_classes)
-        samples.append((img, a, hm, wh, ind, off, mask.float(), "synthetic_%06d" % i))
-    return collate_ctnet(samples)
+        imgs.append((frame.permute(2, 0, 1).float() / 255. - mean) / std)
+        annos_list.append(torch.from_numpy(synth_annotations(rng, boxes_per_image, height, width)))
+    return torch.stack(imgs), annos_list
+
+
+def synth_batch(batch_size, height, width, boxes_per_image=100, seed=219, rank=0, scale_factor=4, num_classes=10,
+                device="cuda"):
+    """One batch in collate_fn_ctnet's order, resident on `device`:
+    (imgs, annos, hms, whs, inds, offsets, reg_masks, names); the targets come from rr_ctnet_targets."""
+    imgs, annos_list = synth_frames(batch_size, height, width, boxes_per_image, seed, rank)
+    annos, hm, wh, ind, off, mask = collate_ctnet_device(annos_list, height, width, scale_factor, num_classes, device)
+    imgs = imgs.to(device).contiguous(memory_format=torch.channels_last)
+    return imgs, annos, hm, wh, ind, off, mask, ["synthetic_%06d" % i for i in range(batch_size)]
 
 
 class SyntheticDronesDET:
@@ -73,14 +69,16 @@ class SyntheticDronesDET:
 
     def __init__(self, cfg, batch_size, height, width, boxes_per_image=100, rank=0, device="cuda", pool=2):
         self.pool = [synth_batch(batch_size, height, width, boxes_per_image, cfg.seed + 1000 * i, rank,
-                                 cfg.Train.scale_factor, cfg.num_classes) for i in range(pool)]
+                                 cfg.Train.scale_factor, cfg.num_classes, device) for i in range(pool)]
         self.device = device
         self.i = 0
 
     def get_batch(self):
+        """The batches are resident on the device.  The annotations are handed out as a copy: the criterion converts
+        them to xyxy in place (rrnet_operator.py:67), which the reference's per-step H2D copy absorbed."""
         b = self.pool[self.i % len(self.pool)]
         self.i += 1
-        return tuple(t.to(self.device, non_blocking=True) if torch.is_tensor(t) else t for t in b)
+        return (b[0], b[1].clone()) + tuple(b[2:])
 
     def __len__(self):
         return len(self.pool)
@@ -93,7 +91,7 @@ def make_dataloader(cfg, collate_fn='rrnet'):
     """datasets/__init__.py make_dataloader surface: (training_loader, validation_loader).  Real
     VisDrone loading / augmentation is out of scope; synthetic frames of the configured crop size.  The generated
     pool is cached per (batch, size, seed, rank): a second operator in the same process (bench.py's secondary
-    workloads) does not pay for the host-side target generation again."""
+    workloads) reuses the resident batches."""
     rank = getattr(cfg.Distributed, "rank", 0)
     h, w = cfg.Train.crop_size
     key = (cfg.Train.batch_size, h, w, cfg.seed, rank, cfg.Train.scale_factor, cfg.num_classes)

@@ -1,4 +1,7 @@
-from .functional import to_heatmap, gaussian_radius, draw_umich_gaussian  # noqa: F401
+"""Transform classes of the reference's datasets/transforms/transforms.py that belong to the target contract."""
+import torch
+
+from .functional import flip_annos, flip_img  # noqa: F401
 
 
 class Compose:
@@ -12,14 +15,20 @@ class Compose:
 
 
 class ToHeatmap:
-    """datasets/transforms/transforms.py ToHeatmap -> functional.to_heatmap."""
+    """datasets/transforms/transforms.py ToHeatmap: (img [3,H,W], annos [n,>=6]) -> (img, annos, hm, wh, ind, offset,
+    reg_mask).  The targets are built by rr_ctnet_targets on the current device and returned as CPU tensors in the
+    reference's shapes (a per-sample transform runs in the loader, before collation)."""
 
     def __init__(self, scale_factor=4, cls_num=10):
         self.scale_factor = scale_factor
         self.cls_num = cls_num
 
     def __call__(self, data):
-        return to_heatmap(data, self.scale_factor, self.cls_num)
+        from rrnet_amd.datasets.synthetic import collate_ctnet_device
+        img, annos = data[0], data[1]
+        _, hm, wh, ind, off, mask = collate_ctnet_device([annos.float()], img.size(1), img.size(2), self.scale_factor,
+                                                         self.cls_num)
+        return (img, annos, hm[0].cpu().contiguous(), wh[0].cpu(), ind[0].cpu(), off[0].cpu(), mask[0].cpu())
 
 
 class Normalize:
@@ -27,7 +36,6 @@ class Normalize:
         self.mean, self.std = mean, std
 
     def __call__(self, data):
-        import torch
         img = data[0]
         mean = torch.tensor(self.mean, dtype=img.dtype).view(-1, 1, 1)
         std = torch.tensor(self.std, dtype=img.dtype).view(-1, 1, 1)

@@ -27,7 +27,7 @@ def _close(a, b, atol=1e-3, rtol=1e-3):
 def test_config1_centernet_tiny_512():
     from oracle import model as om, ops as oo
     from rrnet_amd import functional as RF
-    from rrnet_amd.datasets.synthetic import synth_batch
+    from helpers import host_synth_batch as synth_batch
     from rrnet_amd.models.centernet import CenterNet
     torch.manual_seed(219)
     model = CenterNet(_cfg("hourglass_tiny"))
@@ -54,7 +54,7 @@ def test_config1_centernet_tiny_512():
 
 def test_config2_hourglass104_forward_eval_256():
     from oracle import model as om, ops as oo
-    from rrnet_amd.datasets.synthetic import synth_batch
+    from helpers import host_synth_batch as synth_batch
     from rrnet_amd.models.rrnet import RRNet
     torch.manual_seed(219)
     model = RRNet(_cfg("hourglass"))
@@ -145,11 +145,10 @@ def _matched_batch(sd, imgs, k, per_image=12):
     """Ground truth that the stage-2 criterion can match (otherwise a randomly initialised model has no RoI with
     IoU > 0.5 and the stage-2 loss and its gradients are identically zero): a first oracle forward decodes the
     proposals, `per_image` of them — shifted and rescaled by a few percent, image coordinates — become the
-    annotations, and the stage-1 targets are built from those annotations by the host contract (to_heatmap +
-    collate_fn_ctnet)."""
+    annotations, and the stage-1 targets are built from those annotations by the oracle's host contract
+    (oracle/targets.py: to_heatmap + collate_fn_ctnet)."""
     from oracle import model as om
-    from rrnet_amd.datasets.synthetic import collate_ctnet
-    from rrnet_amd.datasets.transforms.functional import to_heatmap
+    from oracle.targets import collate_ctnet, to_heatmap
     with torch.no_grad():
         P = om.Params({kk: v.clone() for kk, v in sd.items()}, training=True)
         rois = om.rrnet_forward(P, imgs, k=k)[4]
@@ -169,7 +168,7 @@ def _matched_batch(sd, imgs, k, per_image=12):
                       np.zeros(per_image)], 1).astype(np.float32)
         a = torch.from_numpy(a)
         _, a, hm, wh, ind, off, mask = to_heatmap((imgs[b], a), 4, 10)
-        samples.append((imgs[b], a, hm, wh, ind, off, mask.float(), "f%d" % b))
+        samples.append((imgs[b], a, hm, wh, ind, off, mask, "f%d" % b))
     return collate_ctnet(samples)[:7]
 
 
@@ -177,7 +176,7 @@ def _matched_batch(sd, imgs, k, per_image=12):
 def test_config2_hourglass104_train_mode_vs_oracle(size, bs):
     """operators/rrnet_operator.py:42-84,128-138 on the full-depth model in train mode."""
     from rrnet_amd import functional as RF
-    from rrnet_amd.datasets.synthetic import synth_batch
+    from helpers import host_synth_batch as synth_batch
     from rrnet_amd.models.rrnet import RRNet
     k = 100
     torch.manual_seed(219)

@@ -360,7 +360,7 @@ def test_rrnet_with_dcn_heads_vs_oracle_composition():
     the oracle's composition (oracle/model.py:head_conv3x3 -> oracle/dcn.py)."""
     from oracle import model as om, ops as oo
     from rrnet_amd import functional as RF
-    from rrnet_amd.datasets.synthetic import synth_batch
+    from helpers import host_synth_batch as synth_batch
     from rrnet_amd.models.rrnet import RRNet
     torch.manual_seed(11)
     model = RRNet(_dcn_cfg())

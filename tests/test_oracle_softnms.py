@@ -92,3 +92,33 @@ def test_legacy_hard_nms_known_answer():
     b = np.array([[0, 0, 9, 9, 0.9], [0, 0, 9, 4, 0.8]], np.float32)     # areas 100 and 50, inter 50 -> 0.5
     assert onms.legacy_nms(b, 0.5) == [0, 1]
     assert onms.legacy_nms(b, 0.5, inclusive=True) == [0]
+
+
+def test_legacy_nms_vs_reference_goldens(golden_dir):
+    """oracle/nms.py:legacy_nms against the kept-index lists the reference's own numpy NMS returned
+    (/root/reference/ext/nms/nms/py_cpu_nms.py, run by tools/gen_golden_hardnms.py): 32 cases."""
+    z = np.load(os.path.join(golden_dir, "hardnms.npz"))
+    assert len(z["names"]) >= 30
+    for name in z["names"]:
+        name = str(name)
+        d, thr = z[name + "/dets"], float(z[name + "/thresh"])
+        assert nms.legacy_nms(d, thr) == [int(i) for i in z[name + "/keep"]], name
+
+
+def test_tv_style_hard_nms_oracle_pinned_by_reference_on_integer_boxes(golden_dir):
+    """oracle/nms.py:hard_nms (torchvision convention, unpinned by any torchvision output) agrees with the reference's
+    py_cpu_nms on integer boxes after the x2+1 / y2+1 shift that makes the two IoU conventions identical."""
+    z = np.load(os.path.join(golden_dir, "hardnms.npz"))
+    seen = 0
+    for name in z["names"]:
+        name = str(name)
+        if not name.startswith(("integer_grid", "exact_half")):
+            continue
+        d, thr = z[name + "/dets"], float(z[name + "/thresh"])
+        if len(np.unique(d[:, 4])) != d.shape[0]:
+            continue
+        b = d[:, :4].copy()
+        b[:, 2:4] += 1.0
+        assert nms.hard_nms(b, d[:, 4], thr).tolist() == [int(i) for i in z[name + "/keep"]], name
+        seen += 1
+    assert seen >= 2

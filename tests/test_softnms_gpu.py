@@ -140,6 +140,59 @@ def test_legacy_hard_nms_family_vs_oracle():
     assert W.nms(np.zeros((0, 5), np.float32), 0.5) == []
 
 
+def _hardnms_goldens(golden_dir):
+    z = np.load(os.path.join(golden_dir, "hardnms.npz"))
+    for name in z["names"]:
+        name = str(name)
+        yield name, z[name + "/dets"], float(z[name + "/thresh"]), [int(i) for i in z[name + "/keep"]]
+
+
+def test_hard_nms_family_vs_reference_goldens(golden_dir):
+    """rr_nms_sorted through gpu_nms / nms, and the reference's C entry `_nms` (host pointers, pre-sorted boxes,
+    nms_kernel.cu:91-144), against the kept-index lists the reference's own py_cpu_nms.py returned
+    (tools/gen_golden_hardnms.py): 32 cases incl. N = 0 / 1 / 1500, ties, identical boxes, IoU == thresh."""
+    import ctypes
+    from rrnet_amd import _C
+    from rrnet_amd.ext.nms import nms_wrapper as W
+    ncases = 0
+    for name, d, thr, keep in _hardnms_goldens(golden_dir):
+        ncases += 1
+        if d.shape[0] == 0:
+            assert W.nms(d, thr) == [] and keep == []
+            continue
+        assert [int(i) for i in W.gpu_nms(d, thr)] == keep, name
+        np.testing.assert_array_equal(W.nms(d, thr), d[keep])
+        order = d[:, 4].argsort()[::-1]
+        sd = np.ascontiguousarray(d[order])
+        out = np.zeros(d.shape[0], np.int32)
+        num = ctypes.c_int(0)
+        _C.fn("_nms")(out.ctypes.data_as(ctypes.c_void_p), ctypes.cast(ctypes.pointer(num), ctypes.c_void_p),
+                      sd.ctypes.data_as(ctypes.c_void_p), d.shape[0], 5, thr, torch.cuda.current_device())
+        assert [int(i) for i in order[out[:num.value]]] == keep, name
+    assert ncases >= 30
+
+
+def test_stage1_hard_nms_kernel_pinned_by_reference_on_integer_boxes(golden_dir):
+    """The stage-1 default NMS (torchvision convention: plain IoU, `>`; models/rrnet.py:69) has no reference output
+    here.  On integer coordinates IoU(+1) of (x1,y1,x2,y2) IS the plain IoU of (x1,y1,x2+1,y2+1), exactly, so the
+    reference's py_cpu_nms goldens pin the greedy algorithm of rr_hard_nms_segments (visiting order, threshold
+    convention, suppression by kept boxes only)."""
+    from rrnet_amd import ops
+    for name, d, thr, keep in _hardnms_goldens(golden_dir):
+        if not name.startswith(("integer_grid", "exact_half")):
+            continue
+        order = np.argsort(-d[:, 4], kind="stable")
+        if len(np.unique(d[:, 4])) != d.shape[0]:
+            continue                                        # ties: visiting orders may legitimately differ
+        b = d[order].copy()
+        b[:, 2:4] += 1.0
+        rows = torch.from_numpy(np.concatenate([b, np.zeros((b.shape[0], 1), np.float32)], 1)).cuda()
+        seg = torch.tensor([0, b.shape[0]], dtype=torch.int32, device="cuda")
+        n_out = ops.hard_nms_segments(rows, seg, b.shape[0], thr, None)
+        got = rows[:int(n_out[0])].cpu().numpy()
+        np.testing.assert_array_equal(got[:, :5], b[[list(order).index(k) for k in keep]][:, :5])
+
+
 def test_ext_nms_batch_and_auto_evaluate(tmp_path):
     """utils/metrics: the batched per-file / per-class Soft-NMS equals the oracle's ext_nms file by file, bit for
     bit, and auto_evaluate_results == evaluating those results in memory."""

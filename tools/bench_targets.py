@@ -1,5 +1,5 @@
-"""Target generation throughput: rr_ctnet_targets on the device vs the host restatement of the
-reference's to_heatmap + collate_fn_ctnet, B=8 images of 1024x1024 with 100 boxes each (BASELINE config 2 shape).
+"""Target generation throughput: rr_ctnet_targets on the device vs the oracle's host restatement
+(oracle/targets.py, the cpu_baseline leg) of the reference's to_heatmap + collate_fn_ctnet, B=8 images of 1024x1024 with 100 boxes each (BASELINE config 2 shape).
 Prints one JSON line: images/sec on the device (annotations already resident) and on the host cores."""
 import json
 import os
@@ -11,8 +11,8 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 from rrnet_amd import ops  # noqa: E402
-from rrnet_amd.datasets.synthetic import collate_ctnet, synth_annotations  # noqa: E402
-from rrnet_amd.datasets.transforms.functional import to_heatmap  # noqa: E402
+from rrnet_amd.datasets.synthetic import synth_annotations  # noqa: E402
+from oracle.targets import collate_ctnet, to_heatmap  # noqa: E402  (cpu_baseline leg only)
 
 B, H, W, N = 8, 1024, 1024, 100
 rng = np.random.default_rng(219)
@@ -37,7 +37,7 @@ for _ in range(reps):
     samples = []
     for a in annos_list:
         _, aa, hm, wh, ind, off, mask = to_heatmap((img, a), 4, 10)
-        samples.append((img, aa, hm, wh, ind, off, mask.float(), "x"))
+        samples.append((img, aa, hm, wh, ind, off, mask, "x"))
     collate_ctnet(samples)
 cpu_s = (time.perf_counter() - t0) / reps
 hm_bytes = B * 10 * (H // 4) * (W // 4) * 4
