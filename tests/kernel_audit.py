@@ -4,11 +4,25 @@
 signature (kind, shapes, stride, padding, flags) is recomputed on the host the first time it is seen and the
 relative error (max |diff| / max |ref|) is recorded in rec.seen; rec.bad lists the calls over tolerance.  Because
 every call is checked on the inputs the previous kernels actually produced, the check is as tight as a unit test
-(1e-6 level) even inside a 100-layer train step whose end-to-end gradients are chaotic."""
+(1e-6 level) even inside a 100-layer train step whose end-to-end gradients are chaotic.
+
+`audit(sample=True)` is the mode for the BASELINE launch configuration itself (B=8, 1024x1024: 8x256x256x256 maps,
+537 MB per tensor), where a full host recomputation of every call would take hours.  Calls whose host reference costs
+more than SAMPLE_FLOPS are checked on samples that keep the property under test:
+  * fprop / dgrad are local: three 16-row bands (top border, an interior band that straddles tile boundaries, bottom
+    border) of three different images (first, middle, last) are recomputed in fp64 from the sliced input rows;
+  * wgrad reduces over ALL pixels (where the round-2 row-walk defect lived): 16 filters (the first 4, 8 around the
+    128-row tile boundary, the last 4) are recomputed in fp64 over the full pixel range, all channels and taps; for the
+    largest layers the FULL dw is compared with torch-CPU's fp32 conv2d_weight as well;
+  * element-wise BatchNorm / ReLU / fan-in kernels are compared on the first and last image; the reductions
+    (BatchNorm statistics, backward sums, bias gradients) always run over the whole tensor in fp64."""
 import contextlib
 
 import torch
 import torch.nn.functional as F
+
+SAMPLE_FLOPS = 2.0e10          # host-reference cost above which a call is sampled (sample=True only)
+FULL_FP32_WGRAD_FLOPS = 2.5e11   # sampled wgrad calls at least this large also get a full-dw fp32 host reference
 
 
 class Record:
@@ -35,19 +49,112 @@ def _V(t):
     return t.detach().cpu().double().view(1, -1, 1, 1)
 
 
+def _c64(t):
+    return t.detach().cpu().double()
+
+
+def _bands(p):
+    """Output-row bands of a sampled convolution check: (image selector in [0,1], p0, p1)."""
+    if p <= 48:
+        return [(0.0, 0, p)]
+    mid = (p // 2 // 32) * 32 + 24           # crosses a 32-row boundary of the walk
+    return [(0.0, 0, 16), (0.5, mid, min(mid + 16, p)), (1.0, p - 16, p)]
+
+
+def _fprop_band(x, w64, b64, stride, pad, n0, p0, p1):
+    """fp64 conv2d of output rows [p0,p1) of image n0, from the input rows they reach (zero rows beyond the map)."""
+    h = x.shape[2]
+    r = w64.shape[2]
+    h0, h1 = p0 * stride - pad[0], (p1 - 1) * stride - pad[0] + r
+    a, b = max(h0, 0), min(h1, h)
+    xs = F.pad(_c64(x[n0:n0 + 1, :, a:b, :]), (0, 0, a - h0, h1 - b))
+    return F.conv2d(xs, w64, b64, stride, (0, pad[1]))
+
+
+def _dgrad_band(dy, w64, x_shape, stride, pad, n0, h0, h1):
+    """fp64 data gradient rows [h0,h1) of image n0 from the dy rows that reach them."""
+    _, c, h, wd = x_shape
+    k, _, r, s = w64.shape
+    p, q = dy.shape[2], dy.shape[3]
+    pa = max(0, -((-(h0 + pad[0] - r + 1)) // stride))
+    pb = min(p, (h1 - 1 + pad[0]) // stride + 1)
+    ref = torch.zeros((1, c, h1 - h0, wd), dtype=torch.float64)
+    if pb <= pa:
+        return ref
+    opw = wd - ((q - 1) * stride - 2 * pad[1] + s)
+    full = F.conv_transpose2d(_c64(dy[n0:n0 + 1, :, pa:pb, :]), w64, None, stride, (0, pad[1]), (0, opw))
+    base = pa * stride - pad[0]                       # input row of full's row 0
+    lo, hi = max(h0, base), min(h1, base + full.shape[2])
+    if hi > lo:
+        ref[:, :, lo - h0:hi - h0] = full[:, :, lo - base:hi - base]
+    return ref
+
+
+def _k_sample(k):
+    if k <= 16:
+        return list(range(k))
+    mids = [m for m in (128, 256, 384) if m + 4 < k] or [k // 2]     # wgrad tiles are 128 filters tall
+    pick = list(range(4)) + list(range(k - 4, k))
+    for m in mids[:2]:
+        pick += list(range(m - 4, m + 4))
+    return sorted(set(pick))
+
+
+def _img_sample(n):
+    return sorted({0, n - 1})
+
+
+def _colsum64(t):
+    """Per-channel sum over (N,H,W) of a logical NCHW tensor, fp64 accumulation, without an fp64 copy of the tensor."""
+    return t.detach().cpu().sum((0, 2, 3), dtype=torch.float64)
+
+
 @contextlib.contextmanager
-def audit(tol=2e-5, tol_wgrad=2e-4):
+def audit(tol=2e-5, tol_wgrad=2e-4, sample=False):
     from rrnet_amd import ops
     rec = Record()
-    names = ("conv_fprop", "conv_dgrad", "conv_wgrad", "bn_apply", "bn_bwd_reduce", "bn_bwd_apply", "sum_n",
-             "upsample_add_fwd", "upsample_add_bwd", "bias_relu_bwd", "relu_fwd")
+    rec.sampled = set()
+    names = ("conv_fprop", "conv_dgrad", "conv_wgrad", "stem_wgrad_s2d", "bn_apply", "bn_bwd_reduce", "bn_bwd_apply",
+             "sum_n", "upsample_add_fwd", "upsample_add_bwd", "bias_relu_bwd", "relu_fwd", "bn_finalize",
+             "bn_stats_finalize")
     orig = {n: getattr(ops, n) for n in names}
+
+    def big(flops):
+        return sample and flops > SAMPLE_FLOPS
+
+    def big_elems(t):
+        return sample and t.numel() > (1 << 24)
 
     def conv_fprop(x, w, bias=None, stride=1, pad=(0, 0), relu=False, want_stats=False):
         out = orig["conv_fprop"](x, w, bias, stride, pad, relu, want_stats)
         y = out[0] if want_stats else out
         sig = (tuple(x.shape), tuple(w.shape), stride, tuple(pad), bias is not None, relu, want_stats)
-        if ("fprop",) + sig not in rec.seen:
+        flops = 2.0 * y.numel() * w.shape[1] * w.shape[2] * w.shape[3]
+        if ("fprop",) + sig not in rec.seen and big(flops):
+            rec.sampled.add(("fprop",) + sig)
+            w64, b64 = _c64(w), None if bias is None else _c64(bias)
+            err = 0.0
+            for sel, p0, p1 in _bands(y.shape[2]):
+                n0 = int(round(sel * (x.shape[0] - 1)))
+                ref = _fprop_band(x, w64, b64, stride, pad, n0, p0, p1)
+                if relu:
+                    ref = ref.relu()
+                err = max(err, _rel(y[n0:n0 + 1, :, p0:p1, :], ref))
+            rec.note("fprop", sig, err, tol)
+            if want_stats:      # the statistics are a function of y (checked above): compare with fp64 sums of y itself
+                k = w.shape[0]
+                sums = ops.bn_reduce_slab(out[1], k).cpu()
+                yc = y.detach().cpu()
+                s1 = yc.sum((0, 2, 3), dtype=torch.float64)
+                s2 = torch.zeros(k, dtype=torch.float64)
+                sa = torch.zeros(k, dtype=torch.float64)
+                for i in range(yc.shape[0]):
+                    yi = yc[i].double()
+                    s2 += (yi * yi).sum((1, 2))
+                    sa += yi.abs().sum((1, 2))
+                e1 = float((sums[:k] - s1).abs().max() / max(float(sa.max()), 1e-30))
+                rec.note("fprop_stats", sig, max(e1, float((sums[k:2 * k] - s2).abs().max() / float(s2.max()))), tol)
+        elif ("fprop",) + sig not in rec.seen:
             ref = F.conv2d(x.cpu().double(), w.cpu().double(), None if bias is None else bias.cpu().double(), stride, pad)
             if relu:
                 ref = ref.relu()
@@ -64,7 +171,19 @@ def audit(tol=2e-5, tol_wgrad=2e-4):
         base = out.clone() if (out is not None and accumulate) else None
         res = orig["conv_dgrad"](dy, w, x_shape, stride, pad, out, accumulate)
         sig = (tuple(dy.shape), tuple(w.shape), tuple(x_shape), stride, tuple(pad), bool(accumulate))
-        if ("dgrad",) + sig not in rec.seen:
+        flops = 2.0 * dy.numel() * w.shape[1] * w.shape[2] * w.shape[3]
+        if ("dgrad",) + sig not in rec.seen and big(flops):
+            rec.sampled.add(("dgrad",) + sig)
+            w64 = _c64(w)
+            err = 0.0
+            for sel, h0, h1 in _bands(x_shape[2]):
+                n0 = int(round(sel * (x_shape[0] - 1)))
+                ref = _dgrad_band(dy, w64, x_shape, stride, pad, n0, h0, h1)
+                if base is not None:
+                    ref = ref + _c64(base[n0:n0 + 1, :, h0:h1, :])
+                err = max(err, _rel(res[n0:n0 + 1, :, h0:h1, :], ref))
+            rec.note("dgrad", sig, err, tol)
+        elif ("dgrad",) + sig not in rec.seen:
             ref = torch.nn.grad.conv2d_input(tuple(x_shape), w.cpu().double(), dy.cpu().double(), stride, pad)
             if base is not None:
                 ref = ref + base.cpu().double()
@@ -76,9 +195,46 @@ def audit(tol=2e-5, tol_wgrad=2e-4):
         check = ("wgrad",) + sig not in rec.seen and not explicit_out
         base = dw.clone() if check else None
         res = orig["conv_wgrad"](x, dy, dw, stride, pad, explicit_out)
-        if check:
+        flops = 2.0 * dy.numel() * dw.shape[1] * dw.shape[2] * dw.shape[3]
+        if check and big(flops):
+            rec.sampled.add(("wgrad",) + sig)
+            got = _c64(res) - _c64(base)
+            ks = _k_sample(dw.shape[0])
+            x64 = _c64(x)
+            ref = torch.nn.grad.conv2d_weight(x64, (len(ks),) + tuple(dw.shape[1:]), _c64(dy[:, ks]), stride, pad)
+            del x64
+            scale = max(float(ref.abs().max()), 1e-30)
+            err = float((got[ks] - ref).abs().max() / scale)
+            rec.note("wgrad", sig, err, tol_wgrad)
+            if flops >= FULL_FP32_WGRAD_FLOPS:
+                full = torch.nn.grad.conv2d_weight(x.detach().cpu().contiguous(), tuple(dw.shape),
+                                                   dy.detach().cpu().contiguous(), stride, pad).double()
+                rec.note("wgrad_full_fp32", sig, float((got - full).abs().max() / max(float(full.abs().max()), 1e-30)),
+                         tol_wgrad)
+        elif check:
             ref = torch.nn.grad.conv2d_weight(x.cpu().double(), tuple(dw.shape), dy.cpu().double(), stride, pad)
             rec.note("wgrad", sig, _rel(res.cpu().double() - base.cpu().double(), ref), tol_wgrad)
+        return res
+
+    def stem_wgrad_s2d(x, dy, dw):
+        """The 7x7 stride-2 stem's weight gradient, computed by the product on the space-to-depth image."""
+        sig = (tuple(x.shape), tuple(dy.shape), tuple(dw.shape))
+        check = ("stem_wgrad",) + sig not in rec.seen
+        base = dw.clone() if check else None
+        saved = ops.conv_wgrad
+        ops.conv_wgrad = orig["conv_wgrad"]            # the inner explicit-output call is part of this op
+        try:
+            res = orig["stem_wgrad_s2d"](x, dy, dw)
+        finally:
+            ops.conv_wgrad = saved
+        if check:
+            got = _c64(res) - _c64(base)
+            flops = 2.0 * dy.numel() * 3 * 49
+            ks = _k_sample(dw.shape[0]) if big(flops) else list(range(dw.shape[0]))
+            if big(flops):
+                rec.sampled.add(("stem_wgrad",) + sig)
+            ref = torch.nn.grad.conv2d_weight(_c64(x), (len(ks), 3, 7, 7), _c64(dy[:, ks]), 2, (3, 3))
+            rec.note("stem_wgrad", sig, float((got[ks] - ref).abs().max() / max(float(ref.abs().max()), 1e-30)), tol_wgrad)
         return res
 
     def _masked(dz, z, y, mask_scale, mask_shift):
@@ -93,25 +249,33 @@ def audit(tol=2e-5, tol_wgrad=2e-4):
         out = orig["bn_apply"](y, scale, shift, residual, relu, res_scale, res_shift)
         sig = (tuple(y.shape), residual is not None, relu)
         if ("bn_apply",) + sig not in rec.seen:
-            ref = y.detach().cpu().double() * _V(scale) + _V(shift)
+            ns = _img_sample(y.shape[0]) if big_elems(y) else list(range(y.shape[0]))
+            if big_elems(y):
+                rec.sampled.add(("bn_apply",) + sig)
+            ref = _c64(y[ns]) * _V(scale) + _V(shift)
             if residual is not None:
-                ref = ref + residual.detach().cpu().double()
+                ref = ref + _c64(residual[ns])
             if relu:
                 ref = ref.relu()
-            rec.note("bn_apply", sig, _rel(out, ref), tol)
+            rec.note("bn_apply", sig, _rel(out[ns], ref), tol)
         return out
 
     def bn_bwd_reduce(dz, z, y, mean, invstd, extra=0, mask_scale=None, mask_shift=None):
         out = orig["bn_bwd_reduce"](dz, z, y, mean, invstd, extra, mask_scale, mask_shift)
         sig = (tuple(y.shape), z is not None, mask_scale is not None)
         if ("bn_bwd_reduce",) + sig not in rec.seen:
-            d = _masked(dz, z, y, mask_scale, mask_shift)
-            xh = (y.detach().cpu().double() - _V(mean)) * _V(invstd)
             c = y.shape[1]
+            s1, s2, a1, a2 = (torch.zeros(c, dtype=torch.float64) for _ in range(4))
+            for i in range(y.shape[0]):                   # whole tensor, one image at a time (memory)
+                d = _masked(dz[i:i + 1], None if z is None else z[i:i + 1], y[i:i + 1], mask_scale, mask_shift)
+                xh = (_c64(y[i:i + 1]) - _V(mean)) * _V(invstd)
+                s1 += d.sum((0, 2, 3)); a1 += d.abs().sum((0, 2, 3))
+                d = d * xh
+                s2 += d.sum((0, 2, 3)); a2 += d.abs().sum((0, 2, 3))
             o = out.cpu()
             # column sums: error relative to the sum of magnitudes (the quantity the rounding scales with)
-            e1 = float((o[:c] - d.sum((0, 2, 3))).abs().max() / max(float(d.abs().sum((0, 2, 3)).max()), 1e-30))
-            e2 = float((o[c:2 * c] - (d * xh).sum((0, 2, 3))).abs().max() / max(float((d * xh).abs().sum((0, 2, 3)).max()), 1e-30))
+            e1 = float((o[:c] - s1).abs().max() / max(float(a1.max()), 1e-30))
+            e2 = float((o[c:2 * c] - s2).abs().max() / max(float(a2.max()), 1e-30))
             rec.note("bn_bwd_reduce", sig, max(e1, e2), tol)
         return out
 
@@ -121,13 +285,16 @@ def audit(tol=2e-5, tol_wgrad=2e-4):
                                    mask_scale, mask_shift)
         sig = (tuple(y.shape), z is not None, mask_scale is not None, want_g)
         if ("bn_bwd_apply",) + sig not in rec.seen and count_dev is None:
-            d = _masked(dz, z, y, mask_scale, mask_shift)
+            ns = _img_sample(y.shape[0]) if big_elems(y) else list(range(y.shape[0]))
+            if big_elems(y):
+                rec.sampled.add(("bn_bwd_apply",) + sig)
+            d = _masked(dz[ns], None if z is None else z[ns], y[ns], mask_scale, mask_shift)
             c = y.shape[1]
-            xh = (y.detach().cpu().double() - _V(mean)) * _V(invstd)
+            xh = (_c64(y[ns]) - _V(mean)) * _V(invstd)
             ref = _V(gamma) * _V(invstd) * (d - _V(sums[:c]) / count - xh * _V(sums[c:2 * c]) / count)
-            e = float((out[0].detach().cpu().double() - ref).abs().max() / max(float((_V(gamma) * _V(invstd) * d).abs().max()), 1e-30))
+            e = float((_c64(out[0][ns]) - ref).abs().max() / max(float((_V(gamma) * _V(invstd) * d).abs().max()), 1e-30))
             if want_g:
-                e = max(e, _rel(out[1], d))
+                e = max(e, _rel(out[1][ns], d))
             rec.note("bn_bwd_apply", sig, e, tol)
         return out
 
@@ -135,31 +302,38 @@ def audit(tol=2e-5, tol_wgrad=2e-4):
         out = orig["sum_n"](grads, z)
         sig = (tuple(grads[0].shape), len(grads), z is not None)
         if ("sum_n",) + sig not in rec.seen:
-            ref = sum(g.detach().cpu().double() for g in grads)
+            g0 = grads[0]
+            sub = big_elems(g0) and g0.dim() == 4
+            ns = _img_sample(g0.shape[0]) if sub else slice(None)
+            if sub:
+                rec.sampled.add(("sum_n",) + sig)
+            ref = sum(_c64(g[ns]) for g in grads)
             if z is not None:
-                ref = ref * (z.detach().cpu() > 0)
-            rec.note("sum_n", sig, _rel(out, ref), tol)
+                ref = ref * (z[ns].detach().cpu() > 0)
+            rec.note("sum_n", sig, _rel(out[ns], ref), tol)
         return out
 
     def upsample_add_fwd(up1, low):
         out = orig["upsample_add_fwd"](up1, low)
         sig = (tuple(up1.shape), tuple(low.shape))
         if ("upsample_add_fwd",) + sig not in rec.seen:
-            u = F.interpolate(low.detach().cpu().double(), scale_factor=2)
+            ns = _img_sample(up1.shape[0]) if big_elems(up1) else list(range(up1.shape[0]))
+            u = F.interpolate(_c64(low[ns]), scale_factor=2)
             u = F.interpolate(u, size=tuple(up1.shape[2:]), mode="bilinear", align_corners=True)
-            rec.note("upsample_add_fwd", sig, _rel(out, up1.detach().cpu().double() + u), tol)
+            rec.note("upsample_add_fwd", sig, _rel(out[ns], _c64(up1[ns]) + u), tol)
         return out
 
     def upsample_add_bwd(dout, low_shape):
         out = orig["upsample_add_bwd"](dout, low_shape)
         sig = (tuple(dout.shape), tuple(low_shape))
         if ("upsample_add_bwd",) + sig not in rec.seen:
+            ns = _img_sample(dout.shape[0]) if big_elems(dout) else list(range(dout.shape[0]))
             with torch.enable_grad():                 # we are inside autograd's backward: grad mode is off here
-                low = torch.zeros(tuple(low_shape), dtype=torch.float64, requires_grad=True)
+                low = torch.zeros((len(ns),) + tuple(low_shape[1:]), dtype=torch.float64, requires_grad=True)
                 u = F.interpolate(F.interpolate(low, scale_factor=2), size=tuple(dout.shape[2:]), mode="bilinear",
                                   align_corners=True)
-                u.backward(dout.detach().cpu().double())
-            rec.note("upsample_add_bwd", sig, _rel(out, low.grad), tol)
+                u.backward(_c64(dout[ns]))
+            rec.note("upsample_add_bwd", sig, _rel(out[ns], low.grad), tol)
         return out
 
     def bias_relu_bwd(dy, z, dbias):
@@ -168,13 +342,18 @@ def audit(tol=2e-5, tol_wgrad=2e-4):
         c = dbias.numel()
         sig = (tuple(dy.shape), z is not None, c)
         if ("bias_relu_bwd",) + sig not in rec.seen:
-            d = dy.detach().cpu().double()
-            if z is not None:
-                d = d * (z.detach().cpu() > 0)
-            flat = d.permute(0, 2, 3, 1).reshape(-1, c) if d.dim() == 4 else d.reshape(-1, c)
-            e = float(((dbias - base).cpu().double() - flat.sum(0)).abs().max() / max(float(flat.abs().sum(0).max()), 1e-30))
-            if z is not None:
-                e = max(e, _rel(out, d))
+            tot, mag, e = torch.zeros(c, dtype=torch.float64), torch.zeros(c, dtype=torch.float64), 0.0
+            chunks = range(dy.shape[0]) if (dy.dim() == 4 and big_elems(dy)) else [slice(None)]
+            for i in chunks:                              # whole tensor, one image at a time when it is large
+                sl = slice(i, i + 1) if isinstance(i, int) else i
+                d = _c64(dy[sl])
+                if z is not None:
+                    d = d * (z[sl].detach().cpu() > 0)
+                    e = max(e, float((_c64(out[sl]) - d).abs().max()))
+                flat = d.permute(0, 2, 3, 1).reshape(-1, c) if d.dim() == 4 else d.reshape(-1, c)
+                tot += flat.sum(0); mag += flat.abs().sum(0)
+            e = e / max(float(dy.abs().max()), 1e-30)
+            e = max(e, float(((dbias - base).cpu().double() - tot).abs().max() / max(float(mag.max()), 1e-30)))
             rec.note("bias_relu_bwd", sig, e, tol)
         return out
 
@@ -182,10 +361,57 @@ def audit(tol=2e-5, tol_wgrad=2e-4):
         out = orig["relu_fwd"](x)
         sig = (tuple(x.shape),)
         if ("relu_fwd",) + sig not in rec.seen:
-            rec.note("relu_fwd", sig, _rel(out, x.detach().cpu().double().relu()), tol)
+            ns = _img_sample(x.shape[0]) if (big_elems(x) and x.dim() == 4) else slice(None)
+            rec.note("relu_fwd", sig, _rel(out[ns], _c64(x[ns]).relu()), tol)
         return out
 
-    patched = dict(conv_fprop=conv_fprop, conv_dgrad=conv_dgrad, conv_wgrad=conv_wgrad, bn_apply=bn_apply,
+    def _finalize_ref(sums64, count, gamma, beta, rm0, rv0, momentum, eps):
+        c = gamma.numel()
+        m = sums64[:c] / count
+        var = (sums64[c:2 * c] / count - m * m).clamp(min=0)
+        istd = 1.0 / torch.sqrt(var + eps)
+        sc = _c64(gamma) * istd
+        unb = var * count / (count - 1.0) if count > 1 else var
+        return m, istd, sc, _c64(beta) - m * sc, (1 - momentum) * rm0 + momentum * m, (1 - momentum) * rv0 + momentum * unb
+
+    def _finalize_err(got, ref, rm, rv):
+        e = 0.0
+        for g, r in zip(tuple(got) + (rm, rv), ref):
+            e = max(e, float((_c64(g) - r).abs().max() / max(float(r.abs().max()), 1e-30)))
+        return e
+
+    def bn_finalize(sums, count, gamma, beta, running_mean, running_var, momentum, eps, count_dev=None,
+                    num_batches_tracked=None):
+        sig = (gamma.numel(), float(count), count_dev is not None)
+        check = ("bn_finalize",) + sig not in rec.seen and count_dev is None
+        if check:
+            rm0, rv0, nb0 = _c64(running_mean), _c64(running_var), None if num_batches_tracked is None else int(num_batches_tracked)
+        got = orig["bn_finalize"](sums, count, gamma, beta, running_mean, running_var, momentum, eps, count_dev,
+                                  num_batches_tracked)
+        if check:
+            ref = _finalize_ref(sums.detach().cpu().double(), count, gamma, beta, rm0, rv0, momentum, eps)
+            e = _finalize_err(got, ref, running_mean, running_var)
+            if nb0 is not None and int(num_batches_tracked) != nb0 + 1:
+                e = float("inf")
+            rec.note("bn_finalize", sig, e, 1e-5)        # fp32 outputs of fp64 arithmetic: a few ulp
+        return got
+
+    def bn_stats_finalize(slab, count, gamma, beta, running_mean, running_var, momentum, eps, num_batches_tracked=None):
+        c = gamma.numel()
+        sig = (c, float(count), slab.numel() // (2 * c))
+        check = ("bn_stats_finalize",) + sig not in rec.seen
+        if check:
+            rm0, rv0 = _c64(running_mean), _c64(running_var)
+        got = orig["bn_stats_finalize"](slab, count, gamma, beta, running_mean, running_var, momentum, eps,
+                                        num_batches_tracked)
+        if check:
+            sums = slab.detach().cpu().view(-1, 2 * c).sum(0)
+            ref = _finalize_ref(sums, count, gamma, beta, rm0, rv0, momentum, eps)
+            rec.note("bn_stats_finalize", sig, _finalize_err(got, ref, running_mean, running_var), 1e-5)
+        return got
+
+    patched = dict(conv_fprop=conv_fprop, conv_dgrad=conv_dgrad, conv_wgrad=conv_wgrad, stem_wgrad_s2d=stem_wgrad_s2d,
+                   bn_finalize=bn_finalize, bn_stats_finalize=bn_stats_finalize, bn_apply=bn_apply,
                    bn_bwd_reduce=bn_bwd_reduce, bn_bwd_apply=bn_bwd_apply, sum_n=sum_n, upsample_add_fwd=upsample_add_fwd,
                    upsample_add_bwd=upsample_add_bwd, bias_relu_bwd=bias_relu_bwd, relu_fwd=relu_fwd)
     for n, f in patched.items():

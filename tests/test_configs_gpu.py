@@ -123,6 +123,54 @@ _HG104_GRAD_KEYS = (
 )
 
 
+def test_config2_full_size_train_step_every_kernel_call_sampled():
+    """The headline's OWN launches: one train step at BASELINE configs[1] (B=8, 1024x1024, hourglass-104 — the
+    configuration bench.py times) with every distinct conv / BatchNorm / element-wise kernel call audited against a host
+    recomputation from the inputs the call received (tests/kernel_audit.py, sample=True).  The variants that only exist
+    at this size — wgrad's split counts at 8x256x256 pixels, the stem's space-to-depth wgrad at 512x512, stride-2 dgrad
+    512->256, the two-kernel BatchNorm statistics of > 512 pixel tiles, capped reduce grids — are checked in the exact
+    launch configuration the step selects: fprop / dgrad on three 16-row bands of three images (fp64), wgrad on 16-24
+    filters over ALL pixels (fp64) plus the full dw of the largest layers against torch-CPU fp32, reductions over the
+    whole tensors.  Tolerances as in the small audit: 2e-5 (wgrad 2e-4)."""
+    import time
+    from kernel_audit import audit
+    from rrnet_amd.configs.rrnet_config import Config as cfg
+    from rrnet_amd.operators.rrnet_operator import RRNetOperator
+    cfg.Train.batch_size = 8
+    cfg.Train.crop_size = (1024, 1024)
+    cfg.Model.backbone = "hourglass"
+    cfg.Distributed.gpu_id, cfg.Distributed.rank, cfg.Distributed.world_size = 0, 0, 1
+    torch.manual_seed(cfg.seed)
+    op = RRNetOperator(cfg)
+    op.model.train()
+    b = op.training_loader.get_batch()
+    t0 = time.perf_counter()
+    with audit(sample=True) as rec:
+        _, losses = op.train_step(0, b)
+        torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert all(np.isfinite(float(v.detach())) for v in losses)
+    kinds = {}
+    for key, err in rec.seen.items():
+        kinds.setdefault(key[0], []).append(err)
+    print("audit %.0f s: " % dt + "  ".join("%s:%d (max %.1e)" % (kk, len(v), max(v)) for kk, v in sorted(kinds.items())))
+    print("sampled signatures: %d of %d" % (len(rec.sampled), len(rec.seen)))
+    assert not rec.bad, rec.bad[:10]
+    assert len(rec.seen) > 150
+    assert {"fprop", "dgrad", "wgrad", "wgrad_full_fp32", "stem_wgrad", "fprop_stats", "bn_apply", "bn_bwd_apply",
+            "bn_bwd_reduce", "bn_finalize", "bn_stats_finalize", "sum_n", "upsample_add_fwd", "upsample_add_bwd",
+            "bias_relu_bwd"} <= set(kinds), sorted(kinds)
+    # the signatures that exist only at this size were seen AND sampled
+    big = (8, 256, 256, 256)
+    want = [("fprop", big, (256, 256, 3, 3), 1), ("dgrad", big, (256, 256, 3, 3), 1), ("wgrad", big, big, (256, 256, 3, 3), 1),
+            ("fprop", (8, 3, 1024, 1024), (128, 3, 7, 7), 2), ("fprop", (8, 128, 512, 512), (256, 128, 3, 3), 2),
+            ("fprop", (8, 128, 512, 512), (256, 128, 1, 1), 2), ("dgrad", big, (256, 128, 3, 3), (8, 128, 512, 512), 2)]
+    keys = set(rec.seen)
+    for w_ in want:
+        assert any(k[:len(w_)] == w_ for k in keys), (w_, sorted(k for k in keys if k[0] == w_[0])[:5])
+    assert any(k[0] == "stem_wgrad" and k[1] == (8, 3, 1024, 1024) for k in keys)
+
+
 def _hg104_oracle_train(sd, batch, dtype, keys, k, perturb=0.0):
     """One oracle train step (forward, criterion, backward) -> outputs, losses, grads, BN buffers."""
     from oracle import model as om, ops as oo

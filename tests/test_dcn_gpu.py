@@ -443,3 +443,57 @@ def test_rrnet_with_dcn_heads_train_step_bf16():
             if k not in saved:
                 del cfg.Model[k]
         cfg.Model.update(saved)
+
+
+def test_dcn_bench_layer_full_size_vs_column_path_and_cropped_oracle():
+    """The layer bench.py's `config4` times — 256->256 3x3 DCNv2 on B=8 x 256x256 — at its own launch configuration:
+      (i)  fused forward / backward (fp32 operands) against the reference-structured column path of the same library on
+           the full tensors (all four gradients);
+      (ii) against the oracle (oracle/dcn.py) on three cropped windows (top-left corner, an interior window straddling
+           8x16 pixel blocks, bottom-right corner) of three images: the op is local for bounded offsets, so a crop with a
+           margin of 2 x (pad + max|offset| + 1) reproduces out, d offset, d mask and d input of the window's core exactly;
+      (iii) the bf16-operand kernels (BASELINE config 4) against the fp32 result within bf16's rounding."""
+    from oracle import dcn as odcn
+    from rrnet_amd import functional as RF
+    n, c, h, w, k = 8, 256, 256, 256, 256
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn(n, c, h, w, device="cuda", generator=g).contiguous(memory_format=CL)
+    off = torch.randn(n, 18, h, w, device="cuda", generator=g).clamp(-3, 3).contiguous(memory_format=CL)
+    mask = torch.sigmoid(torch.randn(n, 9, h, w, device="cuda", generator=g)).contiguous(memory_format=CL)
+    wt = (torch.randn(k, c, 3, 3, device="cuda", generator=g) / 48.0).contiguous(memory_format=CL)
+    bias = torch.randn(k, device="cuda", generator=g)
+    gy = torch.randn(n, k, h, w, device="cuda", generator=g).contiguous(memory_format=CL)
+    res = {}
+    saved = RF.DCN_FUSED_BWD
+    try:
+        for tag, fused, bf in (("fused", True, False), ("column", False, False), ("bf16", True, True)):
+            RF.DCN_FUSED_BWD = fused
+            ins = [t.clone().requires_grad_() for t in (x, off, mask, wt, bias)]
+            out = RF.dcn_v2_conv(*ins, 1, 1, 1, 1, bf16=bf)
+            out.backward(gy)
+            torch.cuda.synchronize()
+            res[tag] = [out.detach()] + [t.grad for t in ins]
+            del out, ins
+    finally:
+        RF.DCN_FUSED_BWD = saved
+    names = ("out", "dx", "doffset", "dmask", "dw", "db")
+    for name, a, b in zip(names, res["fused"], res["column"]):
+        scale = b.abs().max().item()
+        assert (a - b).abs().max().item() <= 2e-4 * scale, ("fused vs column", name, (a - b).abs().max().item(), scale)
+    for name, a, b in zip(names, res["bf16"], res["fused"]):
+        scale = b.abs().max().item()
+        assert (a - b).abs().max().item() <= 3e-2 * scale, ("bf16 vs fp32", name, (a - b).abs().max().item(), scale)
+    m = 2 * (1 + 3 + 1)
+    for n0, (r0, r1, c0, c1) in ((0, (0, 20, 0, 28)), (3, (117, 141, 104, 140)), (7, (236, 256, 228, 256))):
+        ra, rb, ca, cb = max(0, r0 - m), min(h, r1 + m), max(0, c0 - m), min(w, c1 + m)
+        crop = [t[n0:n0 + 1, :, ra:rb, ca:cb].detach().cpu().contiguous().requires_grad_() for t in (x, off, mask)]
+        ref = odcn.dcn_v2_conv(crop[0], crop[1], crop[2], wt.cpu().contiguous(), bias.cpu(), 1, 1, 1, 1)
+        ref.backward(gy[n0:n0 + 1, :, ra:rb, ca:cb].cpu().contiguous())
+        core = (slice(None), slice(None), slice(r0 - ra, r1 - ra), slice(c0 - ca, c1 - ca))
+        full = (slice(n0, n0 + 1), slice(None), slice(r0, r1), slice(c0, c1))
+        for name, got, exp in (("out", res["fused"][0], ref.detach()), ("dx", res["fused"][1], crop[0].grad),
+                               ("doffset", res["fused"][2], crop[1].grad), ("dmask", res["fused"][3], crop[2].grad)):
+            e = exp[core]
+            tol = 1e-3 * max(1.0, e.abs().max().item())
+            np.testing.assert_allclose(got[full].cpu().numpy(), e.numpy(), atol=tol, rtol=1e-3,
+                                       err_msg="%s vs oracle, image %d window %s" % (name, n0, (r0, r1, c0, c1)))
