@@ -162,7 +162,7 @@ def test_config2_full_size_train_step_every_kernel_call_sampled():
             "bias_relu_bwd"} <= set(kinds), sorted(kinds)
     # the signatures that exist only at this size were seen AND sampled
     big = (8, 256, 256, 256)
-    want = [("fprop", big, (256, 256, 3, 3), 1), ("dgrad", big, (256, 256, 3, 3), 1), ("wgrad", big, big, (256, 256, 3, 3), 1),
+    want = [("fprop", big, (256, 256, 3, 3), 1), ("dgrad", big, (256, 256, 3, 3), big, 1), ("wgrad", big, big, (256, 256, 3, 3), 1),
             ("fprop", (8, 3, 1024, 1024), (128, 3, 7, 7), 2), ("fprop", (8, 128, 512, 512), (256, 128, 3, 3), 2),
             ("fprop", (8, 128, 512, 512), (256, 128, 1, 1), 2), ("dgrad", big, (256, 128, 3, 3), (8, 128, 512, 512), 2)]
     keys = set(rec.seen)
