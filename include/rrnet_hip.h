@@ -81,6 +81,20 @@ int rr_conv_dgrad(const float *dy, const float *w, float *dx, int n, int h, int 
 int rr_weight_flip_transpose(const float *w, float *wt, int k, int c, int r, int s, hipStream_t stream);
 int rr_conv_dgrad_s1(const float *dy, const float *wt, float *dx, int n, int h, int wd, int c, int k,
                      int r, int s, int pad_h, int pad_w, int accumulate, hipStream_t stream);
+/* rr_conv_dgrad_s1 that ALSO returns the BatchNorm-backward sums of the layer that produced the tensor whose gradient
+ * it writes (the conv -> bn -> relu layer in front of this convolution, backbones/hourglass.py:31-40): the epilogue has
+ * the finished gradient dz = dx in registers, reads the producer's pre-BN output prod_y [n,h,w,c] (and prod_z, its
+ * post-activation output, when the ReLU mask cannot be recomputed as prod_y*mask_scale+mask_shift > 0; with neither
+ * the producer has no ReLU and every element counts) and emits per
+ * block sum(dz*mask) and sum(dz*mask*xhat) to `slab` (rr_conv_stat_slab_bytes(n,h,wd,c) bytes), reduced into
+ * sums [2][c] (zeroed by the caller) — exactly what rr_bn_bwd_reduce(dx, prod_z, prod_y, ...) returns, without its
+ * pass over dx and y.  accumulate != 0: dx += ..., the sums are taken of the final values (the last contributor of a
+ * gradient fan-in).  Layers that run split-K fall back to rr_bn_bwd_reduce internally: same contract. */
+int rr_conv_dgrad_s1_bnsum(const float *dy, const float *wt, float *dx, int n, int h, int wd, int c, int k,
+                           int r, int s, int pad_h, int pad_w, int accumulate, const float *prod_y,
+                           const float *prod_z, const float *prod_mean, const float *prod_invstd,
+                           const float *prod_mask_scale, const float *prod_mask_shift, double *slab,
+                           double *sums, hipStream_t stream);
 int rr_conv_wgrad(const float *x, const float *dy, float *dw, int n, int h, int wd, int c, int k,
                   int r, int s, int stride, int pad_h, int pad_w, int out_h, int out_w, hipStream_t stream);
 
@@ -131,6 +145,14 @@ int rr_bn_bwd_apply(const float *dz, const float *z, const float *y, const float
                     const float *invstd, const float *gamma, const float *mask_scale, const float *mask_shift,
                     const double *sums, double count,
                     const double *count_dev, float *dx, float *g_out, float *dgamma, float *dbeta, long total,
+                    int c, hipStream_t stream);
+/* rr_bn_bwd_apply whose masked gradient (the residual branch's share, g) is ADDED into g_acc — the fan-in buffer of the
+ * residual's fan-out when another consumer already left its gradient there (one read-modify-write instead of a write,
+ * an add kernel and its three passes). */
+int rr_bn_bwd_apply_gacc(const float *dz, const float *z, const float *y, const float *mean,
+                    const float *invstd, const float *gamma, const float *mask_scale, const float *mask_shift,
+                    const double *sums, double count,
+                    const double *count_dev, float *dx, float *g_acc, float *dgamma, float *dbeta, long total,
                     int c, hipStream_t stream);
 int rr_relu_fwd(const float *x, float *out, long total, hipStream_t stream);
 int rr_sum_n(const float *const *grads, int n, const float *z, float *out, long total, hipStream_t stream);

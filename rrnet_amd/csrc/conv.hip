@@ -43,6 +43,11 @@ struct ConvArgs {
     float *dst;        // fprop: Y [N,P,Q,K]      dgrad: dX [N,H,W,C]
     const float *bias; // fprop only, [K] or null
     double *stat_slab; // fprop only: [mtiles][2][K] per-block column sums / sums of squares, or null
+    // BatchNorm-backward sums of the layer that PRODUCED the tensor whose gradient this launch writes (stride-1 data
+    // gradient through the forward kernel): with bs_y set the slab receives, per block and column c, sum(d) and
+    // sum(d * xhat) with d = dst * relu-mask (mask from bs_z > 0, or recomputed as bs_y*bs_msc+bs_msh > 0) and
+    // xhat = (bs_y - bs_mean) * bs_invstd — what rr_bn_bwd_reduce would compute in a separate pass over dst and y.
+    const float *bs_y, *bs_z, *bs_mean, *bs_invstd, *bs_msc, *bs_msh;
     int N;
     int SH, SW, SC;    // source spatial / channels
     int DH, DW, DC;    // destination spatial / channels (DC = GEMM N)
@@ -70,7 +75,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nb)
 // PIPE: software-pipelined main loop (global loads two K-steps ahead, LDS fragments one 8-deep group
 // ahead, barrier placed between the third and fourth MFMA group) so that a wave's MFMA stream never
 // waits on a barrier or on LDS latency.
-template <int BN, int MODE, bool SCALAR, int BKT, int PIPE>
+// BNS: the epilogue also emits the producer's BatchNorm-backward sums (ConvArgs::bs_y); a separate instantiation so
+// that the plain kernel keeps its register budget (three workgroups per CU).
+template <int BN, int MODE, bool SCALAR, int BKT, int PIPE, bool BNS = false>
 __global__ __launch_bounds__(256, PIPE == 3 ? 3 : 1) void conv_igemm_kernel(const ConvArgs a)
 {
     constexpr int WN = BN / 64 ? BN / 64 : 1;   // waves along N
@@ -620,6 +627,17 @@ __global__ __launch_bounds__(256, PIPE == 3 ? 3 : 1) void conv_igemm_kernel(cons
     // ---- epilogue.  D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     double *sred = reinterpret_cast<double *>(lds);   // [WM][BN][2], reuses the staging LDS
     const bool do_stats = (MODE == 0) && a.stat_slab != nullptr && a.ksplit <= 1;
+    constexpr bool bnsum = BNS;                                     // statistics = the producer's BN-backward sums
+    // (the host takes the BNS variant only for destinations below 2 GiB; unused and dropped otherwise)
+    auto bs_srd = [](const float *p, long bytes) {
+        const unsigned long long u = reinterpret_cast<unsigned long long>(p);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u);
+        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+        void *q = reinterpret_cast<void *>(((unsigned long long)hi << 32) | lo);
+        return __builtin_amdgcn_make_buffer_rsrc(q, 0, __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
+    };
+    const __amdgpu_buffer_rsrc_t bs_rs_y = bs_srd(BNS ? a.bs_y : a.src, (long)a.M * a.DC * 4);
+    const __amdgpu_buffer_rsrc_t bs_rs_z = bs_srd(BNS && a.bs_z != nullptr ? a.bs_z : a.src, (long)a.M * a.DC * 4);
     const int mode_e = a.ksplit > 1 ? 2 : (a.accumulate ? 1 : 0);   // wave-uniform: hoisted out of the store loops
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -627,8 +645,54 @@ __global__ __launch_bounds__(256, PIPE == 3 ? 3 : 1) void conv_igemm_kernel(cons
         const bool n_ok = ncol < a.DC;
         const float bv = (MODE == 0 && a.bias != nullptr && n_ok) ? a.bias[ncol] : 0.f;
         float s1 = 0.f, s2 = 0.f;
+        float bs_m = 0.f, bs_i = 0.f, bs_sc = 0.f, bs_sh = 0.f;
+        if constexpr (bnsum) {
+            if (n_ok) {
+                bs_m = a.bs_mean[ncol]; bs_i = a.bs_invstd[ncol];
+                if (a.bs_z == nullptr) {
+                    if (a.bs_msc != nullptr) { bs_sc = a.bs_msc[ncol]; bs_sh = a.bs_msh[ncol]; }
+                    else bs_sh = 1.f;          // a layer without ReLU: every element counts
+                }
+            }
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            if constexpr (bnsum) {
+                // Two half-tiles of 8 rows: the producer's pre-BN output (and, for layers with a residual, its
+                // post-activation output) is fetched for a half-tile before the first dependent use.  One per-lane
+                // byte offset (row of this lane half, its column), the row inside the tile goes through the buffer
+                // instruction's scalar offset: no 64-bit address per load, and rows past the end of the tensor read 0.
+                const bool use_z = a.bs_z != nullptr;
+                const unsigned voff = n_ok ? (unsigned)(((m0 + (wm * TM + i) * 32 + 4 * lh) * a.DC + ncol) * 4) : 0xFFFFFFF0u;
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    float yv[8], zv[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int e = hh * 8 + q;
+                        const int soff = __builtin_amdgcn_readfirstlane(((e & 3) + 8 * (e >> 2)) * a.DC * 4);
+                        yv[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bs_rs_y, voff, soff, 0));
+                        zv[q] = use_z ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bs_rs_z, voff, soff, 0)) : 0.f;
+                    }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int e = hh * 8 + q;
+                        const int m = m0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                        if (m < Mloc && n_ok) {
+                            float *p = a.dst + (long)m * a.DC + ncol;
+                            float v = acc[i][j][e];
+                            if (mode_e == 1) v += *p;
+                            *p = v;
+                            const bool on = use_z ? zv[q] > 0.f : __builtin_fmaf(yv[q], bs_sc, bs_sh) > 0.f;
+                            const float d = on ? v : 0.f;
+                            s1 += d;
+                            s2 += d * ((yv[q] - bs_m) * bs_i);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                continue;
+            }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = (e & 3) + 8 * (e >> 2) + 4 * lh;
@@ -1213,6 +1277,21 @@ int launch_igemm(ConvArgs &a, int bn, bool scalar, int blocks, int gy, int gz, h
 #define IG(BNv, SCv, BKv, PIPEv)                                                                                     \
     launch(conv_igemm_kernel<BNv, MODE, SCv, BKv, PIPEv>, blocks,                                                    \
            PIPEv == 3 ? sizeof(float) * (BM + bn) * bk : (PIPEv == 2 ? igemm_lds(bn, MODE == 1, bk, 1) : lds), stream, a, name, gy, gz)
+    if constexpr (MODE == 0) {
+        if (a.bs_y != nullptr) {     // producer's BatchNorm-backward sums in the epilogue: vector kernels, K-step 32
+            const bool small = (long)a.N * a.SH * a.SW * a.SC * 4 < (1l << 31) && (long)a.wK * a.R * a.S * a.wC * 4 < (1l << 31);
+            RR_CHECK_ARG(!scalar && bk == 32, "conv: BatchNorm-backward sums need the vector kernels (C %% 4 == 0, RR_CONV_BK=32)");
+            if (bn == 128)
+                return conv_pipe() >= 1 && small
+                           ? launch(conv_igemm_kernel<128, 0, false, 32, 2, true>, blocks, igemm_lds(bn, false, bk, 1), stream, a, name, gy, gz)
+                           : launch(conv_igemm_kernel<128, 0, false, 32, 0, true>, blocks, lds, stream, a, name, gy, gz);
+            if (bn == 64)
+                return conv_pipe() >= 1 && small
+                           ? launch(conv_igemm_kernel<64, 0, false, 32, 2, true>, blocks, igemm_lds(bn, false, bk, 1), stream, a, name, gy, gz)
+                           : launch(conv_igemm_kernel<64, 0, false, 32, 0, true>, blocks, lds, stream, a, name, gy, gz);
+            return launch(conv_igemm_kernel<32, 0, false, 32, 0, true>, blocks, lds, stream, a, name, gy, gz);
+        }
+    }
     if (bk == 32) {
         // the pipelined kernel addresses both tensors through 32-bit buffer offsets
         const bool small = (long)a.N * a.SH * a.SW * a.SC * 4 < (1l << 31) && (long)a.wK * a.R * a.S * a.wC * 4 < (1l << 31);
@@ -1241,9 +1320,16 @@ extern "C" size_t rr_conv_stat_slab_bytes(int n, int p, int q, int k)
     return (size_t)((M + BM - 1) / BM) * 2 * k * sizeof(double);
 }
 
+// BatchNorm-backward sums of the producer of the tensor a stride-1 data gradient writes (see ConvArgs::bs_y)
+struct BnSumArgs {
+    const float *y, *z, *mean, *invstd, *msc, *msh;
+    double *slab;      // [ceil(M/128)][2][C] scratch
+    double *sums;      // [2][C], zeroed by the caller
+};
+
 static int fprop_impl(const float *x, const float *w, const float *bias, float *y, double *stat_slab,
                       int n, int h, int wd, int c, int k, int r, int s, int stride, int pad_h,
-                      int pad_w, int relu, int accumulate, hipStream_t stream)
+                      int pad_w, int relu, int accumulate, hipStream_t stream, const BnSumArgs *bs = nullptr)
 {
     RR_CHECK_ARG(n > 0 && h > 0 && wd > 0 && c > 0 && k > 0 && r > 0 && s > 0 && stride > 0, "rr_conv_fprop: bad dims");
     ConvArgs a{};
@@ -1268,7 +1354,15 @@ static int fprop_impl(const float *x, const float *w, const float *bias, float *
         a.ksplit = ks;
         if (!accumulate) hipMemsetAsync(y, 0, sizeof(float) * (size_t)M * k, stream);
     }
+    if (bs != nullptr && ks == 1) {      // sums in the epilogue; with split-K the complete values exist only afterwards
+        a.stat_slab = bs->slab;
+        a.bs_y = bs->y; a.bs_z = bs->z; a.bs_mean = bs->mean; a.bs_invstd = bs->invstd; a.bs_msc = bs->msc; a.bs_msh = bs->msh;
+    }
     int rc = launch_igemm<0>(a, bn, scalar, blocks, 1, ks, stream, "rr_conv_fprop");
+    if (rc == RR_OK && bs != nullptr) {
+        if (ks == 1) return rr_bn_reduce_slab(bs->slab, (int)rr_cdiv(M, BM), k, bs->sums, stream);
+        return rr_bn_bwd_reduce(y, bs->z, bs->y, bs->mean, bs->invstd, bs->msc, bs->msh, bs->sums, M, k, 1, stream);
+    }
     if (rc == RR_OK && ks > 1 && stat_slab != nullptr) {
         hipMemsetAsync(stat_slab, 0, rr_conv_stat_slab_bytes(n, a.DH, a.DW, k), stream);
         const int lanes = 256 / (k / 4);
@@ -1323,6 +1417,23 @@ extern "C" int rr_conv_dgrad_s1(const float *dy, const float *wt, float *dx, int
     // a stride-1 data gradient IS a forward convolution of dy with the flipped, transposed filter
     return fprop_impl(dy, wt, nullptr, dx, nullptr, n, p, q, k, c, r, s, 1, r - 1 - pad_h, s - 1 - pad_w, 0, accumulate,
                       stream);
+}
+
+extern "C" int rr_conv_dgrad_s1_bnsum(const float *dy, const float *wt, float *dx, int n, int h, int wd, int c, int k,
+                                      int r, int s, int pad_h, int pad_w, int accumulate, const float *prod_y,
+                                      const float *prod_z, const float *prod_mean, const float *prod_invstd,
+                                      const float *prod_mask_scale, const float *prod_mask_shift, double *slab,
+                                      double *sums, hipStream_t stream)
+{
+    RR_CHECK_ARG(pad_h < r && pad_w < s && pad_h >= 0 && pad_w >= 0, "rr_conv_dgrad_s1_bnsum: pad must be in [0, kernel)");
+    RR_CHECK_ARG(prod_y && prod_mean && prod_invstd && slab && sums && (!prod_mask_scale == !prod_mask_shift),
+                 "rr_conv_dgrad_s1_bnsum: the producer's y / mean / invstd and the two buffers are required");
+    RR_CHECK_ARG(c % 4 == 0 && c <= 1024, "rr_conv_dgrad_s1_bnsum: C=%d must be a multiple of 4 and <= 1024", c);
+    const int p = h + 2 * pad_h - r + 1, q = wd + 2 * pad_w - s + 1;
+    RR_CHECK_ARG(p > 0 && q > 0, "rr_conv_dgrad_s1_bnsum: empty dy");
+    const BnSumArgs bs{prod_y, prod_z, prod_mean, prod_invstd, prod_mask_scale, prod_mask_shift, slab, sums};
+    return fprop_impl(dy, wt, nullptr, dx, nullptr, n, p, q, k, c, r, s, 1, r - 1 - pad_h, s - 1 - pad_w, 0, accumulate,
+                      stream, &bs);
 }
 
 extern "C" int rr_conv_dgrad(const float *dy, const float *w, float *dx, int n, int h, int wd, int c, int k,

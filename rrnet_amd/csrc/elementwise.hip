@@ -223,7 +223,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(const f32x4 *d
                                                                   const float *gamma, const float *mscale, const float *mshift,
                                                                   const double *sums, double count_h,
                                                                   const double *count_d, f32x4 *dx, f32x4 *g_out,
-                                                                  float *dgamma, float *dbeta, long n4, int C)
+                                                                  float *dgamma, float *dbeta, long n4, int C, int g_acc)
 {
     const int C4 = C / 4;
     const double count = count_d ? *count_d : count_h;
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(const f32x4 *d
 #pragma unroll
             for (int e = 0; e < 4; ++e) g[e] = zz[e] > 0.f ? g[e] : 0.f;
         }
-        if (g_out) g_out[i] = g;
+        if (g_out) g_out[i] = g_acc ? g_out[i] + g : g;     // g_acc: the residual branch's fan-in buffer already holds a gradient
         const f32x4 mu = *reinterpret_cast<const f32x4 *>(mean + c), is = *reinterpret_cast<const f32x4 *>(invstd + c);
         const f32x4 ga = *reinterpret_cast<const f32x4 *>(gamma + c);
         const f32x4 xh = (yy - mu) * is;
@@ -674,18 +674,39 @@ extern "C" int rr_bn_bwd_reduce(const float *dz, const float *z, const float *y,
     return RR_OK;
 }
 
+static int bn_bwd_apply_impl(const float *dz, const float *z, const float *y, const float *mean,
+                             const float *invstd, const float *gamma, const float *mask_scale,
+                             const float *mask_shift, const double *sums, double count,
+                             const double *count_dev, float *dx, float *g_out, float *dgamma, float *dbeta,
+                             long total, int c, int g_acc, hipStream_t stream)
+{
+    RR_CHECK_ARG(c % 4 == 0 && total % c == 0, "rr_bn_bwd_apply: C=%d must be a multiple of 4", c);
+    const long n4 = total / 4;
+    EW_LAUNCH(bn_bwd_apply_kernel, n4, stream, (const f32x4 *)dz, (const f32x4 *)z, (const f32x4 *)y, mean, invstd, gamma,
+              mask_scale, mask_shift, sums, count, count_dev, (f32x4 *)dx, (f32x4 *)g_out, dgamma, dbeta, n4, c, g_acc);
+    RR_CHECK_LAUNCH("rr_bn_bwd_apply");
+    return RR_OK;
+}
+
 extern "C" int rr_bn_bwd_apply(const float *dz, const float *z, const float *y, const float *mean,
                                const float *invstd, const float *gamma, const float *mask_scale,
                                const float *mask_shift, const double *sums, double count,
                                const double *count_dev, float *dx, float *g_out, float *dgamma, float *dbeta,
                                long total, int c, hipStream_t stream)
 {
-    RR_CHECK_ARG(c % 4 == 0 && total % c == 0, "rr_bn_bwd_apply: C=%d must be a multiple of 4", c);
-    const long n4 = total / 4;
-    EW_LAUNCH(bn_bwd_apply_kernel, n4, stream, (const f32x4 *)dz, (const f32x4 *)z, (const f32x4 *)y, mean, invstd, gamma,
-              mask_scale, mask_shift, sums, count, count_dev, (f32x4 *)dx, (f32x4 *)g_out, dgamma, dbeta, n4, c);
-    RR_CHECK_LAUNCH("rr_bn_bwd_apply");
-    return RR_OK;
+    return bn_bwd_apply_impl(dz, z, y, mean, invstd, gamma, mask_scale, mask_shift, sums, count, count_dev, dx, g_out, dgamma,
+                             dbeta, total, c, 0, stream);
+}
+
+extern "C" int rr_bn_bwd_apply_gacc(const float *dz, const float *z, const float *y, const float *mean,
+                                    const float *invstd, const float *gamma, const float *mask_scale,
+                                    const float *mask_shift, const double *sums, double count,
+                                    const double *count_dev, float *dx, float *g_acc, float *dgamma, float *dbeta,
+                                    long total, int c, hipStream_t stream)
+{
+    RR_CHECK_ARG(g_acc != nullptr, "rr_bn_bwd_apply_gacc: the fan-in buffer is required");
+    return bn_bwd_apply_impl(dz, z, y, mean, invstd, gamma, mask_scale, mask_shift, sums, count, count_dev, dx, g_acc, dgamma,
+                             dbeta, total, c, 1, stream);
 }
 
 extern "C" int rr_relu_fwd(const float *x, float *out, long total, hipStream_t stream)

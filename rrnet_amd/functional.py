@@ -30,6 +30,7 @@ def _mark(*params):
             flat.mark_ready(p)
 
 
+_G_INTO = os.environ.get("RR_BN_G_INTO", "1") != "0"     # residual gradient added into the fan-in buffer by bn_bwd_apply itself
 BN_FUSED_STATS = os.environ.get("RR_BN_FUSED_STATS", "1") != "0"    # single process: slab -> statistics -> coefficients in one launch
 
 
@@ -44,8 +45,10 @@ class _ConvBnAct(torch.autograd.Function):
     backbones/resnet.py:33-53."""
 
     @staticmethod
-    def forward(ctx, x, w, gamma, beta, residual, bn, stride, pad, relu, x_acc=None, res_acc=None):
+    def forward(ctx, x, w, gamma, beta, residual, bn, stride, pad, relu, x_acc=None, res_acc=None, in_link=None,
+                out_link=None):
         ctx.accs = (x_acc, res_acc)
+        ctx.links = (in_link, out_link)
         x = ops.to_nhwc(x)
         wc = ops.to_nhwc(w)
         n, _, h, wd = x.shape
@@ -86,6 +89,11 @@ class _ConvBnAct(torch.autograd.Function):
             remask = relu and residual is None
             ctx.save_for_backward(x, wc, y, z if (relu and not remask) else None, mean, invstd, gamma, cnt_dev,
                                   scale if remask else None, shift if remask else None)
+            if out_link is not None:
+                # what a consumer's data gradient needs to produce this layer's BatchNorm-backward sums in its epilogue
+                out_link.y, out_link.mean, out_link.invstd = y, mean, invstd
+                out_link.z = z if (relu and not remask) else None
+                out_link.msc, out_link.msh = (scale, shift) if remask else (None, None)
         ctx.cfg = (stride, pad, relu, count, sync, residual is not None)
         ctx.params = (w, gamma, beta)
         ctx.xshape = tuple(x.shape)
@@ -98,7 +106,16 @@ class _ConvBnAct(torch.autograd.Function):
         w, gamma_p, beta_p = ctx.params
         dz = ops.to_nhwc(dz)
         k = y.shape[1]
-        sums = ops.bn_bwd_reduce(dz, z, y, mean, invstd, mask_scale=msc, mask_shift=msh)
+        in_link, out_link = ctx.links
+        sums = None
+        if out_link is not None and out_link.sums is not None:
+            # the data gradient that produced dz already reduced it (rr_conv_dgrad_s1_bnsum) — valid only if what
+            # arrives here is that very tensor (no other consumer's gradient was added on the way)
+            if out_link.dz is not None and out_link.dz.data_ptr() == dz.data_ptr() and out_link.dz.shape == dz.shape:
+                sums = out_link.sums
+            out_link.sums = out_link.dz = None
+        if sums is None:
+            sums = ops.bn_bwd_reduce(dz, z, y, mean, invstd, mask_scale=msc, mask_shift=msh)
         dg_t, db_t = _grad_target(gamma_p), _grad_target(beta_p)
         ret_dg = ret_db = None
         fused_affine = dg_t is not None and db_t is not None and not sync
@@ -114,18 +131,17 @@ class _ConvBnAct(torch.autograd.Function):
         if sync:
             dist.all_reduce(sums)
         want_g = has_res and relu
-        dy, g = ops.bn_bwd_apply(dz, z, y, mean, invstd, gamma, sums, count, want_g,
-                                 dg_t if fused_affine else None, db_t if fused_affine else None, cnt_dev, msc, msh)
         x_acc, res_acc = ctx.accs
+        # the residual's fan-in buffer already holds another consumer's gradient: add the masked gradient into it
+        # inside this kernel (no separate g tensor, no add pass)
+        g_into = res_acc.buf if (want_g and res_acc is not None and res_acc.buf is not None and ctx.needs_input_grad[4]
+                                 and _G_INTO) else None
+        dy, g = ops.bn_bwd_apply(dz, z, y, mean, invstd, gamma, sums, count, want_g,
+                                 dg_t if fused_affine else None, db_t if fused_affine else None, cnt_dev, msc, msh,
+                                 g_into=g_into)
         dx = None
         if ctx.needs_input_grad[0]:
-            if x_acc is not None and x_acc.buf is not None:
-                # another consumer of x already produced its gradient: add into it inside the dgrad epilogue
-                ops.conv_dgrad(dy, wc, ctx.xshape, stride, pad, out=x_acc.buf, accumulate=True)
-            else:
-                dx = ops.conv_dgrad(dy, wc, ctx.xshape, stride, pad)
-                if x_acc is not None:
-                    x_acc.buf = dx
+            dx = _input_grad(dy, wc, ctx.xshape, stride, pad, x_acc, in_link)
         w_t = _grad_target(w)
         ret_dw = None
         stem = (tuple(w.shape[1:]) == (3, 7, 7) and stride == 2 and tuple(pad) == (3, 3)
@@ -144,12 +160,32 @@ class _ConvBnAct(torch.autograd.Function):
         if has_res and ctx.needs_input_grad[4]:
             dres = g if relu else dz
             if res_acc is not None and relu:           # g is a fresh tensor of ours: it may serve as the fan-in target
+                res_acc.pending -= 1
                 if res_acc.buf is None:
                     res_acc.buf = g
                 else:
-                    res_acc.buf.add_(g)
+                    if g_into is None:
+                        res_acc.buf.add_(g)
                     dres = None
-        return dx, ret_dw, ret_dg, ret_db, dres, None, None, None, None, None, None
+        return dx, ret_dw, ret_dg, ret_db, dres, None, None, None, None, None, None, None, None
+
+
+def _input_grad(dy, wc, xshape, stride, pad, x_acc, in_link):
+    """Data gradient of a convolution node -> the tensor to hand to autograd (None when it was added into the fan-in
+    buffer of x's fan-out).  Where the launch can carry them it also produces the BatchNorm-backward sums of the layer
+    that produced x (ops.BnLink): when x has this node as its only consumer, or when this node is the LAST registered
+    contributor to the fan-in buffer of x's fan-out (the epilogue then holds the complete gradient)."""
+    if x_acc is None:
+        link = in_link if (in_link is not None and in_link.consumers == 1) else None
+        return ops.conv_dgrad(dy, wc, xshape, stride, pad, bnsum=link)
+    link = x_acc.link if x_acc.pending == 1 else None
+    x_acc.pending -= 1
+    if x_acc.buf is not None:
+        # another consumer of x already produced its gradient: add into it inside the dgrad epilogue
+        ops.conv_dgrad(dy, wc, xshape, stride, pad, out=x_acc.buf, accumulate=True, bnsum=link)
+        return None
+    x_acc.buf = ops.conv_dgrad(dy, wc, xshape, stride, pad, bnsum=link)
+    return x_acc.buf
 
 
 def conv_bn_act(x, conv, bn, relu=True, residual=None, x_acc=None, res_acc=None):
@@ -159,8 +195,22 @@ def conv_bn_act(x, conv, bn, relu=True, residual=None, x_acc=None, res_acc=None)
         x_acc = getattr(x, "_rr_acc", None)
     if res_acc is None and residual is not None:
         res_acc = getattr(residual, "_rr_acc", None)     # set only on raw fan-out views (identity skip)
-    return _ConvBnAct.apply(x, conv.weight, bn.weight, bn.bias, residual, bn, conv.stride[0], tuple(conv.padding), relu,
-                            x_acc, res_acc)
+    grad_on = torch.is_grad_enabled()
+    in_link = getattr(x, "_rr_bnlink", None) if x_acc is None else None
+    if grad_on and x.requires_grad:
+        # registered contributors of a fan-in buffer: the last one to run its backward may reduce the complete gradient
+        if x_acc is not None:
+            x_acc.pending += 1
+        elif in_link is not None:
+            in_link.consumers += 1
+    if grad_on and res_acc is not None and relu and residual.requires_grad:
+        res_acc.pending += 1
+    out_link = ops.BnLink() if (grad_on and bn.training) else None
+    out = _ConvBnAct.apply(x, conv.weight, bn.weight, bn.bias, residual, bn, conv.stride[0], tuple(conv.padding), relu,
+                           x_acc, res_acc, in_link, out_link)
+    if out_link is not None and out_link.y is not None:
+        out._rr_bnlink = out_link
+    return out
 
 
 class _ConvBias(torch.autograd.Function):
@@ -168,8 +218,9 @@ class _ConvBias(torch.autograd.Function):
     (detectors/centernet_detector.py:62,73,85-93; fasterrcnn_detector.py:17)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, stride, pad, relu, x_acc=None):
+    def forward(ctx, x, w, b, stride, pad, relu, x_acc=None, in_link=None):
         ctx.x_acc = x_acc
+        ctx.in_link = in_link
         x = ops.to_nhwc(x)
         wc = ops.to_nhwc(w)
         y = ops.conv_fprop(x, wc, b, stride, pad, relu)
@@ -197,13 +248,7 @@ class _ConvBias(torch.autograd.Function):
             dy = ops.sum_n([dy], y)
         dx = None
         if ctx.needs_input_grad[0]:
-            x_acc = ctx.x_acc
-            if x_acc is not None and x_acc.buf is not None:
-                ops.conv_dgrad(dy, wc, ctx.xshape, stride, pad, out=x_acc.buf, accumulate=True)
-            else:
-                dx = ops.conv_dgrad(dy, wc, ctx.xshape, stride, pad)
-                if x_acc is not None:
-                    x_acc.buf = dx
+            dx = _input_grad(dy, wc, ctx.xshape, stride, pad, ctx.x_acc, ctx.in_link)
         w_t = _grad_target(w)
         ret_dw = None
         if w_t is not None:
@@ -213,16 +258,27 @@ class _ConvBias(torch.autograd.Function):
             dw = ops.zeros_nhwc(*w.shape, device=x.device)
             ops.conv_wgrad(x, dy, dw, stride, pad)
             ret_dw = dw
-        return dx, ret_dw, ret_db, None, None, None, None
+        return dx, ret_dw, ret_db, None, None, None, None, None
+
+
+def _conv_bias_apply(x, weight, bias, stride, pad, relu):
+    x_acc = getattr(x, "_rr_acc", None)
+    in_link = getattr(x, "_rr_bnlink", None) if x_acc is None else None
+    if torch.is_grad_enabled() and x.requires_grad:
+        if x_acc is not None:
+            x_acc.pending += 1
+        elif in_link is not None:
+            in_link.consumers += 1
+    return _ConvBias.apply(x, weight, bias, stride, pad, relu, x_acc, in_link)
 
 
 def conv_bias(x, conv, relu=False):
-    return _ConvBias.apply(x, conv.weight, conv.bias, conv.stride[0], tuple(conv.padding), relu, getattr(x, "_rr_acc", None))
+    return _conv_bias_apply(x, conv.weight, conv.bias, conv.stride[0], tuple(conv.padding), relu)
 
 
 def conv_weight(x, weight, bias=None, stride=1, pad=(0, 0), relu=False):
     """_ConvBias on a bare weight tensor (e.g. one assembled from several parameters)."""
-    return _ConvBias.apply(x, weight, bias, stride, tuple(pad), relu, getattr(x, "_rr_acc", None))
+    return _conv_bias_apply(x, weight, bias, stride, tuple(pad), relu)
 
 
 class _WHShiftSum(torch.autograd.Function):
@@ -291,10 +347,12 @@ class GradAcc:
     fan-out's backward finds one complete gradient and launches no sum kernel.  The views a fan-out returns carry
     the accumulator as `_rr_acc`; convolution nodes pick it up from their input, and a nested fan-out of such a view
     (a residual block at the head of an hourglass branch) joins the same accumulator."""
-    __slots__ = ("buf",)
+    __slots__ = ("buf", "pending", "link")
 
     def __init__(self):
         self.buf = None
+        self.pending = 0        # registered contributors that have not run their backward yet
+        self.link = None        # ops.BnLink of the fanned-out tensor when a conv -> bn layer produced it
 
 
 def fanout_shared(x, n):
@@ -305,7 +363,10 @@ def fanout_shared(x, n):
     outs = _FanOut.apply(x, n)
     if not _SHARED_ACC:
         return outs + (None,)
-    acc = getattr(x, "_rr_acc", None) or GradAcc()
+    acc = getattr(x, "_rr_acc", None)
+    if acc is None:
+        acc = GradAcc()
+        acc.link = getattr(x, "_rr_bnlink", None)
     for o in outs:
         o._rr_acc = acc
     return outs + (acc,)

@@ -149,8 +149,26 @@ _DGRAD_VIA_FPROP = os.environ.get("RR_DGRAD_VIA_FPROP", "1") != "0"
 _DGRAD_VIA_FPROP_MIN_PIXELS = int(os.environ.get("RR_DGRAD_VIA_FPROP_MIN_PIXELS", "4096"))  # below: the dgrad kernel's split-K wins
 
 
-def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False):
-    """dy [N,K,P,Q], w [K,C,R,S] -> dx [N,C,H,W]; with `out` and accumulate adds into it."""
+class BnLink:
+    """What the data gradient of a convolution needs to ALSO produce the BatchNorm-backward sums of the conv -> bn
+    [-> +residual] -> relu layer that produced its input (rr_conv_dgrad_s1_bnsum): the producer's pre-BN output y, its
+    statistics, and the source of its ReLU mask (z for layers with a residual, scale / shift otherwise).  The consumer's
+    backward leaves `sums` (and the gradient tensor they were taken of) here; the producer's backward picks them up
+    instead of running rr_bn_bwd_reduce when the gradient it receives is that very tensor."""
+    __slots__ = ("y", "z", "mean", "invstd", "msc", "msh", "sums", "dz", "consumers")
+
+    def __init__(self):
+        self.y = self.z = self.mean = self.invstd = self.msc = self.msh = self.sums = self.dz = None
+        self.consumers = 0
+
+
+_DGRAD_BNSUM = os.environ.get("RR_DGRAD_BNSUM", "1") != "0"
+
+
+def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False, bnsum=None):
+    """dy [N,K,P,Q], w [K,C,R,S] -> dx [N,C,H,W]; with `out` and accumulate adds into it.
+    bnsum (BnLink of the layer that produced the convolution's input): when the launch can carry them, the producer's
+    BatchNorm-backward sums are computed in the epilogue and left in bnsum.sums / bnsum.dz."""
     _C.require_cuda(dy, w)
     assert is_nhwc(dy) and is_nhwc(w)
     n, c, h, wd = x_shape
@@ -167,6 +185,21 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False)
         wt = torch.empty(k * c * r * s, dtype=torch.float32, device=dy.device)
         _C.check(_C.fn("rr_weight_flip_transpose")(_C.ptr(w), _C.ptr(wt), k, c, r, s, _C.stream()),
                  "rr_weight_flip_transpose")
+        if (bnsum is not None and _DGRAD_BNSUM and bnsum.y is not None and c <= 1024 and out.numel() * 4 < (1 << 31)
+                and tuple(bnsum.y.shape) == tuple(out.shape)):
+            nb = _C.fn("rr_conv_stat_slab_bytes")(n, h, wd, c)
+            slab = torch.empty(nb // 8, dtype=torch.float64, device=dy.device)
+            sums = _ZEROS.take(2 * c, dy.device)
+            fb = _C.fn("rr_conv_dgrad_s1_bnsum")
+            _C.check(_timed(_igemm_name("fprop", c, False, n * h * wd) + "+bnsum", flops,
+                            lambda: fb(_C.ptr(dy), _C.ptr(wt), _C.ptr(out), n, h, wd, c, k, r, s, pad[0], pad[1],
+                                       int(accumulate), _C.ptr(bnsum.y), _C.ptr(bnsum.z), _C.ptr(bnsum.mean),
+                                       _C.ptr(bnsum.invstd), _C.ptr(bnsum.msc), _C.ptr(bnsum.msh), _C.ptr(slab),
+                                       _C.ptr(sums), _C.stream()), (n, h, wd, c, k, r, s, stride),
+                            4.0 * (dy.numel() + out.numel() * (3 if accumulate else 2) + w.numel())),
+                     "rr_conv_dgrad_s1_bnsum")
+            bnsum.sums, bnsum.dz = sums, out
+            return out
         f1 = _C.fn("rr_conv_dgrad_s1")
         # same HIP kernel instance as a forward convolution: timed under its name
         _C.check(_timed(_igemm_name("fprop", c, False, n * h * wd), flops,
@@ -208,7 +241,11 @@ def _f32(n, device):
 class _ZeroPool:
     """Pre-zeroed float64 scratch handed out in slices: the 163 BatchNorm layers of a step take their statistics
     accumulators from one zeroed chunk (one fill per ~1 MB) instead of one `torch.zeros` launch each.  A slice is
-    never handed out twice; exhausted chunks stay alive as long as their slices do."""
+    never handed out twice; exhausted chunks stay alive as long as their slices do.
+    A chunk belongs to the stream that was current when it was filled: a take() on another stream (the DCN backward's
+    side stream) gets its own chunk, so every slice is ordered behind its fill.  Slices are independent tensors over
+    the chunk's storage (own version counters): an in-place write into one does not invalidate siblings that
+    autograd saved."""
 
     CHUNK = 128 * 1024      # doubles
 
@@ -217,12 +254,12 @@ class _ZeroPool:
 
     def take(self, n, device):
         n8 = (n + 1) // 2 * 2                      # keep slices 16-byte aligned
-        key = (device.type, device.index)
+        key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
         cur = self.buf.get(key)
         if cur is None or cur[1] + n8 > cur[0].numel():
             cur = [torch.zeros(max(self.CHUNK, n8), dtype=torch.float64, device=device), 0]
             self.buf[key] = cur
-        out = cur[0][cur[1]:cur[1] + n]
+        out = torch.empty(0, dtype=torch.float64, device=device).set_(cur[0].untyped_storage(), cur[1], (n,))
         cur[1] += n8
         return out
 
@@ -294,11 +331,16 @@ def bn_bwd_reduce(dz, z, y, mean, invstd, extra=0, mask_scale=None, mask_shift=N
 
 
 def bn_bwd_apply(dz, z, y, mean, invstd, gamma, sums, count, want_g=False, dgamma=None, dbeta=None, count_dev=None,
-                 mask_scale=None, mask_shift=None):
+                 mask_scale=None, mask_shift=None, g_into=None):
+    """-> (dx, g).  g_into: an existing gradient buffer of y's shape that the masked gradient is ADDED to (returned as g)."""
     n, c, h, w = y.shape
     dx = empty_nhwc(n, c, h, w, y.device)
-    g = empty_nhwc(n, c, h, w, y.device) if want_g else None
-    _C.check(_C.fn("rr_bn_bwd_apply")(_C.ptr(dz), _C.ptr(z), _C.ptr(y), _C.ptr(mean), _C.ptr(invstd), _C.ptr(gamma),
+    if g_into is not None:
+        assert is_nhwc(g_into) and g_into.shape == y.shape
+        g = g_into
+    else:
+        g = empty_nhwc(n, c, h, w, y.device) if want_g else None
+    _C.check(_C.fn("rr_bn_bwd_apply_gacc" if g_into is not None else "rr_bn_bwd_apply")(_C.ptr(dz), _C.ptr(z), _C.ptr(y), _C.ptr(mean), _C.ptr(invstd), _C.ptr(gamma),
                                       _C.ptr(mask_scale), _C.ptr(mask_shift), _C.ptr(sums), float(count), _C.ptr(count_dev), _C.ptr(dx), _C.ptr(g), _C.ptr(dgamma), _C.ptr(dbeta),
                                       y.numel(), c, _C.stream()), "rr_bn_bwd_apply")
     return dx, g

@@ -167,9 +167,27 @@ def audit(tol=2e-5, tol_wgrad=2e-4, sample=False):
                 rec.note("fprop_stats", sig, max(e1, _rel(sums[k:2 * k], s2)), tol)
         return out
 
-    def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False):
+    def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False, bnsum=None):
         base = out.clone() if (out is not None and accumulate) else None
-        res = orig["conv_dgrad"](dy, w, x_shape, stride, pad, out, accumulate)
+        res = orig["conv_dgrad"](dy, w, x_shape, stride, pad, out, accumulate, bnsum)
+        if bnsum is not None and bnsum.sums is not None and bnsum.dz is res:
+            # the producer's BatchNorm-backward sums from the epilogue: compare with fp64 sums over the whole of the
+            # gradient this launch left in memory (the gradient itself is checked below)
+            bsig = (tuple(res.shape), bnsum.z is not None, bnsum.msc is not None, bool(accumulate))
+            if ("dgrad_bnsum",) + bsig not in rec.seen:
+                c = res.shape[1]
+                s1, s2, a1, a2 = (torch.zeros(c, dtype=torch.float64) for _ in range(4))
+                for i in range(res.shape[0]):
+                    d = _masked(res[i:i + 1], None if bnsum.z is None else bnsum.z[i:i + 1], bnsum.y[i:i + 1], bnsum.msc,
+                                bnsum.msh)
+                    xh = (_c64(bnsum.y[i:i + 1]) - _V(bnsum.mean)) * _V(bnsum.invstd)
+                    s1 += d.sum((0, 2, 3)); a1 += d.abs().sum((0, 2, 3))
+                    d = d * xh
+                    s2 += d.sum((0, 2, 3)); a2 += d.abs().sum((0, 2, 3))
+                o = bnsum.sums.cpu()
+                e1 = float((o[:c] - s1).abs().max() / max(float(a1.max()), 1e-30))
+                e2 = float((o[c:2 * c] - s2).abs().max() / max(float(a2.max()), 1e-30))
+                rec.note("dgrad_bnsum", bsig, max(e1, e2), tol)
         sig = (tuple(dy.shape), tuple(w.shape), tuple(x_shape), stride, tuple(pad), bool(accumulate))
         flops = 2.0 * dy.numel() * w.shape[1] * w.shape[2] * w.shape[3]
         if ("dgrad",) + sig not in rec.seen and big(flops):
@@ -280,11 +298,13 @@ def audit(tol=2e-5, tol_wgrad=2e-4, sample=False):
         return out
 
     def bn_bwd_apply(dz, z, y, mean, invstd, gamma, sums, count, want_g=False, dgamma=None, dbeta=None, count_dev=None,
-                     mask_scale=None, mask_shift=None):
+                     mask_scale=None, mask_shift=None, g_into=None):
+        sig = (tuple(y.shape), z is not None, mask_scale is not None, want_g, g_into is not None)
+        todo = ("bn_bwd_apply",) + sig not in rec.seen and count_dev is None
+        gbase = g_into.clone() if (g_into is not None and todo) else None
         out = orig["bn_bwd_apply"](dz, z, y, mean, invstd, gamma, sums, count, want_g, dgamma, dbeta, count_dev,
-                                   mask_scale, mask_shift)
-        sig = (tuple(y.shape), z is not None, mask_scale is not None, want_g)
-        if ("bn_bwd_apply",) + sig not in rec.seen and count_dev is None:
+                                   mask_scale, mask_shift, g_into)
+        if todo:
             ns = _img_sample(y.shape[0]) if big_elems(y) else list(range(y.shape[0]))
             if big_elems(y):
                 rec.sampled.add(("bn_bwd_apply",) + sig)
@@ -294,7 +314,7 @@ def audit(tol=2e-5, tol_wgrad=2e-4, sample=False):
             ref = _V(gamma) * _V(invstd) * (d - _V(sums[:c]) / count - xh * _V(sums[c:2 * c]) / count)
             e = float((_c64(out[0][ns]) - ref).abs().max() / max(float((_V(gamma) * _V(invstd) * d).abs().max()), 1e-30))
             if want_g:
-                e = max(e, _rel(out[1][ns], d))
+                e = max(e, _rel(out[1][ns], d if gbase is None else d + _c64(gbase[ns])))
             rec.note("bn_bwd_apply", sig, e, tol)
         return out
 

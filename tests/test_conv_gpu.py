@@ -146,3 +146,94 @@ def test_bias_relu_bwd_column_sums(npix, c, relu):
     ref = want.double().sum(0) + db0.double()
     tol = 1e-6 * want.abs().double().sum(0).max().item() + 1e-6
     assert (db.double() - ref).abs().max().item() <= tol
+
+
+# (N, C = producer's channels, H, W, K = dy channels, R, pad, mask source, accumulate)
+BNSUM_CASES = [
+    (2, 256, 64, 64, 256, 3, 1, "scale", False),      # conv1 -> bn1 -> relu -> conv2: the common case, 128x128 tiles
+    (2, 256, 64, 64, 256, 3, 1, "z", True),           # block output (residual): mask from z, last contributor of a fan-in
+    (2, 256, 64, 64, 384, 1, 0, "z", True),           # projection skip 1x1 as the last contributor
+    (1, 64, 64, 96, 128, 3, 1, "scale", False),       # 64 producer channels: 128x64 tiles
+    (1, 32, 64, 64, 64, 3, 1, "none", False),         # 32 channels: 128x32 tiles; producer without ReLU
+    (1, 384, 64, 64, 384, 3, 1, "scale", False),      # under-filled -> split-K: the entry falls back to a reduce pass
+    (3, 256, 65, 67, 256, 3, 1, "z", False),          # ragged: M not a multiple of 128
+]
+
+
+@pytest.mark.parametrize("cfg", BNSUM_CASES, ids=lambda c: "n%dc%dh%dw%dk%dr%dp%d_%s_acc%d" % c)
+def test_dgrad_with_producer_bn_backward_sums(cfg):
+    """rr_conv_dgrad_s1_bnsum: the stride-1 data gradient whose epilogue also reduces the producer's BatchNorm-backward
+    sums == rr_conv_dgrad_s1 followed by rr_bn_bwd_reduce on its output (and both against an fp64 host evaluation)."""
+    from rrnet_amd import ops
+    n, c, h, w, k, r, pad, mask, acc = cfg
+    g = torch.Generator().manual_seed(sum(cfg[:7]))
+    dy = ops.to_nhwc(torch.randn(n, k, h, w, generator=g).cuda())
+    wt = ops.to_nhwc((torch.randn(k, c, r, r, generator=g) / np.sqrt(k * r * r)).cuda())
+    y = ops.to_nhwc(torch.randn(n, c, h, w, generator=g).cuda())
+    res = ops.to_nhwc(torch.randn(n, c, h, w, generator=g).cuda())
+    mean, var = torch.randn(c, generator=g).cuda() * 0.1, (torch.rand(c, generator=g).cuda() + 0.5)
+    invstd = 1.0 / torch.sqrt(var)
+    scale, shift = (torch.rand(c, generator=g).cuda() + 0.5) * invstd, torch.randn(c, generator=g).cuda() * 0.3
+    link = ops.BnLink()
+    link.y, link.mean, link.invstd = y, mean, invstd
+    if mask == "z":
+        link.z = torch.relu(y * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1) + res).contiguous(memory_format=torch.channels_last)
+    elif mask == "scale":
+        link.msc, link.msh = scale, shift
+    base = ops.to_nhwc(torch.randn(n, c, h, w, generator=g).cuda()) if acc else None
+    out_a = base.clone() if acc else None
+    out_b = base.clone() if acc else None
+    dx_ref = ops.conv_dgrad(dy, wt, (n, c, h, w), 1, (pad, pad), out=out_a, accumulate=acc)
+    sums_ref = ops.bn_bwd_reduce(dx_ref, link.z, y, mean, invstd, mask_scale=link.msc, mask_shift=link.msh)
+    dx = ops.conv_dgrad(dy, wt, (n, c, h, w), 1, (pad, pad), out=out_b, accumulate=acc, bnsum=link)
+    assert link.sums is not None and link.dz is dx
+    assert torch.equal(dx, dx_ref)                                     # same kernel arithmetic, same stores
+    d = dx.double()
+    if mask == "z":
+        d = d * (link.z > 0)
+    elif mask == "scale":
+        d = d * (torch.addcmul(shift.view(1, -1, 1, 1), y, scale.view(1, -1, 1, 1)) > 0)
+    xh = (y.double() - mean.double().view(1, -1, 1, 1)) * invstd.double().view(1, -1, 1, 1)
+    exp = torch.cat([d.sum((0, 2, 3)), (d * xh).sum((0, 2, 3))])
+    mag = torch.cat([d.abs().sum((0, 2, 3)), (d * xh).abs().sum((0, 2, 3))]).max().item()
+    assert (link.sums[:2 * c] - exp).abs().max().item() <= 2e-6 * mag, (link.sums[:2 * c] - exp).abs().max().item() / mag
+    assert (sums_ref[:2 * c] - exp).abs().max().item() <= 2e-6 * mag
+
+
+def test_train_step_gradients_equal_with_and_without_fused_bn_sums():
+    """A tiny hourglass train step with the fused producer sums (default) and with RR_DGRAD_BNSUM / RR_BN_G_INTO off:
+    same losses, same flat gradient up to summation order; the fused path really ran (bn_bwd_reduce launches drop)."""
+    from types import SimpleNamespace
+    from rrnet_amd import functional as RF, ops
+    from rrnet_amd.datasets.synthetic import synth_batch
+    from rrnet_amd.flat import FlatParams
+    from rrnet_amd.models.rrnet import RRNet
+    cfg = SimpleNamespace(num_classes=10, Model=SimpleNamespace(num_stacks=2, backbone="hourglass_tiny",
+                          nms_type_for_stage1="nms", nms_per_class_for_stage1=True))
+    batch = synth_batch(2, 512, 512, boxes_per_image=12)
+    grads, counts = {}, {}
+    saved = (ops._DGRAD_BNSUM, RF._G_INTO, ops.bn_bwd_reduce)
+    try:
+        for fused in (True, False):
+            ops._DGRAD_BNSUM, RF._G_INTO = fused, fused
+            calls = [0]
+
+            def counting(*a, _f=saved[2], **kw):
+                calls[0] += 1
+                return _f(*a, **kw)
+            ops.bn_bwd_reduce = counting
+            torch.manual_seed(219)
+            model = RRNet(cfg).cuda().to(memory_format=torch.channels_last).train()
+            flat = FlatParams(model)
+            imgs, annos, hms, whs, inds, offs, masks, _ = batch
+            outs = model(imgs, k=100)
+            loss = sum(RF.focal_loss_hm_from_logits(outs[0][i], hms) + RF.reg_l1_loss(outs[1][i], masks, inds, whs)
+                       + RF.reg_l1_loss(outs[2][i], masks, inds, offs) for i in range(2))
+            loss.backward()
+            torch.cuda.synchronize()
+            grads[fused], counts[fused] = flat.grad.clone(), calls[0]
+    finally:
+        ops._DGRAD_BNSUM, RF._G_INTO, ops.bn_bwd_reduce = saved
+    assert counts[True] < counts[False], counts          # some reduce passes disappeared
+    scale = grads[False].abs().max().item()
+    assert (grads[True] - grads[False]).abs().max().item() <= 1e-4 * scale, ((grads[True] - grads[False]).abs().max().item(), scale)
