@@ -82,25 +82,27 @@ def _cpu_step(seed, size, k):
 
 def cpu_baseline(seed, k=100, budget_s=150.0):
     """The oracle ("port": torch-CPU restatement of the reference graph, oracle/model.py + ops.py) running the
-    hourglass-104 RRNet train step INCLUDING the Adam update on this box's host cores.  Measured: 512x512 frame, one
-    warm-up then the mean of two timed steps; conv FLOPs scale with the pixel count, so images/sec at 1024^2 =
-    1 / (t_512 * 4).  If the 512x512 runs leave room in the time budget, one real 1024x1024 step is timed too and
-    reported next to the extrapolation (`value` is the measured one when present)."""
+    hourglass-104 RRNet train step INCLUDING the Adam update on this box's host cores.  `value` is the WARM figure:
+    512x512 frame, one warm-up (allocator, oneDNN primitive cache, page faults) then the mean of two timed steps; conv
+    FLOPs scale with the pixel count, so images/sec at 1024^2 = 1 / (t_512 * 4).  It reproduces within a few percent
+    from box to box.  If the budget allows, one real 1024x1024 step is timed as well — a single COLD run (first touch
+    of 4x larger buffers), reported as `t_1024_cold_s` / `images_per_sec_1024_cold` next to it, never as `value`
+    (it moved by +-34 % between boxes in round 2)."""
     t_start = time.perf_counter()
     threads = torch.get_num_threads()
     t512, all512 = _cpu_step(seed, 512, k)
     out = {"value": round(1.0 / (t512 * 4.0), 5), "unit": "images/sec", "cores": threads, "kind": "port",
            "torch_num_threads": threads, "host_cpus": os.cpu_count(),
-           "t_512_s": [round(t, 2) for t in all512], "images_per_sec_from_512": round(1.0 / (t512 * 4.0), 5)}
+           "t_512_s": [round(t, 2) for t in all512]}
     sample = ("oracle torch-CPU RRNet hourglass-104 train step (fwd+losses+bwd+Adam), 1 frame 512x512, k=%d, %d threads: "
-              "warm-up %.2f s, timed %.2f / %.2f s, their mean scaled x4 (conv-FLOP ratio) to 1024x1024"
+              "warm-up %.2f s, timed %.2f / %.2f s, their mean scaled x4 (conv-FLOP ratio) to 1024x1024 -> value"
               % (k, threads, all512[0], all512[1], all512[2]))
     spent = time.perf_counter() - t_start
     if spent + 6.0 * t512 < budget_s:                  # a cold 1024^2 step costs ~4x a warm 512^2 one + warm-up effects
         t1024 = _cpu_step(seed, 1024, k)
-        out["t_1024_s"] = round(t1024, 2)
-        out["value"] = round(1.0 / t1024, 5)
-        sample += "; one real 1024x1024 frame (cold): %.2f s -> value" % t1024
+        out["t_1024_cold_s"] = round(t1024, 2)
+        out["images_per_sec_1024_cold"] = round(1.0 / t1024, 5)
+        sample += "; one real 1024x1024 frame, cold, single run: %.2f s (reported beside, not as value)" % t1024
     out["sample"] = sample
     return out
 
@@ -194,6 +196,8 @@ def main():
         timer = ops.KernelTimer(None if a.detail else {"conv_fprop<BN=128,vec4>"})
         ops.TIMER = timer
     sync_all()
+    from rrnet_amd import dptrace
+    dptrace.reset()
     ops.SYNC_WAIT_S = 0.0
     host_s = 0.0
     t0 = time.perf_counter()
@@ -264,6 +268,11 @@ def main():
                 conv_ms = sum(v["ms"] for v in summ.values())
                 out["conv_time_fraction"] = round(conv_ms / (elapsed * 1e3), 4)
         out["host_enqueue_ms_per_step"] = round(host_enqueue_ms, 2)
+        # collectives issued per step and rank, by communicator (rrnet_amd/dptrace.py): SyncBN statistic exchanges on
+        # the default one, gradient buckets on their own; 0 at N=1
+        cc = dptrace.counts()
+        out["collectives_per_step"] = {"total": round(sum(cc.values()) / a.steps, 1),
+                                       **{k: round(v / a.steps, 1) for k, v in sorted(cc.items())}}
         if a.backbone == "hourglass" and a.size == 1024:
             out["step_mfma_frac"] = round(out["value"] / world * ALGO_TFLOP_PER_IMAGE / FP32_MFMA_PEAK_TFLOPS, 4)
         if world == 1 and not a.no_extras:

@@ -350,7 +350,10 @@ int rr_dcn_col2im(const float *x, const float *offset, const float *mask, const 
  * (rr_dcn_fused_bwd_supported == 0) go through the column path above. */
 /* 1 when rr_dcn_wgrad / rr_dcn_dgrad (and their _bf16 forms) take a layer of this shape, 0 when the host layer has to
  * run the column path (rr_dcn_im2col / rr_dcn_col2im + the conv GEMMs). */
-int rr_dcn_fused_bwd_supported(int c, int k, int r, int s, int stride, int deformable_groups);
+int rr_dcn_fused_bwd_supported(int c, int k, int r, int s, int stride, int deformable_groups);      /* dilation 1 */
+/* The same query with the dilation: deformable groups of 32 / 64 / 96 channels exist on the LDS-window kernels only, and a
+ * dilated filter's window may not fit (3x3 with dilation >= 3: the data-gradient window exceeds 160 KB). */
+int rr_dcn_fused_bwd_supported_dil(int c, int k, int r, int s, int stride, int dilation, int deformable_groups);
 int rr_dcn_wgrad(const float *x, const float *offset, const float *mask, const float *dy, float *dw, int n, int h,
                  int wd, int c, int k, int r, int s, int stride, int pad_h, int pad_w, int dilation,
                  int deformable_groups, hipStream_t stream);
@@ -380,7 +383,8 @@ int rr_dcn_split_bwd(const float *doffset, const float *dmask, const float *mask
 /* ---- deformable PS-RoI pooling (ext/dcn/src/cuda/dcn_v2_psroi_pooling_cuda.cu:59-290; dcn_v2.py:130-300) ------ *
  * x NHWC [b,h,w,c], c = output_dim * group_size^2; rois [n,5] = (image, x1,y1,x2,y2); trans NCHW
  * [n, trans_channels = 2*num_classes, part, part] (ignored when no_trans); out / count NHWC [n, pooled, pooled,
- * output_dim].  Backward: dx (zeroed inside, float atomics) and dtrans (zeroed inside unless no_trans). */
+ * output_dim].  Backward: dx (zeroed inside, float atomics) and dtrans (REQUIRED unless no_trans; zeroed inside).
+ * A RoI whose image index is negative (backward: or >= b, the batch size it is told) pools nothing: out = count = 0. */
 int rr_dcn_psroi_fwd(const float *x, const float *rois, const float *trans, int n, int h, int w, int c,
                      int no_trans, float spatial_scale, int output_dim, int group_size, int pooled_size,
                      int part_size, int sample_per_part, float trans_std, int trans_channels, float *out,

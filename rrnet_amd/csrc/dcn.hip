@@ -1965,6 +1965,25 @@ static int dcn_wgrad_plain(const float *x, const float *offset, const float *mas
 }
 
 // Window kernel for either operand precision; returns -1 when the layer does not qualify (caller takes dcn_wgrad_kernel).
+// LDS footprint of the window kernels for a margin of m pixels (0: the window does not fit with any margin >= 1)
+static size_t dcn_wgrad_win_lds(int r, int s, int dilation, int m)
+{
+    const int npx = (WIN_TH + (r - 1) * dilation + 2 * m + 1) * (WIN_TW + (s - 1) * dilation + 2 * m + 1);
+    return sizeof(float) * (size_t)(npx * 32 + BM * r * s * 4) + sizeof(unsigned short) * (size_t)((256 + r * s * 32) * 72);
+}
+
+static size_t dcn_dgrad_win_lds(int r, int s, int dilation, int m)
+{
+    const int npx = (WIN_TH + (r - 1) * dilation + 2 * m + 1) * (WIN_TW + (s - 1) * dilation + 2 * m + 1);
+    return sizeof(float) * (size_t)(((npx * 33 + 3) & ~3) + BM * r * s * 7 + npx * 32) +
+           sizeof(unsigned short) * (BM * LDKH + r * s * 32 * LDKH);
+}
+
+static bool dcn_win_fits(bool dgrad, int r, int s, int dilation)
+{
+    return (dgrad ? dcn_dgrad_win_lds(r, s, dilation, 1) : dcn_wgrad_win_lds(r, s, dilation, 1)) <= 160 * 1024 - 512;
+}
+
 static int dcn_wgrad_win(const float *x, const float *offset, const float *mask, const float *dy, float *dw, int n, int h,
                          int wd, int c, int k, int r, int s, int stride, int pad_h, int pad_w, int dilation,
                          int deformable_groups, int bf16, hipStream_t stream)
@@ -1983,8 +2002,7 @@ static int dcn_wgrad_win(const float *x, const float *offset, const float *mask,
             wb.w.RW = m;
             wb.w.WH = WIN_TH + (r - 1) * dilation + 2 * m + 1;
             wb.w.WW = WIN_TW + (s - 1) * dilation + 2 * m + 1;
-            const int npx = wb.w.WH * wb.w.WW;
-            ldsw = sizeof(float) * (size_t)(npx * 32 + BM * r * s * 4) + sizeof(unsigned short) * (size_t)((256 + r * s * 32) * 72);
+            ldsw = dcn_wgrad_win_lds(r, s, dilation, m);
             if (ldsw <= 160 * 1024 - 512) break;
         }
         if (ldsw <= 160 * 1024 - 512) {
@@ -2016,12 +2034,21 @@ static int dcn_wgrad_plain(const float *x, const float *offset, const float *mas
 // 1 when rr_dcn_wgrad / rr_dcn_dgrad take this layer (the host layer runs the column path otherwise): K % 4 == 0 and
 // the deformable groups either span whole 128-channel tiles (L2-gather kernels) or the window kernels apply (3x3,
 // stride 1, C % 32 == 0, groups of a multiple of 32 channels).
+extern "C" int rr_dcn_fused_bwd_supported_dil(int c, int k, int r, int s, int stride, int dilation, int deformable_groups)
+{
+    if (c <= 0 || k <= 0 || deformable_groups <= 0 || c % deformable_groups != 0 || k % 4 != 0 || c % 4 != 0 || dilation <= 0)
+        return 0;
+    const int cpg = c / deformable_groups;
+    if (deformable_groups == 1 || cpg % 128 == 0) return 1;     // the L2-gather kernels take these whatever the window does
+    // smaller groups exist on the window kernels only: BOTH of them must fit their LDS windows with a margin >= 1
+    // (a 3x3 filter with dilation >= 3 does not: rr_dcn_dgrad would drop to the L2-gather kernel and refuse the groups)
+    return dcn_win_margin() > 0 && stride == 1 && r * s == 9 && c % 32 == 0 && cpg % 32 == 0 &&
+           dcn_win_fits(false, r, s, dilation) && dcn_win_fits(true, r, s, dilation);
+}
+
 extern "C" int rr_dcn_fused_bwd_supported(int c, int k, int r, int s, int stride, int deformable_groups)
 {
-    if (c <= 0 || k <= 0 || deformable_groups <= 0 || c % deformable_groups != 0 || k % 4 != 0 || c % 4 != 0) return 0;
-    const int cpg = c / deformable_groups;
-    if (deformable_groups == 1 || cpg % 128 == 0) return 1;
-    return dcn_win_margin() > 0 && stride == 1 && r * s == 9 && c % 32 == 0 && cpg % 32 == 0;
+    return rr_dcn_fused_bwd_supported_dil(c, k, r, s, stride, 1, deformable_groups);
 }
 
 extern "C" int rr_dcn_wgrad_bf16(const float *x, const float *offset, const float *mask, const float *dy, float *dw, int n, int h,
@@ -2069,9 +2096,7 @@ static int dcn_dgrad_impl(const float *x, const float *offset, const float *mask
             wb.w.RW = m;
             wb.w.WH = WIN_TH + (r - 1) * dilation + 2 * m + 1;
             wb.w.WW = WIN_TW + (s - 1) * dilation + 2 * m + 1;
-            const int npx = wb.w.WH * wb.w.WW;
-            ldsw = sizeof(float) * (size_t)(((npx * 33 + 3) & ~3) + BM * r * s * 7 + npx * 32) +
-                   sizeof(unsigned short) * (BM * LDKH + r * s * 32 * LDKH);
+            ldsw = dcn_dgrad_win_lds(r, s, dilation, m);
             if (ldsw <= 160 * 1024 - 512) break;
         }
         if (r * s == 9 && ldsw <= 160 * 1024 - 512) {

@@ -80,7 +80,11 @@ __global__ __launch_bounds__(256, 2) void head_tail_kernel(const float *h, const
 #pragma unroll
             for (int e = 0; e < 16; ++e)
                 st[((e & 3) + 8 * (e >> 2) + 4 * lh) * ST_LD + j * 32 + lr] = acc[j][e] * sc[j] + sh[j];
-        // (a wave's own LDS traffic is ordered: no barrier between its store and its reads)
+        // the wave reads back, in another layout, what its own lanes just stored: the hardware orders a wave's LDS
+        // traffic, the fence + wave barrier tell the COMPILER that these stores and the loads below conflict
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         // a lane walks 8 consecutive rows and keeps the running sum of the current RoI in registers: one LDS add per
         // RoI change instead of one per row (and no four-lanes-one-address conflicts)
         f32x4 run = z4;
@@ -104,6 +108,9 @@ __global__ __launch_bounds__(256, 2) void head_tail_kernel(const float *h, const
             for (int c = 0; c < 4; ++c) run[c] += fmaxf(y[c] + rv[s8][c], 0.f);
         }
         flush();
+        // the next sub-tile's stores must not move above this sub-tile's loads of `st`
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
     const float inv = 1.f / (float)HW;

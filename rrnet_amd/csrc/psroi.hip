@@ -20,6 +20,7 @@ struct PsArgs {
     const float *x, *rois, *trans;
     int N, H, W, C, P, out_dim, gs, part, spp, no_trans, num_classes, ch_per_class;
     float scale, trans_std;
+    int batch;     // images in x when known (backward): RoIs naming an image outside [0, batch) are skipped; 0 = only < 0 is
 };
 
 struct Bin {
@@ -67,6 +68,11 @@ __global__ void psroi_fwd_kernel(const PsArgs a, float *out, float *count_out)
         const int ph = (int)(r % a.P);
         const int n = (int)(r / a.P);
         const Bin bn = make_bin(a, n, ctop, ph, pw);
+        if (bn.b < 0 || (a.batch > 0 && bn.b >= a.batch)) {       // a RoI that names no image of the batch
+            out[idx] = 0.f;
+            count_out[idx] = 0.f;
+            continue;
+        }
         const float *img = a.x + (long)bn.b * a.H * a.W * a.C + bn.c;
         float sum = 0.f;
         int cnt = 0;
@@ -99,6 +105,7 @@ __global__ void psroi_bwd_kernel(const PsArgs a, const float *dout, const float 
         const int n = (int)(r / a.P);
         if (count[idx] <= 0.f) continue;
         const Bin bn = make_bin(a, n, ctop, ph, pw);
+        if (bn.b < 0 || (a.batch > 0 && bn.b >= a.batch)) continue;
         const float diff = dout[idx] / count[idx];
         const long base = (long)bn.b * a.H * a.W * a.C + bn.c;
         float gx = 0.f, gy = 0.f;
@@ -176,9 +183,17 @@ extern "C" int rr_dcn_psroi_bwd(const float *dout, const float *x, const float *
                         sample_per_part, trans_std, trans_channels);
     if (rc != RR_OK) return rc;
     RR_CHECK_ARG(b > 0, "rr_dcn_psroi_bwd: bad batch");
-    hipMemsetAsync(dx, 0, sizeof(float) * (size_t)b * h * w * c, stream);
-    if (!no_trans && dtrans)
-        hipMemsetAsync(dtrans, 0, sizeof(float) * (size_t)n * trans_channels * part_size * part_size, stream);
+    RR_CHECK_ARG(no_trans || dtrans != nullptr, "rr_dcn_psroi_bwd: dtrans is required unless no_trans is set");
+    a.batch = b;
+    if (hipMemsetAsync(dx, 0, sizeof(float) * (size_t)b * h * w * c, stream) != hipSuccess) {
+        rr_set_error("rr_dcn_psroi_bwd: clearing dx failed");
+        return RR_ERR_LAUNCH;
+    }
+    if (!no_trans &&
+        hipMemsetAsync(dtrans, 0, sizeof(float) * (size_t)n * trans_channels * part_size * part_size, stream) != hipSuccess) {
+        rr_set_error("rr_dcn_psroi_bwd: clearing dtrans failed");
+        return RR_ERR_LAUNCH;
+    }
     const long total = (long)n * pooled_size * pooled_size * output_dim;
     if (total == 0) return RR_OK;
     long blocks = (total + 255) / 256;

@@ -1,0 +1,43 @@
+"""Collective bookkeeping of the data-parallel path (operators/distributed_wrapper.py:41-43 / DDP + SyncBatchNorm in
+the reference issue their collectives implicitly; here every one is an explicit call and is counted).
+
+Two communicators are in use when world_size > 1: the default one (SyncBN statistic exchanges, enqueued in program
+order from the forward / backward nodes) and the gradient buckets' own one (rrnet_amd.flat, launched from the backward
+nodes the moment a bucket is complete).  RCCL requires that every rank issues the SAME sequence of collectives on each
+communicator; a rank-dependent sequence (a layer skipped on one rank, a bucket launched in a different order) is a
+hang on real hardware, not a wrong number.  `RR_DP_TRACE=1` records, per rank, the sequence of
+(communicator, op, element count) of everything issued plus the `mark_ready` reports of the parameters, so that a
+2-rank test on one box can assert what would otherwise only show up as a hang on an 8-GPU node
+(tests/test_dp_gpu.py::test_two_rank_collective_sequences_are_identical).  The counters are always on (two integer
+adds per collective): bench.py reports `collectives_per_step`."""
+import os
+
+ENABLED = os.environ.get("RR_DP_TRACE", "0") == "1"
+EVENTS = []                 # (communicator, op, numel, note)
+COUNTS = {}                 # communicator -> collectives issued since the last reset()
+
+
+def record(comm, op, numel, note=""):
+    COUNTS[comm] = COUNTS.get(comm, 0) + 1
+    if ENABLED:
+        EVENTS.append((comm, op, int(numel), note))
+
+
+def mark(note):
+    """A non-collective event whose position in the sequence matters (a parameter's gradient reported complete)."""
+    if ENABLED:
+        EVENTS.append(("-", "mark", 0, note))
+
+
+def reset():
+    EVENTS.clear()
+    COUNTS.clear()
+
+
+def counts():
+    return dict(COUNTS)
+
+
+def sequence(comm=None):
+    """The recorded collectives (marks excluded) of one communicator, or of all in issue order."""
+    return [e for e in EVENTS if e[1] != "mark" and (comm is None or e[0] == comm)]

@@ -17,7 +17,7 @@ import os
 import torch
 import torch.distributed as dist
 
-from rrnet_amd import ops
+from rrnet_amd import dptrace, ops
 
 
 class FlatParams:
@@ -67,6 +67,7 @@ class FlatParams:
                 self._bucket_range.append((start, end))
                 self._bucket_need.append(need)
                 start, need = end, 0
+        self._index_of = {id(p): i for i, p in enumerate(params)}
         self.overlap = os.environ.get("RR_DP_OVERLAP", "1") != "0"
         self._pg = None
         self._begin_step()
@@ -92,6 +93,7 @@ class FlatParams:
             # thread and outside backward, so that the bucket launched from an autograd worker thread in the middle of
             # backward (interleaved with SyncBN exchanges on the default communicator) finds it ready
             warm = torch.zeros(1, dtype=torch.float32, device=self.grad.device)
+            dptrace.record("grads", "all_reduce", 1, "communicator warm-up")
             dist.all_reduce(warm, group=self._pg)
             if warm.is_cuda:
                 torch.cuda.current_stream(warm.device).synchronize()
@@ -130,8 +132,10 @@ class FlatParams:
             return
         self._marked.add(key)
         self._ready[b] += 1
+        dptrace.mark("param %d bucket %d" % (self._index_of[key], b))
         if self._ready[b] == self._bucket_need[b] and self._works[b] is None and b not in self._late:
             o0, o1 = self._bucket_range[b]
+            dptrace.record("grads", "all_reduce", o1 - o0, "bucket %d" % b)
             self._works[b] = dist.all_reduce(self.grad[o0:o1], group=self._group(), async_op=True)
 
     def zero_grad(self):
@@ -144,6 +148,7 @@ class FlatParams:
     def broadcast(self, src=0):
         """Initial parameter broadcast (C2 in SURVEY §2.2): one collective."""
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dptrace.record("default", "broadcast", self.flat.numel(), "parameters")
             dist.broadcast(self.flat, src)
             self._group()          # the buckets' communicator is set up here, on the main thread, before any backward
 
@@ -156,6 +161,7 @@ class FlatParams:
             return 1.0 / dist.get_world_size()
         for b, (o0, o1) in enumerate(self._bucket_range):      # buckets that were not complete during backward
             if self._works[b] is None:
+                dptrace.record("grads", "all_reduce", o1 - o0, "bucket %d (end of step)" % b)
                 self._works[b] = dist.all_reduce(self.grad[o0:o1], group=self._group(), async_op=True)
         for w in self._works:
             w.wait()

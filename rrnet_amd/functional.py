@@ -15,7 +15,7 @@ import os
 import torch
 import torch.distributed as dist
 
-from rrnet_amd import ops
+from rrnet_amd import dptrace, ops
 
 
 def _grad_target(p):
@@ -64,6 +64,7 @@ class _ConvBnAct(torch.autograd.Function):
                 sums = ops.bn_reduce_slab(slab, k, extra=1)
                 if sync:
                     sums[2 * k] = count          # the global count stays on the device: no host sync per layer
+                    dptrace.record("default", "all_reduce", sums.numel(), "syncbn_fwd")
                     dist.all_reduce(sums)
                     cnt_dev = sums[2 * k:].clone()   # own storage: `sums` is a slice of a shared zero pool (version counter)
                 mean, invstd, scale, shift = ops.bn_finalize(sums, count, gamma, beta, bn.running_mean, bn.running_var,
@@ -129,6 +130,7 @@ class _ConvBnAct(torch.autograd.Function):
             else:
                 ret_dg, ret_db = dg, db
         if sync:
+            dptrace.record("default", "all_reduce", sums.numel(), "syncbn_bwd")
             dist.all_reduce(sums)
         want_g = has_res and relu
         x_acc, res_acc = ctx.accs
@@ -574,7 +576,7 @@ class _DCNv2(torch.autograd.Function):
         k, c, r, s = w.shape
         w_t = _grad_target(weight)
         dw = w_t if w_t is not None else ops.zeros_nhwc(*weight.shape, device=x.device)
-        if DCN_FUSED_BWD and ops.dcn_fused_bwd_supported(c, k, r, s, stride, dg):
+        if DCN_FUSED_BWD and ops.dcn_fused_bwd_supported(c, k, r, s, stride, dg, dil):
             # fused: the columns live in registers / LDS inside the two GEMM kernels (csrc/dcn.hip).  The two kernels
             # are independent and bound by different things (wgrad: corner gather + MFMA; dgrad: the float atomics of
             # d input at the memory side), so they run concurrently on two HIP streams.

@@ -736,9 +736,9 @@ def dcn_col2im(x, offset, mask, dcol, r, s, stride, pad, dilation, dg):
     return dx, doff, dmask
 
 
-def dcn_fused_bwd_supported(c, k, r, s, stride, dg):
+def dcn_fused_bwd_supported(c, k, r, s, stride, dg, dilation=1):
     """Whether rr_dcn_wgrad / rr_dcn_dgrad take a layer of this shape (else: the column path)."""
-    return bool(_C.fn("rr_dcn_fused_bwd_supported")(c, k, r, s, stride, dg))
+    return bool(_C.fn("rr_dcn_fused_bwd_supported_dil")(c, k, r, s, stride, dilation, dg))
 
 
 def dcn_wgrad(x, offset, mask, dy, dw, stride, pad, dilation, dg, bf16=False):

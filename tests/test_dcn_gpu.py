@@ -23,6 +23,7 @@ CASES = [
     (2, 32, 17, 33, 36, 3, 1, 1, 1, 1),        # ragged 8x16 blocks, K = 36 (one partial 32-filter slab)
     (1, 64, 10, 18, 48, 3, 1, 1, 1, 2),        # two deformable groups of 32 channels: window kernels only (fused backward)
     (1, 128, 9, 17, 32, 3, 1, 1, 1, 4),        # four groups of 32 channels
+    (1, 128, 14, 14, 32, 3, 1, 3, 3, 2),       # groups of 64 channels, dilation 3: the dgrad window does not fit -> column path
 ]
 
 

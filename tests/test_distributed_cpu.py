@@ -193,3 +193,43 @@ def test_bucketed_overlap_bookkeeping_gloo():
         assert ok and launched[-1] < out["nb"]
         assert out["double"] in ("deferred", "raised") and out["deferred_not_launched"]
         assert out["idempotent"] and out["no_sync"]
+
+
+def _buf_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from rrnet_amd import dptrace
+        from rrnet_amd.operators.base_operator import broadcast_buffers
+        torch.manual_seed(rank)
+        net = nn.Sequential(nn.Conv2d(3, 8, 3), nn.BatchNorm2d(8), nn.Conv2d(8, 6, 1), nn.BatchNorm2d(6))
+        for m in net:
+            if isinstance(m, nn.BatchNorm2d):
+                m.running_mean.normal_(); m.running_var.uniform_(0.5, 2.0); m.num_batches_tracked.fill_(1000003 + rank)
+        dptrace.reset()
+        n = broadcast_buffers(net, 0)
+        q.put((rank, n, dptrace.counts(), {k: v.numpy().copy() for k, v in net.state_dict().items() if "running" in k or "tracked" in k}))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_buffers_broadcast_in_one_collective():
+    """RCCLDataParallel's buffer broadcast (operators/base_operator.py:24 in the reference = DDP's constructor): all BN
+    running statistics and the int64 counters arrive exactly, through ONE collective."""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_buf_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in ps], key=lambda r: r[0])
+    for p in ps:
+        p.join(60)
+    assert res[0][1] == res[1][1] == 6
+    assert res[0][2] == res[1][2] == {"default": 1}
+    for k, v in res[0][3].items():
+        np.testing.assert_array_equal(v, res[1][3][k])
+        if "tracked" in k:
+            assert int(v) == 1000003

@@ -86,6 +86,93 @@ def test_two_rank_syncbn_dp_matches_single_rank(tmp_path):
     np.testing.assert_allclose(z["running_mean"], model.backbone.pre_layer[1].running_mean.cpu().numpy(), atol=1e-5)
 
 
+def _trace_worker(rank, world, port, outdir):
+    """One full RRNet train step per rank (SyncBN, bucketed gradient exchange, fused Adam) on DIFFERENT images, so that
+    the ranks' RoI counts — and with them the shapes of every stage-2 tensor — differ; the collective trace is dumped."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import json
+        from rrnet_amd import dptrace, functional as RF
+        from rrnet_amd.datasets.synthetic import synth_batch
+        from rrnet_amd.flat import FlatAdam, FlatParams
+        from rrnet_amd.models.rrnet import RRNet
+        from rrnet_amd.operators.base_operator import broadcast_buffers
+        dptrace.ENABLED = True
+        cfg = SimpleNamespace(num_classes=10, Model=SimpleNamespace(num_stacks=2, backbone="hourglass_tiny",
+                              nms_type_for_stage1="nms", nms_per_class_for_stage1=True))
+        torch.manual_seed(5 + rank)                                    # ranks even start from different weights
+        model = RRNet(cfg).cuda().to(memory_format=torch.channels_last)
+        model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model).train()
+        fp = FlatParams(model, bucket_elems=8192)
+        fp.broadcast(0)
+        nbuf = broadcast_buffers(model, 0)
+        opt = FlatAdam(fp, lr=1e-3)
+        rois = []
+        for step in range(2):
+            dptrace.reset()
+            imgs, annos, hms, whs, inds, offs, masks, _ = synth_batch(2, 128, 160, boxes_per_image=6 + 20 * rank,
+                                                                      seed=100 + 7 * rank + step)
+            opt.zero_grad()
+            outs = model(imgs, k=60 + 90 * rank)                       # different K per rank: different RoI counts
+            rois.append(int(outs[4].shape[0]))
+            loss = sum(RF.focal_loss_hm_from_logits(outs[0][i], hms) + RF.reg_l1_loss(outs[1][i], masks, inds, whs)
+                       + RF.reg_l1_loss(outs[2][i], masks, inds, offs) for i in range(2))
+            annos[:, :, 2:4] += annos[:, :, 0:2]
+            loss = loss + RF.stage2_reg_loss(outs[3], outs[4], annos, 4.0)
+            loss.backward()
+            opt.step()
+            torch.cuda.synchronize()
+        w = fp.flat.detach().cpu().numpy()
+        with open(os.path.join(outdir, "trace%d.json" % rank), "w") as f:
+            json.dump({"events": dptrace.EVENTS, "counts": dptrace.counts(), "rois": rois, "nbuf": nbuf,
+                       "need": fp._bucket_need, "wsum": float(np.abs(w).sum()), "whash": float((w * np.arange(w.size) % 7).sum())}, f)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_collective_sequences_are_identical(tmp_path):
+    """What hangs an 8-GPU node must fail on a 1-GPU box: with ranks that see different images (different RoI counts,
+    different stage-2 shapes) the sequence of (communicator, op, element count) is IDENTICAL on both ranks for each of the
+    two communicators, every gradient bucket's all-reduce is issued after the last `mark_ready` of its parameters (i.e.
+    after the last kernel writing its slice was enqueued) and exactly once, and the ranks end the step with identical
+    parameters."""
+    import json
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_trace_worker, nprocs=2, args=(2, port, str(tmp_path)), join=True)
+    t = [json.load(open(str(tmp_path / ("trace%d.json" % r)))) for r in range(2)]
+    assert t[0]["rois"] != t[1]["rois"], t[0]["rois"]                  # the ranks really did different work
+    for comm in ("default", "grads"):
+        seq = [[e[:3] for e in tr["events"] if e[1] != "mark" and e[0] == comm] for tr in t]
+        assert seq[0] == seq[1], comm
+        assert len(seq[0]) > 0
+    ev = t[0]["events"]
+    need = t[0]["need"]
+    seen = {}
+    launched = {}
+    for i, (comm, op, numel, note) in enumerate(ev):
+        if op == "mark":
+            b = int(note.split()[-1])
+            assert b not in launched, "parameter reported after its bucket's all-reduce was issued: %s" % note
+            seen[b] = seen.get(b, 0) + 1
+        elif comm == "grads":
+            b = int(note.split()[1])
+            assert b not in launched, "bucket %d exchanged twice" % b
+            launched[b] = i
+            if "end of step" not in note:
+                assert seen.get(b, 0) == need[b], (b, seen.get(b, 0), need[b])
+    assert len(launched) == len(need)                                   # every bucket exactly once
+    during = sum(1 for e in ev if e[0] == "grads" and "end of step" not in e[3])
+    assert during >= len(need) - 3, (during, len(need))                 # overlapped with backward
+    n_sync = sum(1 for e in ev if e[0] == "default")
+    print("collectives of one step: %d SyncBN exchanges on the default communicator, %d gradient buckets (%d launched "
+          "during backward); buffers broadcast in one collective (%d buffers)" % (n_sync, len(launched), during, t[0]["nbuf"]))
+    assert t[0]["wsum"] == t[1]["wsum"] and t[0]["whash"] == t[1]["whash"]
+
+
 def _run_bench(extra_env, launcher, port):
     import json
     import subprocess
