@@ -93,7 +93,7 @@ class _ConvBnAct(torch.autograd.Function):
             if out_link is not None:
                 # what a consumer's data gradient needs to produce this layer's BatchNorm-backward sums in its epilogue
                 out_link.y, out_link.mean, out_link.invstd = y, mean, invstd
-                out_link.z = z if (relu and not remask) else None
+                out_link.use_z = bool(relu and not remask)      # mask from this layer's output = the consumer's input
                 out_link.msc, out_link.msh = (scale, shift) if remask else (None, None)
         ctx.cfg = (stride, pad, relu, count, sync, residual is not None)
         ctx.params = (w, gamma, beta)
@@ -143,7 +143,7 @@ class _ConvBnAct(torch.autograd.Function):
                                  g_into=g_into)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = _input_grad(dy, wc, ctx.xshape, stride, pad, x_acc, in_link)
+            dx = _input_grad(dy, wc, ctx.xshape, stride, pad, x_acc, in_link, x)
         w_t = _grad_target(w)
         ret_dw = None
         stem = (tuple(w.shape[1:]) == (3, 7, 7) and stride == 2 and tuple(pad) == (3, 3)
@@ -172,21 +172,21 @@ class _ConvBnAct(torch.autograd.Function):
         return dx, ret_dw, ret_dg, ret_db, dres, None, None, None, None, None, None, None, None
 
 
-def _input_grad(dy, wc, xshape, stride, pad, x_acc, in_link):
+def _input_grad(dy, wc, xshape, stride, pad, x_acc, in_link, x):
     """Data gradient of a convolution node -> the tensor to hand to autograd (None when it was added into the fan-in
     buffer of x's fan-out).  Where the launch can carry them it also produces the BatchNorm-backward sums of the layer
     that produced x (ops.BnLink): when x has this node as its only consumer, or when this node is the LAST registered
     contributor to the fan-in buffer of x's fan-out (the epilogue then holds the complete gradient)."""
     if x_acc is None:
         link = in_link if (in_link is not None and in_link.consumers == 1) else None
-        return ops.conv_dgrad(dy, wc, xshape, stride, pad, bnsum=link)
+        return ops.conv_dgrad(dy, wc, xshape, stride, pad, bnsum=link, bnsum_z=x)
     link = x_acc.link if x_acc.pending == 1 else None
     x_acc.pending -= 1
     if x_acc.buf is not None:
         # another consumer of x already produced its gradient: add into it inside the dgrad epilogue
-        ops.conv_dgrad(dy, wc, xshape, stride, pad, out=x_acc.buf, accumulate=True, bnsum=link)
+        ops.conv_dgrad(dy, wc, xshape, stride, pad, out=x_acc.buf, accumulate=True, bnsum=link, bnsum_z=x)
         return None
-    x_acc.buf = ops.conv_dgrad(dy, wc, xshape, stride, pad, bnsum=link)
+    x_acc.buf = ops.conv_dgrad(dy, wc, xshape, stride, pad, bnsum=link, bnsum_z=x)
     return x_acc.buf
 
 
@@ -250,7 +250,7 @@ class _ConvBias(torch.autograd.Function):
             dy = ops.sum_n([dy], y)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = _input_grad(dy, wc, ctx.xshape, stride, pad, ctx.x_acc, ctx.in_link)
+            dx = _input_grad(dy, wc, ctx.xshape, stride, pad, ctx.x_acc, ctx.in_link, x)
         w_t = _grad_target(w)
         ret_dw = None
         if w_t is not None:

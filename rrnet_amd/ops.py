@@ -155,20 +155,25 @@ class BnLink:
     statistics, and the source of its ReLU mask (z for layers with a residual, scale / shift otherwise).  The consumer's
     backward leaves `sums` (and the gradient tensor they were taken of) here; the producer's backward picks them up
     instead of running rr_bn_bwd_reduce when the gradient it receives is that very tensor."""
-    __slots__ = ("y", "z", "mean", "invstd", "msc", "msh", "sums", "dz", "consumers")
+    __slots__ = ("y", "use_z", "mean", "invstd", "msc", "msh", "sums", "dz", "consumers")
 
     def __init__(self):
-        self.y = self.z = self.mean = self.invstd = self.msc = self.msh = self.sums = self.dz = None
+        self.y = self.mean = self.invstd = self.msc = self.msh = self.sums = self.dz = None
+        # the mask comes from the producer's OUTPUT z (layers with a residual).  The link must not hold z itself — z
+        # carries the link as an attribute, and such a cycle keeps a step's activations alive until the cyclic GC runs
+        # (the caching allocator then thrashes); the consumer passes its own saved input, which IS z.
+        self.use_z = False
         self.consumers = 0
 
 
 _DGRAD_BNSUM = os.environ.get("RR_DGRAD_BNSUM", "1") != "0"
 
 
-def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False, bnsum=None):
+def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False, bnsum=None, bnsum_z=None):
     """dy [N,K,P,Q], w [K,C,R,S] -> dx [N,C,H,W]; with `out` and accumulate adds into it.
     bnsum (BnLink of the layer that produced the convolution's input): when the launch can carry them, the producer's
-    BatchNorm-backward sums are computed in the epilogue and left in bnsum.sums / bnsum.dz."""
+    BatchNorm-backward sums are computed in the epilogue and left in bnsum.sums / bnsum.dz.  bnsum_z: the
+    convolution's input itself (= the producer's output), needed when bnsum.use_z."""
     _C.require_cuda(dy, w)
     assert is_nhwc(dy) and is_nhwc(w)
     n, c, h, wd = x_shape
@@ -186,14 +191,16 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False,
         _C.check(_C.fn("rr_weight_flip_transpose")(_C.ptr(w), _C.ptr(wt), k, c, r, s, _C.stream()),
                  "rr_weight_flip_transpose")
         if (bnsum is not None and _DGRAD_BNSUM and bnsum.y is not None and c <= 1024 and out.numel() * 4 < (1 << 31)
-                and tuple(bnsum.y.shape) == tuple(out.shape)):
+                and tuple(bnsum.y.shape) == tuple(out.shape)
+                and (not bnsum.use_z or (bnsum_z is not None and is_nhwc(bnsum_z) and bnsum_z.shape == out.shape))):
+            zt = bnsum_z if bnsum.use_z else None
             nb = _C.fn("rr_conv_stat_slab_bytes")(n, h, wd, c)
             slab = torch.empty(nb // 8, dtype=torch.float64, device=dy.device)
             sums = _ZEROS.take(2 * c, dy.device)
             fb = _C.fn("rr_conv_dgrad_s1_bnsum")
             _C.check(_timed(_igemm_name("fprop", c, False, n * h * wd) + "+bnsum", flops,
                             lambda: fb(_C.ptr(dy), _C.ptr(wt), _C.ptr(out), n, h, wd, c, k, r, s, pad[0], pad[1],
-                                       int(accumulate), _C.ptr(bnsum.y), _C.ptr(bnsum.z), _C.ptr(bnsum.mean),
+                                       int(accumulate), _C.ptr(bnsum.y), _C.ptr(zt), _C.ptr(bnsum.mean),
                                        _C.ptr(bnsum.invstd), _C.ptr(bnsum.msc), _C.ptr(bnsum.msh), _C.ptr(slab),
                                        _C.ptr(sums), _C.stream()), (n, h, wd, c, k, r, s, stride),
                             4.0 * (dy.numel() + out.numel() * (3 if accumulate else 2) + w.numel())),

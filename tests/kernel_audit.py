@@ -167,19 +167,19 @@ def audit(tol=2e-5, tol_wgrad=2e-4, sample=False):
                 rec.note("fprop_stats", sig, max(e1, _rel(sums[k:2 * k], s2)), tol)
         return out
 
-    def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False, bnsum=None):
+    def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False, bnsum=None, bnsum_z=None):
         base = out.clone() if (out is not None and accumulate) else None
-        res = orig["conv_dgrad"](dy, w, x_shape, stride, pad, out, accumulate, bnsum)
+        res = orig["conv_dgrad"](dy, w, x_shape, stride, pad, out, accumulate, bnsum, bnsum_z)
         if bnsum is not None and bnsum.sums is not None and bnsum.dz is res:
             # the producer's BatchNorm-backward sums from the epilogue: compare with fp64 sums over the whole of the
             # gradient this launch left in memory (the gradient itself is checked below)
-            bsig = (tuple(res.shape), bnsum.z is not None, bnsum.msc is not None, bool(accumulate))
+            zt = bnsum_z if bnsum.use_z else None
+            bsig = (tuple(res.shape), zt is not None, bnsum.msc is not None, bool(accumulate))
             if ("dgrad_bnsum",) + bsig not in rec.seen:
                 c = res.shape[1]
                 s1, s2, a1, a2 = (torch.zeros(c, dtype=torch.float64) for _ in range(4))
                 for i in range(res.shape[0]):
-                    d = _masked(res[i:i + 1], None if bnsum.z is None else bnsum.z[i:i + 1], bnsum.y[i:i + 1], bnsum.msc,
-                                bnsum.msh)
+                    d = _masked(res[i:i + 1], None if zt is None else zt[i:i + 1], bnsum.y[i:i + 1], bnsum.msc, bnsum.msh)
                     xh = (_c64(bnsum.y[i:i + 1]) - _V(bnsum.mean)) * _V(bnsum.invstd)
                     s1 += d.sum((0, 2, 3)); a1 += d.abs().sum((0, 2, 3))
                     d = d * xh

@@ -150,13 +150,14 @@ def test_bias_relu_bwd_column_sums(npix, c, relu):
 
 # (N, C = producer's channels, H, W, K = dy channels, R, pad, mask source, accumulate)
 BNSUM_CASES = [
-    (2, 256, 64, 64, 256, 3, 1, "scale", False),      # conv1 -> bn1 -> relu -> conv2: the common case, 128x128 tiles
-    (2, 256, 64, 64, 256, 3, 1, "z", True),           # block output (residual): mask from z, last contributor of a fan-in
-    (2, 256, 64, 64, 384, 1, 0, "z", True),           # projection skip 1x1 as the last contributor
-    (1, 64, 64, 96, 128, 3, 1, "scale", False),       # 64 producer channels: 128x64 tiles
-    (1, 32, 64, 64, 64, 3, 1, "none", False),         # 32 channels: 128x32 tiles; producer without ReLU
+    (2, 256, 96, 96, 256, 3, 1, "scale", False),      # conv1 -> bn1 -> relu -> conv2: the common case, 128x128 tiles
+    (2, 256, 96, 96, 256, 3, 1, "z", True),           # block output (residual): mask from z, last contributor of a fan-in
+    (2, 256, 96, 96, 384, 1, 0, "z", True),           # projection skip 1x1 as the last contributor
+    (2, 64, 128, 128, 128, 3, 1, "scale", False),     # 64 producer channels: 128x64 tiles
+    (2, 32, 128, 128, 64, 3, 1, "none", False),       # 32 channels: 128x32 tiles; producer without ReLU
     (1, 384, 64, 64, 384, 3, 1, "scale", False),      # under-filled -> split-K: the entry falls back to a reduce pass
-    (3, 256, 65, 67, 256, 3, 1, "z", False),          # ragged: M not a multiple of 128
+    (3, 256, 81, 83, 256, 3, 1, "z", False),          # ragged: M not a multiple of 128
+    (2, 256, 64, 64, 256, 3, 1, "z", True),           # split-K with accumulation
 ]
 
 
@@ -176,21 +177,27 @@ def test_dgrad_with_producer_bn_backward_sums(cfg):
     scale, shift = (torch.rand(c, generator=g).cuda() + 0.5) * invstd, torch.randn(c, generator=g).cuda() * 0.3
     link = ops.BnLink()
     link.y, link.mean, link.invstd = y, mean, invstd
+    z = None
     if mask == "z":
-        link.z = torch.relu(y * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1) + res).contiguous(memory_format=torch.channels_last)
+        link.use_z = True
+        z = torch.relu(y * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1) + res).contiguous(memory_format=torch.channels_last)
     elif mask == "scale":
         link.msc, link.msh = scale, shift
     base = ops.to_nhwc(torch.randn(n, c, h, w, generator=g).cuda()) if acc else None
     out_a = base.clone() if acc else None
     out_b = base.clone() if acc else None
     dx_ref = ops.conv_dgrad(dy, wt, (n, c, h, w), 1, (pad, pad), out=out_a, accumulate=acc)
-    sums_ref = ops.bn_bwd_reduce(dx_ref, link.z, y, mean, invstd, mask_scale=link.msc, mask_shift=link.msh)
-    dx = ops.conv_dgrad(dy, wt, (n, c, h, w), 1, (pad, pad), out=out_b, accumulate=acc, bnsum=link)
+    sums_ref = ops.bn_bwd_reduce(dx_ref, z, y, mean, invstd, mask_scale=link.msc, mask_shift=link.msh)
+    dx = ops.conv_dgrad(dy, wt, (n, c, h, w), 1, (pad, pad), out=out_b, accumulate=acc, bnsum=link, bnsum_z=z)
     assert link.sums is not None and link.dz is dx
-    assert torch.equal(dx, dx_ref)                                     # same kernel arithmetic, same stores
+    mtiles, ntiles = -(-n * h * w // 128), -(-c // 128)
+    if mtiles * ntiles >= 256:
+        assert torch.equal(dx, dx_ref)                                 # same kernel arithmetic, same stores
+    else:                                                              # split-K: float atomics, order varies run to run
+        assert (dx - dx_ref).abs().max().item() <= 1e-5 * dx_ref.abs().max().item()
     d = dx.double()
     if mask == "z":
-        d = d * (link.z > 0)
+        d = d * (z > 0)
     elif mask == "scale":
         d = d * (torch.addcmul(shift.view(1, -1, 1, 1), y, scale.view(1, -1, 1, 1)) > 0)
     xh = (y.double() - mean.double().view(1, -1, 1, 1)) * invstd.double().view(1, -1, 1, 1)
