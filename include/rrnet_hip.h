@@ -81,6 +81,12 @@ int rr_conv_dgrad(const float *dy, const float *w, float *dx, int n, int h, int 
 int rr_weight_flip_transpose(const float *w, float *wt, int k, int c, int r, int s, hipStream_t stream);
 int rr_conv_dgrad_s1(const float *dy, const float *wt, float *dx, int n, int h, int wd, int c, int k,
                      int r, int s, int pad_h, int pad_w, int accumulate, hipStream_t stream);
+/* Small-channel convolutions (the 7x7 stride-2 stem on a 3-channel image, backbones/hourglass.py:143): rr_conv_pack_taps
+ * writes out [n,p,q,kp], out[..,k] = x[n, p*stride-pad_h+r, q*stride-pad_w+s, c] for k = (r*S+s)*c_in + c < r*s*c and 0 up
+ * to kp (a multiple of 4, the caller pads to 32).  The convolution then is a 1x1 rr_conv_fprop over kp channels with the
+ * OHWI weight rows zero-padded to kp, and its weight gradient a 1x1 rr_conv_wgrad — both on the vector MFMA kernels. */
+int rr_conv_pack_taps(const float *x, float *out, int n, int h, int wd, int c, int r, int s, int stride, int pad_h,
+                      int pad_w, int kp, hipStream_t stream);
 /* rr_conv_dgrad_s1 that ALSO returns the BatchNorm-backward sums of the layer that produced the tensor whose gradient
  * it writes (the conv -> bn -> relu layer in front of this convolution, backbones/hourglass.py:31-40): the epilogue has
  * the finished gradient dz = dx in registers, reads the producer's pre-BN output prod_y [n,h,w,c] (and prod_z, its

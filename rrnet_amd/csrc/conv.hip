@@ -1419,6 +1419,50 @@ extern "C" int rr_conv_dgrad_s1(const float *dy, const float *wt, float *dx, int
                       stream);
 }
 
+// out[m][k], m = (n,p,q), k = (r*S + s)*C + c for k < R*S*C and 0 up to KP: the taps of a small-channel convolution laid
+// out as one row per output pixel, so that the 7x7 stride-2 stem (C = 3: 147 -> KP = 160) becomes a 1x1 convolution on the
+// vector kernels (fprop) and a 128 x KP weight-gradient GEMM over all pixels (wgrad) instead of the scalar-gather paths.
+// One thread = one output float4; HBM-bound on the writes (the reads hit L2: every input pixel is wanted R*S/stride^2 times).
+__global__ __launch_bounds__(256) void conv_pack_taps_kernel(const float *x, f32x4 *out, int H, int W, int C, int S, int stride,
+                                                             int pad_h, int pad_w, int P, int Q, int KP4, int Kg, long total)
+{
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int k4 = (int)(i % KP4);
+        long m = i / KP4;
+        const int q = (int)(m % Q); m /= Q;
+        const int p = (int)(m % P);
+        const long n = m / P;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = k4 * 4 + e;
+            if (k < Kg) {
+                const int tap = k / C, c = k - tap * C;
+                const int r = tap / S, sx = tap - r * S;
+                const int ih = p * stride - pad_h + r, iw = q * stride - pad_w + sx;
+                if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) v[e] = x[((n * H + ih) * W + iw) * C + c];
+            }
+        }
+        out[i] = v;
+    }
+}
+
+extern "C" int rr_conv_pack_taps(const float *x, float *out, int n, int h, int wd, int c, int r, int s, int stride, int pad_h,
+                                 int pad_w, int kp, hipStream_t stream)
+{
+    RR_CHECK_ARG(n > 0 && h > 0 && wd > 0 && c > 0 && r > 0 && s > 0 && stride > 0 && kp % 4 == 0 && kp >= r * s * c,
+                 "rr_conv_pack_taps: bad dims (kp must be a multiple of 4 and >= r*s*c)");
+    const int p = (h + 2 * pad_h - r) / stride + 1, q = (wd + 2 * pad_w - s) / stride + 1;
+    RR_CHECK_ARG(p > 0 && q > 0, "rr_conv_pack_taps: empty output");
+    const long total = (long)n * p * q * (kp / 4);
+    long blocks = (total + 255) / 256;
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    hipLaunchKernelGGL(conv_pack_taps_kernel, dim3((int)blocks), dim3(256), 0, stream, x, reinterpret_cast<f32x4 *>(out), h, wd, c,
+                       s, stride, pad_h, pad_w, p, q, kp / 4, r * s * c, total);
+    RR_CHECK_LAUNCH("rr_conv_pack_taps");
+    return RR_OK;
+}
+
 extern "C" int rr_conv_dgrad_s1_bnsum(const float *dy, const float *wt, float *dx, int n, int h, int wd, int c, int k,
                                       int r, int s, int pad_h, int pad_w, int accumulate, const float *prod_y,
                                       const float *prod_z, const float *prod_mean, const float *prod_invstd,

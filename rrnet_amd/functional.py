@@ -54,8 +54,15 @@ class _ConvBnAct(torch.autograd.Function):
         n, _, h, wd = x.shape
         k = w.shape[0]
         sync = _is_sync(bn)
+        ctx.packed = False
         if bn.training:
-            y, slab = ops.conv_fprop(x, wc, None, stride, pad, False, want_stats=True)
+            if ops.conv_packable(x, wc, stride):
+                # very few input channels (the 7x7 stride-2 stem): taps packed per output pixel, 1x1 GEMM on the vector
+                # kernels; the packed image replaces x as the tensor saved for the weight gradient
+                y, slab, x = ops.conv_fprop_packed(x, wc, stride, pad, want_stats=True)
+                ctx.packed = True
+            else:
+                y, slab = ops.conv_fprop(x, wc, None, stride, pad, False, want_stats=True)
             count = float(y.numel() // k)
             cnt_dev = None
             mom = bn.momentum if bn.momentum is not None else 0.1
@@ -97,7 +104,7 @@ class _ConvBnAct(torch.autograd.Function):
                 out_link.msc, out_link.msh = (scale, shift) if remask else (None, None)
         ctx.cfg = (stride, pad, relu, count, sync, residual is not None)
         ctx.params = (w, gamma, beta)
-        ctx.xshape = tuple(x.shape)
+        ctx.xshape = None if ctx.packed else tuple(x.shape)
         return z
 
     @staticmethod
@@ -146,9 +153,14 @@ class _ConvBnAct(torch.autograd.Function):
             dx = _input_grad(dy, wc, ctx.xshape, stride, pad, x_acc, in_link, x)
         w_t = _grad_target(w)
         ret_dw = None
-        stem = (tuple(w.shape[1:]) == (3, 7, 7) and stride == 2 and tuple(pad) == (3, 3)
+        stem = (not ctx.packed and tuple(w.shape[1:]) == (3, 7, 7) and stride == 2 and tuple(pad) == (3, 3)
                 and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0)
-        wg = (lambda tgt: ops.stem_wgrad_s2d(x, dy, tgt)) if stem else (lambda tgt: ops.conv_wgrad(x, dy, tgt, stride, pad))
+        if ctx.packed:                 # x is the packed tap image of the forward
+            wg = lambda tgt: ops.conv_wgrad_packed(x, dy, tgt)
+        elif stem:
+            wg = lambda tgt: ops.stem_wgrad_s2d(x, dy, tgt)
+        else:
+            wg = lambda tgt: ops.conv_wgrad(x, dy, tgt, stride, pad)
         if w_t is not None:
             wg(w_t)
             _mark(w)

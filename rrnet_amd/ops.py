@@ -103,9 +103,10 @@ def out_hw(h, w, r, s, stride, ph, pw):
     return (h + 2 * ph - r) // stride + 1, (w + 2 * pw - s) // stride + 1
 
 
-def conv_fprop(x, w, bias=None, stride=1, pad=(0, 0), relu=False, want_stats=False):
+def conv_fprop(x, w, bias=None, stride=1, pad=(0, 0), relu=False, want_stats=False, algo_kg=None):
     """x [N,C,H,W] (NHWC memory), w [K,C,R,S] (OHWI memory) -> y [N,K,P,Q] (NHWC memory)
-    and, if want_stats, the per-block BatchNorm partial-sum slab (see rr_conv_fprop)."""
+    and, if want_stats, the per-block BatchNorm partial-sum slab (see rr_conv_fprop).
+    algo_kg: the useful reduction length when the operands carry zero padding (timer FLOPs stay algorithmic)."""
     _C.require_cuda(x, w, bias)
     assert x.dtype == torch.float32 and w.dtype == torch.float32
     assert is_nhwc(x) and is_nhwc(w), "conv_fprop wants NHWC activations / OHWI weights"
@@ -119,12 +120,49 @@ def conv_fprop(x, w, bias=None, stride=1, pad=(0, 0), relu=False, want_stats=Fal
         nbytes = _C.fn("rr_conv_stat_slab_bytes")(n, p, q, k)
         slab = torch.empty(nbytes // 8, dtype=torch.float64, device=x.device)
     f = _C.fn("rr_conv_fprop")
-    flops = 2.0 * n * p * q * k * c * r * s
+    flops = 2.0 * n * p * q * k * (c * r * s if algo_kg is None else algo_kg)
     _C.check(_timed(_igemm_name("fprop", k, c % 4 != 0, n * p * q), flops,
                     lambda: f(_C.ptr(x), _C.ptr(w), _C.ptr(bias), _C.ptr(y), _C.ptr(slab), n, h, wd, c, k, r, s,
                               stride, pad[0], pad[1], int(relu), _C.stream()),
                     (n, h, wd, c, k, r, s, stride), 4.0 * (x.numel() + y.numel() + w.numel())), "rr_conv_fprop")
     return (y, slab) if want_stats else y
+
+
+_STEM_PACK = os.environ.get("RR_STEM_PACK", "1") != "0"
+
+
+def conv_packable(x, w, stride):
+    """A convolution on very few channels (the 7x7 stride-2 stem on an RGB image): its taps are packed into one row
+    per output pixel and it runs as a 1x1 convolution on the vector kernels (conv_fprop_packed / conv_wgrad_packed)."""
+    k, c, r, s = w.shape
+    return _STEM_PACK and c % 4 != 0 and 32 < r * s * c <= 512 and k >= 32 and not x.requires_grad
+
+
+def conv_fprop_packed(x, w, stride, pad, want_stats=False):
+    """-> (y, slab | None, xp): xp [N,KP,P,Q] = the packed taps (rr_conv_pack_taps), kept for the weight gradient."""
+    n, c, h, wd = x.shape
+    k, _, r, s = w.shape
+    kg = r * s * c
+    kp = (kg + 31) // 32 * 32
+    p, q = out_hw(h, wd, r, s, stride, pad[0], pad[1])
+    xp = empty_nhwc(n, kp, p, q, x.device)
+    _C.check(_C.fn("rr_conv_pack_taps")(_C.ptr(x), _C.ptr(xp), n, h, wd, c, r, s, stride, pad[0], pad[1], kp, _C.stream()),
+             "rr_conv_pack_taps")
+    wp = torch.zeros((k, kp), dtype=torch.float32, device=x.device)
+    wp[:, :kg] = w.permute(0, 2, 3, 1).reshape(k, kg)                       # OHWI memory = [k][(r,s,c)]
+    out = conv_fprop(xp, wp.view(k, kp, 1, 1), None, 1, (0, 0), False,
+                     want_stats, algo_kg=kg)
+    return (out[0], out[1], xp) if want_stats else (out, None, xp)
+
+
+def conv_wgrad_packed(xp, dy, dw):
+    """dw [K,C,R,S] (OHWI memory) += the weight gradient of the convolution whose packed taps are xp."""
+    k, c, r, s = dw.shape
+    kg, kp = r * s * c, xp.shape[1]
+    dwp = zeros_nhwc(k, kp, 1, 1, xp.device)
+    conv_wgrad(xp, dy, dwp, 1, (0, 0), algo_c=kg)
+    dw.permute(0, 2, 3, 1).add_(dwp.reshape(k, kp)[:, :kg].view(k, r, s, c))
+    return dw
 
 
 def stem_wgrad_s2d(x, dy, dw):
@@ -221,7 +259,7 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False,
     return out
 
 
-def conv_wgrad(x, dy, dw, stride=1, pad=(0, 0), explicit_out=False):
+def conv_wgrad(x, dy, dw, stride=1, pad=(0, 0), explicit_out=False, algo_c=None):
     """dw [K,C,R,S] (OHWI memory) += x (*) dy.  dw must be pre-zeroed / hold the running gradient.
     explicit_out: take the output size from dy (asymmetric padding, `pad` = leading pads)."""
     _C.require_cuda(x, dy, dw)
@@ -230,7 +268,7 @@ def conv_wgrad(x, dy, dw, stride=1, pad=(0, 0), explicit_out=False):
     k, c2, r, s = dw.shape
     assert c == c2 and dy.shape[1] == k
     f = _C.fn("rr_conv_wgrad")
-    flops = 2.0 * dy.shape[0] * dy.shape[2] * dy.shape[3] * k * c * r * s
+    flops = 2.0 * dy.shape[0] * dy.shape[2] * dy.shape[3] * k * (c * r * s if algo_c is None else algo_c)
     _C.check(_timed("conv_wgrad<BN=%d>" % (128 if c > 32 else 32), flops,
                     lambda: f(_C.ptr(x), _C.ptr(dy), _C.ptr(dw), n, h, wd, c, k, r, s, stride, pad[0], pad[1],
                               dy.shape[2] if explicit_out else 0, dy.shape[3] if explicit_out else 0,

@@ -114,7 +114,7 @@ def audit(tol=2e-5, tol_wgrad=2e-4, sample=False):
     from rrnet_amd import ops
     rec = Record()
     rec.sampled = set()
-    names = ("conv_fprop", "conv_dgrad", "conv_wgrad", "stem_wgrad_s2d", "bn_apply", "bn_bwd_reduce", "bn_bwd_apply",
+    names = ("conv_fprop", "conv_dgrad", "conv_wgrad", "stem_wgrad_s2d", "conv_fprop_packed", "conv_wgrad_packed", "bn_apply", "bn_bwd_reduce", "bn_bwd_apply",
              "sum_n", "upsample_add_fwd", "upsample_add_bwd", "bias_relu_bwd", "relu_fwd", "bn_finalize",
              "bn_stats_finalize")
     orig = {n: getattr(ops, n) for n in names}
@@ -125,8 +125,46 @@ def audit(tol=2e-5, tol_wgrad=2e-4, sample=False):
     def big_elems(t):
         return sample and t.numel() > (1 << 24)
 
-    def conv_fprop(x, w, bias=None, stride=1, pad=(0, 0), relu=False, want_stats=False):
-        out = orig["conv_fprop"](x, w, bias, stride, pad, relu, want_stats)
+    packed_src = {}      # data_ptr of a packed tap image -> (x, stride, pad) it was made from
+
+    def conv_fprop_packed(x, w, stride, pad, want_stats=False):
+        """The few-channel stem through tap packing + 1x1 GEMM: checked END TO END against conv2d of the original image
+        (the inner pack / GEMM launches are audited as ordinary calls on top of that)."""
+        y, slab, xp = orig["conv_fprop_packed"](x, w, stride, pad, want_stats)
+        packed_src[xp.data_ptr()] = (x, stride, tuple(pad))
+        sig = (tuple(x.shape), tuple(w.shape), stride, tuple(pad))
+        if ("fprop_packed",) + sig not in rec.seen:
+            w64 = _c64(w)
+            flops = 2.0 * y.numel() * w.shape[1] * w.shape[2] * w.shape[3]
+            if big(flops):
+                rec.sampled.add(("fprop_packed",) + sig)
+                err = 0.0
+                for sel, p0, p1 in _bands(y.shape[2]):
+                    n0 = int(round(sel * (x.shape[0] - 1)))
+                    err = max(err, _rel(y[n0:n0 + 1, :, p0:p1, :], _fprop_band(x, w64, None, stride, pad, n0, p0, p1)))
+            else:
+                err = _rel(y, F.conv2d(_c64(x), w64, None, stride, tuple(pad)))
+            rec.note("fprop_packed", sig, err, tol)
+        return y, slab, xp
+
+    def conv_wgrad_packed(xp, dy, dw):
+        x, stride, pad = packed_src.get(xp.data_ptr(), (None, None, None))
+        sig = (tuple(xp.shape), tuple(dy.shape), tuple(dw.shape))
+        check = x is not None and ("wgrad_packed",) + sig not in rec.seen
+        base = dw.clone() if check else None
+        res = orig["conv_wgrad_packed"](xp, dy, dw)
+        if check:
+            got = _c64(res) - _c64(base)
+            flops = 2.0 * dy.numel() * dw.shape[1] * dw.shape[2] * dw.shape[3]
+            ks = _k_sample(dw.shape[0]) if big(flops) else list(range(dw.shape[0]))
+            if big(flops):
+                rec.sampled.add(("wgrad_packed",) + sig)
+            ref = torch.nn.grad.conv2d_weight(_c64(x), (len(ks),) + tuple(dw.shape[1:]), _c64(dy[:, ks]), stride, pad)
+            rec.note("wgrad_packed", sig, float((got[ks] - ref).abs().max() / max(float(ref.abs().max()), 1e-30)), tol_wgrad)
+        return res
+
+    def conv_fprop(x, w, bias=None, stride=1, pad=(0, 0), relu=False, want_stats=False, algo_kg=None):
+        out = orig["conv_fprop"](x, w, bias, stride, pad, relu, want_stats, algo_kg)
         y = out[0] if want_stats else out
         sig = (tuple(x.shape), tuple(w.shape), stride, tuple(pad), bias is not None, relu, want_stats)
         flops = 2.0 * y.numel() * w.shape[1] * w.shape[2] * w.shape[3]
@@ -208,11 +246,11 @@ def audit(tol=2e-5, tol_wgrad=2e-4, sample=False):
             rec.note("dgrad", sig, _rel(res, ref), tol)
         return res
 
-    def conv_wgrad(x, dy, dw, stride=1, pad=(0, 0), explicit_out=False):
+    def conv_wgrad(x, dy, dw, stride=1, pad=(0, 0), explicit_out=False, algo_c=None):
         sig = (tuple(x.shape), tuple(dy.shape), tuple(dw.shape), stride, tuple(pad), explicit_out)
         check = ("wgrad",) + sig not in rec.seen and not explicit_out
         base = dw.clone() if check else None
-        res = orig["conv_wgrad"](x, dy, dw, stride, pad, explicit_out)
+        res = orig["conv_wgrad"](x, dy, dw, stride, pad, explicit_out, algo_c)
         flops = 2.0 * dy.numel() * dw.shape[1] * dw.shape[2] * dw.shape[3]
         if check and big(flops):
             rec.sampled.add(("wgrad",) + sig)
@@ -431,6 +469,7 @@ def audit(tol=2e-5, tol_wgrad=2e-4, sample=False):
         return got
 
     patched = dict(conv_fprop=conv_fprop, conv_dgrad=conv_dgrad, conv_wgrad=conv_wgrad, stem_wgrad_s2d=stem_wgrad_s2d,
+                   conv_fprop_packed=conv_fprop_packed, conv_wgrad_packed=conv_wgrad_packed,
                    bn_finalize=bn_finalize, bn_stats_finalize=bn_stats_finalize, bn_apply=bn_apply,
                    bn_bwd_reduce=bn_bwd_reduce, bn_bwd_apply=bn_bwd_apply, sum_n=sum_n, upsample_add_fwd=upsample_add_fwd,
                    upsample_add_bwd=upsample_add_bwd, bias_relu_bwd=bias_relu_bwd, relu_fwd=relu_fwd)

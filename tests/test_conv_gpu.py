@@ -244,3 +244,32 @@ def test_train_step_gradients_equal_with_and_without_fused_bn_sums():
     assert counts[True] < counts[False], counts          # some reduce passes disappeared
     scale = grads[False].abs().max().item()
     assert (grads[True] - grads[False]).abs().max().item() <= 1e-4 * scale, ((grads[True] - grads[False]).abs().max().item(), scale)
+
+
+@pytest.mark.parametrize("cfg", [(2, 3, 30, 34, 128, 7, 2, 3), (1, 3, 64, 64, 128, 7, 2, 3), (2, 3, 17, 19, 64, 5, 1, 2),
+                                 (1, 6, 21, 20, 96, 3, 2, 1), (2, 3, 128, 128, 128, 7, 2, 3)],
+                         ids=lambda c: "n%dc%dh%dw%dk%dr%ds%dp%d" % c)
+def test_packed_small_channel_conv_vs_torch(cfg):
+    """The few-channel path (7x7 stride-2 stem, backbones/hourglass.py:143): rr_conv_pack_taps + 1x1 GEMMs on the vector
+    kernels == conv2d / its weight gradient on the original image (fp64 reference)."""
+    from rrnet_amd import ops
+    n, c, h, w, k, r, stride, pad = cfg
+    x = ops.to_nhwc(_mk((n, c, h, w), 1).cuda())
+    wt = ops.to_nhwc((_mk((k, c, r, r), 2) / np.sqrt(c * r * r)).cuda())
+    assert ops.conv_packable(x, wt, stride)
+    y, slab, xp = ops.conv_fprop_packed(x, wt, stride, (pad, pad), want_stats=True)
+    ref = F.conv2d(x.cpu().double(), wt.cpu().double(), None, stride, pad)
+    assert (y.cpu().double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+    unf = F.unfold(x.cpu(), r, padding=pad, stride=stride)                       # [n, c*r*r, P*Q], rows ordered (c, r, s)
+    kg = c * r * r
+    exp = unf.view(n, c, r * r, -1).permute(0, 3, 2, 1).reshape(n, ref.shape[2], ref.shape[3], kg)   # -> (r, s, c) minor
+    got = xp.permute(0, 2, 3, 1).cpu()
+    assert torch.equal(got[..., :kg], exp) and float(got[..., kg:].abs().max() if got.shape[-1] > kg else 0.0) == 0.0
+    sums = ops.bn_reduce_slab(slab, k).cpu()
+    assert (sums[:k] - ref.sum((0, 2, 3))).abs().max().item() <= 1e-4 * ref.abs().sum((0, 2, 3)).max().item()
+    dy = ops.to_nhwc(_mk(tuple(ref.shape), 3).cuda())
+    base = ops.to_nhwc(_mk((k, c, r, r), 4).cuda())
+    dw = base.clone()
+    ops.conv_wgrad_packed(xp, dy, dw)
+    dref = torch.nn.grad.conv2d_weight(x.cpu().double(), (k, c, r, r), dy.cpu().double(), stride, pad)
+    assert ((dw - base).cpu().double() - dref).abs().max().item() <= 2e-5 * dref.abs().max().item()
