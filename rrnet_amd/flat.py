@@ -136,6 +136,9 @@ class FlatParams:
         if self._ready[b] == self._bucket_need[b] and self._works[b] is None and b not in self._late:
             o0, o1 = self._bucket_range[b]
             dptrace.record("grads", "all_reduce", o1 - o0, "bucket %d" % b)
+            # the collective is ordered behind the stream it is launched from; parameters of this bucket may have been
+            # written on another one (weight gradients run on a side stream): wait for those first
+            ops.join_aux_streams(self.grad.device)
             self._works[b] = dist.all_reduce(self.grad[o0:o1], group=self._group(), async_op=True)
 
     def zero_grad(self):
@@ -159,6 +162,7 @@ class FlatParams:
             return 1.0
         if self._reduced:          # idempotent within a step: a second call must not sum the ranks twice
             return 1.0 / dist.get_world_size()
+        ops.join_aux_streams(self.grad.device)
         for b, (o0, o1) in enumerate(self._bucket_range):      # buckets that were not complete during backward
             if self._works[b] is None:
                 dptrace.record("grads", "all_reduce", o1 - o0, "bucket %d (end of step)" % b)
@@ -188,6 +192,7 @@ class FlatAdam(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None):
         assert closure is None
+        ops.join_aux_streams(self.fp.grad.device)     # weight gradients still in flight on their side stream
         scale = self.fp.all_reduce_grads()
         g = self.param_groups[0]
         self.step_count += 1

@@ -30,6 +30,50 @@ def _mark(*params):
             flat.mark_ready(p)
 
 
+# Weight gradients on a second HIP stream.  A layer's wgrad is off the critical path of backward (nothing waits for it
+# before the optimizer step), the HBM-bound kernels between two data gradients (BatchNorm backward of the next layer,
+# fan-in sums, ReLU masks, up-path) are ON it and leave the matrix cores idle.  Schedule: wgrad_L is enqueued on the side
+# stream behind dgrad_L, and the main stream waits for the side stream right before its next data gradient — so wgrad_L
+# runs concurrently with exactly those HBM-bound kernels and never with another MFMA-bound kernel (per-kernel durations
+# stay meaningful).  The side stream is joined at the end of every backward pass (engine callback).
+_WGRAD_STREAM = os.environ.get("RR_WGRAD_STREAM", "1") != "0"
+_WG_STATE = {"pending": False, "cb_queued": False}
+
+
+def _wgrad_join(device):
+    """Main stream waits for the weight gradients in flight on the side stream (before the next MFMA-bound kernel)."""
+    if _WG_STATE["pending"]:
+        torch.cuda.current_stream(device).wait_stream(_side_stream(device, "wgrad"))
+        _WG_STATE["pending"] = False
+
+
+def _wgrad_async(fn, device, *tensors):
+    """Run fn() (a weight-gradient launch + its mark_ready reports) on the side stream, ordered behind everything the
+    current stream holds so far; `tensors` are kept from being recycled by the allocator until the side stream passes."""
+    if not (_WGRAD_STREAM and device.type == "cuda"):
+        return fn()
+    cur = torch.cuda.current_stream(device)
+    side = _side_stream(device, "wgrad")
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        fn()
+    for t in tensors:
+        if t is not None:
+            t.record_stream(side)
+    _WG_STATE["pending"] = True
+    if not _WG_STATE["cb_queued"]:
+        _WG_STATE["cb_queued"] = True
+
+        def _end_of_backward():
+            _WG_STATE["cb_queued"] = False
+            torch.cuda.current_stream(device).wait_stream(side)
+            _WG_STATE["pending"] = False
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward)
+        except RuntimeError:           # not inside a backward pass (a test calling a backward by hand): join right away
+            _end_of_backward()
+
+
 _G_INTO = os.environ.get("RR_BN_G_INTO", "1") != "0"     # residual gradient added into the fan-in buffer by bn_bwd_apply itself
 BN_FUSED_STATS = os.environ.get("RR_BN_FUSED_STATS", "1") != "0"    # single process: slab -> statistics -> coefficients in one launch
 
@@ -162,8 +206,7 @@ class _ConvBnAct(torch.autograd.Function):
         else:
             wg = lambda tgt: ops.conv_wgrad(x, dy, tgt, stride, pad)
         if w_t is not None:
-            wg(w_t)
-            _mark(w)
+            _wgrad_async(lambda: (wg(w_t), _mark(w)), x.device, x, dy)
         else:
             dw = ops.zeros_nhwc(*w.shape, device=x.device)
             wg(dw)
@@ -189,6 +232,7 @@ def _input_grad(dy, wc, xshape, stride, pad, x_acc, in_link, x):
     buffer of x's fan-out).  Where the launch can carry them it also produces the BatchNorm-backward sums of the layer
     that produced x (ops.BnLink): when x has this node as its only consumer, or when this node is the LAST registered
     contributor to the fan-in buffer of x's fan-out (the epilogue then holds the complete gradient)."""
+    _wgrad_join(dy.device)        # the previous layer's weight gradient has had the HBM-bound stretch to itself
     if x_acc is None:
         link = in_link if (in_link is not None and in_link.consumers == 1) else None
         return ops.conv_dgrad(dy, wc, xshape, stride, pad, bnsum=link, bnsum_z=x)
@@ -266,8 +310,7 @@ class _ConvBias(torch.autograd.Function):
         w_t = _grad_target(w)
         ret_dw = None
         if w_t is not None:
-            ops.conv_wgrad(x, dy, w_t, stride, pad)
-            _mark(w)
+            _wgrad_async(lambda: (ops.conv_wgrad(x, dy, w_t, stride, pad), _mark(w)), x.device, x, dy)
         else:
             dw = ops.zeros_nhwc(*w.shape, device=x.device)
             ops.conv_wgrad(x, dy, dw, stride, pad)
@@ -682,11 +725,12 @@ dcn_v2_pooling = _DCNv2Pooling.apply
 _SIDE = {}
 
 
-def _side_stream(device):
-    """One auxiliary HIP stream per device for work that may overlap the current stream."""
-    key = (device.type, device.index)
+def _side_stream(device, tag="dcn"):
+    """Auxiliary HIP streams (one per device and purpose) for work that may overlap the current stream."""
+    key = (device.type, device.index, tag)
     if key not in _SIDE:
         _SIDE[key] = torch.cuda.Stream(device=device)
+        ops.AUX_STREAMS.setdefault((device.type, device.index), []).append(_SIDE[key])
     return _SIDE[key]
 
 

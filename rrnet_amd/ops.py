@@ -53,6 +53,20 @@ class KernelTimer:
         return out
 
 
+AUX_STREAMS = {}       # (device type, index) -> auxiliary HIP streams that may hold kernels writing gradient buffers
+
+
+def join_aux_streams(device):
+    """The current stream waits for everything enqueued on the auxiliary streams (weight gradients on their side
+    stream): called before a collective is launched on, or a consumer reads, the flat gradient buffer."""
+    if device.type != "cuda":
+        return
+    cur = torch.cuda.current_stream(device)
+    for st in AUX_STREAMS.get((device.type, device.index), ()):
+        if st != cur:
+            cur.wait_stream(st)
+
+
 TIMER = None
 SYNC_WAIT_S = 0.0      # host time spent blocked in the RoI-count read (bench.py separates it from the enqueue time)
 
