@@ -40,7 +40,8 @@ def parse():
     ap.add_argument("--backbone", default="hourglass", choices=["hourglass", "hourglass_tiny"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the config-5 / config-4 secondary workloads")
-    ap.add_argument("--extra-frames", type=int, default=1024, help="frames of the config-5 pass")
+    ap.add_argument("--extra-frames", type=int, default=10000, help="frames of the config-5 pass (BASELINE: 10k frames)")
+    ap.add_argument("--extra-pool", type=int, default=512, help="distinct resident frames of the config-5 pass (4 batches of 128)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--detail", action="store_true", help="print a per-layer-shape conv time table to stderr")
     return ap.parse_args()
@@ -114,7 +115,7 @@ def extras(a):
     out = {}
     try:
         import bench_infer
-        r = bench_infer.run(frames=a.extra_frames, batch=128, pool_frames=128, cpu_frames=0)
+        r = bench_infer.run(frames=a.extra_frames, batch=128, pool_frames=max(128, a.extra_pool // 128 * 128), cpu_frames=0)
         out["config5"] = {kk: r[kk] for kk in ("metric", "value", "unit", "frames_per_sec", "frames", "ms_per_batch",
                                                "output_boxes_per_frame")}
         out["config5"]["workload"] = r["config"]["workload"]

@@ -123,8 +123,13 @@ __device__ unsigned int place_threshold(const float *x, long n, int K, int peak,
 {
     const int tid = threadIdx.x;
     if (n <= DEC_CAP) return 0u;
+    // Large maps: the sample is DEC_SAMPLES / 32 whole 128-byte lines (32 consecutive floats each), evenly spaced — a
+    // strided sample touches one line per element (0.54 GB fetched per 128 frames of 270x480x10 in round 2, as much as
+    // the scan itself); lines cost 1/32 of that.  Maps too small for well-spread lines keep the element stride.
+    const bool by_line = n >= 8l * DEC_SAMPLES;
+    const long lstride = by_line ? ((n / (DEC_SAMPLES / 32)) & ~31l) : 0;
     const long stride = n / DEC_SAMPLES > 0 ? n / DEC_SAMPLES : 1;
-    const long ns = (n + stride - 1) / stride;
+    const long ns = by_line ? (long)DEC_SAMPLES : (n + stride - 1) / stride;
     long target = 2l * K > K + 1024l ? 2l * K : K + 1024l;
     if (target > DEC_CAP / 2) target = DEC_CAP / 2;
     if (target < K) return 0xffffffffu;
@@ -138,7 +143,7 @@ __device__ unsigned int place_threshold(const float *x, long n, int K, int peak,
         if (tid == 0) { res[0] = -1; res[1] = 0; }
         __syncthreads();
         for (long j = tid; j < ns; j += blockDim.x) {
-            const long i = j * stride;
+            const long i = by_line ? (j >> 5) * lstride + (j & 31) : j * stride;
             const unsigned int o = f2ord(x[i]);
             if (pass == 0 || (o >> 21) == (prefix >> 21)) {
                 if (!peak || is_peak3x3(x, i, C, H, W, is_logits)) atomicAdd(&hist[(o >> shift) & 2047], 1);

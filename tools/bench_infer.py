@@ -30,7 +30,7 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=10000)
     ap.add_argument("--batch", type=int, default=128)
-    ap.add_argument("--pool", type=int, default=128)
+    ap.add_argument("--pool", type=int, default=512, help="distinct resident frames (default: 4 batches of 128, 68 GB of feature maps)")
     ap.add_argument("--hf", type=int, default=270)
     ap.add_argument("--wf", type=int, default=480)
     ap.add_argument("--k", type=int, default=1500)
@@ -86,11 +86,18 @@ def run(frames=10000, batch=128, pool_frames=128, hf=270, wf=480, k=1500, cpu_fr
     torch.manual_seed(219)
     head = FasterRCNNDetector().to(dev).eval()
     head_sd = {kk: v.detach().clone() for kk, v in head.state_dict().items()}
-    pool = synth_head_outputs(pool_frames, hf, wf, seed=219, device=dev)
-    hm, wh, off, feat = [ops.to_nhwc(t) for t in pool]
     nb = pool_frames // batch
     assert nb >= 1, "--pool must be >= --batch"
-    batches = [tuple(t[i * batch:(i + 1) * batch] for t in (hm, wh, off, feat)) for i in range(nb)]
+    # the pool is generated one batch at a time (own seed each): 128 frames of 270x480x256 fp32 are 17 GB, and the
+    # generator's NCHW temporaries would triple the footprint of a 512-frame pool made in one piece
+    batches, pool = [], None
+    for i in range(nb):
+        chunk = synth_head_outputs(batch, hf, wf, seed=219 + i, device=dev)
+        if i == 0 and cpu_frames > 0:
+            pool = tuple(t[:cpu_frames].clone() for t in chunk)
+        batches.append(tuple(ops.to_nhwc(t) for t in chunk))
+        del chunk
+        torch.cuda.empty_cache()
 
     def step(bt):
         return inference.refine_frames(bt[0], bt[1], bt[2], bt[3], head, k=k, relu_feat=False)
