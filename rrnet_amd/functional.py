@@ -36,7 +36,10 @@ def _mark(*params):
 # stream behind dgrad_L, and the main stream waits for the side stream right before its next data gradient — so wgrad_L
 # runs concurrently with exactly those HBM-bound kernels and never with another MFMA-bound kernel (per-kernel durations
 # stay meaningful).  The side stream is joined at the end of every backward pass (engine callback).
-_WGRAD_STREAM = os.environ.get("RR_WGRAD_STREAM", "1") != "0"
+# Measured (round 3, B=8 1024x1024): 470.0 ms per step with the side stream against 463.0 ms without — the two
+# stream hand-overs per layer and the wgrad kernels slowed by the co-running HBM streams cost more than the ~20 ms of
+# element-wise kernels they hide.  Opt-in (RR_WGRAD_STREAM=1), not the default.
+_WGRAD_STREAM = os.environ.get("RR_WGRAD_STREAM", "0") == "1"
 _WG_STATE = {"pending": False, "cb_queued": False}
 
 

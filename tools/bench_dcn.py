@@ -55,6 +55,21 @@ def run(n=8, c=256, h=256, w=256, k=256, reps=5):
         res["bwd_%s_ms" % tag] = round(ms, 3)
         res["bwd_%s_tflops" % tag] = round(2 * flops / ms / 1e9, 1)
         del y, xg, og, mg, wg
+    # LDS roofline of the bf16 forward (the kernel furthest from the MFMA and HBM roofs): bytes the
+    # workgroups read from LDS per launch, from the kernel's structure — per output pixel, tap and 32-channel chunk:
+    # 4 bilinear corners x 128 B from the fp32 input window (the gather), 8 geometry words per staging thread
+    # (8 threads x 2 x 16 B), and per workgroup and K-step the MFMA fragments (8 waves x 8 ds_read_b128 x 1 KiB).
+    m = n * h * w
+    ksteps = (m // 128) * 9 * (c // 32)
+    lds_read = m * 9 * c * 4 * 4 + ksteps * (512 * 16 * 4) + ksteps * (8 * 8 * 1024) * (k // 256)
+    lds_peak = 150.0                                   # TB/s, ds_read_b64/b128 with every CU streaming (MI355X_MICROARCH.md §LDS)
+    ach = lds_read / (res["fwd_bf16_ms"] * 1e-3) / 1e12
+    res["roofline"] = {"bound": "lds", "kernel": "dcn_fprop_win_kernel<256,false> (bf16 operands)",
+                       "achieved": round(ach, 2), "peak": lds_peak, "unit": "TB/s", "frac": round(ach / lds_peak, 4),
+                       "lds_read_gb_per_launch": round(lds_read / 1e9, 2),
+                       "mfma_frac_bf16": round(res["fwd_bf16_tflops"] / 2500.0, 4),
+                       "note": "neither roof binds: the per-K-step chain gather -> blend -> LDS tile -> barrier -> MFMA "
+                               "at one workgroup per CU sets the time (latency-bound)"}
     return res
 
 
