@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--extra-frames", type=int, default=10000, help="frames of the config-5 pass (BASELINE: 10k frames)")
     ap.add_argument("--extra-pool", type=int, default=512, help="distinct resident frames of the config-5 pass (4 batches of 128)")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--time-every", type=int, default=4, help="HIP-event pair around every n-th launch of the dominant kernel")
     ap.add_argument("--detail", action="store_true", help="print a per-layer-shape conv time table to stderr")
     return ap.parse_args()
 
@@ -194,7 +195,7 @@ def main():
     timer = None
     if not a.no_kernel_timing:
         # HIP events around every launch of the dominant kernel (the roofline leg); --detail times all conv kernels
-        timer = ops.KernelTimer(None if a.detail else {"conv_fprop<BN=128,vec4>"})
+        timer = ops.KernelTimer(None if a.detail else {"conv_fprop<BN=128,vec4>"}, every=1 if a.detail else a.time_every)
         ops.TIMER = timer
     sync_all()
     from rrnet_amd import dptrace
@@ -255,7 +256,8 @@ def main():
                                    "algorithmic_bytes_per_launch": round(timer.bytes.get(dom, 0.0) / d["launches"]),
                                    "kernel": "conv_igemm_kernel<128, 0, false, 32, 2> (implicit-GEMM forward kernel, v_mfma_f32_32x32x2_f32; "
                                              "launched for fprop and for stride-1 dgrad on flipped weights)",
-                                   "launches": d["launches"], "avg_launch_ms": round(d["ms"] / d["launches"], 4),
+                                   "launches": d["launches"], "launches_timed": "every %d-th launch of the timed region (systematic sample)" % a.time_every,
+                                   "avg_launch_ms": round(d["ms"] / d["launches"], 4),
                                    "algorithmic_gflop_per_launch": round(d["flops"] / d["launches"] / 1e9, 3)}
             out["kernels"] = {k: {"launches": v["launches"], "ms": round(v["ms"], 2),
                                   "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else None}

@@ -212,6 +212,7 @@ __global__ __launch_bounds__(256) void dcn_fprop_kernel(const DcnArgs a)
 // row (16-byte aligned rows, one ds_read_b128 = the 8 k values a lane feeds to one MFMA).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int LDKH = BK + 8;
 
 __device__ __forceinline__ unsigned short f2bf(float f)
@@ -477,41 +478,41 @@ __global__ __launch_bounds__(512) void dcn_fprop_win_kernel(const DcnWinArgs wa)
         }
     };
     f32x4 rv[2], rb[BJ];
-    auto build_a = [&](int cch, int tap, int half) {          // blended samples of the rows this thread stages
-        const int c0 = cch * BK;
-        if constexpr (F32) {
-            const unsigned int *go = geo_o + (fa_row * RS + tap) * 4;
-            const float *gw = geo_w + (fa_row * RS + tap) * 4;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    // Operand staging in two phases so that a K-step's MFMAs run UNDER the next step's gather instead of behind it:
+    // gather_a issues the loads (geometry words, then the four corner rows from the window; corners beyond the window
+    // margin come from global memory through an unconditional load that reads the zero page when the corner is inside —
+    // no divergent branch between the LDS reads and the matrix instructions), blend_a does the arithmetic afterwards.
+    constexpr int GJ = F32 ? 1 : 2;
+    f32x4 gxl[4], gwt;
+    u32x4 gof;
+    int g_c0 = 0, g_col = 0;
+    auto gather_a = [&](int cch, int tap, int half, int j) {      // j: which of the thread's (bf16: two) staged rows
+        g_c0 = cch * BK;
+        g_col = F32 ? half * 16 + fa_col : a_col;
+        const int r = F32 ? fa_row : a_row + 64 * j;
+        gof = *reinterpret_cast<const u32x4 *>(geo_o + (r * RS + tap) * 4);
+        gwt = *reinterpret_cast<const f32x4 *>(geo_w + (r * RS + tap) * 4);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const unsigned int o = go[e];
-                const float wgt = gw[e];
-                f32x4 xv;
-                if (o & 0x80000000u) xv = *reinterpret_cast<const f32x4 *>(a.x + (img + (long)(o & 0x7fffffffu)) * a.C + c0 + half * 16 + fa_col);
-                else xv = *reinterpret_cast<const f32x4 *>(win + (size_t)o * BK + half * 16 + fa_col);
-                v += xv * wgt;
-            }
-            rv[0] = v;
-        } else {
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int r = a_row + 64 * j;
-                const unsigned int *go = geo_o + (r * RS + tap) * 4;
-                const float *gw = geo_w + (r * RS + tap) * 4;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const unsigned int o = go[e];
-                    const float wgt = gw[e];
-                    f32x4 xv;
-                    if (o & 0x80000000u) xv = *reinterpret_cast<const f32x4 *>(a.x + (img + (long)(o & 0x7fffffffu)) * a.C + c0 + a_col);
-                    else xv = *reinterpret_cast<const f32x4 *>(win + (size_t)o * BK + a_col);
-                    v += xv * wgt;
-                }
-                rv[j] = v;
-            }
+        for (int e = 0; e < 4; ++e) {
+            const unsigned int o = gof[e];
+            gxl[e] = *reinterpret_cast<const f32x4 *>(win + (size_t)((o & 0x80000000u) ? 0u : o) * BK + g_col);
         }
+    };
+    auto blend_a = [&](int j) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            f32x4 xv = gxl[e];
+            const unsigned int o = gof[e];
+            if (o & 0x80000000u)       // a corner beyond the window margin (rare): straight from global memory
+                xv = *reinterpret_cast<const f32x4 *>(a.x + (img + (long)(o & 0x7fffffffu)) * a.C + g_c0 + g_col);
+            v += xv * gwt[e];
+        }
+        rv[j] = v;
+    };
+    auto build_a = [&](int cch, int tap, int half) {
+#pragma unroll
+        for (int j = 0; j < GJ; ++j) { gather_a(cch, tap, half, j); blend_a(j); }
     };
     auto issue_b = [&](int cch, int tap, int half) {
         const int c0 = cch * BK;
@@ -569,10 +570,7 @@ __global__ __launch_bounds__(512) void dcn_fprop_win_kernel(const DcnWinArgs wa)
         const bool more = kc + 1 < nk;
         const bool new_chunk = more && rem == spc - 1;           // the next K-step opens chunk cch + 1
         if (rem == 0 && cch + 1 < cpt) fetch_window(cch + 1);    // lands under this chunk's K-steps
-        if (more && !new_chunk) {
-            issue_b(cch, (rem + 1) / H, (rem + 1) % H);
-            build_a(cch, (rem + 1) / H, (rem + 1) % H);
-        }
+        const bool stage = more && !new_chunk;
         const unsigned short *A = As + buf * A_ELEMS, *B = Bs + buf * B_ELEMS;
         if constexpr (F32) {
             const float *Af = reinterpret_cast<const float *>(A), *Bf = reinterpret_cast<const float *>(B);
@@ -588,6 +586,11 @@ __global__ __launch_bounds__(512) void dcn_fprop_win_kernel(const DcnWinArgs wa)
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
                     fb[j][u] = *reinterpret_cast<const f32x4 *>(Bf + ((wn * TN + j) * 32 + lr) * LDF + 8 * lh + 4 * u);
+            if (stage) {       // next step's operand loads go out behind this step's fragment reads, ahead of its MFMAs
+                issue_b(cch, (rem + 1) / H, (rem + 1) % H);
+                gather_a(cch, (rem + 1) / H, (rem + 1) % H, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -598,21 +601,45 @@ __global__ __launch_bounds__(512) void dcn_fprop_win_kernel(const DcnWinArgs wa)
                         for (int j = 0; j < TN; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][u][e], fb[j][u][e], acc[i][j], 0, 0, 0);
         } else {
+            bf16x8 fa[BK / 16][TM], fb[BK / 16][TN];
 #pragma unroll
             for (int kk = 0; kk < BK / 16; ++kk) {
-                bf16x8 fa[TM], fb[TN];
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
-                    fa[i] = *reinterpret_cast<const bf16x8 *>(A + ((wm * TM + i) * 32 + lr) * LDKH + kk * 16 + lh * 8);
+                    fa[kk][i] = *reinterpret_cast<const bf16x8 *>(A + ((wm * TM + i) * 32 + lr) * LDKH + kk * 16 + lh * 8);
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    fb[j] = *reinterpret_cast<const bf16x8 *>(B + ((wn * TN + j) * 32 + lr) * LDKH + kk * 16 + lh * 8);
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                    fb[kk][j] = *reinterpret_cast<const bf16x8 *>(B + ((wn * TN + j) * 32 + lr) * LDKH + kk * 16 + lh * 8);
             }
+            // the next step's operand loads go out behind this step's fragment reads and are consumed one MFMA group
+            // later: row 0 of the thread's two staged rows under the first half of the K-step, row 1 under the second
+            if (stage) {
+                issue_b(cch, (rem + 1) / H, (rem + 1) % H);
+                gather_a(cch, (rem + 1) / H, (rem + 1) % H, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[0][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (stage) {
+                blend_a(0);
+                gather_a(cch, (rem + 1) / H, (rem + 1) % H, 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][i], fb[1][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (stage) blend_a(1);
+        }
+        if constexpr (F32) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (stage) blend_a(0);
         }
         if (new_chunk) {
             // every wave is past its last gather from the old window (it built the chunk's last step one K-step ago)
