@@ -43,6 +43,12 @@ class ResidualBlock(nn.Module):
 
     def forward(self, x):
         # both consumers of x (conv1 and the skip path) accumulate their input gradients into one buffer
+        if len(self.skip_connection) and RF.sync_coalescing(self.bn1):
+            # SyncBN across ranks: the projection and conv1 read the same x — one joint node, ONE statistics exchange per
+            # direction for the pair (conv1 first: its 3x3 data gradient writes the shared buffer, the 1x1 accumulates)
+            out, skip = RF.conv_bn_act_multi(x, [(self.conv1, self.bn1, True),
+                                                 (self.skip_connection[0], self.skip_connection[1], False)])
+            return RF.conv_bn_act(out, self.conv2, self.bn2, relu=True, residual=skip)
         xa, xb, _ = RF.fanout_shared(x, 2)
         if len(self.skip_connection):
             # the projection runs BEFORE conv1: autograd then runs conv1's backward first, so the 3x3 data gradient is

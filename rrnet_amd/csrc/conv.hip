@@ -48,6 +48,10 @@ struct ConvArgs {
     // sum(d * xhat) with d = dst * relu-mask (mask from bs_z > 0, or recomputed as bs_y*bs_msc+bs_msh > 0) and
     // xhat = (bs_y - bs_mean) * bs_invstd — what rr_bn_bwd_reduce would compute in a separate pass over dst and y.
     const float *bs_y, *bs_z, *bs_mean, *bs_invstd, *bs_msc, *bs_msh;
+    // bs_relu_bias != 0: the producer is conv + bias + ReLU (a head's 3x3 layer, centernet_detector.py:62): the epilogue
+    // stores the MASKED gradient dst*(bs_z > 0) and the slab's first row holds its column sums = the bias gradient
+    // (what rr_bias_relu_bwd computes in a pass of its own); bs_mean / bs_invstd are not read.
+    int bs_relu_bias;
     int N;
     int SH, SW, SC;    // source spatial / channels
     int DH, DW, DC;    // destination spatial / channels (DC = GEMM N)
@@ -647,7 +651,7 @@ __global__ __launch_bounds__(256, PIPE == 3 ? 3 : 1) void conv_igemm_kernel(cons
         float s1 = 0.f, s2 = 0.f;
         float bs_m = 0.f, bs_i = 0.f, bs_sc = 0.f, bs_sh = 0.f;
         if constexpr (bnsum) {
-            if (n_ok) {
+            if (n_ok && !a.bs_relu_bias) {
                 bs_m = a.bs_mean[ncol]; bs_i = a.bs_invstd[ncol];
                 if (a.bs_z == nullptr) {
                     if (a.bs_msc != nullptr) { bs_sc = a.bs_msc[ncol]; bs_sh = a.bs_msh[ncol]; }
@@ -671,7 +675,7 @@ __global__ __launch_bounds__(256, PIPE == 3 ? 3 : 1) void conv_igemm_kernel(cons
                     for (int q = 0; q < 8; ++q) {
                         const int e = hh * 8 + q;
                         const int soff = __builtin_amdgcn_readfirstlane(((e & 3) + 8 * (e >> 2)) * a.DC * 4);
-                        yv[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bs_rs_y, voff, soff, 0));
+                        yv[q] = a.bs_relu_bias ? 0.f : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bs_rs_y, voff, soff, 0));
                         zv[q] = use_z ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bs_rs_z, voff, soff, 0)) : 0.f;
                     }
 #pragma unroll
@@ -682,9 +686,9 @@ __global__ __launch_bounds__(256, PIPE == 3 ? 3 : 1) void conv_igemm_kernel(cons
                             float *p = a.dst + (long)m * a.DC + ncol;
                             float v = acc[i][j][e];
                             if (mode_e == 1) v += *p;
-                            *p = v;
                             const bool on = use_z ? zv[q] > 0.f : __builtin_fmaf(yv[q], bs_sc, bs_sh) > 0.f;
                             const float d = on ? v : 0.f;
+                            *p = a.bs_relu_bias ? d : v;
                             s1 += d;
                             s2 += d * ((yv[q] - bs_m) * bs_i);
                         }
@@ -1325,6 +1329,7 @@ struct BnSumArgs {
     const float *y, *z, *mean, *invstd, *msc, *msh;
     double *slab;      // [ceil(M/128)][2][C] scratch
     double *sums;      // [2][C], zeroed by the caller
+    int relu_bias;     // producer = conv + bias + ReLU: masked store, sums[0..C) = bias gradient
 };
 
 static int fprop_impl(const float *x, const float *w, const float *bias, float *y, double *stat_slab,
@@ -1350,6 +1355,7 @@ static int fprop_impl(const float *x, const float *w, const float *bias, float *
     const int blocks = rr_cdiv(M, BM) * rr_cdiv(k, bn);
     const int nk = scalar ? rr_cdiv(a.Kg, bk) : rr_cdiv(c, bk) * r * s;
     int ks = (bias == nullptr && !relu && k % 4 == 0 && k <= 1024) ? pick_ksplit(blocks, nk) : 1;
+    if (bs != nullptr && bs->relu_bias) ks = 1;      // the masked store needs the complete value in one workgroup
     if (ks > 1) {
         a.ksplit = ks;
         if (!accumulate) hipMemsetAsync(y, 0, sizeof(float) * (size_t)M * k, stream);
@@ -1357,6 +1363,7 @@ static int fprop_impl(const float *x, const float *w, const float *bias, float *
     if (bs != nullptr && ks == 1) {      // sums in the epilogue; with split-K the complete values exist only afterwards
         a.stat_slab = bs->slab;
         a.bs_y = bs->y; a.bs_z = bs->z; a.bs_mean = bs->mean; a.bs_invstd = bs->invstd; a.bs_msc = bs->msc; a.bs_msh = bs->msh;
+        a.bs_relu_bias = bs->relu_bias;
     }
     int rc = launch_igemm<0>(a, bn, scalar, blocks, 1, ks, stream, "rr_conv_fprop");
     if (rc == RR_OK && bs != nullptr) {
@@ -1475,9 +1482,22 @@ extern "C" int rr_conv_dgrad_s1_bnsum(const float *dy, const float *wt, float *d
     RR_CHECK_ARG(c % 4 == 0 && c <= 1024, "rr_conv_dgrad_s1_bnsum: C=%d must be a multiple of 4 and <= 1024", c);
     const int p = h + 2 * pad_h - r + 1, q = wd + 2 * pad_w - s + 1;
     RR_CHECK_ARG(p > 0 && q > 0, "rr_conv_dgrad_s1_bnsum: empty dy");
-    const BnSumArgs bs{prod_y, prod_z, prod_mean, prod_invstd, prod_mask_scale, prod_mask_shift, slab, sums};
+    const BnSumArgs bs{prod_y, prod_z, prod_mean, prod_invstd, prod_mask_scale, prod_mask_shift, slab, sums, 0};
     return fprop_impl(dy, wt, nullptr, dx, nullptr, n, p, q, k, c, r, s, 1, r - 1 - pad_h, s - 1 - pad_w, 0, accumulate,
                       stream, &bs);
+}
+
+extern "C" int rr_conv_dgrad_s1_relubias(const float *dy, const float *wt, float *dx, int n, int h, int wd, int c, int k,
+                                         int r, int s, int pad_h, int pad_w, const float *prod_z, double *slab, double *sums,
+                                         hipStream_t stream)
+{
+    RR_CHECK_ARG(pad_h < r && pad_w < s && pad_h >= 0 && pad_w >= 0, "rr_conv_dgrad_s1_relubias: pad must be in [0, kernel)");
+    RR_CHECK_ARG(prod_z && slab && sums, "rr_conv_dgrad_s1_relubias: the producer's output and the two buffers are required");
+    RR_CHECK_ARG(c % 4 == 0 && k % 4 == 0 && c <= 1024, "rr_conv_dgrad_s1_relubias: C=%d, K=%d must be multiples of 4", c, k);
+    const int p = h + 2 * pad_h - r + 1, q = wd + 2 * pad_w - s + 1;
+    RR_CHECK_ARG(p > 0 && q > 0, "rr_conv_dgrad_s1_relubias: empty dy");
+    const BnSumArgs bs{prod_z, prod_z, nullptr, nullptr, nullptr, nullptr, slab, sums, 1};
+    return fprop_impl(dy, wt, nullptr, dx, nullptr, n, p, q, k, c, r, s, 1, r - 1 - pad_h, s - 1 - pad_w, 0, 0, stream, &bs);
 }
 
 extern "C" int rr_conv_dgrad(const float *dy, const float *w, float *dx, int n, int h, int wd, int c, int k,

@@ -77,6 +77,7 @@ def _wgrad_async(fn, device, *tensors):
             _end_of_backward()
 
 
+_SYNC_COALESCE = os.environ.get("RR_SYNCBN_COALESCE", "1") != "0"   # joint SyncBN exchange of layers that share their input
 _G_INTO = os.environ.get("RR_BN_G_INTO", "1") != "0"     # residual gradient added into the fan-in buffer by bn_bwd_apply itself
 BN_FUSED_STATS = os.environ.get("RR_BN_FUSED_STATS", "1") != "0"    # single process: slab -> statistics -> coefficients in one launch
 
@@ -274,14 +275,151 @@ def conv_bn_act(x, conv, bn, relu=True, residual=None, x_acc=None, res_acc=None)
     return out
 
 
+class _ConvBnSyncMulti(torch.autograd.Function):
+    """SyncBN, several conv -> bn [-> relu] layers on the SAME input (a projection block's skip and conv1,
+    backbones/hourglass.py:31-40): one autograd node so that their statistic exchanges share ONE all-reduce forward
+    ([sum, sumsq] of every layer + one sample count) and ONE backward ([sum dz, sum dz*xhat] of every layer) instead of
+    one each — the layers are independent given x, so nothing is re-ordered.  Used only when world_size > 1; a single
+    process keeps the per-layer nodes (and their fused single-launch statistics)."""
+
+    @staticmethod
+    def forward(ctx, x, x_acc, specs, *params):
+        # specs: [(bn module, stride, pad, relu)], params: w0, gamma0, beta0, w1, gamma1, beta1, ...
+        x = ops.to_nhwc(x)
+        L = len(specs)
+        ws = [ops.to_nhwc(params[3 * i]) for i in range(L)]
+        ys, ks = [], []
+        for i, (bn, stride, pad, relu) in enumerate(specs):
+            y, slab = ops.conv_fprop(x, ws[i], None, stride, pad, False, want_stats=True)
+            ys.append((y, slab))
+            ks.append(ws[i].shape[0])
+        tot = 2 * sum(ks) + 1
+        packed = ops._ZEROS.take(tot, x.device)                      # [sums_0 | sums_1 | .. | count]
+        off = 0
+        for (y, slab), k in zip(ys, ks):
+            mt = slab.numel() // (2 * k)
+            ops._C.check(ops._C.fn("rr_bn_reduce_slab")(ops._C.ptr(slab), mt, k, ops._C.ptr(packed[off:off + 2 * k]),
+                                                        ops._C.stream()), "rr_bn_reduce_slab")
+            off += 2 * k
+        # every layer of the node sees the same pixels per rank only if their strides agree; the count is exchanged once
+        counts = [float(y.numel() // k) for (y, _), k in zip(ys, ks)]
+        assert all(c == counts[0] for c in counts), "joint SyncBN node: the layers must produce the same number of pixels"
+        packed[tot - 1] = counts[0]
+        dptrace.record("default", "all_reduce", packed.numel(), "syncbn_fwd x%d" % L)
+        dist.all_reduce(packed)
+        cnt_dev = packed[tot - 1:].clone()
+        outs, saved, off = [], [], 0
+        for i, ((bn, stride, pad, relu), (y, _), k) in enumerate(zip(specs, ys, ks)):
+            gamma, beta = params[3 * i + 1], params[3 * i + 2]
+            mom = bn.momentum if bn.momentum is not None else 0.1
+            mean, invstd, scale, shift = ops.bn_finalize(packed[off:off + 2 * k], counts[0], gamma, beta, bn.running_mean,
+                                                         bn.running_var, mom, bn.eps, cnt_dev, bn.num_batches_tracked)
+            off += 2 * k
+            outs.append(ops.bn_apply(y, scale, shift, None, relu))
+            saved += [y, mean, invstd, gamma, scale if relu else None, shift if relu else None]
+        ctx.save_for_backward(x, cnt_dev, *ws, *saved)
+        ctx.meta = (L, [(st, tuple(pd), rl) for (_, st, pd, rl) in specs], ks, counts[0], x_acc, tuple(x.shape))
+        ctx.params = params
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *dzs):
+        L, cfgs, ks, count, x_acc, xshape = ctx.meta
+        t = ctx.saved_tensors
+        x, cnt_dev, ws, rest = t[0], t[1], t[2:2 + L], t[2 + L:]
+        params = ctx.params
+        packed = ops._ZEROS.take(2 * sum(ks), x.device)
+        dzl, off = [], 0
+        for i in range(L):
+            y, mean, invstd, gamma, msc, msh = rest[6 * i:6 * i + 6]
+            dz = ops.to_nhwc(dzs[i]) if dzs[i] is not None else torch.zeros_like(y)
+            dzl.append(dz)
+            k = ks[i]
+            n, c, h, w = y.shape
+            ops._C.check(ops._C.fn("rr_bn_bwd_reduce")(ops._C.ptr(dz), ops._C.ptr(None), ops._C.ptr(y), ops._C.ptr(mean),
+                                                       ops._C.ptr(invstd), ops._C.ptr(msc), ops._C.ptr(msh),
+                                                       ops._C.ptr(packed[off:off + 2 * k]), n * h * w, c, 1, ops._C.stream()),
+                         "rr_bn_bwd_reduce")
+            # gradients of gamma / beta come from the LOCAL sums (averaged later like any gradient)
+            gp, bp = params[3 * i + 1], params[3 * i + 2]
+            dg_t, db_t = _grad_target(gp), _grad_target(bp)
+            if dg_t is not None:
+                db_t.add_(packed[off:off + k].float())
+                dg_t.add_(packed[off + k:off + 2 * k].float())
+                _mark(gp, bp)
+            off += 2 * k
+        local = None
+        if any(_grad_target(params[3 * i + 1]) is None for i in range(L)):
+            local = packed.clone()
+        dptrace.record("default", "all_reduce", packed.numel(), "syncbn_bwd x%d" % L)
+        dist.all_reduce(packed)
+        if x_acc is not None:
+            x_acc.pending += L - 1                 # this node contributes L data gradients to the fan-in buffer
+        grads, dx, off = [], None, 0
+        for i in range(L):
+            y, mean, invstd, gamma, msc, msh = rest[6 * i:6 * i + 6]
+            stride, pad, relu = cfgs[i]
+            k = ks[i]
+            dy, _ = ops.bn_bwd_apply(dzl[i], None, y, mean, invstd, gamma, packed[off:off + 2 * k], count, False, None, None,
+                                     cnt_dev, msc, msh)
+            if ctx.needs_input_grad[0]:
+                if x_acc is not None:
+                    r = _input_grad(dy, ws[i], xshape, stride, pad, x_acc, None, x)
+                    dx = r if r is not None else dx
+                elif dx is None:
+                    dx = ops.conv_dgrad(dy, ws[i], xshape, stride, pad)
+                else:
+                    ops.conv_dgrad(dy, ws[i], xshape, stride, pad, out=dx, accumulate=True)
+            w = params[3 * i]
+            w_t = _grad_target(w)
+            if w_t is not None:
+                ops.conv_wgrad(x, dy, w_t, stride, pad)
+                _mark(w)
+                grads += [None]
+            else:
+                dw = ops.zeros_nhwc(*w.shape, device=x.device)
+                ops.conv_wgrad(x, dy, dw, stride, pad)
+                grads += [dw]
+            if _grad_target(params[3 * i + 1]) is None:
+                grads += [local[off + k:off + 2 * k].float(), local[off:off + k].float()]
+            else:
+                grads += [None, None]
+            off += 2 * k
+        return (dx, None, None) + tuple(grads)
+
+
+def sync_coalescing(bn):
+    """True when the joint SyncBN node applies: statistics exchanged across ranks, training, gradients on."""
+    return _SYNC_COALESCE and _is_sync(bn) and bn.training and torch.is_grad_enabled()
+
+
+def conv_bn_act_multi(x, layers):
+    """layers: [(conv, bn, relu), ...] applied to the same x -> list of outputs.  With SyncBN across ranks the layers'
+    statistic exchanges are coalesced (one all-reduce per direction for the whole group); otherwise the ordinary
+    per-layer nodes run, in the given order."""
+    if (all(sync_coalescing(b) for _, b, _ in layers) and len({c.stride[0] for c, _, _ in layers}) == 1
+            and all(c.kernel_size[0] == 2 * c.padding[0] + 1 and c.kernel_size[1] == 2 * c.padding[1] + 1 for c, _, _ in layers)):
+        # ("same"-padded layers of one stride: every layer sees the same number of output pixels — one sample count)
+        x_acc = getattr(x, "_rr_acc", None)
+        if x.requires_grad and x_acc is not None:
+            x_acc.pending += 1
+        specs = [(bn, conv.stride[0], tuple(conv.padding), relu) for conv, bn, relu in layers]
+        params = []
+        for conv, bn, _ in layers:
+            params += [conv.weight, bn.weight, bn.bias]
+        return list(_ConvBnSyncMulti.apply(x, x_acc, specs, *params))
+    return [conv_bn_act(x, conv, bn, relu=relu) for conv, bn, relu in layers]
+
+
 class _ConvBias(torch.autograd.Function):
     """y = relu?(conv(x, w) + b) — the bias / ReLU live in the conv epilogue
     (detectors/centernet_detector.py:62,73,85-93; fasterrcnn_detector.py:17)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, stride, pad, relu, x_acc=None, in_link=None):
+    def forward(ctx, x, w, b, stride, pad, relu, x_acc=None, in_link=None, out_link=None):
         ctx.x_acc = x_acc
         ctx.in_link = in_link
+        ctx.out_link = out_link
         x = ops.to_nhwc(x)
         wc = ops.to_nhwc(w)
         y = ops.conv_fprop(x, wc, b, stride, pad, relu)
@@ -298,10 +436,20 @@ class _ConvBias(torch.autograd.Function):
         w, b = ctx.params
         dy = ops.to_nhwc(dy)
         ret_db = None
+        ol = ctx.out_link
+        fused = None
+        if ol is not None and ol.sums is not None:
+            # the consumer's data gradient already masked dy with this layer's ReLU and summed its columns
+            if ol.dz is not None and ol.dz.data_ptr() == dy.data_ptr() and ol.dz.shape == dy.shape:
+                fused = ol.sums
+            ol.sums = ol.dz = None
         if b is not None:
             b_t = _grad_target(b)
             tgt = b_t if b_t is not None else torch.zeros_like(b)
-            dy = ops.bias_relu_bwd(dy, y if relu else None, tgt)
+            if fused is not None:
+                tgt.add_(fused[:b.numel()].float())
+            else:
+                dy = ops.bias_relu_bwd(dy, y if relu else None, tgt)
             ret_db = None if b_t is not None else tgt
             if b_t is not None:
                 _mark(b)
@@ -318,18 +466,27 @@ class _ConvBias(torch.autograd.Function):
             dw = ops.zeros_nhwc(*w.shape, device=x.device)
             ops.conv_wgrad(x, dy, dw, stride, pad)
             ret_dw = dw
-        return dx, ret_dw, ret_db, None, None, None, None, None
+        return dx, ret_dw, ret_db, None, None, None, None, None, None
 
 
 def _conv_bias_apply(x, weight, bias, stride, pad, relu):
     x_acc = getattr(x, "_rr_acc", None)
     in_link = getattr(x, "_rr_bnlink", None) if x_acc is None else None
-    if torch.is_grad_enabled() and x.requires_grad:
+    grad_on = torch.is_grad_enabled()
+    if grad_on and x.requires_grad:
         if x_acc is not None:
             x_acc.pending += 1
         elif in_link is not None:
             in_link.consumers += 1
-    return _ConvBias.apply(x, weight, bias, stride, pad, relu, x_acc, in_link)
+    out_link = None
+    if grad_on and relu and bias is not None and weight.shape[0] % 4 == 0:
+        # conv + bias + ReLU: a single consumer's data gradient can apply this layer's ReLU mask and sum its bias gradient
+        out_link = ops.BnLink()
+        out_link.relu_bias = out_link.use_z = True
+    out = _ConvBias.apply(x, weight, bias, stride, pad, relu, x_acc, in_link, out_link)
+    if out_link is not None:
+        out._rr_bnlink = out_link
+    return out
 
 
 def conv_bias(x, conv, relu=False):

@@ -217,10 +217,13 @@ class BnLink:
     statistics, and the source of its ReLU mask (z for layers with a residual, scale / shift otherwise).  The consumer's
     backward leaves `sums` (and the gradient tensor they were taken of) here; the producer's backward picks them up
     instead of running rr_bn_bwd_reduce when the gradient it receives is that very tensor."""
-    __slots__ = ("y", "use_z", "mean", "invstd", "msc", "msh", "sums", "dz", "consumers")
+    __slots__ = ("y", "use_z", "mean", "invstd", "msc", "msh", "sums", "dz", "consumers", "relu_bias")
 
     def __init__(self):
         self.y = self.mean = self.invstd = self.msc = self.msh = self.sums = self.dz = None
+        # relu_bias: the producer is conv + bias + ReLU (a head's 3x3 layer): the consumer's data gradient stores the
+        # ReLU-masked gradient and sums[:c] is the producer's bias gradient (rr_conv_dgrad_s1_relubias)
+        self.relu_bias = False
         # the mask comes from the producer's OUTPUT z (layers with a residual).  The link must not hold z itself — z
         # carries the link as an attribute, and such a cycle keeps a step's activations alive until the cyclic GC runs
         # (the caching allocator then thrashes); the consumer passes its own saved input, which IS z.
@@ -245,6 +248,30 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False,
         out = empty_nhwc(n, c, h, wd, dy.device)
         accumulate = False
     assert is_nhwc(out)
+    if (bnsum is not None and bnsum.relu_bias and _DGRAD_BNSUM and stride == 1 and not accumulate and c % 4 == 0
+            and bnsum_z is not None and is_nhwc(bnsum_z) and bnsum_z.shape == out.shape and out.numel() * 4 < (1 << 31)
+            and r * s <= 64 and pad[0] < r and pad[1] < s and dy.shape[2] * dy.shape[3] >= _DGRAD_VIA_FPROP_MIN_PIXELS):
+        # producer = conv + bias + ReLU: masked gradient + bias column sums in this launch's epilogue.  A 10- or
+        # 2-channel dy (hm / offset heads) is zero-padded to a multiple of 4 for the vector kernel (25 MB at 8x256x256)
+        kp = (k + 3) // 4 * 4
+        dyp, wp = dy, w
+        if kp != k:
+            dyp = zeros_nhwc(dy.shape[0], kp, dy.shape[2], dy.shape[3], dy.device)
+            dyp[:, :k] = dy
+            wp = zeros_nhwc(kp, c, r, s, dy.device)
+            wp[:k] = w
+        wt = torch.empty(kp * c * r * s, dtype=torch.float32, device=dy.device)
+        _C.check(_C.fn("rr_weight_flip_transpose")(_C.ptr(wp), _C.ptr(wt), kp, c, r, s, _C.stream()), "rr_weight_flip_transpose")
+        slab = torch.empty(_C.fn("rr_conv_stat_slab_bytes")(n, h, wd, c) // 8, dtype=torch.float64, device=dy.device)
+        sums = _ZEROS.take(2 * c, dy.device)
+        flops_m = 2.0 * dy.shape[0] * dy.shape[2] * dy.shape[3] * k * c * r * s
+        fr = _C.fn("rr_conv_dgrad_s1_relubias")
+        _C.check(_timed(_igemm_name("fprop", c, False, n * h * wd) + "+relubias", flops_m,
+                        lambda: fr(_C.ptr(dyp), _C.ptr(wt), _C.ptr(out), n, h, wd, c, kp, r, s, pad[0], pad[1], _C.ptr(bnsum_z),
+                                   _C.ptr(slab), _C.ptr(sums), _C.stream()), (n, h, wd, c, k, r, s, stride)),
+                 "rr_conv_dgrad_s1_relubias")
+        bnsum.sums, bnsum.dz = sums, out
+        return out
     flops = 2.0 * dy.shape[0] * dy.shape[2] * dy.shape[3] * k * c * r * s
     if (stride == 1 and k % 4 == 0 and c % 4 == 0 and r * s <= 64 and pad[0] < r and pad[1] < s and _DGRAD_VIA_FPROP
             and dy.shape[2] * dy.shape[3] >= _DGRAD_VIA_FPROP_MIN_PIXELS):
@@ -252,7 +279,7 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False,
         wt = torch.empty(k * c * r * s, dtype=torch.float32, device=dy.device)
         _C.check(_C.fn("rr_weight_flip_transpose")(_C.ptr(w), _C.ptr(wt), k, c, r, s, _C.stream()),
                  "rr_weight_flip_transpose")
-        if (bnsum is not None and _DGRAD_BNSUM and bnsum.y is not None and c <= 1024 and out.numel() * 4 < (1 << 31)
+        if (bnsum is not None and not bnsum.relu_bias and _DGRAD_BNSUM and bnsum.y is not None and c <= 1024 and out.numel() * 4 < (1 << 31)
                 and tuple(bnsum.y.shape) == tuple(out.shape)
                 and (not bnsum.use_z or (bnsum_z is not None and is_nhwc(bnsum_z) and bnsum_z.shape == out.shape))):
             zt = bnsum_z if bnsum.use_z else None

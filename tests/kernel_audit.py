@@ -208,7 +208,20 @@ def audit(tol=2e-5, tol_wgrad=2e-4, sample=False):
     def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False, bnsum=None, bnsum_z=None):
         base = out.clone() if (out is not None and accumulate) else None
         res = orig["conv_dgrad"](dy, w, x_shape, stride, pad, out, accumulate, bnsum, bnsum_z)
-        if bnsum is not None and bnsum.sums is not None and bnsum.dz is res:
+        relu_mask = None          # conv + bias + ReLU producer: this launch stored the masked gradient
+        if bnsum is not None and bnsum.relu_bias and bnsum.sums is not None and bnsum.dz is res:
+            relu_mask = bnsum_z
+            bsig = (tuple(res.shape), tuple(dy.shape))
+            if ("dgrad_relubias",) + bsig not in rec.seen:
+                c = res.shape[1]
+                tot = _colsum64(res)
+                mag = res.detach().cpu().abs().sum((0, 2, 3), dtype=torch.float64)
+                o = bnsum.sums.cpu()
+                e = float((o[:c] - tot).abs().max() / max(float(mag.max()), 1e-30))
+                # nothing may survive where the producer's output is zero
+                e = max(e, float((res * (relu_mask <= 0)).abs().max()))
+                rec.note("dgrad_relubias", bsig, e, tol)
+        elif bnsum is not None and bnsum.sums is not None and bnsum.dz is res:
             # the producer's BatchNorm-backward sums from the epilogue: compare with fp64 sums over the whole of the
             # gradient this launch left in memory (the gradient itself is checked below)
             zt = bnsum_z if bnsum.use_z else None
@@ -226,7 +239,8 @@ def audit(tol=2e-5, tol_wgrad=2e-4, sample=False):
                 e1 = float((o[:c] - s1).abs().max() / max(float(a1.max()), 1e-30))
                 e2 = float((o[c:2 * c] - s2).abs().max() / max(float(a2.max()), 1e-30))
                 rec.note("dgrad_bnsum", bsig, max(e1, e2), tol)
-        sig = (tuple(dy.shape), tuple(w.shape), tuple(x_shape), stride, tuple(pad), bool(accumulate))
+        sig = (tuple(dy.shape), tuple(w.shape), tuple(x_shape), stride, tuple(pad), bool(accumulate)) + \
+              (("relu-masked",) if relu_mask is not None else ())
         flops = 2.0 * dy.numel() * w.shape[1] * w.shape[2] * w.shape[3]
         if ("dgrad",) + sig not in rec.seen and big(flops):
             rec.sampled.add(("dgrad",) + sig)
@@ -237,12 +251,16 @@ def audit(tol=2e-5, tol_wgrad=2e-4, sample=False):
                 ref = _dgrad_band(dy, w64, x_shape, stride, pad, n0, h0, h1)
                 if base is not None:
                     ref = ref + _c64(base[n0:n0 + 1, :, h0:h1, :])
+                if relu_mask is not None:
+                    ref = ref * (relu_mask[n0:n0 + 1, :, h0:h1, :].detach().cpu() > 0)
                 err = max(err, _rel(res[n0:n0 + 1, :, h0:h1, :], ref))
             rec.note("dgrad", sig, err, tol)
         elif ("dgrad",) + sig not in rec.seen:
             ref = torch.nn.grad.conv2d_input(tuple(x_shape), w.cpu().double(), dy.cpu().double(), stride, pad)
             if base is not None:
                 ref = ref + base.cpu().double()
+            if relu_mask is not None:
+                ref = ref * (relu_mask.detach().cpu() > 0)
             rec.note("dgrad", sig, _rel(res, ref), tol)
         return res
 

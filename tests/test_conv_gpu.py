@@ -273,3 +273,31 @@ def test_packed_small_channel_conv_vs_torch(cfg):
     ops.conv_wgrad_packed(xp, dy, dw)
     dref = torch.nn.grad.conv2d_weight(x.cpu().double(), (k, c, r, r), dy.cpu().double(), stride, pad)
     assert ((dw - base).cpu().double() - dref).abs().max().item() <= 2e-5 * dref.abs().max().item()
+
+
+@pytest.mark.parametrize("cfg", [(2, 256, 96, 96, 10, 1, 0), (2, 256, 96, 96, 36, 1, 0), (1, 256, 128, 160, 2, 1, 0),
+                                 (2, 64, 128, 128, 12, 3, 1)], ids=lambda c: "n%dc%dh%dw%dk%dr%dp%d" % c)
+def test_dgrad_with_producer_relu_mask_and_bias_sums(cfg):
+    """rr_conv_dgrad_s1_relubias (producer = conv + bias + ReLU, the heads' 3x3 layers): the data gradient stores
+    dx * (z > 0) and returns its column sums == rr_conv_dgrad followed by rr_bias_relu_bwd; K = 10 / 2 go through the
+    zero-padding to a multiple of 4."""
+    from rrnet_amd import ops
+    n, c, h, w, k, r, pad = cfg
+    g = torch.Generator().manual_seed(sum(cfg))
+    dy = ops.to_nhwc(torch.randn(n, k, h, w, generator=g).cuda())
+    wt = ops.to_nhwc((torch.randn(k, c, r, r, generator=g) / np.sqrt(k * r * r)).cuda())
+    z = ops.to_nhwc(torch.relu(torch.randn(n, c, h, w, generator=g)).cuda())
+    link = ops.BnLink()
+    link.relu_bias = link.use_z = True
+    dx = ops.conv_dgrad(dy, wt, (n, c, h, w), 1, (pad, pad), bnsum=link, bnsum_z=z)
+    assert link.sums is not None and link.dz is dx
+    ref = ops.conv_dgrad(dy, wt, (n, c, h, w), 1, (pad, pad))
+    db = torch.zeros(c, device="cuda")
+    masked = ops.bias_relu_bwd(ref, z, db)
+    scale = ref.abs().max().item()
+    assert (dx - masked).abs().max().item() <= 2e-6 * scale                 # K padded: another K-step split, same values
+    assert float((dx * (z <= 0)).abs().max()) == 0.0
+    exp = masked.double().sum((0, 2, 3))
+    mag = masked.double().abs().sum((0, 2, 3)).max().item()
+    assert (link.sums[:c] - exp).abs().max().item() <= 2e-6 * mag
+    assert (db.double() - exp).abs().max().item() <= 1e-4 * mag
