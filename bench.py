@@ -240,12 +240,13 @@ def main():
                 # (tools/prof_bench.sh -> tools/pmc_traffic.py -> profiles/rNN_traffic_pmc.json); PMC counters
                 # cannot be read from inside the process, so the field names its source
                 traffic, traffic_source = None, None
-                for tag in ("r02", "r01"):
+                for tag in ("r03", "r02", "r01"):
                     tpath = os.path.join(ROOT, "profiles", "%s_traffic_pmc.json" % tag)
                     if os.path.exists(tpath) and a.backbone == "hourglass" and a.size == 1024 and a.batch == 8:
                         with open(tpath) as f:
                             tj = json.load(f)
-                        traffic = tj.get("conv_igemm_kernel<128, 0, false, 32, 2>", {}).get("traffic_bytes_per_launch")
+                        traffic = (tj.get("conv_igemm_kernel<128, 0, false, 32, 2, false>") or
+                                   tj.get("conv_igemm_kernel<128, 0, false, 32, 2>", {})).get("traffic_bytes_per_launch")
                         # not a live measurement: the file and the commit the PMC passes were taken at
                         traffic_source = "profiles/%s_traffic_pmc.json (rocprofv3 FETCH_SIZE + WRITE_SIZE passes of this command at commit %s)" % (
                             tag, tj.get("_commit", "bb2459f" if tag == "r01" else "unrecorded"))
@@ -254,8 +255,9 @@ def main():
                                    "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
                                    "traffic": traffic, "traffic_source": traffic_source,
                                    "algorithmic_bytes_per_launch": round(timer.bytes.get(dom, 0.0) / d["launches"]),
-                                   "kernel": "conv_igemm_kernel<128, 0, false, 32, 2> (implicit-GEMM forward kernel, v_mfma_f32_32x32x2_f32; "
-                                             "launched for fprop and for stride-1 dgrad on flipped weights)",
+                                   "kernel": "conv_igemm_kernel<128, 0, false, 32, 2, false> (implicit-GEMM forward kernel, v_mfma_f32_32x32x2_f32; "
+                                             "launched for fprop and for stride-1 dgrad on flipped weights; the dgrad launches that also "
+                                             "reduce the producer's BatchNorm-backward sums are the <..., true> instantiation)",
                                    "launches": d["launches"], "launches_timed": "every %d-th launch of the timed region (systematic sample)" % a.time_every,
                                    "avg_launch_ms": round(d["ms"] / d["launches"], 4),
                                    "algorithmic_gflop_per_launch": round(d["flops"] / d["launches"] / 1e9, 3)}
