@@ -31,21 +31,24 @@ def _mark(*params):
 
 
 # Weight gradients on a second HIP stream.  A layer's wgrad is off the critical path of backward (nothing waits for it
-# before the optimizer step), the HBM-bound kernels between two data gradients (BatchNorm backward of the next layer,
-# fan-in sums, ReLU masks, up-path) are ON it and leave the matrix cores idle.  Schedule: wgrad_L is enqueued on the side
-# stream behind dgrad_L, and the main stream waits for the side stream right before its next data gradient — so wgrad_L
-# runs concurrently with exactly those HBM-bound kernels and never with another MFMA-bound kernel (per-kernel durations
-# stay meaningful).  The side stream is joined at the end of every backward pass (engine callback).
-# Measured (round 3, B=8 1024x1024): 470.0 ms per step with the side stream against 463.0 ms without — the two
-# stream hand-overs per layer and the wgrad kernels slowed by the co-running HBM streams cost more than the ~20 ms of
-# element-wise kernels they hide.  Opt-in (RR_WGRAD_STREAM=1), not the default.
-_WGRAD_STREAM = os.environ.get("RR_WGRAD_STREAM", "0") == "1"
+# before the optimizer step / the gradient exchange), so it is enqueued on a side stream behind the kernels that produce
+# its operands and runs concurrently with whatever the main stream does next.  Both streams are mostly MFMA-bound, so
+# this is not "more FLOPs at once"; what it buys is filled tails (a 256x256 layer is 10.67 rounds of resident workgroups:
+# the last third of a round idles 3 % of the launch) and HBM-bound stretches (BatchNorm backward, fan-in sums) that no
+# longer leave the matrix cores idle.  Measured at B=8, 1024x1024 on one box, back to back: 455.4 ms per step against 459.6 ms
+# (step_mfma_frac 0.784 / 0.777); the dominant kernel's own launches lengthen by 1.7 % (0.868 -> 0.853 of the MFMA peak)
+# because some of them now share the chip with a wgrad.  RR_WGRAD_STREAM: 2 (default) free-running side stream, joined
+# at the end of backward, before a gradient bucket's all-reduce and before the optimizer step; 1: additionally joined
+# before every data gradient, so that wgrad only ever overlaps the HBM-bound stretch (measured SLOWER than no side
+# stream at all: 470.0 vs 463.0 ms — two stream hand-overs per layer); 0: everything on one stream.
+_WGRAD_STREAM = os.environ.get("RR_WGRAD_STREAM", "2") in ("1", "2")
+_WGRAD_FREE = os.environ.get("RR_WGRAD_STREAM", "2") == "2"
 _WG_STATE = {"pending": False, "cb_queued": False}
 
 
 def _wgrad_join(device):
     """Main stream waits for the weight gradients in flight on the side stream (before the next MFMA-bound kernel)."""
-    if _WG_STATE["pending"]:
+    if _WG_STATE["pending"] and not _WGRAD_FREE:
         torch.cuda.current_stream(device).wait_stream(_side_stream(device, "wgrad"))
         _WG_STATE["pending"] = False
 
