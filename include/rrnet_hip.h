@@ -347,6 +347,14 @@ int rr_dcn_fwd(const float *x, const float *offset, const float *mask, const flo
 int rr_dcn_fwd_bf16(const float *x, const float *offset, const float *mask, const float *w, const float *bias, float *y,
                     int n, int h, int wd, int c, int k, int r, int s, int stride, int pad_h, int pad_w, int dilation,
                     int deformable_groups, hipStream_t stream);
+/* rr_dcn_fwd_bf16 with caller scratch for the weights re-packed to bf16 [tap][32-channel chunk][filter][32]
+ * (rr_dcn_wpack_bytes(c,k,r,s) bytes, filled inside by one small kernel per call): on the LDS-window kernel with 256-filter
+ * tiles the weight operand then goes global -> LDS by buffer_load ... lds (no staging registers, converts or ds_writes).
+ * Layers that kernel does not take run exactly as rr_dcn_fwd_bf16. */
+size_t rr_dcn_wpack_bytes(int c, int k, int r, int s);
+int rr_dcn_fwd_bf16_packed(const float *x, const float *offset, const float *mask, const float *w, const float *bias,
+                           float *y, int n, int h, int wd, int c, int k, int r, int s, int stride, int pad_h, int pad_w,
+                           int dilation, int deformable_groups, void *wpack, hipStream_t stream);
 size_t rr_dcn_col_bytes(int n, int h, int wd, int c, int r, int s, int stride, int pad_h, int pad_w, int dilation);
 int rr_dcn_im2col(const float *x, const float *offset, const float *mask, float *col, int n, int h, int wd, int c,
                   int r, int s, int stride, int pad_h, int pad_w, int dilation, int deformable_groups,

@@ -215,17 +215,17 @@ typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int LDKH = BK + 8;
 
+// float -> bf16, round to nearest even, on the hardware converter (v_cvt_pk_bf16_f32: two values per instruction).  The
+// integer emulation this replaces (add 0x7fff + lsb, shift: four VALU operations per value) was a third of the VALU work of
+// every staging thread — 192 of ≈330 operations per thread and K-step in the forward.
+typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ unsigned short f2bf(float f)
 {
-    unsigned int u = __float_as_uint(f);
-    u += 0x7fffu + ((u >> 16) & 1u);          // round to nearest even (inputs are finite)
-    return (unsigned short)(u >> 16);
+    return __builtin_bit_cast(unsigned short, (__bf16)f);
 }
 __device__ __forceinline__ u16x4 f2bf4(f32x4 v)
 {
-    u16x4 r;
-    r[0] = f2bf(v[0]); r[1] = f2bf(v[1]); r[2] = f2bf(v[2]); r[3] = f2bf(v[3]);
-    return r;
+    return __builtin_bit_cast(u16x4, __builtin_convertvector(v, bf16x4v));
 }
 
 template <int BN>
@@ -385,6 +385,10 @@ struct DcnWinArgs {
     DcnArgs a;
     int RW, WH, WW;        // margin, window height / width in pixels
     int tiles_y, tiles_x;  // pixel blocks per image
+    // bf16 forward: the weights pre-packed to bf16 [tap][32-channel chunk][filter][32] (rr_dcn_pack_weights_bf16), or null.
+    // With them a K-step's B tile (256 filters x 32 channels = 16 KB, contiguous) goes global -> LDS by
+    // buffer_load ... lds: no staging registers, no converts, no ds_write for the weight operand.
+    const unsigned short *wpk;
 };
 
 // F32: fp32 matrix operands (v_mfma_f32_32x32x2_f32); a K-step is then HALF a window chunk (16 channels of one tap),
@@ -539,8 +543,10 @@ __global__ __launch_bounds__(512) void dcn_fprop_win_kernel(const DcnWinArgs wa)
         } else {
 #pragma unroll
             for (int j = 0; j < 2; ++j) *reinterpret_cast<u16x4 *>(A + (a_row + 64 * j) * LDKH + a_col) = f2bf4(rv[j]);
+            if (!(BN == 256 && wa.wpk != nullptr)) {
 #pragma unroll
-            for (int j = 0; j < BJ; ++j) *reinterpret_cast<u16x4 *>(B + (a_row + 64 * j) * LDKH + a_col) = f2bf4(rb[j]);
+                for (int j = 0; j < BJ; ++j) *reinterpret_cast<u16x4 *>(B + (a_row + 64 * j) * LDKH + a_col) = f2bf4(rb[j]);
+            }
         }
     };
 
@@ -553,14 +559,43 @@ __global__ __launch_bounds__(512) void dcn_fprop_win_kernel(const DcnWinArgs wa)
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     const int lr = lane & 31, lh = lane >> 5;
 
+    // ---- pre-packed bf16 weights: B tile by LDS-DMA.  Image = [256 filters][32 k] bf16, 64-byte rows WITHOUT padding (a
+    // wave-instruction's 64 x 16 B land contiguously), 16-byte chunks XOR-swizzled with (row >> 2) & 3 so that the 16 lanes
+    // of a ds_read_b128 group (rows r, r+4, r+8, r+12 share a 16-bank quadrant) hit four different chunks.
+    constexpr bool CAN_DMA = !F32 && BN == 256;
+    const bool dma = CAN_DMA && wa.wpk != nullptr;
+    typedef __attribute__((address_space(3))) void lds_void;
+    __amdgpu_buffer_rsrc_t rs_wpk;
+    {
+        const unsigned long long u = reinterpret_cast<unsigned long long>(dma ? (const void *)wa.wpk : (const void *)a.w);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u);
+        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+        void *q = reinterpret_cast<void *>(((unsigned long long)hi << 32) | lo);
+        rs_wpk = __builtin_amdgcn_make_buffer_rsrc(q, 0, __builtin_amdgcn_readfirstlane((int)((long)RS * cpt * a.K * BK * 2)), 0x00020000);
+    }
+    auto dma_b = [&](int cch, int tap, int buf) {
+        if constexpr (CAN_DMA) {
+            unsigned short *B = Bs + buf * B_ELEMS;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = wave * 32 + i * 16 + (lane >> 2);           // filter row inside the tile
+                const int chunk = (lane & 3) ^ ((row >> 2) & 3);             // global chunk that belongs in this lane's slot
+                const int ko = n0 + row;
+                const unsigned off = ko < a.K ? (unsigned)(((((long)tap * cpt + cch) * a.K + ko) * BK + chunk * 8) * 2) : 0x80000000u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wpk, (lds_void *)(B + (wave * 32 + i * 16) * BK), 16, off, 0, 0, 0);
+            }
+        }
+    };
+
     int g_cur = 0;
     build_geo(0);
     fetch_window(0);
     store_window();
     __syncthreads();
     build_a(0, 0, 0);
-    issue_b(0, 0, 0);
+    if (dma) dma_b(0, 0, 0); else issue_b(0, 0, 0);
     commit(0);
+    if (dma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const int spc = RS * H;                                      // K-steps per window chunk: (tap, half) pairs
     const int nk = cpt * spc;
@@ -608,13 +643,16 @@ __global__ __launch_bounds__(512) void dcn_fprop_win_kernel(const DcnWinArgs wa)
                 for (int i = 0; i < TM; ++i)
                     fa[kk][i] = *reinterpret_cast<const bf16x8 *>(A + ((wm * TM + i) * 32 + lr) * LDKH + kk * 16 + lh * 8);
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    fb[kk][j] = *reinterpret_cast<const bf16x8 *>(B + ((wn * TN + j) * 32 + lr) * LDKH + kk * 16 + lh * 8);
+                for (int j = 0; j < TN; ++j) {
+                    const int row = (wn * TN + j) * 32 + lr;
+                    fb[kk][j] = dma ? *reinterpret_cast<const bf16x8 *>(B + row * BK + (((kk * 2 + lh) ^ ((row >> 2) & 3)) * 8))
+                                    : *reinterpret_cast<const bf16x8 *>(B + row * LDKH + kk * 16 + lh * 8);
+                }
             }
             // the next step's operand loads go out behind this step's fragment reads and are consumed one MFMA group
             // later: row 0 of the thread's two staged rows under the first half of the K-step, row 1 under the second
             if (stage) {
-                issue_b(cch, (rem + 1) / H, (rem + 1) % H);
+                if (dma) dma_b(cch, (rem + 1) / H, buf ^ 1); else issue_b(cch, (rem + 1) / H, (rem + 1) % H);
                 gather_a(cch, (rem + 1) / H, (rem + 1) % H, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -648,10 +686,11 @@ __global__ __launch_bounds__(512) void dcn_fprop_win_kernel(const DcnWinArgs wa)
             const int g = ((cch + 1) * BK) / cpg;
             if (g != g_cur) { g_cur = g; build_geo(g); }
             __syncthreads();
-            issue_b(cch + 1, 0, 0);
+            if (dma) dma_b(cch + 1, 0, buf ^ 1); else issue_b(cch + 1, 0, 0);
             build_a(cch + 1, 0, 0);
         }
         if (more) commit(buf ^ 1);
+        if (dma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the next B tile has landed
         __syncthreads();
     }
 #pragma unroll
@@ -2068,8 +2107,23 @@ static int dcn_win_margin()
 }
 
 // LDS-window forward for either operand precision; -1 when the layer does not qualify.
+// wpk[((tap * C/32 + cch) * K + ko) * 32 + cl] = bf16(w[(ko * RS + tap) * C + cch * 32 + cl]): one thread = 4 values
+__global__ __launch_bounds__(256) void dcn_pack_weights_kernel(const float *w, unsigned short *wpk, int K, int C, int RS)
+{
+    const long total = (long)K * RS * C / 4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c4 = (int)(i % (C / 4));
+        long rest = i / (C / 4);
+        const int tap = (int)(rest % RS);
+        const int ko = (int)(rest / RS);
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(w + ((long)ko * RS + tap) * C + c4 * 4);
+        const int cch = (c4 * 4) / BK, cl = (c4 * 4) % BK;
+        *reinterpret_cast<u16x4 *>(wpk + ((((long)tap * (C / BK) + cch) * K + ko) * BK + cl)) = f2bf4(v);
+    }
+}
+
 static int dcn_fwd_win(const DcnArgs &a, int n, int k, int r, int s, int stride, int dilation, int c, int h, int wd, int bf16,
-                       hipStream_t stream, const char *name)
+                       hipStream_t stream, const char *name, unsigned short *wpk = nullptr)
 {
     const int rw = dcn_win_margin();
     if (!(rw > 0 && stride == 1 && k > 32 && c % BK == 0 && (long)h * wd < (1l << 30))) return -1;
@@ -2100,7 +2154,14 @@ static int dcn_fwd_win(const DcnArgs &a, int n, int k, int r, int s, int stride,
     static int ws_mode = -1;
     if (ws_mode < 0) {
         const char *e = getenv("RR_DCN_WS");
-        ws_mode = e ? atoi(e) : 1;      // 1: producer / consumer waves for the bf16 256-filter forward (0: lockstep kernel)
+        ws_mode = e ? atoi(e) : 0;      // 1: producer / consumer waves for the bf16 256-filter forward: built, measured SLOWER
+                                        // (2.17 vs 1.79 ms: the staging, not its serialisation with the MFMAs, sets the time)
+    }
+    wa.wpk = nullptr;
+    if (wbn == 256 && bf16 && wpk != nullptr) {      // B tile by LDS-DMA from the weights packed to bf16 once per call
+        hipLaunchKernelGGL(dcn_pack_weights_kernel, dim3(rr_cdiv((long)k * r * s * c / 4, 256)), dim3(256), 0, stream, a.w, wpk, k, c,
+                           r * s);
+        wa.wpk = wpk;
     }
     if (wbn == 256 && bf16 && ws_mode) {
         hipFuncSetAttribute(reinterpret_cast<const void *>(dcn_fprop_ws_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -2156,6 +2217,26 @@ extern "C" int rr_dcn_fwd_bf16(const float *x, const float *offset, const float 
     else hipLaunchKernelGGL(dcn_fprop_bf16_kernel<32>, dim3(blocks), dim3(256), lds, stream, a);
     RR_CHECK_LAUNCH("rr_dcn_fwd_bf16");
     return RR_OK;
+}
+
+extern "C" size_t rr_dcn_wpack_bytes(int c, int k, int r, int s)
+{
+    return (size_t)k * r * s * c * sizeof(unsigned short);
+}
+
+extern "C" int rr_dcn_fwd_bf16_packed(const float *x, const float *offset, const float *mask, const float *w, const float *bias,
+                                      float *y, int n, int h, int wd, int c, int k, int r, int s, int stride, int pad_h,
+                                      int pad_w, int dilation, int deformable_groups, void *wpack, hipStream_t stream)
+{
+    RR_CHECK_ARG(wpack != nullptr, "rr_dcn_fwd_bf16_packed: wpack (rr_dcn_wpack_bytes) is required");
+    DcnArgs a{};
+    const int rc = fill_args(a, x, offset, mask, w, n, h, wd, c, k, r, s, stride, pad_h, pad_w, dilation, deformable_groups);
+    if (rc != RR_OK) return rc;
+    a.bias = bias; a.y = y;
+    const int wrc = dcn_fwd_win(a, n, k, r, s, stride, dilation, c, h, wd, 1, stream, "rr_dcn_fwd_bf16_packed",
+                                (c % 32 == 0 && (long)k * r * s * c * 2 < (1l << 31)) ? static_cast<unsigned short *>(wpack) : nullptr);
+    if (wrc != -1) return wrc;
+    return rr_dcn_fwd_bf16(x, offset, mask, w, bias, y, n, h, wd, c, k, r, s, stride, pad_h, pad_w, dilation, deformable_groups, stream);
 }
 
 extern "C" size_t rr_dcn_col_bytes(int n, int h, int wd, int c, int r, int s, int stride, int pad_h, int pad_w, int dilation)

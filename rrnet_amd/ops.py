@@ -799,12 +799,22 @@ def roi_align_bwd(dout, rois, feat_shape, out_size, spatial_scale=1.0, sampling_
 # ---------------------------------------------------------------------------------------------
 # DCNv2
 # ---------------------------------------------------------------------------------------------
+_DCN_WPACK = os.environ.get("RR_DCN_WPACK", "1") != "0"
+
+
 def dcn_fwd(x, offset, mask, w, bias, stride, pad, dilation, dg, bf16=False):
     assert is_nhwc(x) and is_nhwc(offset) and is_nhwc(mask) and is_nhwc(w)
     n, c, h, wd = x.shape
     k, _, r, s = w.shape
     p, q = offset.shape[2], offset.shape[3]
     y = empty_nhwc(n, k, p, q, x.device)
+    if bf16 and _DCN_WPACK:
+        # weights re-packed to bf16 inside the call (one small kernel): the B operand then reaches LDS by DMA
+        wpack = torch.empty(_C.fn("rr_dcn_wpack_bytes")(c, k, r, s), dtype=torch.uint8, device=x.device)
+        _C.check(_C.fn("rr_dcn_fwd_bf16_packed")(_C.ptr(x), _C.ptr(offset), _C.ptr(mask), _C.ptr(w), _C.ptr(bias), _C.ptr(y),
+                                                 n, h, wd, c, k, r, s, stride, pad[0], pad[1], dilation, dg, _C.ptr(wpack),
+                                                 _C.stream()), "rr_dcn_fwd_bf16_packed")
+        return y
     name = "rr_dcn_fwd_bf16" if bf16 else "rr_dcn_fwd"
     _C.check(_C.fn(name)(_C.ptr(x), _C.ptr(offset), _C.ptr(mask), _C.ptr(w), _C.ptr(bias), _C.ptr(y), n, h, wd,
                          c, k, r, s, stride, pad[0], pad[1], dilation, dg, _C.stream()), name)
