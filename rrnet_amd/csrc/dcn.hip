@@ -709,230 +709,6 @@ __global__ __launch_bounds__(512) void dcn_fprop_win_kernel(const DcnWinArgs wa)
     }
 }
 
-// ---- forward, bf16 operands, producer / consumer waves ---------------------------------------------------------------
-// Same block (8x16 pixels x 256 filters), window, geometry tables and operand images as dcn_fprop_win_kernel<256,false>,
-// but the eight waves no longer all do everything in lockstep: waves 0-3 only run the MFMAs of K-step k (each a 64 x 128
-// part of the 128 x 256 tile: 16 v_mfma_f32_32x32x16_bf16 per step), waves 4-7 only stage K-step k+1 (gather + blend + bf16
-// A tile, weight rows -> bf16 B tile) into the other LDS image.  One barrier per K-step hands the images over.  The gather
-// chain (geometry words -> four corner rows -> blend -> convert -> ds_write) of the lockstep kernel sat between two MFMA
-// groups of the SAME wave (≈3500 cycles per K-step for 512 cycles of MFMA); here it runs beside them on the other waves.
-__global__ __launch_bounds__(512) void dcn_fprop_ws_kernel(const DcnWinArgs wa)
-{
-    const DcnArgs &a = wa.a;
-    constexpr int NT = 512, BN = 256;
-    constexpr int A_ELEMS = BM * LDKH, B_ELEMS = BN * LDKH;
-    extern __shared__ __align__(16) unsigned char smem[];
-    const int RS = a.R * a.S;
-    const int npx = wa.WH * wa.WW;
-    float *win = reinterpret_cast<float *>(smem);                               // [npx][32]
-    unsigned int *geo_o = reinterpret_cast<unsigned int *>(win + (size_t)npx * BK);   // [BM][RS][4]
-    float *geo_w = reinterpret_cast<float *>(geo_o + BM * RS * 4);              // [BM][RS][4]
-    unsigned short *As = reinterpret_cast<unsigned short *>(geo_w + BM * RS * 4);
-    unsigned short *Bs = As + 2 * A_ELEMS;
-
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const bool producer = wave >= 4;
-    const int pt = t & 255;                                      // index inside the role
-    const int ntiles = (a.K + BN - 1) / BN;
-    int bid = blockIdx.x;
-    const int n_tile = bid % ntiles; bid /= ntiles;
-    const int txi = bid % wa.tiles_x; bid /= wa.tiles_x;
-    const int tyi = bid % wa.tiles_y;
-    const int n = bid / wa.tiles_y;
-    const int y0 = tyi * WIN_TH, x0 = txi * WIN_TW, n0 = n_tile * BN;
-    const int wy0 = y0 - a.pad_h - wa.RW, wx0 = x0 - a.pad_w - wa.RW;
-    const int cpt = a.C / BK;
-    const int cpg = a.C / a.dg;
-    const int a_col = (pt & 7) * 4, a_row = pt >> 3;              // staging: rows a_row + 32 j
-    const long img = (long)n * a.H * a.W;
-
-    auto build_geo = [&](int g) {
-        for (int it = t; it < BM * RS; it += NT) {
-            const int r = it / RS, tap = it - r * RS;
-            const int p = y0 + r / WIN_TW, q = x0 + r % WIN_TW;
-            unsigned int o[4] = {0u, 0u, 0u, 0u};
-            float w4[4] = {0.f, 0.f, 0.f, 0.f};
-            if (p < a.P && q < a.Q) {
-                const long m = ((long)n * a.P + p) * a.Q + q;
-                const float *po = a.offset + m * (2 * a.dg * RS) + g * 2 * RS + 2 * tap;
-                const float mk = a.mask[m * (a.dg * RS) + g * RS + tap];
-                const int ti = tap / a.S, tj = tap - ti * a.S;
-                const float h = (float)(p - a.pad_h + ti * a.dil) + po[0];
-                const float w = (float)(q - a.pad_w + tj * a.dil) + po[1];
-                const bool inside = h > -1.f && w > -1.f && h < (float)a.H && w < (float)a.W;
-                const float hf = floorf(h), wf = floorf(w);
-                const int h0 = (int)hf, w0 = (int)wf;
-                const float lh = h - hf, lw = w - wf, hh = 1.f - lh, hw = 1.f - lw;
-                const float cw[4] = {hh * hw, hh * lw, lh * hw, lh * lw};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int hy = h0 + (e >> 1), wx = w0 + (e & 1);
-                    if (inside && hy >= 0 && hy <= a.H - 1 && wx >= 0 && wx <= a.W - 1) {
-                        w4[e] = cw[e] * mk;
-                        const int ly = hy - wy0, lx = wx - wx0;
-                        o[e] = (ly >= 0 && ly < wa.WH && lx >= 0 && lx < wa.WW) ? (unsigned int)(ly * wa.WW + lx)
-                                                                               : (0x80000000u | (unsigned int)(hy * a.W + wx));
-                    }
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { geo_o[it * 4 + e] = o[e]; geo_w[it * 4 + e] = w4[e]; }
-        }
-    };
-    constexpr int WREG = 7;
-    f32x4 wreg[WREG];
-    auto fetch_window = [&](int cch) {
-        const int c0 = cch * BK;
-#pragma unroll
-        for (int u = 0; u < WREG; ++u) {
-            const int i = t + u * NT;
-            const int px = i >> 3, c4 = (i & 7) * 4;
-            const int ly = px / wa.WW, lx = px - ly * wa.WW;
-            const int gy = wy0 + ly, gx = wx0 + lx;
-            const bool ok = px < npx && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-            wreg[u] = *reinterpret_cast<const f32x4 *>(ok ? a.x + (img + (long)gy * a.W + gx) * a.C + c0 + c4 : a.zero);
-        }
-    };
-    auto store_window = [&]() {
-#pragma unroll
-        for (int u = 0; u < WREG; ++u) {
-            const int i = t + u * NT;
-            if ((i >> 3) < npx) *reinterpret_cast<f32x4 *>(win + (size_t)i * 4) = wreg[u];
-        }
-    };
-    // producer: stage K-step (cch, tap) into image `buf`
-    auto stage = [&](int cch, int tap, int buf) {
-        const int c0 = cch * BK;
-        unsigned short *A = As + buf * A_ELEMS, *B = Bs + buf * B_ELEMS;
-        f32x4 rb[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {                             // weight rows: global (L2) -> registers
-            const int ko = n0 + a_row + 32 * j;
-            rb[j] = *reinterpret_cast<const f32x4 *>(ko < a.K ? a.w + ((long)ko * RS + tap) * a.C + c0 + a_col : a.zero);
-        }
-        u32x4 go[4];
-        f32x4 gw[4], gx[4][4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int r = a_row + 32 * j;
-            go[j] = *reinterpret_cast<const u32x4 *>(geo_o + (r * RS + tap) * 4);
-            gw[j] = *reinterpret_cast<const f32x4 *>(geo_w + (r * RS + tap) * 4);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const unsigned int o = go[j][e];
-                gx[j][e] = *reinterpret_cast<const f32x4 *>(win + (size_t)((o & 0x80000000u) ? 0u : o) * BK + a_col);
-            }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                f32x4 xv = gx[j][e];
-                const unsigned int o = go[j][e];
-                if (o & 0x80000000u)       // a corner beyond the window margin (rare): straight from global memory
-                    xv = *reinterpret_cast<const f32x4 *>(a.x + (img + (long)(o & 0x7fffffffu)) * a.C + c0 + a_col);
-                v += xv * gw[j][e];
-            }
-            *reinterpret_cast<u16x4 *>(A + (a_row + 32 * j) * LDKH + a_col) = f2bf4(v);
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) *reinterpret_cast<u16x4 *>(B + (a_row + 32 * j) * LDKH + a_col) = f2bf4(rb[j]);
-    };
-
-    // The two roles run SEPARATE loops with the same barrier sequence (a wave's role is fixed): the accumulators exist in
-    // the consumers' loop only, the staging registers in the producers' — one loop with a role branch made the register
-    // allocator carry both sets (256 VGPRs + 512 bytes of scratch per lane).
-    const int nk = cpt * RS;
-    int g_cur = 0;
-    build_geo(0);
-    fetch_window(0);
-    store_window();
-    __syncthreads();
-    if (producer) stage(0, 0, 0);
-    __syncthreads();
-    auto swap_window = [&](int cch_next) {       // every thread, between two barriers of its loop
-        store_window();
-        const int g = (cch_next * BK) / cpg;
-        if (g != g_cur) { g_cur = g; build_geo(g); }
-    };
-    if (producer) {
-        for (int kc = 0; kc < nk; ++kc) {
-            const int buf = kc & 1;
-            const int cch = kc / RS, rem = kc - cch * RS;
-            const bool more = kc + 1 < nk;
-            const bool new_chunk = more && rem == RS - 1;
-            if (rem == 0 && cch + 1 < cpt) fetch_window(cch + 1);    // lands under this chunk's K-steps
-            if (more && !new_chunk) stage(cch, rem + 1, buf ^ 1);
-            if (new_chunk) {
-                // past the last gather from the old window (this chunk's last step was staged one K-step ago)
-                __syncthreads();
-                swap_window(cch + 1);
-                __syncthreads();
-                stage(cch + 1, 0, buf ^ 1);
-            }
-            __syncthreads();
-        }
-        return;
-    }
-    // consumer wave cw: rows 64 (cw & 1) .. +63, filters 128 (cw >> 1) .. +127
-    constexpr int TM = 2, TN = 4;
-    const int cw = wave & 3, rm0 = (cw & 1) * 64, cn0 = (cw >> 1) * 128;
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    const int lr = lane & 31, lh = lane >> 5;
-    for (int kc = 0; kc < nk; ++kc) {
-        const int buf = kc & 1;
-        const int cch = kc / RS, rem = kc - cch * RS;
-        const bool more = kc + 1 < nk;
-        const bool new_chunk = more && rem == RS - 1;
-        if (rem == 0 && cch + 1 < cpt) fetch_window(cch + 1);
-        const unsigned short *A = As + buf * A_ELEMS, *B = Bs + buf * B_ELEMS;
-#pragma unroll
-        for (int kk = 0; kk < BK / 16; ++kk) {
-            bf16x8 fa[TM], fb[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-                fa[i] = *reinterpret_cast<const bf16x8 *>(A + (rm0 + i * 32 + lr) * LDKH + kk * 16 + lh * 8);
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                fb[j] = *reinterpret_cast<const bf16x8 *>(B + (cn0 + j * 32 + lr) * LDKH + kk * 16 + lh * 8);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-        }
-        if (new_chunk) {
-            __syncthreads();
-            swap_window(cch + 1);
-            __syncthreads();
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int ko = n0 + cn0 + j * 32 + lr;
-        if (ko >= a.K) continue;
-        const float bv = a.bias ? a.bias[ko] : 0.f;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int r = rm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                const int p = y0 + r / WIN_TW, q = x0 + r % WIN_TW;
-                if (p < a.P && q < a.Q) a.y[(((long)n * a.P + p) * a.Q + q) * a.K + ko] = acc[i][j][e] + bv;
-            }
-    }
-}
-
 // columns [M][R*S*C] = mask * bilinear samples (only the backward needs them materialised)
 __global__ __launch_bounds__(256) void dcn_im2col_kernel(const DcnArgs a, float *col)
 {
@@ -2151,24 +1927,6 @@ static int dcn_fwd_win(const DcnArgs &a, int n, int k, int r, int s, int stride,
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                        \
         hipLaunchKernelGGL((dcn_fprop_win_kernel<BNV, F32V>), dim3(blocks), dim3(512), lds, stream, wa);                  \
     } while (0)
-    static int ws_mode = -1;
-    if (ws_mode < 0) {
-        const char *e = getenv("RR_DCN_WS");
-        ws_mode = e ? atoi(e) : 0;      // 1: producer / consumer waves for the bf16 256-filter forward: built, measured SLOWER
-                                        // (2.17 vs 1.79 ms: the staging, not its serialisation with the MFMAs, sets the time)
-    }
-    wa.wpk = nullptr;
-    if (wbn == 256 && bf16 && wpk != nullptr) {      // B tile by LDS-DMA from the weights packed to bf16 once per call
-        hipLaunchKernelGGL(dcn_pack_weights_kernel, dim3(rr_cdiv((long)k * r * s * c / 4, 256)), dim3(256), 0, stream, a.w, wpk, k, c,
-                           r * s);
-        wa.wpk = wpk;
-    }
-    if (wbn == 256 && bf16 && ws_mode) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(dcn_fprop_ws_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(dcn_fprop_ws_kernel, dim3(blocks), dim3(512), lds, stream, wa);
-        RR_CHECK_LAUNCH(name);
-        return RR_OK;
-    }
     if (wbn == 256) { if (bf16) RR_WIN_LAUNCH(256, false); else RR_WIN_LAUNCH(256, true); }
     else { if (bf16) RR_WIN_LAUNCH(128, false); else RR_WIN_LAUNCH(128, true); }
 #undef RR_WIN_LAUNCH
