@@ -43,7 +43,7 @@ def _mark(*params):
 # stream at all: 470.0 vs 463.0 ms — two stream hand-overs per layer); 0: everything on one stream.
 _WGRAD_STREAM = os.environ.get("RR_WGRAD_STREAM", "2") in ("1", "2")
 _WGRAD_FREE = os.environ.get("RR_WGRAD_STREAM", "2") == "2"
-_WG_STATE = {"pending": False, "cb_queued": False}
+_WG_STATE = {"pending": False, "task": None}      # task: the autograd graph task whose end-of-backward join is queued
 
 
 def _wgrad_join(device):
@@ -67,17 +67,17 @@ def _wgrad_async(fn, device, *tensors):
         if t is not None:
             t.record_stream(side)
     _WG_STATE["pending"] = True
-    if not _WG_STATE["cb_queued"]:
-        _WG_STATE["cb_queued"] = True
+    task = torch._C._current_graph_task_id()       # one join per backward pass (a pass that raised leaves no stale flag)
+    if task < 0:                                   # not inside a backward pass (a backward called by hand): join right away
+        torch.cuda.current_stream(device).wait_stream(side)
+        _WG_STATE["pending"] = False
+    elif _WG_STATE["task"] != task:
+        _WG_STATE["task"] = task
 
         def _end_of_backward():
-            _WG_STATE["cb_queued"] = False
             torch.cuda.current_stream(device).wait_stream(side)
             _WG_STATE["pending"] = False
-        try:
-            torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward)
-        except RuntimeError:           # not inside a backward pass (a test calling a backward by hand): join right away
-            _end_of_backward()
+        torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward)
 
 
 _SYNC_COALESCE = os.environ.get("RR_SYNCBN_COALESCE", "1") != "0"   # joint SyncBN exchange of layers that share their input
