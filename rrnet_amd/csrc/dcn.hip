@@ -1927,6 +1927,12 @@ static int dcn_fwd_win(const DcnArgs &a, int n, int k, int r, int s, int stride,
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                        \
         hipLaunchKernelGGL((dcn_fprop_win_kernel<BNV, F32V>), dim3(blocks), dim3(512), lds, stream, wa);                  \
     } while (0)
+    wa.wpk = nullptr;
+    if (wbn == 256 && bf16 && wpk != nullptr) {      // B tile by LDS-DMA from the weights packed to bf16 once per call
+        hipLaunchKernelGGL(dcn_pack_weights_kernel, dim3(rr_cdiv((long)k * r * s * c / 4, 256)), dim3(256), 0, stream, a.w, wpk, k, c,
+                           r * s);
+        wa.wpk = wpk;
+    }
     if (wbn == 256) { if (bf16) RR_WIN_LAUNCH(256, false); else RR_WIN_LAUNCH(256, true); }
     else { if (bf16) RR_WIN_LAUNCH(128, false); else RR_WIN_LAUNCH(128, true); }
 #undef RR_WIN_LAUNCH
