@@ -81,7 +81,6 @@ def _wgrad_async(fn, device, *tensors):
 
 
 _SYNC_COALESCE = os.environ.get("RR_SYNCBN_COALESCE", "1") != "0"   # joint SyncBN exchange of layers that share their input
-_PREFLIP = os.environ.get("RR_PREFLIP", "1") != "0"       # flipped filters of the stride-1 data gradients made during forward
 _G_INTO = os.environ.get("RR_BN_G_INTO", "1") != "0"     # residual gradient added into the fan-in buffer by bn_bwd_apply itself
 BN_FUSED_STATS = os.environ.get("RR_BN_FUSED_STATS", "1") != "0"    # single process: slab -> statistics -> coefficients in one launch
 
@@ -157,12 +156,6 @@ class _ConvBnAct(torch.autograd.Function):
         ctx.cfg = (stride, pad, relu, count, sync, residual is not None)
         ctx.params = (w, gamma, beta)
         ctx.xshape = None if ctx.packed else tuple(x.shape)
-        # the flipped filter of the stride-1 data gradient, made NOW: in backward the tiny kernel would wait for a free CU
-        # behind the weight gradients of the side stream
-        ctx.wt = None
-        if bn.training and not ctx.packed and _PREFLIP and ctx.needs_input_grad[0] and \
-                ops.dgrad_takes_flipped(wc.shape, stride, pad, y.shape[2:]):
-            ctx.wt = ops.weight_flip_transpose(wc)
         return z
 
     @staticmethod
@@ -208,7 +201,7 @@ class _ConvBnAct(torch.autograd.Function):
                                  g_into=g_into)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = _input_grad(dy, wc, ctx.xshape, stride, pad, x_acc, in_link, x, ctx.wt)
+            dx = _input_grad(dy, wc, ctx.xshape, stride, pad, x_acc, in_link, x)
         w_t = _grad_target(w)
         ret_dw = None
         stem = (not ctx.packed and tuple(w.shape[1:]) == (3, 7, 7) and stride == 2 and tuple(pad) == (3, 3)
@@ -241,7 +234,7 @@ class _ConvBnAct(torch.autograd.Function):
         return dx, ret_dw, ret_dg, ret_db, dres, None, None, None, None, None, None, None, None
 
 
-def _input_grad(dy, wc, xshape, stride, pad, x_acc, in_link, x, wt=None):
+def _input_grad(dy, wc, xshape, stride, pad, x_acc, in_link, x):
     """Data gradient of a convolution node -> the tensor to hand to autograd (None when it was added into the fan-in
     buffer of x's fan-out).  Where the launch can carry them it also produces the BatchNorm-backward sums of the layer
     that produced x (ops.BnLink): when x has this node as its only consumer, or when this node is the LAST registered
@@ -249,14 +242,14 @@ def _input_grad(dy, wc, xshape, stride, pad, x_acc, in_link, x, wt=None):
     _wgrad_join(dy.device)        # the previous layer's weight gradient has had the HBM-bound stretch to itself
     if x_acc is None:
         link = in_link if (in_link is not None and in_link.consumers == 1) else None
-        return ops.conv_dgrad(dy, wc, xshape, stride, pad, bnsum=link, bnsum_z=x, wt=wt)
+        return ops.conv_dgrad(dy, wc, xshape, stride, pad, bnsum=link, bnsum_z=x)
     link = x_acc.link if x_acc.pending == 1 else None
     x_acc.pending -= 1
     if x_acc.buf is not None:
         # another consumer of x already produced its gradient: add into it inside the dgrad epilogue
-        ops.conv_dgrad(dy, wc, xshape, stride, pad, out=x_acc.buf, accumulate=True, bnsum=link, bnsum_z=x, wt=wt)
+        ops.conv_dgrad(dy, wc, xshape, stride, pad, out=x_acc.buf, accumulate=True, bnsum=link, bnsum_z=x)
         return None
-    x_acc.buf = ops.conv_dgrad(dy, wc, xshape, stride, pad, bnsum=link, bnsum_z=x, wt=wt)
+    x_acc.buf = ops.conv_dgrad(dy, wc, xshape, stride, pad, bnsum=link, bnsum_z=x)
     return x_acc.buf
 
 
@@ -437,9 +430,6 @@ class _ConvBias(torch.autograd.Function):
         ctx.cfg = (stride, pad, relu)
         ctx.params = (w, b)
         ctx.xshape = tuple(x.shape)
-        ctx.wt = None
-        if _PREFLIP and torch.is_grad_enabled() and x.requires_grad and ops.dgrad_takes_flipped(wc.shape, stride, pad, y.shape[2:]):
-            ctx.wt = ops.weight_flip_transpose(wc)
         return y
 
     @staticmethod
@@ -470,7 +460,7 @@ class _ConvBias(torch.autograd.Function):
             dy = ops.sum_n([dy], y)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = _input_grad(dy, wc, ctx.xshape, stride, pad, ctx.x_acc, ctx.in_link, x, ctx.wt)
+            dx = _input_grad(dy, wc, ctx.xshape, stride, pad, ctx.x_acc, ctx.in_link, x)
         w_t = _grad_target(w)
         ret_dw = None
         if w_t is not None:

@@ -234,22 +234,7 @@ class BnLink:
 _DGRAD_BNSUM = os.environ.get("RR_DGRAD_BNSUM", "1") != "0"
 
 
-def dgrad_takes_flipped(w_shape, stride, pad, out_hw_):
-    """Whether conv_dgrad will run this layer's data gradient through the forward kernel on flipped weights."""
-    k, c, r, s = w_shape
-    return (stride == 1 and k % 4 == 0 and c % 4 == 0 and r * s <= 64 and pad[0] < r and pad[1] < s and _DGRAD_VIA_FPROP
-            and out_hw_[0] * out_hw_[1] >= _DGRAD_VIA_FPROP_MIN_PIXELS)
-
-
-def weight_flip_transpose(w):
-    """w [K,C,R,S] (OHWI memory) -> wt[c][R-1-r][S-1-s][k] (flat), the filter of the equivalent forward convolution."""
-    k, c, r, s = w.shape
-    wt = torch.empty(k * c * r * s, dtype=torch.float32, device=w.device)
-    _C.check(_C.fn("rr_weight_flip_transpose")(_C.ptr(w), _C.ptr(wt), k, c, r, s, _C.stream()), "rr_weight_flip_transpose")
-    return wt
-
-
-def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False, bnsum=None, bnsum_z=None, wt=None):
+def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False, bnsum=None, bnsum_z=None):
     """dy [N,K,P,Q], w [K,C,R,S] -> dx [N,C,H,W]; with `out` and accumulate adds into it.
     bnsum (BnLink of the layer that produced the convolution's input): when the launch can carry them, the producer's
     BatchNorm-backward sums are computed in the epilogue and left in bnsum.sums / bnsum.dz.  bnsum_z: the
@@ -290,11 +275,10 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False,
     flops = 2.0 * dy.shape[0] * dy.shape[2] * dy.shape[3] * k * c * r * s
     if (stride == 1 and k % 4 == 0 and c % 4 == 0 and r * s <= 64 and pad[0] < r and pad[1] < s and _DGRAD_VIA_FPROP
             and dy.shape[2] * dy.shape[3] >= _DGRAD_VIA_FPROP_MIN_PIXELS):
-        # the forward kernel on dy with the flipped / transposed filter.  `wt`: made by the caller during the forward pass
-        # (rrnet_amd.functional) — in backward the tiny transpose kernel would queue behind the weight gradients that
-        # fill the chip from the side stream (0.66 ms each instead of 5 us, 73 of them per step on the critical path)
-        if wt is None:
-            wt = weight_flip_transpose(w)
+        # the forward kernel on dy with the flipped / transposed filter (one tiny transpose per layer and step)
+        wt = torch.empty(k * c * r * s, dtype=torch.float32, device=dy.device)
+        _C.check(_C.fn("rr_weight_flip_transpose")(_C.ptr(w), _C.ptr(wt), k, c, r, s, _C.stream()),
+                 "rr_weight_flip_transpose")
         if (bnsum is not None and not bnsum.relu_bias and _DGRAD_BNSUM and bnsum.y is not None and c <= 1024 and out.numel() * 4 < (1 << 31)
                 and tuple(bnsum.y.shape) == tuple(out.shape)
                 and (not bnsum.use_z or (bnsum_z is not None and is_nhwc(bnsum_z) and bnsum_z.shape == out.shape))):

@@ -1,5 +1,5 @@
 export TMPDIR=/tmp
-TAG=${1:-r03}
+TAG=r02
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_dcn_${c}_$TAG -- python3 tools/bench_dcn.py > gpurun_out/pmc_dcn_${c}_$TAG.log 2>&1
 done
