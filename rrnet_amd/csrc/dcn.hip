@@ -1513,8 +1513,11 @@ __global__ __launch_bounds__(512) void dcn_dgrad_win_kernel(const DcnWinBwdArgs 
             const bool nonfinite = bbits > 0x7f7fffff || mkmax_bits > 0x7f7fffff || !(bound <= 3.0e38f);
             int ex = 0;
             frexpf(bound, &ex);
-            fxs[t] = (bound > 0.f && !nonfinite) ? ldexpf(1.f, 30 - ex) : 0.f;
-            fxi[t] = nonfinite ? __int_as_float(0x7fc00000) : ldexpf(1.f, ex - 30);
+            // the scale is a power of two 2^sh with sh <= 126: for bounds below 2^-96 (vanishing gradients) 2^(30 - ex)
+            // itself would overflow to inf and the integer adds would saturate
+            const int sh = 30 - ex > 126 ? 126 : 30 - ex;
+            fxs[t] = (bound > 0.f && !nonfinite) ? ldexpf(1.f, sh) : 0.f;
+            fxi[t] = nonfinite ? __int_as_float(0x7fc00000) : ldexpf(1.f, -sh);
         }
         __syncthreads();
         const f32x4 fx4 = *reinterpret_cast<const f32x4 *>(fxs + a_col);      // this thread's four channels

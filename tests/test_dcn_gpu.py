@@ -498,3 +498,21 @@ def test_dcn_bench_layer_full_size_vs_column_path_and_cropped_oracle():
             tol = 1e-3 * max(1.0, e.abs().max().item())
             np.testing.assert_allclose(got[full].cpu().numpy(), e.numpy(), atol=tol, rtol=1e-3,
                                        err_msg="%s vs oracle, image %d window %s" % (name, n0, (r0, r1, c0, c1)))
+
+
+def test_dcn_dgrad_fixed_point_scale_with_vanishing_gradients():
+    """column gradients around 1e-35 (bound below 2^-96) must not overflow the power-of-two scale of the
+    fixed-point window: d input equals the fp32 column path's result scaled down (the op is linear in dy)."""
+    from rrnet_amd import ops
+    g = torch.Generator().manual_seed(77)
+    n, c, h, w, k = 1, 64, 16, 24, 64
+    x = ops.to_nhwc(torch.randn(n, c, h, w, generator=g).cuda())
+    off = ops.to_nhwc((torch.randn(n, 18, h, w, generator=g) * 0.7).cuda())
+    mask = ops.to_nhwc(torch.sigmoid(torch.randn(n, 9, h, w, generator=g)).cuda())
+    wt = ops.to_nhwc((torch.randn(k, c, 3, 3, generator=g) / 24.0).cuda())
+    dy = ops.to_nhwc(torch.randn(n, k, h, w, generator=g).cuda())
+    ref = ops.dcn_dgrad(x, off, mask, wt, dy, 1, (1, 1), 1, 1)[0]
+    tiny = ops.dcn_dgrad(x, off, mask, wt, dy * 1e-34, 1, (1, 1), 1, 1)[0]
+    assert torch.isfinite(tiny).all()
+    scale = ref.abs().max().item()
+    assert ((tiny * 1e34) - ref).abs().max().item() <= 1e-3 * scale      # fp32 denormal range starts near 1e-38
