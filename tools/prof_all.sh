@@ -1,7 +1,7 @@
 # All rocprofv3 passes whose summaries go to profiles/ (run on the GPU box via gpurun): bench kernel stats + PMC traffic,
 # inference kernel stats + PMC traffic, DCN layer kernel stats + PMC traffic.   bash tools/prof_all.sh <tag>
 export TMPDIR=/tmp
-TAG=${1:-r02}
+TAG=${1:-r03}
 mkdir -p gpurun_out
 bash tools/prof_bench.sh $TAG > gpurun_out/prof_bench_$TAG.out 2>&1
 bash tools/prof_infer.sh $TAG > gpurun_out/prof_infer_$TAG.out 2>&1

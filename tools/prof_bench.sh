@@ -1,6 +1,6 @@
 # rocprofv3 passes of the default bench command; summaries are copied into profiles/ by hand
 export TMPDIR=/tmp
-TAG=${1:-r01}
+TAG=${1:-r03}
 mkdir -p gpurun_out
 timeout 1400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > gpurun_out/bench_prof_$TAG.log 2>&1
 grep "^{\"metric\"" gpurun_out/bench_prof_$TAG.log > gpurun_out/bench_prof_$TAG.json

@@ -1,6 +1,6 @@
 # rocprofv3 kernel stats of the inference post-process bench; summary copied into profiles/ by hand
 export TMPDIR=/tmp
-TAG=${1:-r01}
+TAG=${1:-r03}
 mkdir -p gpurun_out
 python3 tools/bench_infer.py --frames 2048 > gpurun_out/infer_$TAG.json 2> gpurun_out/infer_$TAG.err
 tail -3 gpurun_out/infer_$TAG.err
