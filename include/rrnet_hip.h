@@ -105,10 +105,13 @@ int rr_conv_dgrad_s1_bnsum(const float *dy, const float *wt, float *dx, int n, i
  * whose output prod_z [n,h,w,c] is this convolution's input): dx = relu-masked gradient (dx * (prod_z > 0) is what is
  * STORED) and sums[0..c) = its column sums = the producer's bias gradient — what rr_bias_relu_bwd computes in a pass of
  * its own.  slab: rr_conv_stat_slab_bytes(n,h,wd,c) bytes; sums [2][c] doubles, zeroed by the caller (the second row is
- * not meaningful).  K and C multiples of 4 (the host layer zero-pads a 10- or 2-channel dy to 12 / 4). */
+ * not meaningful).  K and C multiples of 4 (the host layer zero-pads a 10- or 2-channel dy to 12 / 4).
+ * accumulate != 0: dx holds the gradients of the producer's other consumers; the mask is applied to the SUM (the last
+ * contributor of a fan-in: the three heads' 3x3 layers behind relu(feature), models/centernet.py:20-24), which also serves
+ * a bare ReLU producer (its backward then is the identity on this tensor). */
 int rr_conv_dgrad_s1_relubias(const float *dy, const float *wt, float *dx, int n, int h, int wd, int c, int k,
-                              int r, int s, int pad_h, int pad_w, const float *prod_z, double *slab, double *sums,
-                              hipStream_t stream);
+                              int r, int s, int pad_h, int pad_w, int accumulate, const float *prod_z, double *slab,
+                              double *sums, hipStream_t stream);
 int rr_conv_wgrad(const float *x, const float *dy, float *dw, int n, int h, int wd, int c, int k,
                   int r, int s, int stride, int pad_h, int pad_w, int out_h, int out_w, hipStream_t stream);
 

@@ -1488,8 +1488,8 @@ extern "C" int rr_conv_dgrad_s1_bnsum(const float *dy, const float *wt, float *d
 }
 
 extern "C" int rr_conv_dgrad_s1_relubias(const float *dy, const float *wt, float *dx, int n, int h, int wd, int c, int k,
-                                         int r, int s, int pad_h, int pad_w, const float *prod_z, double *slab, double *sums,
-                                         hipStream_t stream)
+                                         int r, int s, int pad_h, int pad_w, int accumulate, const float *prod_z, double *slab,
+                                         double *sums, hipStream_t stream)
 {
     RR_CHECK_ARG(pad_h < r && pad_w < s && pad_h >= 0 && pad_w >= 0, "rr_conv_dgrad_s1_relubias: pad must be in [0, kernel)");
     RR_CHECK_ARG(prod_z && slab && sums, "rr_conv_dgrad_s1_relubias: the producer's output and the two buffers are required");
@@ -1497,7 +1497,8 @@ extern "C" int rr_conv_dgrad_s1_relubias(const float *dy, const float *wt, float
     const int p = h + 2 * pad_h - r + 1, q = wd + 2 * pad_w - s + 1;
     RR_CHECK_ARG(p > 0 && q > 0, "rr_conv_dgrad_s1_relubias: empty dy");
     const BnSumArgs bs{prod_z, prod_z, nullptr, nullptr, nullptr, nullptr, slab, sums, 1};
-    return fprop_impl(dy, wt, nullptr, dx, nullptr, n, p, q, k, c, r, s, 1, r - 1 - pad_h, s - 1 - pad_w, 0, 0, stream, &bs);
+    return fprop_impl(dy, wt, nullptr, dx, nullptr, n, p, q, k, c, r, s, 1, r - 1 - pad_h, s - 1 - pad_w, 0, accumulate, stream,
+                      &bs);
 }
 
 extern "C" int rr_conv_dgrad(const float *dy, const float *w, float *dx, int n, int h, int wd, int c, int k,

@@ -594,21 +594,37 @@ def fanout_shared(x, n):
 
 class _ReLU(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, out_link=None):
         x = ops.to_nhwc(x) if x.dim() == 4 else x.contiguous()
         z = ops.relu_fwd(x)
         ctx.save_for_backward(z)
+        ctx.out_link = out_link
         return z
 
     @staticmethod
     def backward(ctx, dz):
         (z,) = ctx.saved_tensors
         dz = ops.to_nhwc(dz) if dz.dim() == 4 else dz.contiguous()
-        return ops.sum_n([dz], z)
+        ol = ctx.out_link
+        if ol is not None and ol.sums is not None:
+            # the data gradient that completed dz (the one consumer, or the last contributor of the fan-in) already
+            # stored it masked with z > 0: the backward of the ReLU is the identity on that very tensor
+            same = ol.dz is not None and ol.dz.data_ptr() == dz.data_ptr() and ol.dz.shape == dz.shape
+            ol.sums = ol.dz = None
+            if same:
+                return dz, None
+        return ops.sum_n([dz], z), None
 
 
 def relu(x):
-    return _ReLU.apply(x)
+    link = None
+    if torch.is_grad_enabled() and x.requires_grad and x.dim() == 4 and x.shape[1] % 4 == 0:
+        link = ops.BnLink()
+        link.relu_bias = link.use_z = True
+    out = _ReLU.apply(x, link)
+    if link is not None:
+        out._rr_bnlink = link
+    return out
 
 
 class _UpsampleAdd(torch.autograd.Function):

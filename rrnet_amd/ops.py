@@ -248,7 +248,7 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False,
         out = empty_nhwc(n, c, h, wd, dy.device)
         accumulate = False
     assert is_nhwc(out)
-    if (bnsum is not None and bnsum.relu_bias and _DGRAD_BNSUM and stride == 1 and not accumulate and c % 4 == 0
+    if (bnsum is not None and bnsum.relu_bias and _DGRAD_BNSUM and stride == 1 and c % 4 == 0
             and bnsum_z is not None and is_nhwc(bnsum_z) and bnsum_z.shape == out.shape and out.numel() * 4 < (1 << 31)
             and r * s <= 64 and pad[0] < r and pad[1] < s and dy.shape[2] * dy.shape[3] >= _DGRAD_VIA_FPROP_MIN_PIXELS):
         # producer = conv + bias + ReLU: masked gradient + bias column sums in this launch's epilogue.  A 10- or
@@ -267,8 +267,8 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False,
         flops_m = 2.0 * dy.shape[0] * dy.shape[2] * dy.shape[3] * k * c * r * s
         fr = _C.fn("rr_conv_dgrad_s1_relubias")
         _C.check(_timed(_igemm_name("fprop", c, False, n * h * wd) + "+relubias", flops_m,
-                        lambda: fr(_C.ptr(dyp), _C.ptr(wt), _C.ptr(out), n, h, wd, c, kp, r, s, pad[0], pad[1], _C.ptr(bnsum_z),
-                                   _C.ptr(slab), _C.ptr(sums), _C.stream()), (n, h, wd, c, k, r, s, stride)),
+                        lambda: fr(_C.ptr(dyp), _C.ptr(wt), _C.ptr(out), n, h, wd, c, kp, r, s, pad[0], pad[1], int(accumulate),
+                                   _C.ptr(bnsum_z), _C.ptr(slab), _C.ptr(sums), _C.stream()), (n, h, wd, c, k, r, s, stride)),
                  "rr_conv_dgrad_s1_relubias")
         bnsum.sums, bnsum.dz = sums, out
         return out

@@ -301,3 +301,22 @@ def test_dgrad_with_producer_relu_mask_and_bias_sums(cfg):
     mag = masked.double().abs().sum((0, 2, 3)).max().item()
     assert (link.sums[:c] - exp).abs().max().item() <= 2e-6 * mag
     assert (db.double() - exp).abs().max().item() <= 1e-4 * mag
+
+
+def test_dgrad_relu_mask_on_the_sum_of_a_fan_in():
+    """accumulate form of rr_conv_dgrad_s1_relubias: the last contributor adds its gradient to the others' and stores the
+    SUM masked with the producer's output (relu(feature) fanned out to the three heads' 3x3 layers)."""
+    from rrnet_amd import ops
+    n, c, h, w, k = 2, 256, 96, 96, 256
+    g = torch.Generator().manual_seed(5)
+    dy = ops.to_nhwc(torch.randn(n, k, h, w, generator=g).cuda())
+    wt = ops.to_nhwc((torch.randn(k, c, 3, 3, generator=g) / 48.0).cuda())
+    z = ops.to_nhwc(torch.relu(torch.randn(n, c, h, w, generator=g)).cuda())
+    others = ops.to_nhwc(torch.randn(n, c, h, w, generator=g).cuda())
+    link = ops.BnLink()
+    link.relu_bias = link.use_z = True
+    buf = others.clone()
+    ops.conv_dgrad(dy, wt, (n, c, h, w), 1, (1, 1), out=buf, accumulate=True, bnsum=link, bnsum_z=z)
+    assert link.sums is not None and link.dz is buf
+    ref = (ops.conv_dgrad(dy, wt, (n, c, h, w), 1, (1, 1)) + others) * (z > 0)
+    assert (buf - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
