@@ -167,6 +167,9 @@ def test_two_rank_collective_sequences_are_identical(tmp_path):
     assert len(launched) == len(need)                                   # every bucket exactly once
     during = sum(1 for e in ev if e[0] == "grads" and "end of step" not in e[3])
     assert during >= len(need) - 3, (during, len(need))                 # overlapped with backward
+    # a projection block's skip and conv1 share ONE statistics exchange per direction (functional._ConvBnSyncMulti)
+    joint = [e for e in ev if e[0] == "default" and e[3].endswith("x2")]
+    assert len(joint) >= 2 and len(joint) % 2 == 0, [e[3] for e in ev if e[0] == "default"][:12]
     n_sync = sum(1 for e in ev if e[0] == "default")
     print("collectives of one step: %d SyncBN exchanges on the default communicator, %d gradient buckets (%d launched "
           "during backward); buffers broadcast in one collective (%d buffers)" % (n_sync, len(launched), during, t[0]["nbuf"]))
