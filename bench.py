@@ -125,7 +125,8 @@ def extras(a):
     torch.cuda.empty_cache()
     try:
         import bench_dcn
-        out["config4"] = {"layer": bench_dcn.run()}
+        layer = bench_dcn.run()
+        out["config4"] = {"layer": layer, "roofline": layer.get("roofline")}      # LDS roofline of the bf16 forward
         if a.backbone == "hourglass" and a.size == 1024:
             out["config4"].update(config4_train_step(a))
     except Exception as e:
