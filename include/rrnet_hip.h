@@ -385,6 +385,13 @@ int rr_dcn_wgrad(const float *x, const float *offset, const float *mask, const f
 int rr_dcn_dgrad(const float *x, const float *offset, const float *mask, const float *w, const float *dy, float *dx,
                  float *doffset, float *dmask, int n, int h, int wd, int c, int k, int r, int s, int stride, int pad_h,
                  int pad_w, int dilation, int deformable_groups, hipStream_t stream);
+/* rr_dcn_dgrad_bf16 with caller scratch for dY rounded to bf16 (rr_dcn_dyb_bytes(n,p,q,k) bytes, written inside by one
+ * pass per call): the K sweep re-reads a block's dY tile once per 32-channel chunk — as bf16 those re-reads stay in L2
+ * (64 KB per workgroup instead of 128 KB) and the operand staging needs no convert.  Same results bit for bit. */
+size_t rr_dcn_dyb_bytes(int n, int p, int q, int k);
+int rr_dcn_dgrad_bf16_ws(const float *x, const float *offset, const float *mask, const float *w, const float *dy, float *dx,
+                         float *doffset, float *dmask, int n, int h, int wd, int c, int k, int r, int s, int stride, int pad_h,
+                         int pad_w, int dilation, int deformable_groups, void *dyb, hipStream_t stream);
 /* rr_dcn_dgrad with bf16 matrix operands (dY, W rounded to bf16; fp32 accumulation and scatter): the backward of
  * rr_dcn_fwd_bf16.  Layers the window kernel does not take run rr_dcn_dgrad's fp32 kernel. */
 int rr_dcn_dgrad_bf16(const float *x, const float *offset, const float *mask, const float *w, const float *dy, float *dx,

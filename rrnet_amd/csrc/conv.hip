@@ -66,6 +66,10 @@ struct ConvArgs {
     int parity_order;  // dgrad, stride 2: 4 x 2 bits, parity class handled by blockIdx.y = 0..3 (most taps first)
     int parity;        // dgrad, stride 2: blockIdx.y = output parity class (h%2, w%2); only the taps that
                        // can reach that class are visited (1/2/2/4 of a 3x3) instead of masking 3/4 of the MFMAs
+    int pos_major;     // fprop on tiny maps (the stage-2 head's 3x3 convolution on 3x3 RoI maps, fasterrcnn_detector.py:18
+                       // -> Bottleneck.conv2): an M tile = ONE output pixel of 128 consecutive images, so the taps that
+                       // fall into the padding are the same for every row of the tile and are skipped, not masked
+                       // (a padded 3x3 on a 3x3 map: 49 of 81 (pixel, tap) pairs are real)
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nb)
@@ -115,7 +119,8 @@ __global__ __launch_bounds__(256, PIPE == 3 ? 3 : 1) void conv_igemm_kernel(cons
     const int ntiles = (a.DC + BN - 1) / BN;
     const int logical = xcd_remap(blockIdx.x, gridDim.x);
     const int n_tile = logical % ntiles, m_tile = logical / ntiles;
-    const int m0 = m_tile * BM, n0 = n_tile * BN;
+    int m0 = m_tile * BM;
+    const int n0 = n_tile * BN;
 
     const int RS = a.R * a.S;
     // tap sub-lattice visited by this block: all taps, or (parity mode) r = r0, r0+2, ..  s = s0, s0+2, ..
@@ -131,6 +136,20 @@ __global__ __launch_bounds__(256, PIPE == 3 ? 3 : 1) void conv_igemm_kernel(cons
         r0 = (ph + a.pad_h) & 1; s0 = (pw + a.pad_w) & 1; tstep = 2;
         Rc = r0 < a.R ? (a.R - r0 + 1) / 2 : 0;
         Sc = s0 < a.S ? (a.S - s0 + 1) / 2 : 0;
+    }
+    int pm_pix = 0;
+    if (MODE == 0 && a.pos_major) {
+        // the nine tiles of one block of images are neighbours in the launch order (same XCD: the input rows they
+        // share come from its L2)
+        const int hw = a.DH * a.DW;
+        pm_pix = m_tile % hw;
+        m0 = (m_tile / hw) * BM;
+        Mloc = a.N;
+        ph = pm_pix / a.DW; pw = pm_pix - ph * a.DW;
+        const int h_lo = ph * a.stride - a.pad_h, w_lo = pw * a.stride - a.pad_w;   // source pixel under tap (0,0)
+        r0 = h_lo < 0 ? -h_lo : 0; s0 = w_lo < 0 ? -w_lo : 0;
+        const int r1 = a.SH - h_lo < a.R ? a.SH - h_lo : a.R, s1 = a.SW - w_lo < a.S ? a.SW - w_lo : a.S;
+        Rc = r1 > r0 ? r1 - r0 : 0; Sc = s1 > s0 ? s1 - s0 : 0;
     }
     const int RSc = Rc * Sc;
     const int cpt = (a.SC + BKT - 1) / BKT;                // channel chunks per tap (vector mode)
@@ -152,7 +171,9 @@ __global__ __launch_bounds__(256, PIPE == 3 ? 3 : 1) void conv_igemm_kernel(cons
 #pragma unroll
     for (int j = 0; j < AJ; ++j) {
         const int m = m0 + a_row + RPP * j;
-        if (m < Mloc) {
+        if (m < Mloc && MODE == 0 && a.pos_major) {
+            a_n[j] = m; a_h[j] = ph; a_w[j] = pw;
+        } else if (m < Mloc) {
             const int hw = Hc * Wc;
             const int n = m / hw, rem = m - n * hw;
             const int h = rem / Wc;
@@ -178,7 +199,7 @@ __global__ __launch_bounds__(256, PIPE == 3 ? 3 : 1) void conv_igemm_kernel(cons
         for (int j = 0; j < AJ; ++j) {
             int ih0, iw0;
             if (MODE == 0) {
-                ih0 = a_h[j] * a.stride - a.pad_h; iw0 = a_w[j] * a.stride - a.pad_w;
+                ih0 = a_h[j] * a.stride - a.pad_h + r0; iw0 = a_w[j] * a.stride - a.pad_w + s0;   // r0 = s0 = 0 unless pos_major
             } else if (a.parity) {
                 ih0 = (a_h[j] - ph) / 2 + (ph + a.pad_h - r0) / 2; iw0 = (a_w[j] - pw) / 2 + (pw + a.pad_w - s0) / 2;
             } else {
@@ -705,6 +726,7 @@ __global__ __launch_bounds__(256, PIPE == 3 ? 3 : 1) void conv_igemm_kernel(cons
                 if (MODE == 0 && a.relu) v = v > 0.f ? v : 0.f;
                 if (m < Mloc && n_ok) {
                     long pix = m;
+                    if (MODE == 0 && a.pos_major) pix = (long)m * (a.DH * a.DW) + pm_pix;
                     if (MODE == 1 && a.parity) {
                         const int hw = Hc * Wc;
                         const int n = m / hw, rem = m - n * hw;
@@ -1162,6 +1184,16 @@ size_t igemm_lds(int bn, bool b_kn, int bk, int nbuf = 2)
     return sizeof(float) * nbuf * (BM * (bk + 4) + (b_kn ? bk * bn : bn * (bk + 4)));
 }
 
+int conv_pos_major()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("RR_CONV_POS_MAJOR");
+        v = (e == nullptr || atoi(e) != 0) ? 1 : 0;
+    }
+    return v;
+}
+
 int wgrad_aligned()
 {
     static int v = -1;
@@ -1352,10 +1384,18 @@ static int fprop_impl(const float *x, const float *w, const float *bias, float *
     int bn = k > 64 ? 128 : (k > 32 ? (!scalar && bk == 32 ? 64 : 128) : 32);
     if (bn == 128 && !scalar && rr_cdiv(M, BM) * rr_cdiv(k, 128) <= small_tiles()) bn = 32;   // tiny layers: 4x the tiles
     else if (bn == 128 && !scalar && bk == 32 && rr_cdiv(M, BM) * rr_cdiv(k, 128) <= mid_tiles()) bn = 64;
-    const int blocks = rr_cdiv(M, BM) * rr_cdiv(k, bn);
+    int blocks = rr_cdiv(M, BM) * rr_cdiv(k, bn);
     const int nk = scalar ? rr_cdiv(a.Kg, bk) : rr_cdiv(c, bk) * r * s;
     int ks = (bias == nullptr && !relu && k % 4 == 0 && k <= 1024) ? pick_ksplit(blocks, nk) : 1;
     if (bs != nullptr && bs->relu_bias) ks = 1;      // the masked store needs the complete value in one workgroup
+    // padded filter on a tiny map, many images (the stage-2 head on 3x3 RoI maps): one output pixel per M tile, padding
+    // taps skipped (ConvArgs::pos_major).  Not with statistics in the epilogue (their slab is sized by ceil(M/128) tiles).
+    if (conv_pos_major() && !scalar && stat_slab == nullptr && bs == nullptr && (pad_h > 0 || pad_w > 0) && r * s > 1
+        && a.DH * a.DW <= 16 && n >= 16 * BM) {
+        a.pos_major = 1;
+        ks = 1;
+        blocks = a.DH * a.DW * rr_cdiv(n, BM) * rr_cdiv(k, bn);
+    }
     if (ks > 1) {
         a.ksplit = ks;
         if (!accumulate) hipMemsetAsync(y, 0, sizeof(float) * (size_t)M * k, stream);

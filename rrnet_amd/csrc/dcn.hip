@@ -1243,6 +1243,11 @@ struct DcnWinBwdArgs {
     DcnWinArgs w;
     const float *dy;
     float *dx, *doffset, *dmask;
+    // bf16 data gradient: dY already rounded to bf16 (rr_dcn_dgrad_bf16_ws converts it once per call), or null.  The sweep
+    // re-reads a block's dY tile once per 32-channel chunk; as 128 KB of fp32 per workgroup those re-reads miss the XCD's
+    // 4 MB L2 (32 workgroups x 128 KB) and come from HBM eight times (4.3 of the 5.9 GB the kernel fetched in round 2);
+    // as 64 KB of bf16 they stay in L2, and the staging needs no convert.
+    const unsigned short *dyb;
 };
 
 // F32: the matrix operands stay fp32 (v_mfma_f32_32x32x2_f32, K-steps of 16 filters: the same LDS bytes as 32 in bf16);
@@ -1367,6 +1372,7 @@ __global__ __launch_bounds__(512) void dcn_dgrad_win_kernel(const DcnWinBwdArgs 
     __syncthreads();
 
     f32x4 ra[2], rb[TG];
+    u16x4 rah[2];
     for (int cch = 0; cch < cpt; ++cch) {
         const int c0 = cch * CW;
         const int g = c0 / cpg;
@@ -1407,8 +1413,12 @@ __global__ __launch_bounds__(512) void dcn_dgrad_win_kernel(const DcnWinBwdArgs 
                     const int r = a_row + 64 * j;
                     const int p = y0 + r / WIN_TW, q = x0 + r % WIN_TW;
                     const int ko = kc * BKW + a_col;
-                    ra[j] = *reinterpret_cast<const f32x4 *>((p < a.P && q < a.Q && ko < a.K)
-                                                                 ? wb.dy + (((long)n * a.P + p) * a.Q + q) * a.K + ko : a.zero);
+                    const bool ok = p < a.P && q < a.Q && ko < a.K;
+                    const long idx = (((long)n * a.P + p) * a.Q + q) * a.K + ko;
+                    if (wb.dyb != nullptr)
+                        rah[j] = *reinterpret_cast<const u16x4 *>(ok ? (const void *)(wb.dyb + idx) : (const void *)a.zero);
+                    else
+                        ra[j] = *reinterpret_cast<const f32x4 *>(ok ? wb.dy + idx : a.zero);
                 }
                 const int kb = kc * BKW + b_row;         // one ko row per 8 threads, 4 channels each, five taps
 #pragma unroll
@@ -1431,7 +1441,8 @@ __global__ __launch_bounds__(512) void dcn_dgrad_win_kernel(const DcnWinBwdArgs 
                 }
             } else {
 #pragma unroll
-                for (int j = 0; j < 2; ++j) *reinterpret_cast<u16x4 *>(As + (a_row + 64 * j) * LDKH + a_col) = f2bf4(ra[j]);
+                for (int j = 0; j < 2; ++j)
+                    *reinterpret_cast<u16x4 *>(As + (a_row + 64 * j) * LDKH + a_col) = wb.dyb != nullptr ? rah[j] : f2bf4(ra[j]);
 #pragma unroll
                 for (int i = 0; i < TG; ++i) {
                     const int tap = b_tg * TG + i;
@@ -2180,9 +2191,16 @@ extern "C" int rr_dcn_wgrad(const float *x, const float *offset, const float *ma
 }
 
 // Fused backward, part 2: dx (zeroed here, then float atomics on the bilinear corners), doffset, dmask (plain stores).
+// dy (fp32) -> bf16, round to nearest even: one pass per data-gradient call (see DcnWinBwdArgs::dyb)
+__global__ __launch_bounds__(256) void dcn_to_bf16_kernel(const f32x4 *src, u16x4 *dst, long n4)
+{
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) dst[i] = f2bf4(src[i]);
+}
+
 static int dcn_dgrad_impl(const float *x, const float *offset, const float *mask, const float *w, const float *dy,
                           float *dx, float *doffset, float *dmask, int n, int h, int wd, int c, int k, int r, int s,
-                          int stride, int pad_h, int pad_w, int dilation, int deformable_groups, int bf16, hipStream_t stream)
+                          int stride, int pad_h, int pad_w, int dilation, int deformable_groups, int bf16, hipStream_t stream,
+                          unsigned short *dyb = nullptr)
 {
     DcnBwdArgs b{};
     const int rc = fill_args(b.a, x, offset, mask, w, n, h, wd, c, k, r, s, stride, pad_h, pad_w, dilation, deformable_groups);
@@ -2199,6 +2217,7 @@ static int dcn_dgrad_impl(const float *x, const float *offset, const float *mask
         wb.w.tiles_y = rr_cdiv(b.a.P, WIN_TH);
         wb.w.tiles_x = rr_cdiv(b.a.Q, WIN_TW);
         wb.dy = dy; wb.dx = dx; wb.doffset = doffset; wb.dmask = dmask;
+        wb.dyb = nullptr;
         // two windows live in LDS here (d input in fixed point, input values): the margin is the largest <= the
         // requested one that fits (2 pixels for a 3x3 filter with dilation 1)
         size_t ldsw = 0;
@@ -2212,6 +2231,14 @@ static int dcn_dgrad_impl(const float *x, const float *offset, const float *mask
         if (r * s == 9 && ldsw <= 160 * 1024 - 512) {
             const dim3 grid(n * wb.w.tiles_y * wb.w.tiles_x);
             if (bf16) {
+                if (dyb != nullptr && k % 4 == 0) {
+                    const long n4 = (long)b.a.M * k / 4;
+                    long cb = (n4 + 255) / 256;
+                    if (cb > 256 * 32) cb = 256 * 32;
+                    hipLaunchKernelGGL(dcn_to_bf16_kernel, dim3((int)cb), dim3(256), 0, stream, reinterpret_cast<const f32x4 *>(dy),
+                                       reinterpret_cast<u16x4 *>(dyb), n4);
+                    wb.dyb = dyb;
+                }
                 hipFuncSetAttribute(reinterpret_cast<const void *>(dcn_dgrad_win_kernel<9, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw);
                 hipLaunchKernelGGL((dcn_dgrad_win_kernel<9, false>), grid, dim3(512), ldsw, stream, wb);
             } else {
@@ -2247,6 +2274,20 @@ extern "C" int rr_dcn_dgrad_bf16(const float *x, const float *offset, const floa
 {
     return dcn_dgrad_impl(x, offset, mask, w, dy, dx, doffset, dmask, n, h, wd, c, k, r, s, stride, pad_h, pad_w, dilation,
                           deformable_groups, 1, stream);
+}
+
+extern "C" size_t rr_dcn_dyb_bytes(int n, int p, int q, int k)
+{
+    return (size_t)n * p * q * k * sizeof(unsigned short);
+}
+
+extern "C" int rr_dcn_dgrad_bf16_ws(const float *x, const float *offset, const float *mask, const float *w, const float *dy,
+                                    float *dx, float *doffset, float *dmask, int n, int h, int wd, int c, int k, int r, int s,
+                                    int stride, int pad_h, int pad_w, int dilation, int deformable_groups, void *dyb,
+                                    hipStream_t stream)
+{
+    return dcn_dgrad_impl(x, offset, mask, w, dy, dx, doffset, dmask, n, h, wd, c, k, r, s, stride, pad_h, pad_w, dilation,
+                          deformable_groups, 1, stream, static_cast<unsigned short *>(dyb));
 }
 
 extern "C" int rr_dcn_split_fwd(const float *om, long m, int third, float *offset, float *mask, hipStream_t stream)

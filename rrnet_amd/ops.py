@@ -800,6 +800,7 @@ def roi_align_bwd(dout, rois, feat_shape, out_size, spatial_scale=1.0, sampling_
 # DCNv2
 # ---------------------------------------------------------------------------------------------
 _DCN_WPACK = os.environ.get("RR_DCN_WPACK", "1") != "0"
+_DCN_DYB = os.environ.get("RR_DCN_DYB", "1") != "0"      # bf16 data gradient stages dY from a bf16 copy made once per call
 
 
 def dcn_fwd(x, offset, mask, w, bias, stride, pad, dilation, dg, bf16=False):
@@ -869,6 +870,13 @@ def dcn_dgrad(x, offset, mask, w, dy, stride, pad, dilation, dg, bf16=False):
     doff = torch.empty_like(offset)
     dmask = torch.empty_like(mask)
     assert doff.stride() == offset.stride() and dmask.stride() == mask.stride()
+    if bf16 and _DCN_DYB:
+        # dY rounded to bf16 once per call (caller scratch): the sweep's eight re-reads of a block's dY tile stay in L2
+        dyb = torch.empty(_C.fn("rr_dcn_dyb_bytes")(dy.shape[0], dy.shape[2], dy.shape[3], k), dtype=torch.uint8, device=x.device)
+        _C.check(_C.fn("rr_dcn_dgrad_bf16_ws")(_C.ptr(x), _C.ptr(offset), _C.ptr(mask), _C.ptr(w), _C.ptr(dy), _C.ptr(dx),
+                                               _C.ptr(doff), _C.ptr(dmask), n, h, wd, c, k, r, s, stride, pad[0], pad[1],
+                                               dilation, dg, _C.ptr(dyb), _C.stream()), "rr_dcn_dgrad_bf16_ws")
+        return dx, doff, dmask
     name = "rr_dcn_dgrad_bf16" if bf16 else "rr_dcn_dgrad"
     _C.check(_C.fn(name)(_C.ptr(x), _C.ptr(offset), _C.ptr(mask), _C.ptr(w), _C.ptr(dy), _C.ptr(dx), _C.ptr(doff),
                          _C.ptr(dmask), n, h, wd, c, k, r, s, stride, pad[0], pad[1], dilation, dg, _C.stream()), name)

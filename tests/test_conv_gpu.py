@@ -109,6 +109,55 @@ def test_conv_fprop_dgrad_wgrad(cfg):
     np.testing.assert_allclose(dw.cpu().numpy(), wr.grad.numpy(), atol=tol, rtol=2e-4)
 
 
+# (N, C, H, W, K, R, S, pad_h, pad_w, bias, relu): tiny maps, many images — the stage-2 head's geometry
+POS_MAJOR = [
+    (2500, 64, 3, 3, 64, 3, 3, 1, 1, True, True),       # Bottleneck.conv2 on RoI maps (N not a multiple of 128)
+    (2048, 32, 2, 4, 48, 3, 5, 1, 2, False, False),     # non-square map and filter, K = 48 (masked N tile)
+    (2100, 64, 4, 4, 128, 3, 3, 1, 1, True, False),     # 16 pixels, two N tiles at BN = 64
+    (2304, 16, 1, 3, 32, 3, 3, 1, 1, False, True),      # one row: only the middle filter row is real
+    (2050, 64, 3, 3, 64, 5, 5, 2, 2, False, False),     # filter wider than the map
+]
+
+
+@pytest.mark.parametrize("cfg", POS_MAJOR, ids=lambda c: "n%dc%dh%dw%dk%dr%ds%d" % c[:7])
+def test_conv_position_major_tiles_skip_padding_taps(cfg):
+    """Padded filters on tiny maps with >= 2048 images take the position-major tiling (ConvArgs::pos_major: one output
+    pixel per M tile, padding taps skipped): forward (no statistics requested) and the stride-1 data gradient through the
+    forward kernel, plain and accumulating, against torch-CPU conv2d / autograd."""
+    from rrnet_amd import ops
+    n, c, h, w, k, r, s, ph, pw, use_bias, relu = cfg
+    x = _mk((n, c, h, w), 11)
+    wt = _mk((k, c, r, s), 12) * (1.0 / np.sqrt(c * r * s))
+    b = _mk((k,), 13) if use_bias else None
+    xr = x.clone().requires_grad_()
+    y_ref = F.conv2d(xr, wt, b, stride=1, padding=(ph, pw))
+    if relu:
+        y_ref = F.relu(y_ref)
+    gy = _mk(tuple(y_ref.shape), 14)
+    y_ref.backward(gy * (y_ref.detach() > 0).float() if relu else gy)
+    xd, wd = ops.to_nhwc(x.cuda()), ops.to_nhwc(wt.cuda())
+    y = ops.conv_fprop(xd, wd, b.cuda() if use_bias else None, 1, (ph, pw), relu)
+    np.testing.assert_allclose(y.cpu().numpy(), y_ref.detach().numpy(), atol=2e-5 * np.sqrt(c * r * s), rtol=1e-4)
+    # with statistics the ordinary tiling runs: same values up to summation order
+    y2, _ = ops.conv_fprop(xd, wd, None, 1, (ph, pw), False, want_stats=True)
+    y3 = ops.conv_fprop(xd, wd, None, 1, (ph, pw), False)
+    np.testing.assert_allclose(y3.cpu().numpy(), y2.cpu().numpy(), atol=2e-5 * np.sqrt(c * r * s), rtol=1e-4)
+    if 2 * ph == r - 1 and 2 * pw == s - 1:
+        gyd = ops.to_nhwc((gy * (y_ref.detach() > 0).float() if relu else gy).cuda())
+        saved = ops._DGRAD_VIA_FPROP, ops._DGRAD_VIA_FPROP_MIN_PIXELS
+        ops._DGRAD_VIA_FPROP, ops._DGRAD_VIA_FPROP_MIN_PIXELS = True, 0
+        try:
+            tol = 2e-5 * np.sqrt(k * r * s)
+            dx = ops.conv_dgrad(gyd, wd, (n, c, h, w), 1, (ph, pw))
+            np.testing.assert_allclose(dx.cpu().numpy(), xr.grad.numpy(), atol=tol, rtol=1e-4)
+            base = _mk((n, c, h, w), 15)
+            acc = ops.to_nhwc(base.cuda()).clone(memory_format=torch.channels_last)
+            ops.conv_dgrad(gyd, wd, (n, c, h, w), 1, (ph, pw), out=acc, accumulate=True)
+            np.testing.assert_allclose(acc.cpu().numpy(), (xr.grad + base).numpy(), atol=tol, rtol=1e-4)
+        finally:
+            ops._DGRAD_VIA_FPROP, ops._DGRAD_VIA_FPROP_MIN_PIXELS = saved
+
+
 def test_conv_linearity_large():
     """Size-independent property at a BASELINE-sized layer (256->256 3x3 on 256x256, B=1):
     conv(a*x1 + x2) == a*conv(x1) + conv(x2) within fp32 rounding, and a spot check of one
