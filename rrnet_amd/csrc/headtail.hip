@@ -4,11 +4,14 @@
 // frames at config 5) only for the next kernel to read it back with the residual and reduce it 9:1; here only the
 // pooled [R, 256] tensor is written.  HBM-bound: algorithmic bytes per RoI = 9*(K + N)*4 read + N*4 written
 // (K = 64, N = 256: 11.5 KB, 2.2 GB per 128 frames).
-// One workgroup per 32 RoIs (288 rows for 3x3 RoIs), four waves = four 64-column slices of the output; a wave keeps
-// its slice of W3 (64 x K) in 64 registers for the whole workgroup, streams the rows through in sub-tiles of 32
-// (operand fragments straight from global memory: the tile is consumed once), and adds relu(...) of every row into
-// the RoI's pooled accumulator in LDS (ds_add_f32).  No global atomics, no zero-fill of the output; several
-// workgroups per CU overlap each other's fetches.
+// One workgroup per 32 RoIs, four waves = four 64-column slices of the output; a wave keeps its slice of W3 (64 x K) in
+// 64 registers for the whole workgroup.  The rows are taken POSITION-MAJOR: MFMA tile p holds pixel p of each of the 32
+// RoIs (row stride HW), so the average pool is a plain sum of the HW tiles' activated accumulators, element by element
+// in registers — no transpose through LDS, no pooled buffer, no atomics (the row-major version of round 2 spent ~500
+// VALU instructions and 40 LDS operations per tile on exactly that and used 67 KB of LDS per workgroup).  Operand
+// fragments come straight from global memory (the tile is consumed once); the residual is read in the accumulator
+// layout (lane = column: a wave's load covers two rows x 128 B).  The next tile's residual is requested before, its
+// operand rows right after the MFMAs of the current tile.
 #include "common.h"
 #include "rrnet_hip.h"
 
@@ -16,22 +19,16 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int HT_ROIS = 32, HT_NMAX = 256, ST_LD = 68;
+constexpr int HT_ROIS = 32, HT_NMAX = 256;
 
 template <int KK>   // KK = K / 8
 __global__ __launch_bounds__(256, 2) void head_tail_kernel(const float *h, const float *w, const float *scale, const float *shift,
                                                         const float *res, float *out, long R, int N, int HW)
 {
-    __shared__ float pooled[HT_ROIS * HT_NMAX];
-    __shared__ __align__(16) float stage[4 * 32 * ST_LD];
     constexpr int K = KK * 8;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6, lr = lane & 31, lh = lane >> 5;
     const long r0 = (long)blockIdx.x * HT_ROIS;
-    const long M = R * HW;
-    const long m_begin = r0 * HW;
-    long m_end = (r0 + HT_ROIS) * HW;
-    if (m_end > M) m_end = M;
-    for (int i = t; i < HT_ROIS * HT_NMAX; i += 256) pooled[i] = 0.f;
+    const int nroi = R - r0 < HT_ROIS ? (int)(R - r0) : HT_ROIS;
     // this wave's columns [64 wv, 64 wv + 64): B fragments b[j][kk] = W[n = 64 wv + 32 j + lr][8 kk + 4 lh .. +3]
     f32x4 bfr[2][KK];
     float sc[2], sh[2];
@@ -45,25 +42,54 @@ __global__ __launch_bounds__(256, 2) void head_tail_kernel(const float *h, const
         for (int kk = 0; kk < KK; ++kk)
             bfr[j][kk] = n < N ? *reinterpret_cast<const f32x4 *>(w + (long)n * K + kk * 8 + lh * 4) : z4;
     }
-    __syncthreads();
-    const int nsub = (int)((m_end - m_begin + 31) / 32);
-    float *st = stage + wv * (32 * ST_LD);             // this wave's [32 rows][64 cols] transpose buffer
-    for (int sub = 0; sub < nsub; ++sub) {
-        const long mb = m_begin + (long)sub * 32;
-        // operand rows straight from global memory (16 B per lane) and the residual in row-major order (16 B per lane,
-        // 4 rows x 256 B per instruction): the accumulators are transposed through LDS to meet it
-        f32x4 afr[KK], rv[8];
-        const long mrow = mb + lr;
+    // Both streams go through buffer descriptors that cover exactly this workgroup's RoIs: rows past the last RoI read
+    // 0 from the hardware's range check, per-lane state is ONE 32-bit offset per stream, and the tile / row / K-step
+    // part of every address travels in the instruction's scalar offset (no 64-bit address per load: 32 of them per
+    // tile spilled).  Descriptor words pass through readfirstlane so that the compiler sees them wave-uniform.
+    auto make_srd = [](const float *p, long bytes) {
+        const unsigned long long u = reinterpret_cast<unsigned long long>(p);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u);
+        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+        void *q = reinterpret_cast<void *>(((unsigned long long)hi << 32) | lo);
+        return __builtin_amdgcn_make_buffer_rsrc(q, 0, __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
+    };
+    const __amdgpu_buffer_rsrc_t rs_h = make_srd(h + r0 * HW * K, (long)nroi * HW * K * 4);
+    const __amdgpu_buffer_rsrc_t rs_r = make_srd(res + r0 * HW * N, (long)nroi * HW * N * 4);
+    // A fragment: lane (lr, lh) = RoI lr, reduction indices 8 kk + 4 lh .. +3 of pixel p
+    const unsigned a_voff = (unsigned)((lr * HW * K + lh * 4) * 4);
+    // D layout: col = lr, row (= RoI) = (e & 3) + 8 * (e >> 2) + 4 * lh
+    unsigned r_voff[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+        r_voff[j] = wv * 64 + j * 32 + lr < N ? (unsigned)((4 * lh * HW * N + wv * 64 + j * 32 + lr) * 4) : 0xFFFFFFF0u;
+    f32x4 afr[KK];
+    float rv[2][16], rv_n[2][16];
+    auto fetch_a = [&](int p) {
+        const unsigned v = p < HW ? a_voff : 0xFFFFFFF0u;
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk)
-            afr[kk] = mrow < m_end ? *reinterpret_cast<const f32x4 *>(h + mrow * K + kk * 8 + lh * 4) : z4;
-        const int rrow = lane >> 4, rcol = (lane & 15) * 4;      // row-major view: lane group g owns rows 8g .. 8g+7
+            afr[kk] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_h, v, (p * K + kk * 8) * 4, 0));
+    };
+    auto fetch_r = [&](int p, float (&fr)[2][16]) {
 #pragma unroll
-        for (int s8 = 0; s8 < 8; ++s8) {
-            const long m = mb + rrow * 8 + s8;
-            const int n = wv * 64 + rcol;
-            rv[s8] = (m < m_end && n < N) ? *reinterpret_cast<const f32x4 *>(res + m * N + n) : z4;
+        for (int j = 0; j < 2; ++j) {
+            const unsigned v = p < HW ? r_voff[j] : 0xFFFFFFF0u;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = (e & 3) + 8 * (e >> 2);
+                fr[j][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, v, (row * HW + p) * N * 4, 0));
+            }
         }
+    };
+    f32x16 pool[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) pool[j][e] = 0.f;
+    fetch_a(0);
+    fetch_r(0, rv);
+    for (int p = 0; p < HW; ++p) {
+        fetch_r(p + 1, rv_n);
         f32x16 acc[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j)
@@ -75,50 +101,25 @@ __global__ __launch_bounds__(256, 2) void head_tail_kernel(const float *h, const
             for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[kk][e], bfr[j][kk][e], acc[j], 0, 0, 0);
+        // the MFMAs have read their operands at issue: the next tile's rows are fetched into the same registers
+        __builtin_amdgcn_sched_barrier(0);
+        fetch_a(p + 1);
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e)
-                st[((e & 3) + 8 * (e >> 2) + 4 * lh) * ST_LD + j * 32 + lr] = acc[j][e] * sc[j] + sh[j];
-        // the wave reads back, in another layout, what its own lanes just stored: the hardware orders a wave's LDS
-        // traffic, the fence + wave barrier tell the COMPILER that these stores and the loads below conflict
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // a lane walks 8 consecutive rows and keeps the running sum of the current RoI in registers: one LDS add per
-        // RoI change instead of one per row (and no four-lanes-one-address conflicts)
-        f32x4 run = z4;
-        int cur = -1;
-        auto flush = [&]() {
-            if (cur < 0) return;
-            float *p = pooled + cur * HT_NMAX + wv * 64 + rcol;
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-                if (wv * 64 + rcol + c < N) atomicAdd(p + c, run[c]);   // ds_add_f32
-        };
-#pragma unroll
-        for (int s8 = 0; s8 < 8; ++s8) {
-            const int rl = rrow * 8 + s8;
-            const long m = mb + rl;
-            if (m >= m_end) break;
-            const int roi = (int)((m - m_begin) / HW);
-            if (roi != cur) { flush(); cur = roi; run = z4; }
-            const f32x4 y = *reinterpret_cast<const f32x4 *>(st + rl * ST_LD + rcol);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) run[c] += fmaxf(y[c] + rv[s8][c], 0.f);
-        }
-        flush();
-        // the next sub-tile's stores must not move above this sub-tile's loads of `st`
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+            for (int e = 0; e < 16; ++e) {
+                pool[j][e] += fmaxf(__builtin_fmaf(acc[j][e], sc[j], sh[j]) + rv[j][e], 0.f);
+                rv[j][e] = rv_n[j][e];
+            }
     }
-    __syncthreads();
     const float inv = 1.f / (float)HW;
-    const int nroi = (int)((m_end - m_begin) / HW);
-    for (int i = t; i < nroi * N; i += 256) {
-        const int rl = i / N, n = i - rl * N;
-        out[(r0 + rl) * N + n] = pooled[rl * HT_NMAX + n] * inv;
-    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = (e & 3) + 8 * (e >> 2) + 4 * lh, n = wv * 64 + j * 32 + lr;
+            if (row < nroi && n < N) out[(r0 + row) * N + n] = pool[j][e] * inv;
+        }
 }
 
 }  // namespace
