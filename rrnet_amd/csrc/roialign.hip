@@ -185,6 +185,7 @@ __global__ __launch_bounds__(256) void roi_align_sep_kernel(const float *feat, c
 // belongs to — (3g+1)^2 row reads instead of 9(g+1)^2 (100 vs 144 at a 3x3 sampling grid).  Axis weights per bin over
 // the footprint live in LDS; the bin loops are wave-uniform branches on "weight != 0".
 constexpr int FP_MAX = 3 * (SEP_MAXG + 2);
+constexpr int ROI_MLP = 8;    // footprint pixels (1 KB each per wave) requested before the first is used
 
 struct AxisFP {
     float w[3][FP_MAX];
@@ -274,24 +275,38 @@ __global__ __launch_bounds__(256) void roi_align_3x3_kernel(const float *feat, c
         for (int rr = 0; rr < fy.n; ++rr) {
             const float wy0 = fy.w[0][rr], wy1 = fy.w[1][rr], wy2 = fy.w[2][rr];
             const float *row = img + ((long)(fy.base + rr) * W + fx.base) * C + c0;
-            for (int cc = 0; cc < fx.n; ++cc) {
-                const f32x4 v = *reinterpret_cast<const f32x4 *>(row + (long)cc * C);
-                const float wx0 = fx.w[0][cc], wx1 = fx.w[1][cc], wx2 = fx.w[2][cc];
-                // wave-uniform: a pixel lies in at most two bins per axis
-                if (wy0 != 0.f) {
-                    if (wx0 != 0.f) acc[0][0] += (wy0 * wx0) * v;
-                    if (wx1 != 0.f) acc[0][1] += (wy0 * wx1) * v;
-                    if (wx2 != 0.f) acc[0][2] += (wy0 * wx2) * v;
-                }
-                if (wy1 != 0.f) {
-                    if (wx0 != 0.f) acc[1][0] += (wy1 * wx0) * v;
-                    if (wx1 != 0.f) acc[1][1] += (wy1 * wx1) * v;
-                    if (wx2 != 0.f) acc[1][2] += (wy1 * wx2) * v;
-                }
-                if (wy2 != 0.f) {
-                    if (wx0 != 0.f) acc[2][0] += (wy2 * wx0) * v;
-                    if (wx1 != 0.f) acc[2][1] += (wy2 * wx1) * v;
-                    if (wx2 != 0.f) acc[2][2] += (wy2 * wx2) * v;
+            // ROI_MLP pixels of the row are requested before the first is used: with one load in flight per wave (round 2)
+            // a RoI took ~145 us (100 footprint pixels x ~1.45 us) and the kernel ran at 5.3 TB/s on occupancy alone;
+            // 8 in flight: 2.73 ms instead of 3.43 per 128 frames at config 5 (4 / 12 / 16 in flight: 2.89 / 2.95 / 2.94 —
+            // registers cost occupancy).  Capping the occupancy instead (to shorten the time between two overlapping RoIs'
+            // reads of a shared line below the caches' residency) only loses: 4.7 ms at 3, 8.9 ms at 2 workgroups per CU.
+            for (int cb = 0; cb < fx.n; cb += ROI_MLP) {
+                f32x4 vv[ROI_MLP];
+#pragma unroll
+                for (int u = 0; u < ROI_MLP; ++u)
+                    vv[u] = cb + u < fx.n ? *reinterpret_cast<const f32x4 *>(row + (long)(cb + u) * C) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int u = 0; u < ROI_MLP; ++u) {
+                    const int cc = cb + u;
+                    if (cc >= fx.n) break;
+                    const f32x4 v = vv[u];
+                    const float wx0 = fx.w[0][cc], wx1 = fx.w[1][cc], wx2 = fx.w[2][cc];
+                    // wave-uniform: a pixel lies in at most two bins per axis
+                    if (wy0 != 0.f) {
+                        if (wx0 != 0.f) acc[0][0] += (wy0 * wx0) * v;
+                        if (wx1 != 0.f) acc[0][1] += (wy0 * wx1) * v;
+                        if (wx2 != 0.f) acc[0][2] += (wy0 * wx2) * v;
+                    }
+                    if (wy1 != 0.f) {
+                        if (wx0 != 0.f) acc[1][0] += (wy1 * wx0) * v;
+                        if (wx1 != 0.f) acc[1][1] += (wy1 * wx1) * v;
+                        if (wx2 != 0.f) acc[1][2] += (wy1 * wx2) * v;
+                    }
+                    if (wy2 != 0.f) {
+                        if (wx0 != 0.f) acc[2][0] += (wy2 * wx0) * v;
+                        if (wx1 != 0.f) acc[2][1] += (wy2 * wx1) * v;
+                        if (wx2 != 0.f) acc[2][2] += (wy2 * wx2) * v;
+                    }
                 }
             }
         }
