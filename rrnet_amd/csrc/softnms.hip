@@ -206,17 +206,22 @@ __device__ void soft_nms_segment(SegView v, const int n, const float sigma, cons
     if (tid == 0) *out_n = N;
 }
 
+constexpr int SMALL_SEG = 192;   // segments up to this many boxes run on one wave
+constexpr int MID_SEG = 512;     // first launch of the two-launch split: LDS for this many boxes (12.8 KB)
+
 // LDS-resident: dynamic LDS = n_max * 25 bytes (rounded), boxes are loaded AoS->SoA and stored back.
 template <int T>
 __global__ __launch_bounds__(T) void soft_nms_kernel(float *boxes, const int *seg_off, const int *seg_len, int stride,
                                                      float sigma, float Nt, float thr, int method,
-                                                     int cap, int *n_out, int *err, float *gws)
+                                                     int cap, int *n_out, int *err, float *gws, int n_lo, int n_hi)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ int red[20];
     const int seg = blockIdx.x;
     const int off = seg_off[seg];
     const int n = seg_len ? seg_len[seg] : seg_off[seg + 1] - off;
+    // two-launch split (soft_nms_launch): this launch takes the segments of n_lo < n <= n_hi boxes
+    if (n <= n_lo || n > n_hi) return;
     float *b = boxes + (size_t)off * stride;
     SegView v;
     if (gws == nullptr) {
@@ -239,7 +244,7 @@ __global__ __launch_bounds__(T) void soft_nms_kernel(float *boxes, const int *se
     __syncthreads();
     __shared__ int outn;
     if (threadIdx.x == 0) outn = n;
-    if (T > 64 && n <= 192) {
+    if (T > 64 && n <= SMALL_SEG) {
         // The launch is sized for the LONGEST possible segment (the caller's bound, e.g. K = 1500), the typical
         // (frame, class) segment holds ~150 boxes: those run on the first wave alone — same algorithm, wave
         // shuffles instead of block barriers in every one of its ~N steps (the barriers were most of the step).
@@ -287,17 +292,27 @@ static int soft_nms_launch(float *boxes, const int *seg_off, const int *seg_len,
     const int cap = (max_seg_boxes + 3) & ~3;
     const size_t lds = in_lds ? (size_t)cap * 25 + 16 : 0;
     float *gws = in_lds ? nullptr : reinterpret_cast<float *>(workspace);
-#define LAUNCH(T)                                                                                     \
+#define LAUNCH(T, LDS, CAP, LO, HI)                                                                    \
     do {                                                                                              \
-        if (lds > 48 * 1024)                                                                          \
+        if ((LDS) > 48 * 1024)                                                                        \
             hipFuncSetAttribute(reinterpret_cast<const void *>(soft_nms_kernel<T>),                   \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                \
-        hipLaunchKernelGGL(soft_nms_kernel<T>, dim3(nseg), dim3(T), lds, stream, boxes, seg_off,      \
-                           seg_len, stride, sigma, Nt, threshold, method, cap, n_out, err_flag, gws);          \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS));              \
+        hipLaunchKernelGGL(soft_nms_kernel<T>, dim3(nseg), dim3(T), (LDS), stream, boxes, seg_off,    \
+                           seg_len, stride, sigma, Nt, threshold, method, (CAP), n_out, err_flag, gws, (LO), (HI)); \
     } while (0)
-    if (max_seg_boxes <= 192) LAUNCH(64);
-    else if (max_seg_boxes <= 2560) LAUNCH(256);
-    else LAUNCH(1024);
+    constexpr int ALL = 0x7fffffff;
+    if (max_seg_boxes <= SMALL_SEG) LAUNCH(64, lds, cap, -1, ALL);
+    else if (in_lds && max_seg_boxes > MID_SEG) {
+        // The caller's bound is the LONGEST possible segment (K = 1500 at inference: 37.5 KB of LDS per workgroup = four
+        // segments per CU) while a typical (frame, class) segment holds ~150 boxes.  Two launches: the segments of up to
+        // MID_SEG boxes with 12.8 KB of LDS each (all 1280 segments of a 128-frame batch are resident at once: the launch
+        // lasts as long as its longest segment instead of a round and a quarter), then the larger ones with the LDS
+        // they need (workgroups of the others return at once).
+        LAUNCH(256, (size_t)MID_SEG * 25 + 16, MID_SEG, -1, MID_SEG);
+        if (max_seg_boxes <= 2560) LAUNCH(256, lds, cap, MID_SEG, ALL);
+        else LAUNCH(1024, lds, cap, MID_SEG, ALL);
+    } else if (max_seg_boxes <= 2560) LAUNCH(256, lds, cap, -1, ALL);
+    else LAUNCH(1024, lds, cap, -1, ALL);
 #undef LAUNCH
     RR_CHECK_LAUNCH("rr_soft_nms_segments");
     return RR_OK;
