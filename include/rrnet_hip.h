@@ -172,6 +172,10 @@ int rr_bn_bwd_apply_gacc(const float *dz, const float *z, const float *y, const 
                     const double *count_dev, float *dx, float *g_acc, float *dgamma, float *dbeta, long total,
                     int c, hipStream_t stream);
 int rr_relu_fwd(const float *x, float *out, long total, hipStream_t stream);
+/* [npix][k] -> [npix][kp], channels k..kp-1 zero (kp a multiple of 4): the 10- / 2-channel gradients of the hm / offset
+ * heads' last 1x1 convolutions (detectors/centernet_detector.py:14-16) enter the vector data-gradient kernel as 12 / 4
+ * channels.  (A strided torch copy into a channel slice took 3.6 ms per head at 8x256x256 — 10.8 ms of a 457 ms step.) */
+int rr_pad_channels(const float *src, float *dst, long npix, int k, int kp, hipStream_t stream);
 int rr_sum_n(const float *const *grads, int n, const float *z, float *out, long total, hipStream_t stream);
 int rr_bias_relu_bwd(const float *dy, const float *z, float *dy_masked, float *dbias, long npix, int c,
                      hipStream_t stream);

@@ -85,7 +85,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nb)
 // waits on a barrier or on LDS latency.
 // BNS: the epilogue also emits the producer's BatchNorm-backward sums (ConvArgs::bs_y); a separate instantiation so
 // that the plain kernel keeps its register budget (three workgroups per CU).
-template <int BN, int MODE, bool SCALAR, int BKT, int PIPE, bool BNS = false>
+// POSM: position-major M tiles (ConvArgs::pos_major); like BNS a separate instantiation — folded into the plain kernel
+// the extra state cost 20 registers and the third workgroup per CU (457 -> 466 ms per train step).
+template <int BN, int MODE, bool SCALAR, int BKT, int PIPE, bool BNS = false, bool POSM = false>
 __global__ __launch_bounds__(256, PIPE == 3 ? 3 : 1) void conv_igemm_kernel(const ConvArgs a)
 {
     constexpr int WN = BN / 64 ? BN / 64 : 1;   // waves along N
@@ -138,7 +140,7 @@ __global__ __launch_bounds__(256, PIPE == 3 ? 3 : 1) void conv_igemm_kernel(cons
         Sc = s0 < a.S ? (a.S - s0 + 1) / 2 : 0;
     }
     int pm_pix = 0;
-    if (MODE == 0 && a.pos_major) {
+    if constexpr (POSM) {
         // the nine tiles of one block of images are neighbours in the launch order (same XCD: the input rows they
         // share come from its L2)
         const int hw = a.DH * a.DW;
@@ -171,7 +173,7 @@ __global__ __launch_bounds__(256, PIPE == 3 ? 3 : 1) void conv_igemm_kernel(cons
 #pragma unroll
     for (int j = 0; j < AJ; ++j) {
         const int m = m0 + a_row + RPP * j;
-        if (m < Mloc && MODE == 0 && a.pos_major) {
+        if (POSM && m < Mloc) {
             a_n[j] = m; a_h[j] = ph; a_w[j] = pw;
         } else if (m < Mloc) {
             const int hw = Hc * Wc;
@@ -726,7 +728,7 @@ __global__ __launch_bounds__(256, PIPE == 3 ? 3 : 1) void conv_igemm_kernel(cons
                 if (MODE == 0 && a.relu) v = v > 0.f ? v : 0.f;
                 if (m < Mloc && n_ok) {
                     long pix = m;
-                    if (MODE == 0 && a.pos_major) pix = (long)m * (a.DH * a.DW) + pm_pix;
+                    if constexpr (POSM) pix = (long)m * (a.DH * a.DW) + pm_pix;
                     if (MODE == 1 && a.parity) {
                         const int hw = Hc * Wc;
                         const int n = m / hw, rem = m - n * hw;
@@ -1314,6 +1316,10 @@ int launch_igemm(ConvArgs &a, int bn, bool scalar, int blocks, int gy, int gz, h
     launch(conv_igemm_kernel<BNv, MODE, SCv, BKv, PIPEv>, blocks,                                                    \
            PIPEv == 3 ? sizeof(float) * (BM + bn) * bk : (PIPEv == 2 ? igemm_lds(bn, MODE == 1, bk, 1) : lds), stream, a, name, gy, gz)
     if constexpr (MODE == 0) {
+        if (a.pos_major) {           // host rule (fprop_impl): vector gather, both tensors below 2 GiB
+            if (bn == 128) return launch(conv_igemm_kernel<128, 0, false, 32, 2, false, true>, blocks, igemm_lds(bn, false, 32, 1), stream, a, name, gy, gz);
+            return launch(conv_igemm_kernel<64, 0, false, 32, 2, false, true>, blocks, igemm_lds(64, false, 32, 1), stream, a, name, gy, gz);
+        }
         if (a.bs_y != nullptr) {     // producer's BatchNorm-backward sums in the epilogue: vector kernels, K-step 32
             const bool small = (long)a.N * a.SH * a.SW * a.SC * 4 < (1l << 31) && (long)a.wK * a.R * a.S * a.wC * 4 < (1l << 31);
             RR_CHECK_ARG(!scalar && bk == 32, "conv: BatchNorm-backward sums need the vector kernels (C %% 4 == 0, RR_CONV_BK=32)");
@@ -1390,8 +1396,10 @@ static int fprop_impl(const float *x, const float *w, const float *bias, float *
     if (bs != nullptr && bs->relu_bias) ks = 1;      // the masked store needs the complete value in one workgroup
     // padded filter on a tiny map, many images (the stage-2 head on 3x3 RoI maps): one output pixel per M tile, padding
     // taps skipped (ConvArgs::pos_major).  Not with statistics in the epilogue (their slab is sized by ceil(M/128) tiles).
+    // The variant exists for the pipelined 128- and 64-column kernels (K-step 32, 32-bit buffer offsets).
     if (conv_pos_major() && !scalar && stat_slab == nullptr && bs == nullptr && (pad_h > 0 || pad_w > 0) && r * s > 1
-        && a.DH * a.DW <= 16 && n >= 16 * BM) {
+        && a.DH * a.DW <= 16 && n >= 16 * BM && bk == 32 && bn >= 64 && conv_pipe() >= 2
+        && (long)n * h * wd * c * 4 < (1l << 31) && (long)k * r * s * c * 4 < (1l << 31)) {
         a.pos_major = 1;
         ks = 1;
         blocks = a.DH * a.DW * rr_cdiv(n, BM) * rr_cdiv(k, bn);

@@ -261,6 +261,20 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(const f32x4 *d
     }
 }
 
+// ---- channel padding -----------------------------------------------------------------------
+// [npix][k] -> [npix][kp] (kp = k rounded up to 4, the tail zero): one float4 of the output per thread
+__global__ __launch_bounds__(EW_THREADS) void pad_channels_kernel(const float *src, f32x4 *dst, long n4, int k, int kp4)
+{
+    for (long i = (long)blockIdx.x * EW_THREADS + threadIdx.x; i < n4; i += (long)gridDim.x * EW_THREADS) {
+        const long pix = i / kp4;
+        const int c0 = (int)(i - pix * kp4) * 4;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = c0 + e < k ? src[pix * k + c0 + e] : 0.f;
+        dst[i] = v;
+    }
+}
+
 // ---- ReLU / sums ---------------------------------------------------------------------------
 __global__ __launch_bounds__(EW_THREADS) void relu_fwd_kernel(const f32x4 *x, f32x4 *out, long n4)
 {
@@ -714,6 +728,14 @@ extern "C" int rr_relu_fwd(const float *x, float *out, long total, hipStream_t s
     RR_CHECK_ARG(total % 4 == 0, "rr_relu_fwd: element count must be a multiple of 4");
     EW_LAUNCH(relu_fwd_kernel, total / 4, stream, (const f32x4 *)x, (f32x4 *)out, total / 4);
     RR_CHECK_LAUNCH("rr_relu_fwd");
+    return RR_OK;
+}
+
+extern "C" int rr_pad_channels(const float *src, float *dst, long npix, int k, int kp, hipStream_t stream)
+{
+    RR_CHECK_ARG(npix >= 0 && k > 0 && kp >= k && kp % 4 == 0, "rr_pad_channels: k=%d kp=%d (kp >= k, multiple of 4)", k, kp);
+    EW_LAUNCH(pad_channels_kernel, npix * (kp / 4), stream, src, (f32x4 *)dst, npix * (kp / 4), k, kp / 4);
+    RR_CHECK_LAUNCH("rr_pad_channels");
     return RR_OK;
 }
 

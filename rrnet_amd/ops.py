@@ -256,8 +256,9 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False,
         kp = (k + 3) // 4 * 4
         dyp, wp = dy, w
         if kp != k:
-            dyp = zeros_nhwc(dy.shape[0], kp, dy.shape[2], dy.shape[3], dy.device)
-            dyp[:, :k] = dy
+            dyp = empty_nhwc(dy.shape[0], kp, dy.shape[2], dy.shape[3], dy.device)
+            _C.check(_C.fn("rr_pad_channels")(_C.ptr(dy), _C.ptr(dyp), dy.shape[0] * dy.shape[2] * dy.shape[3], k, kp, _C.stream()),
+                     "rr_pad_channels")
             wp = zeros_nhwc(kp, c, r, s, dy.device)
             wp[:k] = w
         wt = torch.empty(kp * c * r * s, dtype=torch.float32, device=dy.device)

@@ -15,8 +15,15 @@ torch.manual_seed(cfg.seed)
 op = RRNetOperator(cfg); op.model.train()
 for i in range(2): op.train_step(i, op.training_loader.get_batch())
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
     op.train_step(2, op.training_loader.get_batch())
     torch.cuda.synchronize()
 print(prof.key_averages().table(sort_by="self_cuda_time_total", row_limit=40, max_name_column_width=70))
 print(prof.key_averages(group_by_stack_n=6).table(sort_by="count", row_limit=40, max_name_column_width=60, max_src_column_width=110))
+# the copies, one by one: device time, shapes and the chain of enclosing ops (autograd node / function) that asked for them
+ev = [e for e in prof.events() if e.name in ("aten::copy_", "aten::clone", "aten::contiguous") and e.device_time_total > 20]
+for e in sorted(ev, key=lambda e: -e.device_time_total)[:12]:
+    chain, q = [], e.cpu_parent
+    while q is not None and len(chain) < 6:
+        chain.append(q.name[:60]); q = q.cpu_parent
+    print("%-14s %8.1f us  %s  <- %s" % (e.name, e.device_time_total, e.input_shapes, " <- ".join(chain)))
