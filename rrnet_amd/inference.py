@@ -20,7 +20,10 @@ from rrnet_amd.ext.nms.nms_wrapper import soft_nms_segments
 from rrnet_amd.models.rrnet import stage1_proposals
 
 
-ROI_SPATIAL_ORDER = os.environ.get("RR_ROI_ORDER", "1") != "0"      # A/B switch of the RoIAlign processing order (+0.5 % at config 5)
+# RoIAlign processing order: per-frame spatial sort (rr_roi_spatial_order).  Off by default since round 3: with eight
+# footprint pixels in flight per wave the kernel runs as fast in decode order (2.66-2.73 ms against 2.62-2.87 ms sorted, per
+# 128 frames at config 5) and the sort is a launch of its own (0.05 ms); RR_ROI_ORDER=1 turns it on.
+ROI_SPATIAL_ORDER = os.environ.get("RR_ROI_ORDER", "0") != "0"
 
 
 @torch.no_grad()
