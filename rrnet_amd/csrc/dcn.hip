@@ -1553,7 +1553,34 @@ __global__ __launch_bounds__(512) void dcn_dgrad_win_kernel(const DcnWinBwdArgs 
                 const int gi = geo_i[r * RS + tap];
                 const int valid = (gi >> 16) & 15;
                 float s_m = 0.f, s_h = 0.f, s_w = 0.f;
-                if (valid) {
+                if (!(gi & GEO_SLOW)) {
+                    // Fast samples (the whole 2x2 footprint inside the window; also samples without any valid corner:
+                    // gi == 0, mask 0): BRANCH-FREE.  A corner outside the image has its weight zeroed (it adds 0 to a
+                    // window pixel the flush skips) and reads a window pixel that was filled with zeros; the per-corner
+                    // `if valid` / `if weight != 0` tests of round 2 were four divergent-branch sequences per sample —
+                    // a third of the ~510 VALU + ~150 SALU instructions this loop issued per tap and wave.
+                    const float flh = geo_f[(r * RS + tap) * 3], flw = geo_f[(r * RS + tap) * 3 + 1], mk = geo_f[(r * RS + tap) * 3 + 2];
+                    const float hh = 1.f - flh, hw = 1.f - flw;
+                    const float wt[4] = {(valid & 1) ? hh * hw : 0.f, (valid & 2) ? hh * flw : 0.f, (valid & 4) ? flh * hw : 0.f,
+                                         (valid & 8) ? flh * flw : 0.f};
+                    const float dhw[4] = {-hw, -flw, hw, flw};
+                    const float dww[4] = {-hh, hh, -flh, flh};
+                    const f32x4 gcol = *reinterpret_cast<const f32x4 *>(stage + r * SST + a_col);
+                    const f32x4 gs = gcol * (fx4 * mk);                    // column gradient x mask in each channel's fixed-point unit
+                    const float *xb = xw + (size_t)(gi & 0xffff) * CW + a_col;
+                    int *db = dxw + (gi & 0xffff) * WSTR + a_col;
+                    // d mask = sum_e wt_e <gcol, x_e>, d offset = mask * sum_e dwt_e <gcol, x_e>: one dot product per corner
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int po = (e >> 1) * wa.WW + (e & 1);
+                        const f32x4 xv = *reinterpret_cast<const f32x4 *>(xb + po * CW);
+                        const float d = gcol[0] * xv[0] + gcol[1] * xv[1] + gcol[2] * xv[2] + gcol[3] * xv[3];
+                        s_m += wt[e] * d; s_h += dhw[e] * d; s_w += dww[e] * d;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) atomicAdd(db + po * WSTR + c, __float2int_rn(gs[c] * wt[e]));   // ds_add_u32
+                    }
+                    s_h *= mk; s_w *= mk;
+                } else if (valid) {
                     const float flh = geo_f[(r * RS + tap) * 3], flw = geo_f[(r * RS + tap) * 3 + 1], mk = geo_f[(r * RS + tap) * 3 + 2];
                     const float hh = 1.f - flh, hw = 1.f - flw;
                     const float wt[4] = {hh * hw, hh * flw, flh * hw, flh * flw};
@@ -1561,24 +1588,7 @@ __global__ __launch_bounds__(512) void dcn_dgrad_win_kernel(const DcnWinBwdArgs 
                     const float dww[4] = {-hh, hh, -flh, flh};
                     const f32x4 gcol = *reinterpret_cast<const f32x4 *>(stage + r * SST + a_col);
                     const f32x4 gs = gcol * fx4;                           // column gradient in each channel's fixed-point unit
-                    // d mask = sum_e wt_e <gcol, x_e>, d offset = mask * sum_e dwt_e <gcol, x_e>: one dot product per corner
-                    if (!(gi & GEO_SLOW)) {
-                        const float *xb = xw + (size_t)(gi & 0xffff) * CW + a_col;
-                        int *db = dxw + (gi & 0xffff) * WSTR + a_col;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            if (!((valid >> e) & 1)) continue;                                   // corner outside the image
-                            const int po = (e >> 1) * wa.WW + (e & 1);
-                            const f32x4 xv = *reinterpret_cast<const f32x4 *>(xb + po * CW);
-                            const float d = gcol[0] * xv[0] + gcol[1] * xv[1] + gcol[2] * xv[2] + gcol[3] * xv[3];
-                            s_m += wt[e] * d; s_h += dhw[e] * d; s_w += dww[e] * d;
-                            const float f = mk * wt[e];
-                            if (f != 0.f) {
-#pragma unroll
-                                for (int c = 0; c < 4; ++c) atomicAdd(db + po * WSTR + c, __float2int_rn(gs[c] * f));   // ds_add_u32
-                            }
-                        }
-                    } else {
+                    {
                         // footprint not inside the window (offset beyond the margin): position again from the offsets
                         const int p = y0 + r / WIN_TW, q = x0 + r % WIN_TW;
                         const float *po = a.offset + (((long)n * a.P + p) * a.Q + q) * (2 * a.dg * RS) + g_cur * 2 * RS + 2 * tap;
