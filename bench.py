@@ -246,7 +246,8 @@ def main():
                     if os.path.exists(tpath) and a.backbone == "hourglass" and a.size == 1024 and a.batch == 8:
                         with open(tpath) as f:
                             tj = json.load(f)
-                        traffic = (tj.get("conv_igemm_kernel<128, 0, false, 32, 2, false>") or
+                        traffic = (tj.get("conv_igemm_kernel<128, 0, false, 32, 2, false, false>") or
+                                   tj.get("conv_igemm_kernel<128, 0, false, 32, 2, false>") or
                                    tj.get("conv_igemm_kernel<128, 0, false, 32, 2>", {})).get("traffic_bytes_per_launch")
                         # not a live measurement: the file and the commit the PMC passes were taken at
                         traffic_source = "profiles/%s_traffic_pmc.json (rocprofv3 FETCH_SIZE + WRITE_SIZE passes of this command at commit %s)" % (
@@ -256,7 +257,7 @@ def main():
                                    "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
                                    "traffic": traffic, "traffic_source": traffic_source,
                                    "algorithmic_bytes_per_launch": round(timer.bytes.get(dom, 0.0) / d["launches"]),
-                                   "kernel": "conv_igemm_kernel<128, 0, false, 32, 2, false> (implicit-GEMM forward kernel, v_mfma_f32_32x32x2_f32; "
+                                   "kernel": "conv_igemm_kernel<128, 0, false, 32, 2, false, false> (implicit-GEMM forward kernel, v_mfma_f32_32x32x2_f32; "
                                              "launched for fprop and for stride-1 dgrad on flipped weights; the dgrad launches that also "
                                              "reduce the producer's BatchNorm-backward sums are the <..., true> instantiation)",
                                    "launches": d["launches"], "launches_timed": "every %d-th launch of the timed region (systematic sample)" % a.time_every,

@@ -12,4 +12,8 @@ done
 python3 tools/pmc_traffic.py gpurun_out/pmc_infer_FETCH_SIZE_$TAG gpurun_out/pmc_infer_WRITE_SIZE_$TAG > gpurun_out/traffic_infer_$TAG.json
 python3 tools/pmc_traffic.py gpurun_out/pmc_dcn_FETCH_SIZE_$TAG gpurun_out/pmc_dcn_WRITE_SIZE_$TAG > gpurun_out/traffic_dcn_$TAG.json
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_dcn_$TAG -- python3 tools/bench_dcn.py > gpurun_out/dcn_$TAG.json 2> gpurun_out/dcn_$TAG.err
-ls gpurun_out | grep $TAG | head -40
+ls gpurun_out | grep $TAG | head -60
+# the raw traces are tens of MB each (gpurun merges at most 64 MiB back): keep the summaries only
+find gpurun_out -name "*_kernel_trace.csv" -delete
+find gpurun_out -name "*_counter_collection.csv" -delete
+du -sh gpurun_out
