@@ -95,7 +95,8 @@ int rr_conv_pack_taps(const float *x, float *out, int n, int h, int wd, int c, i
  * block sum(dz*mask) and sum(dz*mask*xhat) to `slab` (rr_conv_stat_slab_bytes(n,h,wd,c) bytes), reduced into
  * sums [2][c] (zeroed by the caller) — exactly what rr_bn_bwd_reduce(dx, prod_z, prod_y, ...) returns, without its
  * pass over dx and y.  accumulate != 0: dx += ..., the sums are taken of the final values (the last contributor of a
- * gradient fan-in).  Layers that run split-K fall back to rr_bn_bwd_reduce internally: same contract. */
+ * gradient fan-in).  Layers that run split-K, and sizes with n*h*wd not a multiple of 128 (the epilogue addresses whole
+ * 128-row tiles), fall back to rr_bn_bwd_reduce internally: same contract. */
 int rr_conv_dgrad_s1_bnsum(const float *dy, const float *wt, float *dx, int n, int h, int wd, int c, int k,
                            int r, int s, int pad_h, int pad_w, int accumulate, const float *prod_y,
                            const float *prod_z, const float *prod_mean, const float *prod_invstd,
@@ -105,7 +106,8 @@ int rr_conv_dgrad_s1_bnsum(const float *dy, const float *wt, float *dx, int n, i
  * whose output prod_z [n,h,w,c] is this convolution's input): dx = relu-masked gradient (dx * (prod_z > 0) is what is
  * STORED) and sums[0..c) = its column sums = the producer's bias gradient — what rr_bias_relu_bwd computes in a pass of
  * its own.  slab: rr_conv_stat_slab_bytes(n,h,wd,c) bytes; sums [2][c] doubles, zeroed by the caller (the second row is
- * not meaningful).  K and C multiples of 4 (the host layer zero-pads a 10- or 2-channel dy to 12 / 4).
+ * not meaningful).  K and C multiples of 4 (the host layer zero-pads a 10- or 2-channel dy to 12 / 4); n*h*wd a multiple
+ * of 128 (refused otherwise: the host layer then runs rr_conv_dgrad + rr_bias_relu_bwd).
  * accumulate != 0: dx holds the gradients of the producer's other consumers; the mask is applied to the SUM (the last
  * contributor of a fan-in: the three heads' 3x3 layers behind relu(feature), models/centernet.py:20-24), which also serves
  * a bare ReLU producer (its backward then is the identity on this tensor). */
@@ -192,6 +194,11 @@ int rr_avgpool_bwd(const float *dout, float *dx, long r, int hw, int c, hipStrea
  * out[r,c] = mean over the hw positions of relu(y[r,p,c]*scale[c] + shift[c] + res[r,p,c]); y, res NHWC [r,hw,c]. */
 int rr_bn_res_relu_avgpool(const float *y, const float *scale, const float *shift, const float *res, float *out,
                            long r, int hw, int c, hipStream_t stream);
+/* 1x1 convolution to at most 64 output channels on many rows (the stage-2 head's conv1, backbones/resnet.py:33-35 through
+ * detectors/fasterrcnn_detector.py:17-18, at inference on R*9 RoI rows): y[m][n] = relu?(x[m][:] . w[n][:] + bias[n]), x [M][K]
+ * (K = 128 or 256, M*K*4 < 2 GiB), w [N][K], y [M][N].  Weights live in registers, rows stream through persistent workgroups. */
+int rr_conv1x1_rows(const float *x, const float *w, const float *bias, float *y, long m, int k, int n, int relu,
+                    hipStream_t stream);
 /* The same tail with the 1x1 convolution in front of it fused in (inference): out [r, n] = mean over the hw rows of a
  * RoI of relu((h [r*hw, k] x w [n, k]^T) * scale + shift + res [r*hw, n]); the convolution's output never reaches
  * HBM.  k = 32 or 64, n a multiple of 4 and <= 256 (backbones/resnet.py:46-53 with planes = 64,

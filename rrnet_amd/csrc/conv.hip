@@ -1186,6 +1186,16 @@ size_t igemm_lds(int bn, bool b_kn, int bk, int nbuf = 2)
     return sizeof(float) * nbuf * (BM * (bk + 4) + (b_kn ? bk * bn : bn * (bk + 4)));
 }
 
+int conv_rows_kernel()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("RR_CONV_ROWS");
+        v = (e == nullptr || atoi(e) != 0) ? 1 : 0;
+    }
+    return v;
+}
+
 int conv_pos_major()
 {
     static int v = -1;
@@ -1385,6 +1395,11 @@ static int fprop_impl(const float *x, const float *w, const float *bias, float *
     const long M = (long)n * a.DH * a.DW;
     RR_CHECK_ARG(M < (1l << 31) && (long)n * h * wd * c < (1l << 40), "rr_conv_fprop: tensor too large");
     a.M = (int)M; a.Kg = r * s * c; a.wK = k; a.wC = c;
+    // 1x1 to at most 64 channels on very many rows without statistics (the stage-2 head's conv1 at inference): the
+    // row-streaming kernel of csrc/headtail.hip (weights in registers, no per-tile prologue) — 0.72 -> see DESIGN 4.8
+    if (conv_rows_kernel() && r == 1 && s == 1 && stride == 1 && pad_h == 0 && pad_w == 0 && (c == 128 || c == 256) && k <= 64
+        && stat_slab == nullptr && bs == nullptr && !accumulate && M >= 64 * 1024 && M * c * 4 < (1l << 31))
+        return rr_conv1x1_rows(x, w, bias, y, M, c, k, relu, stream);
     const bool scalar = (c % 4) != 0 || r * s > 64;   // the vector path keeps a 64-bit tap mask per row
     const int bk = conv_bk();
     int bn = k > 64 ? 128 : (k > 32 ? (!scalar && bk == 32 ? 64 : 128) : 32);
@@ -1408,14 +1423,20 @@ static int fprop_impl(const float *x, const float *w, const float *bias, float *
         a.ksplit = ks;
         if (!accumulate) hipMemsetAsync(y, 0, sizeof(float) * (size_t)M * k, stream);
     }
-    if (bs != nullptr && ks == 1) {      // sums in the epilogue; with split-K the complete values exist only afterwards
+    // The epilogue reads the producer's tensors through buffer descriptors with the row inside the tile in the SCALAR offset,
+    // which the hardware's range check does not cover: in a partial last tile it would read up to 11 rows past the end of
+    // the tensor.  Fused sums therefore only for M % 128 == 0 (every size the training configurations produce); other
+    // sizes take the separate reduce pass below, and the masked-store mode — which has no such fallback — is refused.
+    const bool tiles_full = M % BM == 0;
+    RR_CHECK_ARG(bs == nullptr || !bs->relu_bias || tiles_full, "rr_conv_dgrad_s1_relubias: N*H*W = %ld must be a multiple of 128", M);
+    if (bs != nullptr && ks == 1 && tiles_full) {      // sums in the epilogue; with split-K the complete values exist only afterwards
         a.stat_slab = bs->slab;
         a.bs_y = bs->y; a.bs_z = bs->z; a.bs_mean = bs->mean; a.bs_invstd = bs->invstd; a.bs_msc = bs->msc; a.bs_msh = bs->msh;
         a.bs_relu_bias = bs->relu_bias;
     }
     int rc = launch_igemm<0>(a, bn, scalar, blocks, 1, ks, stream, "rr_conv_fprop");
     if (rc == RR_OK && bs != nullptr) {
-        if (ks == 1) return rr_bn_reduce_slab(bs->slab, (int)rr_cdiv(M, BM), k, bs->sums, stream);
+        if (ks == 1 && tiles_full) return rr_bn_reduce_slab(bs->slab, (int)rr_cdiv(M, BM), k, bs->sums, stream);
         return rr_bn_bwd_reduce(y, bs->z, bs->y, bs->mean, bs->invstd, bs->msc, bs->msh, bs->sums, M, k, 1, stream);
     }
     if (rc == RR_OK && ks > 1 && stat_slab != nullptr) {

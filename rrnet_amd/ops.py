@@ -250,7 +250,8 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False,
     assert is_nhwc(out)
     if (bnsum is not None and bnsum.relu_bias and _DGRAD_BNSUM and stride == 1 and c % 4 == 0
             and bnsum_z is not None and is_nhwc(bnsum_z) and bnsum_z.shape == out.shape and out.numel() * 4 < (1 << 31)
-            and r * s <= 64 and pad[0] < r and pad[1] < s and dy.shape[2] * dy.shape[3] >= _DGRAD_VIA_FPROP_MIN_PIXELS):
+            and r * s <= 64 and pad[0] < r and pad[1] < s and dy.shape[2] * dy.shape[3] >= _DGRAD_VIA_FPROP_MIN_PIXELS
+            and (n * h * wd) % 128 == 0):      # whole 128-row tiles only (see fprop_impl in csrc/conv.hip)
         # producer = conv + bias + ReLU: masked gradient + bias column sums in this launch's epilogue.  A 10- or
         # 2-channel dy (hm / offset heads) is zero-padded to a multiple of 4 for the vector kernel (25 MB at 8x256x256)
         kp = (k + 3) // 4 * 4
