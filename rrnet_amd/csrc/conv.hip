@@ -1395,9 +1395,10 @@ static int fprop_impl(const float *x, const float *w, const float *bias, float *
     const long M = (long)n * a.DH * a.DW;
     RR_CHECK_ARG(M < (1l << 31) && (long)n * h * wd * c < (1l << 40), "rr_conv_fprop: tensor too large");
     a.M = (int)M; a.Kg = r * s * c; a.wK = k; a.wC = c;
-    // 1x1 to at most 64 channels on very many rows without statistics (the stage-2 head's conv1 at inference): the
-    // row-streaming kernel of csrc/headtail.hip (weights in registers, no per-tile prologue) — 0.72 -> see DESIGN 4.8
-    if (conv_rows_kernel() && r == 1 && s == 1 && stride == 1 && pad_h == 0 && pad_w == 0 && (c == 128 || c == 256) && k <= 64
+    // 1x1 to 49..64 channels (both 32-column tiles of the rows kernel in use) on very many rows without statistics — the
+    // stage-2 head's conv1 at inference: the row-streaming kernel of csrc/headtail.hip (weights in registers, no per-tile
+    // prologue)
+    if (conv_rows_kernel() && r == 1 && s == 1 && stride == 1 && pad_h == 0 && pad_w == 0 && (c == 128 || c == 256) && k > 48 && k <= 64
         && stat_slab == nullptr && bs == nullptr && !accumulate && M >= 64 * 1024 && M * c * 4 < (1l << 31))
         return rr_conv1x1_rows(x, w, bias, y, M, c, k, relu, stream);
     const bool scalar = (c % 4) != 0 || r * s > 64;   // the vector path keeps a 64-bit tap mask per row
