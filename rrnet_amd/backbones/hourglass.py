@@ -41,14 +41,24 @@ class ResidualBlock(nn.Module):
             nn.BatchNorm2d(planes)) if projected else nn.Sequential()
         self.stride = stride
 
+    def first_layers(self):
+        """The conv -> bn [-> relu] layers that read the block's input: conv1 and, in a projection block, the skip."""
+        layers = [(self.conv1, self.bn1, True)]
+        if len(self.skip_connection):
+            layers.append((self.skip_connection[0], self.skip_connection[1], False))
+        return layers
+
+    def tail(self, out, skip):
+        """relu(bn2(conv2(out)) + skip): BN apply, residual add and ReLU are one kernel."""
+        return RF.conv_bn_act(out, self.conv2, self.bn2, relu=True, residual=skip)
+
     def forward(self, x):
         # both consumers of x (conv1 and the skip path) accumulate their input gradients into one buffer
         if len(self.skip_connection) and RF.sync_coalescing(self.bn1):
             # SyncBN across ranks: the projection and conv1 read the same x — one joint node, ONE statistics exchange per
             # direction for the pair (conv1 first: its 3x3 data gradient writes the shared buffer, the 1x1 accumulates)
-            out, skip = RF.conv_bn_act_multi(x, [(self.conv1, self.bn1, True),
-                                                 (self.skip_connection[0], self.skip_connection[1], False)])
-            return RF.conv_bn_act(out, self.conv2, self.bn2, relu=True, residual=skip)
+            out, skip = RF.conv_bn_act_multi(x, self.first_layers())
+            return self.tail(out, skip)
         xa, xb, _ = RF.fanout_shared(x, 2)
         if len(self.skip_connection):
             # the projection runs BEFORE conv1: autograd then runs conv1's backward first, so the 3x3 data gradient is
@@ -110,6 +120,21 @@ class Hourglass(nn.Module):
     make_upsample_layer = staticmethod(lambda: nn.Upsample(scale_factor=2))
 
     def forward(self, x):
+        u0, l0 = self.up1[0], self.low1[0]
+        if RF.sync_coalescing(u0.bn1) and not len(u0.skip_connection) and len(l0.skip_connection):
+            # SyncBN across ranks: the first layers of both branches (up1's conv1, low1's stride-2 conv1 and its
+            # projection) read the same x and are independent given x — ONE statistics exchange per direction for the
+            # three of them (the joint node carries one sample count per layer).  x's other consumer is the identity skip
+            # of up1's first block.
+            xa, xb, _ = RF.fanout_shared(x, 2)
+            outs = RF.conv_bn_act_multi(xa, u0.first_layers() + l0.first_layers())
+            up1 = u0.tail(outs[0], xb)
+            for blk in list(self.up1)[1:]:
+                up1 = blk(up1)
+            low1 = l0.tail(outs[1], outs[2])
+            for blk in list(self.low1)[1:]:
+                low1 = blk(low1)
+            return RF.upsample_add(up1, self.low3(self.low2(low1)))
         xa, xb, _ = RF.fanout_shared(x, 2)              # both branches start with a residual block: one accumulator
         up1 = self.up1(xa)
         low3 = self.low3(self.low2(self.low1(xb)))

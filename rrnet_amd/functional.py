@@ -280,10 +280,11 @@ def conv_bn_act(x, conv, bn, relu=True, residual=None, x_acc=None, res_acc=None)
 
 class _ConvBnSyncMulti(torch.autograd.Function):
     """SyncBN, several conv -> bn [-> relu] layers on the SAME input (a projection block's skip and conv1,
-    backbones/hourglass.py:31-40): one autograd node so that their statistic exchanges share ONE all-reduce forward
-    ([sum, sumsq] of every layer + one sample count) and ONE backward ([sum dz, sum dz*xhat] of every layer) instead of
-    one each — the layers are independent given x, so nothing is re-ordered.  Used only when world_size > 1; a single
-    process keeps the per-layer nodes (and their fused single-launch statistics)."""
+    backbones/hourglass.py:31-40; the first layers of an hourglass module's up1 and low1 branches, :96-101): one autograd
+    node so that their statistic exchanges share ONE all-reduce forward ([sum, sumsq] of every layer + one sample count
+    per layer: the strides may differ) and ONE backward ([sum dz, sum dz*xhat] of every layer) instead of one each — the
+    layers are independent given x, so nothing is re-ordered.  Used only when world_size > 1; a single process keeps the
+    per-layer nodes (and their fused single-launch statistics)."""
 
     @staticmethod
     def forward(ctx, x, x_acc, specs, *params):
@@ -296,40 +297,40 @@ class _ConvBnSyncMulti(torch.autograd.Function):
             y, slab = ops.conv_fprop(x, ws[i], None, stride, pad, False, want_stats=True)
             ys.append((y, slab))
             ks.append(ws[i].shape[0])
-        tot = 2 * sum(ks) + 1
-        packed = ops._ZEROS.take(tot, x.device)                      # [sums_0 | sums_1 | .. | count]
+        tot = 2 * sum(ks) + L
+        packed = ops._ZEROS.take(tot, x.device)                      # [sums_0 | sums_1 | .. | count_0 | count_1 | ..]
         off = 0
         for (y, slab), k in zip(ys, ks):
             mt = slab.numel() // (2 * k)
             ops._C.check(ops._C.fn("rr_bn_reduce_slab")(ops._C.ptr(slab), mt, k, ops._C.ptr(packed[off:off + 2 * k]),
                                                         ops._C.stream()), "rr_bn_reduce_slab")
             off += 2 * k
-        # every layer of the node sees the same pixels per rank only if their strides agree; the count is exchanged once
+        # one sample count per layer (layers of different stride see different numbers of pixels)
         counts = [float(y.numel() // k) for (y, _), k in zip(ys, ks)]
-        assert all(c == counts[0] for c in counts), "joint SyncBN node: the layers must produce the same number of pixels"
-        packed[tot - 1] = counts[0]
+        for i, cnt in enumerate(counts):
+            packed[tot - L + i] = cnt
         dptrace.record("default", "all_reduce", packed.numel(), "syncbn_fwd x%d" % L)
         dist.all_reduce(packed)
-        cnt_dev = packed[tot - 1:].clone()
+        cnt_devs = [packed[tot - L + i:tot - L + i + 1].clone() for i in range(L)]
         outs, saved, off = [], [], 0
         for i, ((bn, stride, pad, relu), (y, _), k) in enumerate(zip(specs, ys, ks)):
             gamma, beta = params[3 * i + 1], params[3 * i + 2]
             mom = bn.momentum if bn.momentum is not None else 0.1
-            mean, invstd, scale, shift = ops.bn_finalize(packed[off:off + 2 * k], counts[0], gamma, beta, bn.running_mean,
-                                                         bn.running_var, mom, bn.eps, cnt_dev, bn.num_batches_tracked)
+            mean, invstd, scale, shift = ops.bn_finalize(packed[off:off + 2 * k], counts[i], gamma, beta, bn.running_mean,
+                                                         bn.running_var, mom, bn.eps, cnt_devs[i], bn.num_batches_tracked)
             off += 2 * k
             outs.append(ops.bn_apply(y, scale, shift, None, relu))
             saved += [y, mean, invstd, gamma, scale if relu else None, shift if relu else None]
-        ctx.save_for_backward(x, cnt_dev, *ws, *saved)
-        ctx.meta = (L, [(st, tuple(pd), rl) for (_, st, pd, rl) in specs], ks, counts[0], x_acc, tuple(x.shape))
+        ctx.save_for_backward(x, *cnt_devs, *ws, *saved)
+        ctx.meta = (L, [(st, tuple(pd), rl) for (_, st, pd, rl) in specs], ks, counts, x_acc, tuple(x.shape))
         ctx.params = params
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *dzs):
-        L, cfgs, ks, count, x_acc, xshape = ctx.meta
+        L, cfgs, ks, counts, x_acc, xshape = ctx.meta
         t = ctx.saved_tensors
-        x, cnt_dev, ws, rest = t[0], t[1], t[2:2 + L], t[2 + L:]
+        x, cnt_devs, ws, rest = t[0], t[1:1 + L], t[1 + L:1 + 2 * L], t[1 + 2 * L:]
         params = ctx.params
         packed = ops._ZEROS.take(2 * sum(ks), x.device)
         dzl, off = [], 0
@@ -363,8 +364,8 @@ class _ConvBnSyncMulti(torch.autograd.Function):
             y, mean, invstd, gamma, msc, msh = rest[6 * i:6 * i + 6]
             stride, pad, relu = cfgs[i]
             k = ks[i]
-            dy, _ = ops.bn_bwd_apply(dzl[i], None, y, mean, invstd, gamma, packed[off:off + 2 * k], count, False, None, None,
-                                     cnt_dev, msc, msh)
+            dy, _ = ops.bn_bwd_apply(dzl[i], None, y, mean, invstd, gamma, packed[off:off + 2 * k], counts[i], False, None, None,
+                                     cnt_devs[i], msc, msh)
             if ctx.needs_input_grad[0]:
                 if x_acc is not None:
                     r = _input_grad(dy, ws[i], xshape, stride, pad, x_acc, None, x)
@@ -400,9 +401,7 @@ def conv_bn_act_multi(x, layers):
     """layers: [(conv, bn, relu), ...] applied to the same x -> list of outputs.  With SyncBN across ranks the layers'
     statistic exchanges are coalesced (one all-reduce per direction for the whole group); otherwise the ordinary
     per-layer nodes run, in the given order."""
-    if (all(sync_coalescing(b) for _, b, _ in layers) and len({c.stride[0] for c, _, _ in layers}) == 1
-            and all(c.kernel_size[0] == 2 * c.padding[0] + 1 and c.kernel_size[1] == 2 * c.padding[1] + 1 for c, _, _ in layers)):
-        # ("same"-padded layers of one stride: every layer sees the same number of output pixels — one sample count)
+    if all(sync_coalescing(b) for _, b, _ in layers):
         x_acc = getattr(x, "_rr_acc", None)
         if x.requires_grad and x_acc is not None:
             x_acc.pending += 1

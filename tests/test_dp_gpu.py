@@ -170,6 +170,12 @@ def test_two_rank_collective_sequences_are_identical(tmp_path):
     # a projection block's skip and conv1 share ONE statistics exchange per direction (functional._ConvBnSyncMulti)
     joint = [e for e in ev if e[0] == "default" and e[3].endswith("x2")]
     assert len(joint) >= 2 and len(joint) % 2 == 0, [e[3] for e in ev if e[0] == "default"][:12]
+    # the first layers of an hourglass module's two branches (up1.conv1, low1.conv1 stride 2, low1's projection) share ONE
+    # exchange per direction as well: three layers, three sample counts in the forward message
+    joint3 = [e for e in ev if e[0] == "default" and e[3].endswith("x3")]
+    assert len(joint3) >= 2 and len(joint3) % 2 == 0, sorted({e[3] for e in ev if e[0] == "default"})
+    fwd3 = [e for e in joint3 if "fwd" in e[3]]
+    assert fwd3 and all((e[2] - 3) % 2 == 0 for e in fwd3)               # [sum, sumsq] of the layers' channels + 3 counts
     n_sync = sum(1 for e in ev if e[0] == "default")
     print("collectives of one step: %d SyncBN exchanges on the default communicator, %d gradient buckets (%d launched "
           "during backward); buffers broadcast in one collective (%d buffers)" % (n_sync, len(launched), during, t[0]["nbuf"]))
