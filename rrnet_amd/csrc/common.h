@@ -31,6 +31,20 @@ void rr_set_error(const char *fmt, ...);
 
 static inline int rr_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// y*scale + shift of a BatchNorm layer as ONE explicit fma.  The forward (bn_apply), the two backward passes that recompute
+// the ReLU mask from y instead of reading z (bn_bwd_reduce / bn_bwd_apply) and the data-gradient epilogue that carries the
+// sums (conv.hip, rr_conv_dgrad_s1_bnsum) must agree on the sign of this value bit for bit: all four go through here, so
+// the agreement does not hang on the compiler contracting (or not contracting) a mul + add the same way in each file.
+__device__ __forceinline__ float rr_bn_affine(float y, float sc, float sh) { return __builtin_fmaf(y, sc, sh); }
+typedef float rr_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ rr_f32x4 rr_bn_affine4(rr_f32x4 y, rr_f32x4 sc, rr_f32x4 sh)
+{
+    rr_f32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = __builtin_fmaf(y[e], sc[e], sh[e]);
+    return r;
+}
+
 __device__ __forceinline__ float wave_sum(float v)
 {
 #pragma unroll

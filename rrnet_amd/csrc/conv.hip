@@ -709,7 +709,7 @@ __global__ __launch_bounds__(256, PIPE == 3 ? 3 : 1) void conv_igemm_kernel(cons
                             float *p = a.dst + (long)m * a.DC + ncol;
                             float v = acc[i][j][e];
                             if (mode_e == 1) v += *p;
-                            const bool on = use_z ? zv[q] > 0.f : __builtin_fmaf(yv[q], bs_sc, bs_sh) > 0.f;
+                            const bool on = use_z ? zv[q] > 0.f : rr_bn_affine(yv[q], bs_sc, bs_sh) > 0.f;
                             const float d = on ? v : 0.f;
                             *p = a.bs_relu_bias ? d : v;
                             s1 += d;

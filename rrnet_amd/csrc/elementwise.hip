@@ -135,7 +135,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_apply_kernel(const f32x4 *y, co
         const int c = (int)(i % C4) * 4;
         f32x4 v = y[i];
         const f32x4 sc = *reinterpret_cast<const f32x4 *>(scale + c), sh = *reinterpret_cast<const f32x4 *>(shift + c);
-        v = v * sc + sh;
+        v = rr_bn_affine4(v, sc, sh);
         if (res) {
             f32x4 r = res[i];
             if (res_scale) {
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_kernel(const float *
 #pragma unroll
                         for (int e = 0; e < 4; ++e) g[e] = zz[e] > 0.f ? g[e] : 0.f;
                     } else if (mscale) {      // ReLU mask recomputed from y: z = relu(y*scale+shift), no residual
-                        const f32x4 zz = yy * msc + msh;
+                        const f32x4 zz = rr_bn_affine4(yy, msc, msh);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) g[e] = zz[e] > 0.f ? g[e] : 0.f;
                     }
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(const f32x4 *d
 #pragma unroll
             for (int e = 0; e < 4; ++e) g[e] = zz[e] > 0.f ? g[e] : 0.f;
         } else if (mscale) {
-            const f32x4 zz = yy * *reinterpret_cast<const f32x4 *>(mscale + c) + *reinterpret_cast<const f32x4 *>(mshift + c);
+            const f32x4 zz = rr_bn_affine4(yy, *reinterpret_cast<const f32x4 *>(mscale + c), *reinterpret_cast<const f32x4 *>(mshift + c));
 #pragma unroll
             for (int e = 0; e < 4; ++e) g[e] = zz[e] > 0.f ? g[e] : 0.f;
         }

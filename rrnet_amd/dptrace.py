@@ -13,6 +13,18 @@ adds per collective): bench.py reports `collectives_per_step`."""
 import os
 
 ENABLED = os.environ.get("RR_DP_TRACE", "0") == "1"
+# RR_DP_FORCE=1: a process group of ONE rank is treated as data parallel — SyncBN statistic exchanges, parameter / buffer
+# broadcasts and the bucketed gradient all-reduce all go through the backend (RCCL on the GPU box) as identity
+# collectives.  A 1-GPU box cannot host two RCCL ranks; this is how the real backend's stream semantics (collectives
+# ordered behind the CURRENT stream, async work handles, a second communicator used from autograd worker threads) meet
+# the code that was written for them (tests/test_dp_gpu.py::test_rccl_single_rank_*; bench.py under RR_DP_FORCE=1).
+FORCE = os.environ.get("RR_DP_FORCE", "0") == "1"
+
+
+def dp_active():
+    """True when collectives must be issued: a process group of more than one rank (or of one rank under RR_DP_FORCE)."""
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or FORCE)
 EVENTS = []                 # (communicator, op, numel, note)
 COUNTS = {}                 # communicator -> collectives issued since the last reset()
 

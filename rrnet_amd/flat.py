@@ -81,7 +81,7 @@ class FlatParams:
         self._reduced = False      # this step's gradient exchange has completed
 
     def _distributed(self):
-        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        return dptrace.dp_active()
 
     def _group(self):
         """Own communicator (= own RCCL stream) for the gradient buckets: on the default one a 64 MB bucket would sit in
@@ -150,7 +150,7 @@ class FlatParams:
 
     def broadcast(self, src=0):
         """Initial parameter broadcast (C2 in SURVEY §2.2): one collective."""
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if self._distributed():
             dptrace.record("default", "broadcast", self.flat.numel(), "parameters")
             dist.broadcast(self.flat, src)
             self._group()          # the buckets' communicator is set up here, on the main thread, before any backward

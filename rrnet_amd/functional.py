@@ -44,6 +44,18 @@ def _mark(*params):
 _WGRAD_STREAM = os.environ.get("RR_WGRAD_STREAM", "2") in ("1", "2")
 _WGRAD_FREE = os.environ.get("RR_WGRAD_STREAM", "2") == "2"
 _WG_STATE = {"pending": False, "task": None}      # task: the autograd graph task whose end-of-backward join is queued
+# RR_WGRAD_STRESS=<cycles> (test switch, tests/test_streams_gpu.py): a spin kernel of that many clock cycles is put in front
+# of every side-stream launch, so the side stream falls further and further behind the main one; an operand that is not
+# kept alive (record_stream) or not ordered (event) for the side stream then shows up as a wrong gradient instead of
+# passing because the two streams happened to run in step.  "1" = 2 M cycles (~1 ms) per launch.
+_STRESS_CYCLES = int(os.environ.get("RR_WGRAD_STRESS", "0") or 0)
+if _STRESS_CYCLES == 1:
+    _STRESS_CYCLES = 2_000_000
+
+
+def _stress_delay():
+    if _STRESS_CYCLES > 0:
+        torch.cuda._sleep(_STRESS_CYCLES)
 
 
 def _wgrad_join(device):
@@ -62,6 +74,7 @@ def _wgrad_async(fn, device, *tensors):
     side = _side_stream(device, "wgrad")
     side.wait_stream(cur)
     with torch.cuda.stream(side):
+        _stress_delay()
         fn()
     for t in tensors:
         if t is not None:
@@ -86,8 +99,7 @@ BN_FUSED_STATS = os.environ.get("RR_BN_FUSED_STATS", "1") != "0"    # single pro
 
 
 def _is_sync(bn):
-    return isinstance(bn, torch.nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized() \
-        and dist.get_world_size() > 1
+    return isinstance(bn, torch.nn.SyncBatchNorm) and dptrace.dp_active()
 
 
 class _ConvBnAct(torch.autograd.Function):
@@ -107,7 +119,9 @@ class _ConvBnAct(torch.autograd.Function):
         sync = _is_sync(bn)
         ctx.packed = False
         if bn.training:
-            if ops.conv_packable(x, wc, stride):
+            # (packability is decided from the node's own needs_input_grad: inside Function.forward grad mode is off and a
+            # layout-converted copy of an input that wants a gradient would look like a constant)
+            if not ctx.needs_input_grad[0] and ops.conv_packable(x, wc, stride):
                 # very few input channels (the 7x7 stride-2 stem): taps packed per output pixel, 1x1 GEMM on the vector
                 # kernels; the packed image replaces x as the tensor saved for the weight gradient
                 y, slab, x = ops.conv_fprop_packed(x, wc, stride, pad, want_stats=True)
@@ -820,6 +834,7 @@ class _DCNv2(torch.autograd.Function):
             if side is not None:
                 side.wait_stream(cur)
                 with torch.cuda.stream(side):
+                    _stress_delay()
                     ops.dcn_wgrad(x, off, m, dy, dw, stride, pad, dil, dg, bf16=bf)
             else:
                 ops.dcn_wgrad(x, off, m, dy, dw, stride, pad, dil, dg, bf16=bf)

@@ -41,8 +41,8 @@ class RCCLDataParallel(nn.Module):
         self.flat.broadcast(0)
         # buffers (BN running statistics and counters) start identical on all ranks — rank 0's — through ONE broadcast
         # of a packed fp64 image (490 single-buffer broadcasts in round 2; fp64 holds the int64 counters exactly)
-        if torch.distributed.is_available() and torch.distributed.is_initialized() \
-                and torch.distributed.get_world_size() > 1:
+        from rrnet_amd import dptrace
+        if dptrace.dp_active():
             broadcast_buffers(module, 0)
 
     def forward(self, *a, **kw):

@@ -1,0 +1,168 @@
+"""Child process of tests/test_streams_gpu.py: ONE configuration of the stream switches (taken from the environment:
+RR_WGRAD_STREAM, RR_WGRAD_STRESS, RR_DCN_BWD_STREAMS), `--repeats` train steps of RRNet from the SAME initial state on the
+SAME batch.  Writes, into --out:
+  grad.bin / param.bin   flat gradient after the first step / flat parameters after its Adam update (raw float32)
+  buffers.bin            every floating-point buffer of the model (BatchNorm running statistics) after the first step
+  meta.json              the four losses of every repeat, and for repeats 2.. the worst per-parameter difference of the
+                         gradient / updated parameters / buffers against repeat 1 (relative to that parameter's scale)
+Reference semantics: operators/rrnet_operator.py:116-144 — one stream, every kernel ordered behind the previous one."""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import torch  # noqa: E402
+
+
+def param_slices(fp):
+    base = fp.grad.data_ptr()
+    return [((p._rr_grad.data_ptr() - base) // 4, p.numel()) for p in fp.params]
+
+
+def rel_per_param(a, b, slices):
+    """per parameter slice: max|a - b| / max|b| -> (rel [P] float64, scale [P])."""
+    d = (a - b).abs()
+    dm = torch.stack([d[o:o + n].max() for o, n in slices])
+    sm = torch.stack([b[o:o + n].abs().max() for o, n in slices])
+    rel = (dm / sm.clamp_min(1e-30)).double()
+    rel = torch.where(sm > 0, rel, (dm > 0).double() * 1e30)        # an all-zero reference slice must stay all-zero
+    return rel, sm
+
+
+def worst_rel(a, b, slices):
+    """max over parameters of max|a - b| / max|b| (per parameter slice) -> (worst, index of the worst parameter, its scale)."""
+    rel, sm = rel_per_param(a, b, slices)
+    arg = int(rel.argmax())
+    return float(rel.max()), arg, float(sm[arg])
+
+
+def frac_moved(a, b, lr=2.5e-4):
+    """Share of parameter elements whose Adam update differs by more than half a step.  Adam's first update is
+    lr * g / (|g| + eps) ~ lr * sign(g): elements whose gradient is ~0 may legitimately flip between two runs (a vanishing
+    share); a gradient that had not landed when Adam ran moves whole tensors."""
+    return float(((a - b).abs() > 0.5 * lr).float().mean())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", required=True)
+    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--backbone", default="hourglass")
+    ap.add_argument("--repeats", type=int, default=1)
+    ap.add_argument("--step", type=int, default=0, help="step number handed to train_step (>= 2000 switches the stage-2 loss on)")
+    ap.add_argument("--dcn", action="store_true", help="config 4: DCN heads with bf16 operands")
+    ap.add_argument("--perturb", type=float, default=0.0, help="repeats 2.. see the images multiplied by (1 + perturb * N(0,1)): "
+                    "the conditioning of the gradient w.r.t. rounding-sized input noise")
+    ap.add_argument("--sabotage", action="store_true", help="drop every wait ON a side stream (the joins): the test's own "
+                    "sensitivity check — the product code is not touched, torch.cuda.Stream.wait_stream is patched here")
+    a = ap.parse_args()
+
+    from rrnet_amd.configs.rrnet_config import Config as cfg
+    from rrnet_amd.operators.rrnet_operator import RRNetOperator
+    cfg.Train.batch_size = a.batch
+    cfg.Train.crop_size = (a.size, a.size)
+    cfg.Model.backbone = a.backbone
+    if a.dcn:
+        cfg.Model.dcn_heads = True
+        cfg.Model.dcn_bf16 = True
+    cfg.Distributed.gpu_id, cfg.Distributed.rank, cfg.Distributed.world_size = 0, 0, 1
+    torch.cuda.set_device(0)
+    if os.environ.get("RR_DP_FORCE") == "1":
+        # a ONE-rank RCCL process group: the data-parallel path's collectives are issued for real (rrnet_amd/dptrace.py)
+        import socket
+        import torch.distributed as dist
+        sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        dist.init_process_group("nccl", world_size=1, rank=0)
+    torch.manual_seed(219)
+    op = RRNetOperator(cfg)
+    op.model.train()
+    if a.dcn:                      # non-degenerate offsets / masks (the DCN's offset convolution is zero-initialised)
+        g = torch.Generator(device="cuda").manual_seed(7)
+        for m in op.model.modules():
+            if type(m).__name__ == "DCN":
+                m.conv_offset_mask.weight.data.normal_(0, 0.01, generator=g)
+                m.conv_offset_mask.bias.data.normal_(0, 1.0, generator=g)
+    if a.sabotage:
+        from rrnet_amd import functional as RF
+        orig = torch.cuda.Stream.wait_stream
+
+        def patched(self, other):
+            if any(other is s for s in RF._SIDE.values()):
+                return None
+            return orig(self, other)
+        torch.cuda.Stream.wait_stream = patched
+    fp = op.optimizer.fp
+    batch = op.training_loader.get_batch()
+    slices = param_slices(fp)
+    p0 = fp.flat.clone()
+    bufs = [b for b in op.model.buffers()]
+    b0 = [b.clone() for b in bufs]
+    sched0 = op.lr_sch.state_dict()
+    ref = None
+    from rrnet_amd import dptrace
+    meta = {"env": {k: os.environ.get(k) for k in ("RR_WGRAD_STREAM", "RR_WGRAD_STRESS", "RR_DCN_BWD_STREAMS", "RR_DP_FORCE")},
+            "losses": [], "repeat_vs_first": [], "collectives": [], "buckets": len(fp._bucket_range)}
+    for r in range(a.repeats):
+        with torch.no_grad():
+            fp.flat.copy_(p0)
+            for b, v in zip(bufs, b0):
+                b.copy_(v)
+            op.optimizer.exp_avg.zero_()
+            op.optimizer.exp_avg_sq.zero_()
+            op.optimizer.step_count = 0
+        op.lr_sch.load_state_dict(sched0)
+        dptrace.reset()
+        imgs = batch[0]
+        if a.perturb > 0 and r > 0:
+            gp = torch.Generator(device=imgs.device).manual_seed(1000 + r)
+            imgs = imgs * (1 + a.perturb * torch.randn(imgs.shape, generator=gp, device=imgs.device)).to(memory_format=torch.channels_last)
+        _, losses = op.train_step(a.step, (imgs, batch[1].clone()) + tuple(batch[2:]))
+        torch.cuda.synchronize()
+        meta["collectives"].append(dptrace.counts())
+        meta["losses"].append([float(v.detach()) for v in losses])
+        fb = torch.cat([b.detach().float().reshape(-1) for b in bufs if b.is_floating_point()])
+        if ref is None:
+            ref = (fp.grad.clone(), fp.flat.clone(), fb.clone())
+            ref[0].cpu().numpy().tofile(os.path.join(a.out, "grad.bin"))
+            ref[1].cpu().numpy().tofile(os.path.join(a.out, "param.bin"))
+            ref[2].cpu().numpy().tofile(os.path.join(a.out, "buffers.bin"))
+        else:
+            gw = worst_rel(fp.grad, ref[0], slices)
+            pw = frac_moved(fp.flat, ref[1])
+            bw = float(((fb - ref[2]).abs() / ref[2].abs().clamp_min(1e-3)).max())
+            meta["repeat_vs_first"].append({"grad": gw, "param": pw, "buffers": bw})
+            if r == 1:          # the second run's gradient too: the parent measures per-parameter run-to-run spread from it
+                fp.grad.cpu().numpy().tofile(os.path.join(a.out, "grad2.bin"))
+            if os.environ.get("RR_STREAM_TEST_VERBOSE"):
+                d = (fp.grad - ref[0]).abs()
+                dm = torch.stack([d[o:o + n].max() for o, n in slices])
+                sm = torch.stack([ref[0][o:o + n].abs().max() for o, n in slices])
+                rel = dm / sm.clamp_min(1e-30)
+                top = torch.argsort(rel, descending=True)[:12].tolist()
+                names = [by for by in [None]]
+                nm = {id(p): n for n, p in op.model.named_parameters()}
+                for t in top:
+                    print("  #%d %-60s rel %.3e  scale %.3e  numel %d" % (t, nm.get(id(fp.params[t]), "?"), float(rel[t]), float(sm[t]), slices[t][1]), flush=True)
+    meta["slices"] = slices
+    by_id = {id(p): n for n, p in op.model.named_parameters()}
+    meta["names"] = [by_id.get(id(p), "?") for p in fp.params]
+    meta["finite"] = bool(torch.isfinite(ref[0]).all() and torch.isfinite(ref[1]).all())
+    with open(os.path.join(a.out, "meta.json"), "w") as f:
+        json.dump(meta, f)
+    print("worker done:", json.dumps(meta["losses"]), flush=True)
+    if os.environ.get("RR_DP_FORCE") == "1":
+        import torch.distributed as dist
+        meta_backend = dist.get_backend()
+        dist.barrier()
+        dist.destroy_process_group()
+        print("backend:", meta_backend, flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -216,3 +216,50 @@ def test_bench_two_ranks_through_the_launcher():
     assert two["value"] > 0 and abs(two["value"] - 8 * 1e3 / two["ms_per_step"]) < 1e-2 * two["value"]
     print("1 rank: %.1f img/s, 2 ranks on one GPU over gloo: %.1f img/s" % (one["value"], two["value"]))
     assert two["value"] >= 0.35 * one["value"], (one["value"], two["value"])
+
+
+def test_rccl_single_rank_step_matches_non_distributed(tmp_path):
+    """RCCL itself, on the one GPU this box has: a ONE-rank `nccl` process group with RR_DP_FORCE=1, so that
+    init_process_group('nccl'), dist.new_group(), the parameter / buffer broadcasts, every SyncBN all_reduce (enqueued
+    from forward and from autograd worker threads) and every gradient bucket's all_reduce(async_op=True) — launched from
+    inside the weight-gradient side stream's context the moment its last parameter reports — go through
+    ProcessGroupNCCL for a full hourglass-104 train step (operators/distributed_wrapper.py:40-42,
+    operators/base_operator.py:24 in the reference), with the side stream delayed (RR_WGRAD_STRESS) so that a bucket
+    launched before its gradients have landed would send incomplete data.
+    All collectives are identities at world size 1, so the step must equal the non-distributed one up to the summation
+    ORDER of the BatchNorm statistics (slab -> all-reduce -> finalize instead of the fused single launch; the coalesced
+    SyncBN nodes reduce dz in a pass of their own).  That re-association is rounding-sized noise, which the deep levels of
+    this network amplify (tests/test_streams_gpu.py, module docstring): the comparison is therefore made on the
+    parameters whose gradient moves by <= 1e-5 under a 1e-7 input perturbation, with 1e-4 of their scale as the bound; a
+    collective that ran before its operand was complete, or an exchange left out, is O(1) on ALL of them.  The forced run
+    itself must repeat within 1e-5 on every parameter.  This cannot show a cross-rank ordering bug
+    (test_two_rank_collective_sequences_are_identical does that over gloo); it shows crashes, hangs and stream hand-over
+    mistakes of the real backend."""
+    from test_streams_gpu import DET, _load, _moved, _rel, _run
+    plain = _run(tmp_path, "plain", dict(DET, RR_WGRAD_STREAM="2"), 256, 2, 2, ["--perturb", "1e-7"])
+    forced = _run(tmp_path, "rccl1", dict(DET, RR_WGRAD_STREAM="2", RR_DP_FORCE="1", RR_WGRAD_STRESS="1"), 256, 2, 2)
+    cc = forced[1]["collectives"]
+    nb = forced[1]["buckets"]
+    print("collectives of one step through RCCL: %s; %d gradient buckets" % (cc[0], nb))
+    assert plain[1]["collectives"][0] == {}
+    for c in cc:
+        assert c["grads"] == nb, (c, nb)          # one all-reduce per gradient bucket, each exactly once
+        assert c["default"] == cc[0]["default"] and c["default"] >= 2 * 100 and c["default"] % 2 == 0, c
+    la, lb = np.array(plain[1]["losses"][0]), np.array(forced[1]["losses"][0])
+    assert np.all(np.abs(la - lb) <= 1e-4 * np.maximum(np.abs(la), 1e-3)), (la, lb)
+    sl = plain[1]["slices"]
+    g0 = _load(plain[0], "grad.bin")
+    sens, _ = _rel(_load(plain[0], "grad2.bin"), g0, sl)              # response to 1e-7 input noise
+    cross, _ = _rel(_load(forced[0], "grad.bin"), g0, sl)
+    good = sens <= 1e-5
+    print("one-rank RCCL step vs non-distributed step: %d of %d parameters well-conditioned; on those the worst gradient "
+          "difference is %.2e of the parameter's scale (all parameters: median %.2e, worst %.2e; 1e-7 input noise alone: "
+          "median %.2e, worst %.2e)" % (int(good.sum()), good.numel(), float(cross[good].max()), float(cross.median()),
+                                         float(cross.max()), float(sens.median()), float(sens.max())))
+    assert int(good.sum()) >= 10                  # the layers downstream of the last hourglass (its heads)
+    assert float(cross[good].max()) <= 1e-4
+    # everywhere else: not beyond the network's own amplification of rounding-sized noise
+    assert float(cross.median()) <= 3 * max(float(sens.median()), 1e-5)
+    assert float(cross.max()) <= 3 * max(float(sens.max()), 1e-3)
+    r = forced[1]["repeat_vs_first"][0]
+    assert r["grad"][0] <= 1e-5 and r["buffers"] <= 2e-5, r

@@ -1,0 +1,166 @@
+"""Soft-NMS N-sweep (SURVEY §8(d) "boxes/sec and µs per outer step vs the 64-lane reduction latency
+floor"): the bit-exact kernel (rr_soft_nms_segments) on ONE segment and on 1 280 segments (= the (frame, class) segments
+of a 128-frame config-5 batch) of N in {150, 1500, 9000} boxes, gaussian, sigma 0.5, Nt 0.7, threshold 0.1 — the
+parameters of `RRNetOperator._ext_nms` (/root/reference/operators/rrnet_operator.py:223) — next to
+
+  * the CPU oracle on the same boxes (oracle/liboracle.so, the C restatement of cpu_nms.pyx:17-120, one core), and
+  * the measured latency floor of one outer step (tools/softnms_floor.hip: a 64-lane arg-max + one LDS exchange behind
+    one barrier, serially dependent from step to step, nothing else).
+
+N = 9000 (the six-scale evaluation, configs/rrnet_config.py:69) exceeds the LDS-resident limit (RR_SOFT_NMS_LDS_MAX = 6000)
+and takes the global-workspace path.
+
+  python tools/bench_softnms.py            -> one JSON line; bench.py embeds it as `config5.softnms`."""
+import ctypes
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+FLOOR_SRC = os.path.join(HERE, "softnms_floor.hip")
+FLOOR_SO = os.path.join(HERE, "softnms_floor.so")
+
+
+def build_floor():
+    if os.path.exists(FLOOR_SO) and os.path.getmtime(FLOOR_SO) >= os.path.getmtime(FLOOR_SRC):
+        return FLOOR_SO
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-o", FLOOR_SO, FLOOR_SRC],
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed for softnms_floor.hip:\n" + r.stderr)
+    return FLOOR_SO
+
+
+def gen_boxes(n, rng, extent=None):
+    """Clustered detections like a decoded frame: 2/3 of the boxes jitter around n/12 objects, the rest are clutter; sizes
+    8..120 px, scores U(0.1, 1) (everything stage 1 hands on is above the 0.1 score threshold)."""
+    extent = extent if extent is not None else max(400.0, 40.0 * np.sqrt(n))
+    nobj = max(n // 12, 1)
+    centers = rng.uniform(0, extent, (nobj, 2))
+    sizes = rng.uniform(8, 120, (nobj, 2))
+    nclu = 2 * n // 3
+    idx = rng.integers(0, nobj, nclu)
+    c = centers[idx] + rng.normal(0, 4.0, (nclu, 2))
+    wh = sizes[idx] * rng.uniform(0.8, 1.25, (nclu, 2))
+    c2 = rng.uniform(0, extent, (n - nclu, 2))
+    wh2 = rng.uniform(8, 120, (n - nclu, 2))
+    c, wh = np.concatenate([c, c2]), np.concatenate([wh, wh2])
+    s = rng.uniform(0.1, 1.0, (n, 1))
+    return np.concatenate([c - wh / 2, c + wh / 2, s], 1).astype(np.float32)
+
+
+def time_gpu(fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    return float(np.median(ts))
+
+
+def floor_table(dev):
+    """µs per step of the bare dependency chain: one wave (segments <= 192 boxes), four waves (<= 2560), sixteen."""
+    lib = ctypes.CDLL(build_floor())
+    lib.softnms_floor_run.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    seed = torch.rand(4096, device=dev) + 0.5
+    out = torch.empty(4096, device=dev)
+    res = {}
+    steps = 20000
+    for threads in (64, 256, 1024):
+        for blocks in (1, 1280):
+            st = torch.cuda.current_stream().cuda_stream
+
+            def run(s=steps):
+                rc = lib.softnms_floor_run(threads, blocks, s, seed.data_ptr(), out.data_ptr(), st)
+                assert rc == 0, rc
+            t_full = time_gpu(run, 5)
+            t_half = time_gpu(lambda: run(steps // 2), 5)
+            res["T%d_x%d" % (threads, blocks)] = round((t_full - t_half) * 1e3 / (steps // 2), 4)     # launch cost cancels
+    return res
+
+
+def run(sizes=(150, 1500, 9000), many=1280, cpu=True, reps=5):
+    from rrnet_amd.ext.nms.nms_wrapper import soft_nms_segments
+    dev = torch.device("cuda", torch.cuda.current_device())
+    rng = np.random.default_rng(219)
+    oracle = None
+    if cpu:
+        from oracle import nms as onms
+        oracle = onms
+    floor = None
+    try:
+        floor = floor_table(dev)
+    except Exception as e:                      # hipcc missing on the box: the table still carries the kernel's numbers
+        floor = {"error": repr(e)}
+    rows = []
+    for n in sizes:
+        one = gen_boxes(n, rng)
+        # CPU oracle: one core, same boxes
+        cpu_ms, kept_cpu = None, None
+        if oracle is not None:
+            t_best = 1e30
+            for _ in range(3 if n <= 1500 else 1):
+                w = one.copy()
+                t0 = time.perf_counter()
+                keep = oracle.cpu_soft_nms(w, 0.5, 0.7, 0.1, 2)
+                t_best = min(t_best, time.perf_counter() - t0)
+            cpu_ms, kept_cpu = t_best * 1e3, len(keep)
+        for nseg in (1, many):
+            if nseg == 1:
+                host = one
+            else:
+                # distinct boxes per segment (same recipe, own draw), all of length n: 1280 x 9000 x 20 B = 230 MB
+                host = np.concatenate([one] + [gen_boxes(n, rng) for _ in range(min(nseg - 1, 15))])
+                reps_seg = -(-nseg // (host.shape[0] // n))
+                host = np.tile(host, (reps_seg, 1))[:nseg * n]
+            base = torch.from_numpy(host).to(dev)
+            seg_off = torch.arange(0, (nseg + 1) * n, n, dtype=torch.int32, device=dev)
+            work = base.clone()
+            n_out = None
+
+            def go():
+                nonlocal n_out
+                work.copy_(base)
+                n_out, _ = soft_nms_segments(work, seg_off, n, 0.5, 0.7, 0.1, 2, check=False)
+            t_all = time_gpu(go, reps)
+            t_copy = time_gpu(lambda: work.copy_(base), reps)
+            ms = max(t_all - t_copy, 1e-6)
+            kept = int(n_out[0].item())
+            if nseg == 1 and kept_cpu is not None:
+                assert kept == kept_cpu, (n, kept, kept_cpu)      # same algorithm, same boxes (bit-exactness: tests/)
+            # outer steps executed by the longest segment = boxes it keeps (the loop ends when i reaches the shrunk N)
+            steps = int(n_out.max().item())
+            threads = 64 if n <= 192 else (256 if n <= 2560 else 1024)
+            fl = floor.get("T%d_x%d" % (threads, 1 if nseg == 1 else many)) if isinstance(floor, dict) else None
+            rows.append({"N": n, "segments": nseg, "ms": round(ms, 4), "boxes_per_sec": round(nseg * n / (ms * 1e-3), 1),
+                         "kept": kept, "outer_steps": steps, "us_per_outer_step": round(ms * 1e3 / max(steps, 1), 4),
+                         "floor_us_per_step": fl, "threads_per_segment": threads,
+                         "path": "LDS" if n <= 6000 else "global workspace",
+                         "cpu_oracle_ms_per_segment": None if cpu_ms is None else round(cpu_ms, 3),
+                         "cpu_oracle_boxes_per_sec": None if cpu_ms is None else round(n / (cpu_ms * 1e-3), 1)})
+            del base, work
+            torch.cuda.empty_cache()
+    return {"params": "gaussian (method 2), sigma 0.5, Nt 0.7, threshold 0.1", "rows": rows, "floor_us_per_step": floor,
+            "floor_definition": "64-lane (score, index) arg-max + one LDS exchange behind one workgroup barrier, serially "
+                                "dependent step to step (tools/softnms_floor.hip); T = threads per segment, x = concurrent segments",
+            "cpu": "oracle/liboracle.so (C restatement of cpu_nms.pyx:17-120), 1 core"}
+
+
+if __name__ == "__main__":
+    torch.cuda.set_device(0)
+    print(json.dumps(run()))

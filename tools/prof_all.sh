@@ -14,6 +14,10 @@ python3 tools/pmc_traffic.py gpurun_out/pmc_dcn_FETCH_SIZE_$TAG gpurun_out/pmc_d
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_dcn_$TAG -- python3 tools/bench_dcn.py > gpurun_out/dcn_$TAG.json 2> gpurun_out/dcn_$TAG.err
 ls gpurun_out | grep $TAG | head -60
 # the raw traces are tens of MB each (gpurun merges at most 64 MiB back): keep the summaries only
-find gpurun_out -name "*_kernel_trace.csv" -delete
-find gpurun_out -name "*_counter_collection.csv" -delete
+# (this tag's directories only: tools/trace_gaps.py and a re-run of tools/pmc_traffic.py read other tags' raw traces)
+for d in gpurun_out/*_$TAG; do
+  [ -d "$d" ] || continue
+  find "$d" -name "*_kernel_trace.csv" -delete
+  find "$d" -name "*_counter_collection.csv" -delete
+done
 du -sh gpurun_out
