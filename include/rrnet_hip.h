@@ -117,6 +117,31 @@ int rr_conv_dgrad_s1_relubias(const float *dy, const float *wt, float *dx, int n
 int rr_conv_wgrad(const float *x, const float *dy, float *dw, int n, int h, int wd, int c, int k,
                   int r, int s, int stride, int pad_h, int pad_w, int out_h, int out_w, hipStream_t stream);
 
+/* ---- bf16-operand convolutions (BASELINE config 4, "bf16"; csrc/conv_bf16.hip) ------------------------------------- *
+ * The reference is fp32-only (backbones/hourglass.py:12-61,127-199 -> nn.Conv2d), so this precision is builder-defined
+ * and opt-in (cfg.Model.bf16): SAME tensors, layouts and semantics as the entry points above without the suffix — fp32
+ * activations / weights / gradients in HBM — but the two operands of every product are rounded to bf16
+ * (round-to-nearest-even) on their way into LDS and multiplied on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.
+ * Contract: result == the fp32 entry point run on bf16-rounded operands, up to the summation order.
+ * Vector shapes only (C % 4 == 0, R*S <= 64, for rr_conv_wgrad_bf16 also K % 4 == 0; every tensor < 2 GiB): the host
+ * layer keeps the fp32 entry points for the rest (stride-2 data gradients, the 17-tap WH head, the 3-channel stem's
+ * unpacked form).  rr_conv_dgrad_s1*_bf16 take the flipped / transposed filter of rr_weight_flip_transpose (fp32). */
+int rr_conv_fprop_bf16(const float *x, const float *w, const float *bias, float *y, double *stat_slab,
+                       int n, int h, int wd, int c, int k, int r, int s, int stride, int pad_h, int pad_w,
+                       int relu, hipStream_t stream);
+int rr_conv_dgrad_s1_bf16(const float *dy, const float *wt, float *dx, int n, int h, int wd, int c, int k,
+                          int r, int s, int pad_h, int pad_w, int accumulate, hipStream_t stream);
+int rr_conv_dgrad_s1_bnsum_bf16(const float *dy, const float *wt, float *dx, int n, int h, int wd, int c, int k,
+                                int r, int s, int pad_h, int pad_w, int accumulate, const float *prod_y,
+                                const float *prod_z, const float *prod_mean, const float *prod_invstd,
+                                const float *prod_mask_scale, const float *prod_mask_shift, double *slab,
+                                double *sums, hipStream_t stream);
+int rr_conv_dgrad_s1_relubias_bf16(const float *dy, const float *wt, float *dx, int n, int h, int wd, int c, int k,
+                                   int r, int s, int pad_h, int pad_w, int accumulate, const float *prod_z,
+                                   double *slab, double *sums, hipStream_t stream);
+int rr_conv_wgrad_bf16(const float *x, const float *dy, float *dw, int n, int h, int wd, int c, int k,
+                       int r, int s, int stride, int pad_h, int pad_w, int out_h, int out_w, hipStream_t stream);
+
 /* ---- BatchNorm / ReLU / residual / up-path / Adam (HBM-bound NHWC elementwise) -------- *
  * Replace nn.BatchNorm2d (SyncBatchNorm via operators/rrnet_operator.py:27) + ReLU + residual
  * add of backbones/hourglass.py:18-19,22,26,34-40,51,59-60 and backbones/resnet.py:23-50;

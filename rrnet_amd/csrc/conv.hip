@@ -1675,3 +1675,8 @@ extern "C" int rr_conv_wgrad(const float *x, const float *dy, float *dw, int n, 
     return bn == 128 ? WG(32, 128) : WG(32, 32);
 #undef WG
 }
+
+// shared with csrc/conv_bf16.hip: one occupancy model / tile policy for both precisions
+int rr_conv_pick_ksplit(int blocks, int nk) { return pick_ksplit(blocks, nk); }
+int rr_conv_small_tiles() { return small_tiles(); }
+int rr_conv_mid_tiles() { return mid_tiles(); }

@@ -127,6 +127,17 @@ def out_hw(h, w, r, s, stride, ph, pw):
     return (h + 2 * ph - r) // stride + 1, (w + 2 * pw - s) // stride + 1
 
 
+# bf16 matrix operands for the convolutions (BASELINE config 4; csrc/conv_bf16.hip).  A process-wide switch set by the
+# model (cfg.Model.bf16 -> rrnet_amd.models.rrnet) for the duration of its forward / backward: same tensors (fp32 in
+# HBM), same autograd graph, only the kernels the launches go to differ.  The headline configuration never sets it.
+BF16 = os.environ.get("RR_CONV_BF16", "0") == "1"
+
+
+def _bf16_ok(c, k, r, s, *tensors):
+    """Shapes csrc/conv_bf16.hip takes: vector path (C and K multiples of 4, <= 64 taps), tensors below 2 GiB."""
+    return BF16 and c % 4 == 0 and k % 4 == 0 and r * s <= 64 and all(t.numel() * 4 < (1 << 31) for t in tensors)
+
+
 def conv_fprop(x, w, bias=None, stride=1, pad=(0, 0), relu=False, want_stats=False, algo_kg=None):
     """x [N,C,H,W] (NHWC memory), w [K,C,R,S] (OHWI memory) -> y [N,K,P,Q] (NHWC memory)
     and, if want_stats, the per-block BatchNorm partial-sum slab (see rr_conv_fprop).
@@ -143,9 +154,10 @@ def conv_fprop(x, w, bias=None, stride=1, pad=(0, 0), relu=False, want_stats=Fal
     if want_stats:
         nbytes = _C.fn("rr_conv_stat_slab_bytes")(n, p, q, k)
         slab = torch.empty(nbytes // 8, dtype=torch.float64, device=x.device)
-    f = _C.fn("rr_conv_fprop")
+    bf = _bf16_ok(c, 4, r, s, x, w, y)
+    f = _C.fn("rr_conv_fprop_bf16" if bf else "rr_conv_fprop")
     flops = 2.0 * n * p * q * k * (c * r * s if algo_kg is None else algo_kg)
-    _C.check(_timed(_igemm_name("fprop", k, c % 4 != 0, n * p * q), flops,
+    _C.check(_timed(_igemm_name("fprop", k, c % 4 != 0, n * p * q) + ("+bf16" if bf else ""), flops,
                     lambda: f(_C.ptr(x), _C.ptr(w), _C.ptr(bias), _C.ptr(y), _C.ptr(slab), n, h, wd, c, k, r, s,
                               stride, pad[0], pad[1], int(relu), _C.stream()),
                     (n, h, wd, c, k, r, s, stride), 4.0 * (x.numel() + y.numel() + w.numel())), "rr_conv_fprop")
@@ -267,8 +279,9 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False,
         slab = torch.empty(_C.fn("rr_conv_stat_slab_bytes")(n, h, wd, c) // 8, dtype=torch.float64, device=dy.device)
         sums = _ZEROS.take(2 * c, dy.device)
         flops_m = 2.0 * dy.shape[0] * dy.shape[2] * dy.shape[3] * k * c * r * s
-        fr = _C.fn("rr_conv_dgrad_s1_relubias")
-        _C.check(_timed(_igemm_name("fprop", c, False, n * h * wd) + "+relubias", flops_m,
+        bf = _bf16_ok(kp, c, r, s, dyp, out)
+        fr = _C.fn("rr_conv_dgrad_s1_relubias_bf16" if bf else "rr_conv_dgrad_s1_relubias")
+        _C.check(_timed(_igemm_name("fprop", c, False, n * h * wd) + "+relubias" + ("+bf16" if bf else ""), flops_m,
                         lambda: fr(_C.ptr(dyp), _C.ptr(wt), _C.ptr(out), n, h, wd, c, kp, r, s, pad[0], pad[1], int(accumulate),
                                    _C.ptr(bnsum_z), _C.ptr(slab), _C.ptr(sums), _C.stream()), (n, h, wd, c, k, r, s, stride)),
                  "rr_conv_dgrad_s1_relubias")
@@ -281,6 +294,8 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False,
         wt = torch.empty(k * c * r * s, dtype=torch.float32, device=dy.device)
         _C.check(_C.fn("rr_weight_flip_transpose")(_C.ptr(w), _C.ptr(wt), k, c, r, s, _C.stream()),
                  "rr_weight_flip_transpose")
+        bf = _bf16_ok(k, c, r, s, dy, out)
+        sfx, tsfx = ("_bf16", "+bf16") if bf else ("", "")
         if (bnsum is not None and not bnsum.relu_bias and _DGRAD_BNSUM and bnsum.y is not None and c <= 1024 and out.numel() * 4 < (1 << 31)
                 and tuple(bnsum.y.shape) == tuple(out.shape)
                 and (not bnsum.use_z or (bnsum_z is not None and is_nhwc(bnsum_z) and bnsum_z.shape == out.shape))):
@@ -288,8 +303,8 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False,
             nb = _C.fn("rr_conv_stat_slab_bytes")(n, h, wd, c)
             slab = torch.empty(nb // 8, dtype=torch.float64, device=dy.device)
             sums = _ZEROS.take(2 * c, dy.device)
-            fb = _C.fn("rr_conv_dgrad_s1_bnsum")
-            _C.check(_timed(_igemm_name("fprop", c, False, n * h * wd) + "+bnsum", flops,
+            fb = _C.fn("rr_conv_dgrad_s1_bnsum" + sfx)
+            _C.check(_timed(_igemm_name("fprop", c, False, n * h * wd) + "+bnsum" + tsfx, flops,
                             lambda: fb(_C.ptr(dy), _C.ptr(wt), _C.ptr(out), n, h, wd, c, k, r, s, pad[0], pad[1],
                                        int(accumulate), _C.ptr(bnsum.y), _C.ptr(zt), _C.ptr(bnsum.mean),
                                        _C.ptr(bnsum.invstd), _C.ptr(bnsum.msc), _C.ptr(bnsum.msh), _C.ptr(slab),
@@ -298,9 +313,9 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False,
                      "rr_conv_dgrad_s1_bnsum")
             bnsum.sums, bnsum.dz = sums, out
             return out
-        f1 = _C.fn("rr_conv_dgrad_s1")
+        f1 = _C.fn("rr_conv_dgrad_s1" + sfx)
         # same HIP kernel instance as a forward convolution: timed under its name
-        _C.check(_timed(_igemm_name("fprop", c, False, n * h * wd), flops,
+        _C.check(_timed(_igemm_name("fprop", c, False, n * h * wd) + tsfx, flops,
                         lambda: f1(_C.ptr(dy), _C.ptr(wt), _C.ptr(out), n, h, wd, c, k, r, s, pad[0], pad[1],
                                    int(accumulate), _C.stream()), (n, h, wd, c, k, r, s, stride),
                         4.0 * (dy.numel() + out.numel() * (2 if accumulate else 1) + w.numel())), "rr_conv_dgrad_s1")
@@ -320,9 +335,10 @@ def conv_wgrad(x, dy, dw, stride=1, pad=(0, 0), explicit_out=False, algo_c=None)
     n, c, h, wd = x.shape
     k, c2, r, s = dw.shape
     assert c == c2 and dy.shape[1] == k
-    f = _C.fn("rr_conv_wgrad")
+    bf = _bf16_ok(c, k, r, s, x, dy) and c > 32 and k > 32
+    f = _C.fn("rr_conv_wgrad_bf16" if bf else "rr_conv_wgrad")
     flops = 2.0 * dy.shape[0] * dy.shape[2] * dy.shape[3] * k * (c * r * s if algo_c is None else algo_c)
-    _C.check(_timed("conv_wgrad<BN=%d>" % (128 if c > 32 else 32), flops,
+    _C.check(_timed("conv_wgrad<BN=%d>%s" % (128 if c > 32 else 32, "+bf16" if bf else ""), flops,
                     lambda: f(_C.ptr(x), _C.ptr(dy), _C.ptr(dw), n, h, wd, c, k, r, s, stride, pad[0], pad[1],
                               dy.shape[2] if explicit_out else 0, dy.shape[3] if explicit_out else 0,
                               _C.stream()), (n, h, wd, c, k, r, s, stride)), "rr_conv_wgrad")
