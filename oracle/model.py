@@ -34,9 +34,13 @@ class Params:
     uses batch statistics and updates running_mean/var/num_batches_tracked in place, like
     nn.BatchNorm2d."""
 
-    def __init__(self, sd, training=True):
+    def __init__(self, sd, training=True, bf16=False):
         self.sd = sd
         self.training = training
+        # builder-defined precision of BASELINE configs[3] (the reference is fp32-only): both operands of every
+        # convolution rounded to bf16 (nearest even), products and sums in the tensors' own dtype (fp32 / fp64) —
+        # the contract of rrnet_amd/csrc/conv_bf16.hip, restated so that a bf16 model run has an oracle
+        self.bf16 = bf16
 
     def has(self, key):
         return key in self.sd
@@ -48,8 +52,15 @@ class Params:
         return (max(idx) + 1) if idx else 0
 
 
+def _bf16_round(t):
+    return t.to(torch.bfloat16).to(t.dtype)
+
+
 def conv(P, key, x, stride=1, padding=0):
-    return F.conv2d(x, P.sd[key + ".weight"], P.sd.get(key + ".bias"), stride=stride, padding=padding)
+    w = P.sd[key + ".weight"]
+    if P.bf16:
+        x, w = _bf16_round(x), _bf16_round(w)
+    return F.conv2d(x, w, P.sd.get(key + ".bias"), stride=stride, padding=padding)
 
 
 def bn(P, key, x):

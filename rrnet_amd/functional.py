@@ -112,6 +112,7 @@ class _ConvBnAct(torch.autograd.Function):
                 out_link=None):
         ctx.accs = (x_acc, res_acc)
         ctx.links = (in_link, out_link)
+        ctx.bf16 = ops.BF16
         x = ops.to_nhwc(x)
         wc = ops.to_nhwc(w)
         n, _, h, wd = x.shape
@@ -174,6 +175,11 @@ class _ConvBnAct(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dz):
+        with ops.bf16_scope(ctx.bf16):      # the precision this node's forward ran at
+            return _ConvBnAct._backward(ctx, dz)
+
+    @staticmethod
+    def _backward(ctx, dz):
         x, wc, y, z, mean, invstd, gamma, cnt_dev, msc, msh = ctx.saved_tensors
         stride, pad, relu, count, sync, has_res = ctx.cfg
         w, gamma_p, beta_p = ctx.params
@@ -303,6 +309,7 @@ class _ConvBnSyncMulti(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, x_acc, specs, *params):
         # specs: [(bn module, stride, pad, relu)], params: w0, gamma0, beta0, w1, gamma1, beta1, ...
+        ctx.bf16 = ops.BF16
         x = ops.to_nhwc(x)
         L = len(specs)
         ws = [ops.to_nhwc(params[3 * i]) for i in range(L)]
@@ -342,6 +349,11 @@ class _ConvBnSyncMulti(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *dzs):
+        with ops.bf16_scope(ctx.bf16):
+            return _ConvBnSyncMulti._backward(ctx, *dzs)
+
+    @staticmethod
+    def _backward(ctx, *dzs):
         L, cfgs, ks, counts, x_acc, xshape = ctx.meta
         t = ctx.saved_tensors
         x, cnt_devs, ws, rest = t[0], t[1:1 + L], t[1 + L:1 + 2 * L], t[1 + 2 * L:]
@@ -436,6 +448,7 @@ class _ConvBias(torch.autograd.Function):
         ctx.x_acc = x_acc
         ctx.in_link = in_link
         ctx.out_link = out_link
+        ctx.bf16 = ops.BF16
         x = ops.to_nhwc(x)
         wc = ops.to_nhwc(w)
         y = ops.conv_fprop(x, wc, b, stride, pad, relu)
@@ -447,6 +460,11 @@ class _ConvBias(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        with ops.bf16_scope(ctx.bf16):
+            return _ConvBias._backward(ctx, dy)
+
+    @staticmethod
+    def _backward(ctx, dy):
         x, wc, y = ctx.saved_tensors
         stride, pad, relu = ctx.cfg
         w, b = ctx.params

@@ -64,8 +64,16 @@ class RRNet(nn.Module):
         self.wh = CenterNetWHDetector(planes=1, num_stacks=self.num_stacks, dcn=dcn, dcn_bf16=dcn_bf16)
         self.offset_reg = CenterNetDetector(planes=2, num_stacks=self.num_stacks, dcn=dcn, dcn_bf16=dcn_bf16)
         self.head_detector = FasterRCNNDetector()
+        # builder-defined (BASELINE configs[3] "bf16"; the reference is fp32-only): bf16 matrix operands with fp32
+        # accumulation in every convolution of the backbone and the heads (csrc/conv_bf16.hip); activations, weights,
+        # BatchNorm statistics, losses and the optimizer stay fp32
+        self.bf16 = bool(getattr(cfg.Model, "bf16", False))
 
     def forward(self, x, k=1500):
+        with ops.bf16_scope(self.bf16):
+            return self._forward(x, k)
+
+    def _forward(self, x, k=1500):
         feats = self.backbone(x)
         last_a, last_b = RF.fanout(feats[-1], 2)
         hms, whs, offsets = self.forward_stage1(list(feats[:-1]) + [last_a])

@@ -130,7 +130,26 @@ def out_hw(h, w, r, s, stride, ph, pw):
 # bf16 matrix operands for the convolutions (BASELINE config 4; csrc/conv_bf16.hip).  A process-wide switch set by the
 # model (cfg.Model.bf16 -> rrnet_amd.models.rrnet) for the duration of its forward / backward: same tensors (fp32 in
 # HBM), same autograd graph, only the kernels the launches go to differ.  The headline configuration never sets it.
-BF16 = os.environ.get("RR_CONV_BF16", "0") == "1"
+_BF16_ENV = os.environ.get("RR_CONV_BF16", "0") == "1"      # force it on for everything (experiments)
+BF16 = _BF16_ENV
+
+
+class bf16_scope:
+    """`with ops.bf16_scope(flag):` — the convolutions launched inside take the bf16-operand kernels when `flag`.
+    RRNet.forward opens it for a model built with cfg.Model.bf16; every convolution node remembers the setting of its
+    forward and re-opens it around its backward (rrnet_amd/functional.py)."""
+
+    def __init__(self, on):
+        self.on = bool(on) or _BF16_ENV
+
+    def __enter__(self):
+        global BF16
+        self.prev, BF16 = BF16, self.on
+
+    def __exit__(self, *exc):
+        global BF16
+        BF16 = self.prev
+
 
 
 def _bf16_ok(c, k, r, s, *tensors):
@@ -288,8 +307,9 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False,
         bnsum.sums, bnsum.dz = sums, out
         return out
     flops = 2.0 * dy.shape[0] * dy.shape[2] * dy.shape[3] * k * c * r * s
+    # (bf16 operands: the forward kernel at every size — its split-K covers the small maps, and the dgrad kernel is fp32-only)
     if (stride == 1 and k % 4 == 0 and c % 4 == 0 and r * s <= 64 and pad[0] < r and pad[1] < s and _DGRAD_VIA_FPROP
-            and dy.shape[2] * dy.shape[3] >= _DGRAD_VIA_FPROP_MIN_PIXELS):
+            and (dy.shape[2] * dy.shape[3] >= _DGRAD_VIA_FPROP_MIN_PIXELS or _bf16_ok(k, c, r, s, dy, out))):
         # the forward kernel on dy with the flipped / transposed filter (one tiny transpose per layer and step)
         wt = torch.empty(k * c * r * s, dtype=torch.float32, device=dy.device)
         _C.check(_C.fn("rr_weight_flip_transpose")(_C.ptr(w), _C.ptr(wt), k, c, r, s, _C.stream()),

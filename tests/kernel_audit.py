@@ -53,6 +53,13 @@ def _c64(t):
     return t.detach().cpu().double()
 
 
+def _q64(t, on):
+    """fp64 copy of a convolution operand; with `on` rounded to bf16 first — the contract of the bf16-operand kernels
+    (csrc/conv_bf16.hip: both operands of every product rounded to nearest even, fp32 accumulation)."""
+    t = t.detach().cpu()
+    return (t.to(torch.bfloat16).to(torch.float32) if on else t).double()
+
+
 def _bands(p):
     """Output-row bands of a sampled convolution check: (image selector in [0,1], p0, p1)."""
     if p <= 48:
@@ -61,17 +68,17 @@ def _bands(p):
     return [(0.0, 0, 16), (0.5, mid, min(mid + 16, p)), (1.0, p - 16, p)]
 
 
-def _fprop_band(x, w64, b64, stride, pad, n0, p0, p1):
+def _fprop_band(x, w64, b64, stride, pad, n0, p0, p1, quant=False):
     """fp64 conv2d of output rows [p0,p1) of image n0, from the input rows they reach (zero rows beyond the map)."""
     h = x.shape[2]
     r = w64.shape[2]
     h0, h1 = p0 * stride - pad[0], (p1 - 1) * stride - pad[0] + r
     a, b = max(h0, 0), min(h1, h)
-    xs = F.pad(_c64(x[n0:n0 + 1, :, a:b, :]), (0, 0, a - h0, h1 - b))
+    xs = F.pad(_q64(x[n0:n0 + 1, :, a:b, :], quant), (0, 0, a - h0, h1 - b))
     return F.conv2d(xs, w64, b64, stride, (0, pad[1]))
 
 
-def _dgrad_band(dy, w64, x_shape, stride, pad, n0, h0, h1):
+def _dgrad_band(dy, w64, x_shape, stride, pad, n0, h0, h1, quant=False):
     """fp64 data gradient rows [h0,h1) of image n0 from the dy rows that reach them."""
     _, c, h, wd = x_shape
     k, _, r, s = w64.shape
@@ -82,7 +89,7 @@ def _dgrad_band(dy, w64, x_shape, stride, pad, n0, h0, h1):
     if pb <= pa:
         return ref
     opw = wd - ((q - 1) * stride - 2 * pad[1] + s)
-    full = F.conv_transpose2d(_c64(dy[n0:n0 + 1, :, pa:pb, :]), w64, None, stride, (0, pad[1]), (0, opw))
+    full = F.conv_transpose2d(_q64(dy[n0:n0 + 1, :, pa:pb, :], quant), w64, None, stride, (0, pad[1]), (0, opw))
     base = pa * stride - pad[0]                       # input row of full's row 0
     lo, hi = max(h0, base), min(h1, base + full.shape[2])
     if hi > lo:
@@ -134,16 +141,17 @@ def audit(tol=2e-5, tol_wgrad=2e-4, sample=False):
         packed_src[xp.data_ptr()] = (x, stride, tuple(pad))
         sig = (tuple(x.shape), tuple(w.shape), stride, tuple(pad))
         if ("fprop_packed",) + sig not in rec.seen:
-            w64 = _c64(w)
+            qq = ops._bf16_ok(xp.shape[1], 4, 1, 1, xp, y)        # the inner 1x1 GEMM rounds the packed taps = rounds x, w
+            w64 = _q64(w, qq)
             flops = 2.0 * y.numel() * w.shape[1] * w.shape[2] * w.shape[3]
             if big(flops):
                 rec.sampled.add(("fprop_packed",) + sig)
                 err = 0.0
                 for sel, p0, p1 in _bands(y.shape[2]):
                     n0 = int(round(sel * (x.shape[0] - 1)))
-                    err = max(err, _rel(y[n0:n0 + 1, :, p0:p1, :], _fprop_band(x, w64, None, stride, pad, n0, p0, p1)))
+                    err = max(err, _rel(y[n0:n0 + 1, :, p0:p1, :], _fprop_band(x, w64, None, stride, pad, n0, p0, p1, qq)))
             else:
-                err = _rel(y, F.conv2d(_c64(x), w64, None, stride, tuple(pad)))
+                err = _rel(y, F.conv2d(_q64(x, qq), w64, None, stride, tuple(pad)))
             rec.note("fprop_packed", sig, err, tol)
         return y, slab, xp
 
@@ -159,7 +167,8 @@ def audit(tol=2e-5, tol_wgrad=2e-4, sample=False):
             ks = _k_sample(dw.shape[0]) if big(flops) else list(range(dw.shape[0]))
             if big(flops):
                 rec.sampled.add(("wgrad_packed",) + sig)
-            ref = torch.nn.grad.conv2d_weight(_c64(x), (len(ks),) + tuple(dw.shape[1:]), _c64(dy[:, ks]), stride, pad)
+            qq = ops._bf16_ok(xp.shape[1], dy.shape[1], 1, 1, xp, dy) and xp.shape[1] > 32 and dy.shape[1] > 32
+            ref = torch.nn.grad.conv2d_weight(_q64(x, qq), (len(ks),) + tuple(dw.shape[1:]), _q64(dy[:, ks], qq), stride, pad)
             rec.note("wgrad_packed", sig, float((got[ks] - ref).abs().max() / max(float(ref.abs().max()), 1e-30)), tol_wgrad)
         return res
 
@@ -168,13 +177,16 @@ def audit(tol=2e-5, tol_wgrad=2e-4, sample=False):
         y = out[0] if want_stats else out
         sig = (tuple(x.shape), tuple(w.shape), stride, tuple(pad), bias is not None, relu, want_stats)
         flops = 2.0 * y.numel() * w.shape[1] * w.shape[2] * w.shape[3]
+        qq = ops._bf16_ok(w.shape[1], 4, w.shape[2], w.shape[3], x, w, y)
+        if qq:
+            sig = sig + ("bf16",)
         if ("fprop",) + sig not in rec.seen and big(flops):
             rec.sampled.add(("fprop",) + sig)
-            w64, b64 = _c64(w), None if bias is None else _c64(bias)
+            w64, b64 = _q64(w, qq), None if bias is None else _c64(bias)
             err = 0.0
             for sel, p0, p1 in _bands(y.shape[2]):
                 n0 = int(round(sel * (x.shape[0] - 1)))
-                ref = _fprop_band(x, w64, b64, stride, pad, n0, p0, p1)
+                ref = _fprop_band(x, w64, b64, stride, pad, n0, p0, p1, qq)
                 if relu:
                     ref = ref.relu()
                 err = max(err, _rel(y[n0:n0 + 1, :, p0:p1, :], ref))
@@ -193,7 +205,7 @@ def audit(tol=2e-5, tol_wgrad=2e-4, sample=False):
                 e1 = float((sums[:k] - s1).abs().max() / max(float(sa.max()), 1e-30))
                 rec.note("fprop_stats", sig, max(e1, float((sums[k:2 * k] - s2).abs().max() / float(s2.max()))), tol)
         elif ("fprop",) + sig not in rec.seen:
-            ref = F.conv2d(x.cpu().double(), w.cpu().double(), None if bias is None else bias.cpu().double(), stride, pad)
+            ref = F.conv2d(_q64(x, qq), _q64(w, qq), None if bias is None else bias.cpu().double(), stride, pad)
             if relu:
                 ref = ref.relu()
             rec.note("fprop", sig, _rel(y, ref), tol)
@@ -242,13 +254,18 @@ def audit(tol=2e-5, tol_wgrad=2e-4, sample=False):
         sig = (tuple(dy.shape), tuple(w.shape), tuple(x_shape), stride, tuple(pad), bool(accumulate)) + \
               (("relu-masked",) if relu_mask is not None else ())
         flops = 2.0 * dy.numel() * w.shape[1] * w.shape[2] * w.shape[3]
+        # bf16 operands: stride-1 layers (the forward kernel on the flipped filter); a 10- / 2-channel dy was zero-padded to 12 / 4
+        qq = stride == 1 and pad[0] < w.shape[2] and pad[1] < w.shape[3] and \
+            ops._bf16_ok(w.shape[0] if relu_mask is None else (w.shape[0] + 3) // 4 * 4, w.shape[1], w.shape[2], w.shape[3], dy, res)
+        if qq:
+            sig = sig + ("bf16",)
         if ("dgrad",) + sig not in rec.seen and big(flops):
             rec.sampled.add(("dgrad",) + sig)
-            w64 = _c64(w)
+            w64 = _q64(w, qq)
             err = 0.0
             for sel, h0, h1 in _bands(x_shape[2]):
                 n0 = int(round(sel * (x_shape[0] - 1)))
-                ref = _dgrad_band(dy, w64, x_shape, stride, pad, n0, h0, h1)
+                ref = _dgrad_band(dy, w64, x_shape, stride, pad, n0, h0, h1, qq)
                 if base is not None:
                     ref = ref + _c64(base[n0:n0 + 1, :, h0:h1, :])
                 if relu_mask is not None:
@@ -256,7 +273,7 @@ def audit(tol=2e-5, tol_wgrad=2e-4, sample=False):
                 err = max(err, _rel(res[n0:n0 + 1, :, h0:h1, :], ref))
             rec.note("dgrad", sig, err, tol)
         elif ("dgrad",) + sig not in rec.seen:
-            ref = torch.nn.grad.conv2d_input(tuple(x_shape), w.cpu().double(), dy.cpu().double(), stride, pad)
+            ref = torch.nn.grad.conv2d_input(tuple(x_shape), _q64(w, qq), _q64(dy, qq), stride, pad)
             if base is not None:
                 ref = ref + base.cpu().double()
             if relu_mask is not None:
@@ -266,6 +283,9 @@ def audit(tol=2e-5, tol_wgrad=2e-4, sample=False):
 
     def conv_wgrad(x, dy, dw, stride=1, pad=(0, 0), explicit_out=False, algo_c=None):
         sig = (tuple(x.shape), tuple(dy.shape), tuple(dw.shape), stride, tuple(pad), explicit_out)
+        qq = ops._bf16_ok(x.shape[1], dy.shape[1], dw.shape[2], dw.shape[3], x, dy) and x.shape[1] > 32 and dy.shape[1] > 32
+        if qq:
+            sig = sig + ("bf16",)
         check = ("wgrad",) + sig not in rec.seen and not explicit_out
         base = dw.clone() if check else None
         res = orig["conv_wgrad"](x, dy, dw, stride, pad, explicit_out, algo_c)
@@ -274,19 +294,19 @@ def audit(tol=2e-5, tol_wgrad=2e-4, sample=False):
             rec.sampled.add(("wgrad",) + sig)
             got = _c64(res) - _c64(base)
             ks = _k_sample(dw.shape[0])
-            x64 = _c64(x)
-            ref = torch.nn.grad.conv2d_weight(x64, (len(ks),) + tuple(dw.shape[1:]), _c64(dy[:, ks]), stride, pad)
+            x64 = _q64(x, qq)
+            ref = torch.nn.grad.conv2d_weight(x64, (len(ks),) + tuple(dw.shape[1:]), _q64(dy[:, ks], qq), stride, pad)
             del x64
             scale = max(float(ref.abs().max()), 1e-30)
             err = float((got[ks] - ref).abs().max() / scale)
             rec.note("wgrad", sig, err, tol_wgrad)
             if flops >= FULL_FP32_WGRAD_FLOPS:
-                full = torch.nn.grad.conv2d_weight(x.detach().cpu().contiguous(), tuple(dw.shape),
-                                                   dy.detach().cpu().contiguous(), stride, pad).double()
+                full = torch.nn.grad.conv2d_weight(_q64(x, qq).float().contiguous(), tuple(dw.shape),
+                                                   _q64(dy, qq).float().contiguous(), stride, pad).double()
                 rec.note("wgrad_full_fp32", sig, float((got - full).abs().max() / max(float(full.abs().max()), 1e-30)),
                          tol_wgrad)
         elif check:
-            ref = torch.nn.grad.conv2d_weight(x.cpu().double(), tuple(dw.shape), dy.cpu().double(), stride, pad)
+            ref = torch.nn.grad.conv2d_weight(_q64(x, qq), tuple(dw.shape), _q64(dy, qq), stride, pad)
             rec.note("wgrad", sig, _rel(res.cpu().double() - base.cpu().double(), ref), tol_wgrad)
         return res
 

@@ -18,13 +18,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def run(batch=8, size=1024, steps=2, dcn=True, backbone="hourglass"):
+def run(batch=8, size=1024, steps=5, dcn=True, backbone="hourglass", bf16=None):
+    """bf16 (default: with the DCN heads): cfg.Model.bf16 — bf16 matrix operands in EVERY convolution of the backbone and
+    the heads (csrc/conv_bf16.hip), not only in the six deformable layers."""
+    bf16 = dcn if bf16 is None else bf16
     from rrnet_amd.configs.rrnet_config import Config as cfg
     from rrnet_amd.operators.rrnet_operator import RRNetOperator
     saved = (cfg.Train.batch_size, cfg.Train.crop_size, cfg.Model.backbone, getattr(cfg.Model, "dcn_heads", False),
-             getattr(cfg.Model, "dcn_bf16", False))
+             getattr(cfg.Model, "dcn_bf16", False), getattr(cfg.Model, "bf16", False))
     cfg.Train.batch_size, cfg.Train.crop_size, cfg.Model.backbone = batch, (size, size), backbone
-    cfg.Model.dcn_heads, cfg.Model.dcn_bf16 = dcn, dcn
+    cfg.Model.dcn_heads, cfg.Model.dcn_bf16, cfg.Model.bf16 = dcn, dcn, bf16
     if cfg.Distributed.gpu_id < 0:
         cfg.Distributed.gpu_id, cfg.Distributed.rank, cfg.Distributed.world_size = 0, 0, 1
     try:
@@ -53,13 +56,21 @@ def run(batch=8, size=1024, steps=2, dcn=True, backbone="hourglass"):
             one()
         torch.cuda.synchronize()
         t = (time.perf_counter() - t0) / steps
-        return {"value": round(batch / t, 4), "unit": "images/sec", "ms_per_step": round(t * 1e3, 2), "steps": steps,
-                "dcn_layers": n_dcn,
-                "workload": ("RRNet hourglass-104 + %d DCN head layers (bf16 matrix operands, offsets ~ N(0,1)) train step, "
-                             "B=%d, %dx%d" % (n_dcn, batch, size, size)) if dcn else
-                            "RRNet hourglass-104 train step, B=%d, %dx%d (no DCN heads)" % (batch, size, size)}
+        out = {"value": round(batch / t, 4), "unit": "images/sec", "ms_per_step": round(t * 1e3, 2), "steps": steps,
+               "dcn_layers": n_dcn, "dtype": "bf16 matrix operands, fp32 accumulation / storage" if bf16 else "f32",
+               "workload": (("RRNet hourglass-104 + %d DCN head layers (offsets ~ N(0,1)) train step, B=%d, %dx%d"
+                             % (n_dcn, batch, size, size)) if dcn else
+                            "RRNet hourglass-104 train step, B=%d, %dx%d (no DCN heads)" % (batch, size, size))
+                           + (", bf16 operands in every convolution" if bf16 else "")}
+        if backbone == "hourglass" and size == 1024:
+            # 7.02 TFLOP of convolution per image; the six DCN layers replace plain 3x3 layers of the same FLOPs
+            peak = 2500.0 if bf16 else 157.3
+            out["step_mfma_frac"] = round(out["value"] * 7.02 / peak, 4)
+            out["mfma_peak_tflops"] = peak
+        return out
     finally:
-        (cfg.Train.batch_size, cfg.Train.crop_size, cfg.Model.backbone, cfg.Model.dcn_heads, cfg.Model.dcn_bf16) = saved
+        (cfg.Train.batch_size, cfg.Train.crop_size, cfg.Model.backbone, cfg.Model.dcn_heads, cfg.Model.dcn_bf16,
+         cfg.Model.bf16) = saved
 
 
 if __name__ == "__main__":
@@ -68,7 +79,10 @@ if __name__ == "__main__":
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--backbone", default="hourglass")
-    ap.add_argument("--plain", action="store_true")
+    ap.add_argument("--plain", action="store_true", help="no DCN heads")
+    ap.add_argument("--fp32", action="store_true", help="fp32 convolutions (round 3's config-4 definition: only the DCN layers in bf16)")
+    ap.add_argument("--bf16", action="store_true", help="bf16 convolutions even with --plain")
     a = ap.parse_args()
     torch.cuda.set_device(0)
-    print(json.dumps(run(a.batch, a.size, a.steps, not a.plain, a.backbone)))
+    bf16 = True if a.bf16 else (False if a.fp32 else None)
+    print(json.dumps(run(a.batch, a.size, a.steps, not a.plain, a.backbone, bf16)))
