@@ -141,6 +141,12 @@ int rr_conv_dgrad_s1_relubias_bf16(const float *dy, const float *wt, float *dx, 
                                    double *slab, double *sums, hipStream_t stream);
 int rr_conv_wgrad_bf16(const float *x, const float *dy, float *dw, int n, int h, int wd, int c, int k,
                        int r, int s, int stride, int pad_h, int pad_w, int out_h, int out_w, hipStream_t stream);
+/* Stride-2 data gradient (rr_conv_dgrad with stride 2) on the bf16 forward kernel: one launch per output parity class
+ * (h % 2, w % 2) with that class's sub-filter (1 / 2 / 2 / 4 taps of a 3x3), written to every second pixel of dx
+ * [n,h,w,c]; classes no tap reaches are zeroed (unless accumulating).  w OHWI fp32; wsub: k*r*s*c floats of caller
+ * scratch (the packed sub-filters).  C, K multiples of 4. */
+int rr_conv_dgrad_s2_bf16(const float *dy, const float *w, float *dx, int n, int h, int wd, int c, int k,
+                          int r, int s, int pad_h, int pad_w, int accumulate, float *wsub, hipStream_t stream);
 
 /* ---- BatchNorm / ReLU / residual / up-path / Adam (HBM-bound NHWC elementwise) -------- *
  * Replace nn.BatchNorm2d (SyncBatchNorm via operators/rrnet_operator.py:27) + ReLU + residual

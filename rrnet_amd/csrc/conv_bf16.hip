@@ -73,6 +73,9 @@ struct ConvArgs {
     int relu, accumulate;
     int M, wK, wC;
     int ksplit;
+    // strided destination (stride-2 data gradient, one output parity class per launch): logical output pixel (n, h, w) of
+    // the DH x DW grid lands at physical pixel (n, h * osh + oh0, w * osw + ow0) of an OH x OW map; osh == 0: dense
+    int OH, OW, osh, osw, oh0, ow0;
 };
 
 // 128 x BN output tile, 256 threads = 4 waves (BN 128: 2x2 waves of 64x64; BN 64: 4x1 waves of 32x64; BN 32: 4x1 of 32x32)
@@ -190,9 +193,8 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(const ConvArgs a)
         for (int j = 0; j < AJ; ++j)
             *reinterpret_cast<u16x4 *>(A + (a_row + RPP * j) * LDK + a_col) = f2bf4(ra[j]);
 #pragma unroll
-        for (int j = 0; j < BJ; ++j)
-            if ((a_row + RPP * j) < BN)
-                *reinterpret_cast<u16x4 *>(B + (a_row + RPP * j) * LDK + a_col) = f2bf4(rb[j]);
+        for (int j = 0; j < BJ; ++j)          // (a_row + RPP * j < BN always: BJ = BN / RPP, a_row < RPP — no guard, no exec-mask branch)
+            *reinterpret_cast<u16x4 *>(B + (a_row + RPP * j) * LDK + a_col) = f2bf4(rb[j]);
     };
 
     f32x16 acc[TM][TN];
@@ -304,7 +306,13 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(const ConvArgs a)
                 float v = acc[i][j][e] + bv;
                 if (a.relu) v = v > 0.f ? v : 0.f;
                 if (m < a.M && n_ok) {
-                    float *p = a.dst + (long)m * a.DC + ncol;
+                    long pix = m;
+                    if (a.osh) {
+                        const int n = m / hw, rem = m - n * hw;
+                        const int h = rem / a.DW;
+                        pix = ((long)n * a.OH + (h * a.osh + a.oh0)) * a.OW + ((rem - h * a.DW) * a.osw + a.ow0);
+                    }
+                    float *p = a.dst + pix * a.DC + ncol;
                     if (mode_e == 2) {
                         unsafeAtomicAdd(p, v);
                     } else {
@@ -376,6 +384,8 @@ struct BnSumArgs {
     int relu_bias;
 };
 
+struct OutMap { int DH, DW, OH, OW, osh, osw, oh0, ow0; };   // explicit logical output grid + strided destination
+
 size_t igemm_lds(int bn) { return sizeof(unsigned short) * 2 * (size_t)(BM + bn) * LDK; }
 
 template <typename K>
@@ -390,7 +400,7 @@ int launch(K kern, int blocks, int gz, size_t lds, hipStream_t stream, const Con
 
 int fprop_impl(const float *x, const float *w, const float *bias, float *y, double *stat_slab, int n, int h, int wd, int c,
                int k, int r, int s, int stride, int pad_h, int pad_w, int relu, int accumulate, hipStream_t stream,
-               const BnSumArgs *bs = nullptr)
+               const BnSumArgs *bs = nullptr, const OutMap *om = nullptr)
 {
     RR_CHECK_ARG(n > 0 && h > 0 && wd > 0 && c > 0 && k > 0 && r > 0 && s > 0 && stride > 0, "rr_conv_fprop_bf16: bad dims");
     RR_CHECK_ARG(c % 4 == 0 && r * s <= 64, "rr_conv_fprop_bf16: C=%d must be a multiple of 4 and R*S <= 64 (fp32 path for the rest)", c);
@@ -398,20 +408,30 @@ int fprop_impl(const float *x, const float *w, const float *bias, float *y, doub
     a.src = x; a.w = w; a.dst = y; a.bias = bias; a.stat_slab = stat_slab;
     a.N = n; a.SH = h; a.SW = wd; a.SC = c;
     a.DH = (h + 2 * pad_h - r) / stride + 1; a.DW = (wd + 2 * pad_w - s) / stride + 1; a.DC = k;
+    if (om != nullptr) {        // pads are LEADING pads; taps past the far edge are masked by the gather
+        a.DH = om->DH; a.DW = om->DW; a.OH = om->OH; a.OW = om->OW; a.osh = om->osh; a.osw = om->osw; a.oh0 = om->oh0; a.ow0 = om->ow0;
+    }
     RR_CHECK_ARG(a.DH > 0 && a.DW > 0, "rr_conv_fprop_bf16: empty output");
     a.R = r; a.S = s; a.stride = stride; a.pad_h = pad_h; a.pad_w = pad_w;
     a.relu = relu; a.accumulate = accumulate; a.ksplit = 1;
     const long M = (long)n * a.DH * a.DW;
     RR_CHECK_ARG(M < (1l << 31) && (long)n * h * wd * c * 4 < (1l << 31) && (long)k * r * s * c * 4 < (1l << 31) && M * k * 4 < (1l << 31),
                  "rr_conv_fprop_bf16: tensors must stay below 2 GiB (32-bit buffer offsets)");
+    RR_CHECK_ARG(om == nullptr || (bs == nullptr && stat_slab == nullptr), "rr_conv_fprop_bf16: strided destination without fused sums");
     a.M = (int)M; a.wK = k; a.wC = c;
     int bn = k > 64 ? 128 : (k > 32 ? 64 : 32);
+    {
+        static int force = -1;          // experiment switch: RR_BF16_BN=64 runs the wide layers on 128 x 64 tiles
+        if (force < 0) { const char *e = getenv("RR_BF16_BN"); force = e ? atoi(e) : 0; }
+        if (force == 64 && bn == 128) bn = 64;
+    }
     if (bn == 128 && rr_cdiv(M, BM) * rr_cdiv(k, 128) <= rr_conv_small_tiles()) bn = 32;
     else if (bn == 128 && rr_cdiv(M, BM) * rr_cdiv(k, 128) <= rr_conv_mid_tiles()) bn = 64;
     const int blocks = rr_cdiv(M, BM) * rr_cdiv(k, bn);
     const int nk = rr_cdiv(c, BK) * r * s;
     int ks = (bias == nullptr && !relu && k % 4 == 0 && k <= 1024) ? rr_conv_pick_ksplit(blocks, nk) : 1;
     if (bs != nullptr && bs->relu_bias) ks = 1;
+    if (om != nullptr) ks = 1;       // (the zero fill of a split-K destination would wipe the other parity classes)
     if (ks > 1) {
         a.ksplit = ks;
         if (!accumulate) hipMemsetAsync(y, 0, sizeof(float) * (size_t)M * k, stream);
@@ -643,6 +663,77 @@ extern "C" int rr_conv_dgrad_s1_relubias_bf16(const float *dy, const float *wt, 
     RR_CHECK_ARG(p > 0 && q > 0, "rr_conv_dgrad_s1_relubias_bf16: empty dy");
     const BnSumArgs bs{prod_z, prod_z, nullptr, nullptr, nullptr, nullptr, slab, sums, 1};
     return fprop_impl(dy, wt, nullptr, dx, nullptr, n, p, q, k, c, r, s, 1, r - 1 - pad_h, s - 1 - pad_w, 0, accumulate, stream, &bs);
+}
+
+// Stride-2 data gradient on the forward kernel: dx[n, 2a+ph, 2b+pw, c] = sum over the taps r = r0 + 2i, s = s0 + 2j that
+// reach output parity class (ph, pw) (r0 = (ph + pad_h) & 1) of dY[n, a + (ph+pad_h-r0)/2 - i, ..., k] * w[k][r][s][c] — per
+// class a stride-1 correlation of dY with a sub-filter of ceil / floor (R/2) x (S/2) taps, written to every second pixel.
+// The four sub-filters are packed, flipped and transposed ([c][i'][j'][k], i' = Rc-1-i), into caller scratch of
+// k*r*s*c floats by one kernel; a 3x3 visits 1 / 2 / 2 / 4 taps instead of masking three quarters of a dilated filter.
+__global__ __launch_bounds__(256) void weight_parity_pack_kernel(const float *w, float *wsub, int K, int C, int R, int S,
+                                                                 int pad_h, int pad_w, long total)
+{
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int k = (int)(idx % K);
+        long rest = idx / K;
+        const int tap = (int)(rest % (R * S));
+        const int c = (int)(rest / (R * S));
+        const int r = tap / S, s = tap - r * S;
+        const int ph = (r - pad_h) & 1, pw = (s - pad_w) & 1;
+        const int r0 = (ph + pad_h) & 1, s0 = (pw + pad_w) & 1;
+        const int Rc = (R - r0 + 1) / 2, Sc = (S - s0 + 1) / 2;
+        // class blocks in the order (0,0), (0,1), (1,0), (1,1); block size C * Rc * Sc * K
+        long base = 0;
+        for (int cl = 0; cl < ph * 2 + pw; ++cl) {
+            const int q0 = ((cl >> 1) + pad_h) & 1, t0 = ((cl & 1) + pad_w) & 1;
+            base += (long)C * (q0 < R ? (R - q0 + 1) / 2 : 0) * (t0 < S ? (S - t0 + 1) / 2 : 0) * K;
+        }
+        const int ii = Rc - 1 - (r - r0) / 2, jj = Sc - 1 - (s - s0) / 2;
+        wsub[base + (((long)c * Rc + ii) * Sc + jj) * K + k] = w[((long)k * R * S + tap) * C + c];
+    }
+}
+
+extern "C" int rr_conv_dgrad_s2_bf16(const float *dy, const float *w, float *dx, int n, int h, int wd, int c, int k,
+                                     int r, int s, int pad_h, int pad_w, int accumulate, float *wsub, hipStream_t stream)
+{
+    RR_CHECK_ARG(n > 0 && h > 0 && wd > 0 && c > 0 && k > 0 && r > 0 && s > 0, "rr_conv_dgrad_s2_bf16: bad dims");
+    RR_CHECK_ARG(c % 4 == 0 && k % 4 == 0 && r * s <= 64 && pad_h >= 0 && pad_w >= 0 && wsub != nullptr,
+                 "rr_conv_dgrad_s2_bf16: C, K multiples of 4, R*S <= 64, scratch of k*r*s*c floats required");
+    const int p = (h + 2 * pad_h - r) / 2 + 1, q = (wd + 2 * pad_w - s) / 2 + 1;
+    RR_CHECK_ARG(p > 0 && q > 0, "rr_conv_dgrad_s2_bf16: empty dy");
+    const long total = (long)k * c * r * s;
+    hipLaunchKernelGGL(weight_parity_pack_kernel, dim3((int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256)), dim3(256), 0,
+                       stream, w, wsub, k, c, r, s, pad_h, pad_w, total);
+    RR_CHECK_LAUNCH("rr_conv_dgrad_s2_bf16(pack)");
+    int Rc[4], Sc[4], lead_h[4], lead_w[4];
+    bool any_empty = false;
+    for (int cl = 0; cl < 4; ++cl) {
+        const int ph = cl >> 1, pw = cl & 1;
+        const int r0 = (ph + pad_h) & 1, s0 = (pw + pad_w) & 1;
+        Rc[cl] = r0 < r ? (r - r0 + 1) / 2 : 0;
+        Sc[cl] = s0 < s ? (s - s0 + 1) / 2 : 0;
+        lead_h[cl] = (Rc[cl] - 1) - (ph + pad_h - r0) / 2;
+        lead_w[cl] = (Sc[cl] - 1) - (pw + pad_w - s0) / 2;
+        const int Hc = (h - ph + 1) / 2, Wc = (wd - pw + 1) / 2;
+        if (Hc > 0 && Wc > 0 && Rc[cl] * Sc[cl] == 0) any_empty = true;
+        RR_CHECK_ARG(Rc[cl] * Sc[cl] == 0 || (lead_h[cl] >= 0 && lead_w[cl] >= 0), "rr_conv_dgrad_s2_bf16: unsupported padding %d,%d", pad_h, pad_w);
+    }
+    // parity classes no tap reaches (a 1x1 stride 2: three of four) are zero
+    if (any_empty && !accumulate) hipMemsetAsync(dx, 0, sizeof(float) * (size_t)n * h * wd * c, stream);
+    long base = 0;
+    for (int cl = 0; cl < 4; ++cl) {
+        const int ph = cl >> 1, pw = cl & 1;
+        const int Hc = (h - ph + 1) / 2, Wc = (wd - pw + 1) / 2;
+        const long blk = (long)c * Rc[cl] * Sc[cl] * k;
+        if (blk > 0 && Hc > 0 && Wc > 0) {
+            const OutMap om{Hc, Wc, h, wd, 2, 2, ph, pw};
+            const int rc = fprop_impl(dy, wsub + base, nullptr, dx, nullptr, n, p, q, k, c, Rc[cl], Sc[cl], 1, lead_h[cl], lead_w[cl], 0,
+                                      accumulate, stream, nullptr, &om);
+            if (rc != RR_OK) return rc;
+        }
+        base += blk;
+    }
+    return RR_OK;
 }
 
 extern "C" int rr_conv_wgrad_bf16(const float *x, const float *dy, float *dw, int n, int h, int wd, int c, int k,

@@ -5,6 +5,7 @@ initialisation (uniform(-1/sqrt(n), 1/sqrt(n)) weights, zero bias, zero-initiali
 `dcn_v2_pooling`, `DCNv2Pooling`, `DCNPooling` (:130-300, deformable PS-RoI pooling; no caller anywhere in the
 reference) on rr_dcn_psroi_fwd / _bwd."""
 import math
+import os
 
 import torch
 from torch import nn
@@ -46,6 +47,9 @@ class DCNv2(nn.Module):
                            self.deformable_groups, bf16=self.bf16)
 
 
+_PAD_OFFSET_CONV = os.environ.get("RR_DCN_PAD_OFFSET_CONV", "1") != "0"     # A/B switch
+
+
 class DCN(DCNv2):
     def __init__(self, in_channels, out_channels, kernel_size, stride, padding, dilation=1, deformable_groups=1):
         super().__init__(in_channels, out_channels, kernel_size, stride, padding, dilation, deformable_groups)
@@ -62,7 +66,19 @@ class DCN(DCNv2):
         # `input` has two consumers here (the offset/mask conv and the deformable conv): plain fan-out views, so that a
         # shared gradient accumulator tagged on `input` by an outer fan-out is not mistaken for a single-consumer tag
         xa, xb = RF.fanout(input, 2)
-        out = RF.conv_bias(xa, self.conv_offset_mask)             # the offset / mask conv runs on the MFMA conv kernels
+        # the offset / mask conv runs on the MFMA conv kernels.  Its 3 * dg * kh * kw output channels (27 for a 3x3) are
+        # not a multiple of 4, which would put its two gradients on the scalar-gather kernels (28 ms per config-4 step
+        # for the six head layers): the filter bank is zero-padded to the next multiple of 4 and the extra channel
+        # dropped — same values, vector (and, under cfg.Model.bf16, bf16-operand) kernels forward and backward
+        com = self.conv_offset_mask
+        k = com.weight.shape[0]
+        kp = (k + 3) // 4 * 4
+        if kp != k and _PAD_OFFSET_CONV:
+            wp = torch.cat((com.weight, com.weight.new_zeros((kp - k,) + tuple(com.weight.shape[1:]))), 0)
+            bp = torch.cat((com.bias, com.bias.new_zeros(kp - k))) if com.bias is not None else None
+            out = RF.conv_weight(xa, wp, bp, com.stride[0], tuple(com.padding))[:, :k]
+        else:
+            out = RF.conv_bias(xa, com)
         offset, mask = RF.dcn_offset_mask(out)                    # chunk(3) + cat(o1, o2) + sigmoid(mask): one kernel
         return dcn_v2_conv(xb, offset, mask, self.weight, self.bias, self.stride, self.padding, self.dilation,
                            self.deformable_groups, bf16=self.bf16)

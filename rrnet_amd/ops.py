@@ -263,6 +263,7 @@ class BnLink:
 
 
 _DGRAD_BNSUM = os.environ.get("RR_DGRAD_BNSUM", "1") != "0"
+_BF16_S2_DGRAD = os.environ.get("RR_BF16_S2_DGRAD", "1") != "0"     # A/B: stride-2 data gradients stay on the fp32 kernel
 
 
 def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False, bnsum=None, bnsum_z=None):
@@ -339,6 +340,14 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False,
                         lambda: f1(_C.ptr(dy), _C.ptr(wt), _C.ptr(out), n, h, wd, c, k, r, s, pad[0], pad[1],
                                    int(accumulate), _C.stream()), (n, h, wd, c, k, r, s, stride),
                         4.0 * (dy.numel() + out.numel() * (2 if accumulate else 1) + w.numel())), "rr_conv_dgrad_s1")
+        return out
+    if stride == 2 and _bf16_ok(k, c, r, s, dy, out) and _BF16_S2_DGRAD:
+        # bf16 operands: one launch of the forward kernel per output parity class on its packed sub-filter
+        wsub = torch.empty(k * c * r * s, dtype=torch.float32, device=dy.device)
+        f2 = _C.fn("rr_conv_dgrad_s2_bf16")
+        _C.check(_timed("conv_dgrad_s2+bf16", flops,
+                        lambda: f2(_C.ptr(dy), _C.ptr(w), _C.ptr(out), n, h, wd, c, k, r, s, pad[0], pad[1], int(accumulate),
+                                   _C.ptr(wsub), _C.stream()), (n, h, wd, c, k, r, s, stride)), "rr_conv_dgrad_s2_bf16")
         return out
     f = _C.fn("rr_conv_dgrad")
     _C.check(_timed(_igemm_name("dgrad", c, (k % 4 != 0) or (c % 4 != 0), n * h * wd, stride), flops,

@@ -255,7 +255,7 @@ def audit(tol=2e-5, tol_wgrad=2e-4, sample=False):
               (("relu-masked",) if relu_mask is not None else ())
         flops = 2.0 * dy.numel() * w.shape[1] * w.shape[2] * w.shape[3]
         # bf16 operands: stride-1 layers (the forward kernel on the flipped filter); a 10- / 2-channel dy was zero-padded to 12 / 4
-        qq = stride == 1 and pad[0] < w.shape[2] and pad[1] < w.shape[3] and \
+        qq = (stride == 1 or (stride == 2 and ops._BF16_S2_DGRAD)) and pad[0] < w.shape[2] and pad[1] < w.shape[3] and \
             ops._bf16_ok(w.shape[0] if relu_mask is None else (w.shape[0] + 3) // 4 * 4, w.shape[1], w.shape[2], w.shape[3], dy, res)
         if qq:
             sig = sig + ("bf16",)

@@ -73,17 +73,22 @@ def test_bf16_model_heatmaps_within_the_derived_bound(backbone, size, bs, traini
 
 
 def test_bf16_block_gradients_match_fp32_at_bf16_level():
-    """A well-conditioned slice of the model — ResidualBlock (conv-bn-relu-conv-bn + projection skip, train-mode BN over
-    4 x 64 x 64 samples) followed by a head convolution with bias + ReLU — forward and backward in both precisions from the
-    same weights: outputs and every parameter gradient agree within 2e-2 of their scale (bf16 operands carry 2^-9
-    relative rounding), and differ by more than 1e-4 (the bf16 kernels really ran).  The full network's gradient is not
-    compared end to end: at its random initialisation it is ill-conditioned even in fp32 (tests/test_streams_gpu.py)."""
+    """A slice of the model — ResidualBlock (conv-bn-relu-conv-bn + projection skip, train-mode BN over 4 x 32 x 32
+    samples) followed by a head convolution with bias + ReLU — forward and backward in both precisions from the same
+    weights and a fixed random cotangent.  The output differs by ~4e-3 of its scale (2^-9 per operand).  The gradients
+    differ by more than that, and must: ~0.3 % of the ReLU inputs lie within the forward's bf16 noise of zero and flip
+    their mask, each flip an O(1) change of one element, i.e. ~sqrt(0.003) = 5 % in a sum over pixels (measured: median
+    6.5e-2 of the parameter's max).  So the statement is directional: every parameter gradient (and the input gradient)
+    keeps cosine similarity >= 0.99 and a norm within 5 % of the fp32 one — a wrong operand / scaling / tap order in a
+    bf16 backward kernel gives cos ~ 0 — and the two are not identical (the bf16 kernels really ran).  The kernels
+    themselves are pinned exactly (2e-5) in tests/test_conv_bf16_gpu.py and by the full-size audit below."""
     import torch.nn as nn
     from rrnet_amd import functional as RF, ops
     from rrnet_amd.backbones.hourglass import ResidualBlock
     from rrnet_amd.flat import FlatParams
     res = {}
     x0 = torch.randn(4, 128, 64, 64, generator=torch.Generator().manual_seed(3))
+    g0 = torch.randn(4, 256, 32, 32, generator=torch.Generator().manual_seed(4)).cuda().to(memory_format=CL)
     for bf16 in (False, True):
         torch.manual_seed(5)
         blk = ResidualBlock(128, 256, stride=2).cuda().to(memory_format=CL).train()
@@ -94,19 +99,26 @@ def test_bf16_block_gradients_match_fp32_at_bf16_level():
         x = x0.cuda().to(memory_format=CL).requires_grad_()
         with ops.bf16_scope(bf16):
             y = RF.conv_bias(blk(x), head, relu=True)
-        (y * y).mean().backward()
+        (y * g0).mean().backward()
         torch.cuda.synchronize()
         res[bf16] = (y.detach().clone(), x.grad.clone(), fp.grad.clone(),
                      [((p._rr_grad.data_ptr() - fp.grad.data_ptr()) // 4, p.numel()) for p in fp.params])
     y32, ybf = res[False][0], res[True][0]
     dy = float((ybf - y32).abs().max() / y32.abs().max())
-    dx = float((res[True][1] - res[False][1]).abs().max() / res[False][1].abs().max())
+
+    def cos_ratio(a, b):
+        a, b = a.double().flatten(), b.double().flatten()
+        return float((a @ b) / (a.norm() * b.norm())), float(a.norm() / b.norm())
+    cx = cos_ratio(res[True][1], res[False][1])
     g32, gbf, sl = res[False][2], res[True][2], res[False][3]
-    rel = torch.stack([(gbf[o:o + n] - g32[o:o + n]).abs().max() / g32[o:o + n].abs().max().clamp_min(1e-30) for o, n in sl])
-    print("ResidualBlock + head, bf16 vs fp32: output %.2e, input gradient %.2e, parameter gradients median %.2e worst %.2e"
-          % (dy, dx, float(rel.median()), float(rel.max())))
-    assert 1e-4 < dy < 2e-2 and 1e-4 < dx < 2e-2, (dy, dx)
-    assert float(rel.max()) < 2e-2 and float(rel.median()) > 1e-4, rel
+    cr = [cos_ratio(gbf[o:o + n], g32[o:o + n]) for o, n in sl]
+    print("ResidualBlock + head, bf16 vs fp32: output %.2e of its scale; input gradient cos %.5f norm ratio %.4f; parameter "
+          "gradients: worst cos %.5f, norm ratio in [%.4f, %.4f]" % (dy, cx[0], cx[1], min(c for c, _ in cr),
+                                                                     min(r for _, r in cr), max(r for _, r in cr)))
+    assert 1e-4 < dy < 2e-2, dy
+    assert cx[0] >= 0.99 and abs(cx[1] - 1) < 0.05, cx
+    assert all(c >= 0.99 and abs(r - 1) < 0.05 for c, r in cr), cr
+    assert not torch.equal(g32, gbf)
 
 
 def test_bf16_rrnet_tiny_overfits_one_batch():

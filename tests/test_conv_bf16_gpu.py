@@ -20,7 +20,9 @@ pytestmark = pytest.mark.gpu
 SHAPES = [
     (2, 256, 16, 16, 256, 3, 3, 1, 1, 1, False, False),
     (1, 64, 9, 13, 128, 3, 3, 1, 1, 1, False, False),       # ragged M / N tiles
-    (2, 128, 16, 16, 256, 3, 3, 2, 1, 1, False, False),     # stride-2 3x3 (fprop + wgrad in bf16, dgrad stays fp32)
+    (2, 128, 16, 16, 256, 3, 3, 2, 1, 1, False, False),     # stride-2 3x3 (dgrad: one launch per output parity class)
+    (2, 64, 15, 17, 128, 3, 3, 2, 1, 1, False, False),      # ... odd H and W: the four classes have different sizes
+    (1, 64, 12, 12, 64, 3, 3, 2, 0, 0, False, False),       # ... no padding
     (2, 128, 15, 17, 256, 1, 1, 2, 0, 0, False, False),     # stride-2 1x1 skip, odd size
     (2, 256, 8, 8, 384, 1, 1, 1, 0, 0, False, False),
     (1, 256, 12, 12, 10, 1, 1, 1, 0, 0, True, False),       # hm head 1x1 (BN = 32 tile, N masked)
@@ -92,7 +94,7 @@ def test_bf16_kernels_equal_fp32_kernels_on_rounded_operands(cfg, bf16_switch):
     saved = ops._DGRAD_VIA_FPROP_MIN_PIXELS
     ops._DGRAD_VIA_FPROP_MIN_PIXELS = 0
     try:
-        if stride == 1 and k % 4 == 0:
+        if stride in (1, 2) and k % 4 == 0:
             bf16_switch(True)
             dx = ops.conv_dgrad(gy, wt, (n, c, h, w), stride, (ph, pw))
             base = ops.to_nhwc(_mk((n, c, h, w), 5).cuda())
