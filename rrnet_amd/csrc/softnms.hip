@@ -206,6 +206,323 @@ __device__ void soft_nms_segment(SegView v, const int n, const float sigma, cons
     if (tid == 0) *out_n = N;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Register-resident form (round 4).  The LDS-resident loop above spends ~3.5 us per outer step on an arg-max pass over
+// LDS, five barriers and a compaction that physically moves rows.  Here every lane OWNS NB boxes for the whole run
+// (coordinates, score, precomputed area and the box's current POSITION in the reference's array in registers); nothing
+// is moved, only positions change:
+//   * swap(i, maxpos)                       -> the two boxes exchange their position numbers (two compares per box);
+//   * decay + "is it dead" + the lane's best remaining candidate are ONE pass over the lane's registers;
+//   * the block-wide arg-max is a DPP wave reduction of a sortable (score, ~position) key — ties go to the lowest
+//     position, cpu_nms.pyx:44-52 — plus, for T > 64, one LDS exchange behind ONE barrier (double-buffered slots);
+//     the winner's coordinates travel with its key, so the next step starts right behind that barrier;
+//   * the expensive half of the decay (double-precision union, IEEE division, double exp) runs once per OVERLAPPING box
+//     of the busiest lane, not once per register slot;
+//   * the reference's swap-with-last compaction (pyx:108-115 = a Hoare partition, see above) only renumbers: dead
+//     positions are bits of an LDS mask, a surviving box above the new N finds its hole by two popcount scans, and so
+//     does — redundantly in every lane — the already selected next box: no second reduction unless the maximal score
+//     was tied.  Steps without a death never touch it;
+//   * two waves per SIMD (one wave alone issues a vector instruction every 4 cycles, two waves every 2).
+// Measured on one box, interleaved (round 4): 1.23 us per outer step at N = 150 and 2.28 at N = 1500 against 2.19 / 3.36
+// for the LDS-resident loop (0.94 / 1.58 on steps without deaths); the floor of the bare reduction + exchange chain is
+// 0.64 us (tools/softnms_floor.hip).  A third variant (one DPP prefix scan of the mask + an LDS hole table instead of the
+// popcount searches) was built, bit-exact, and measured no faster: removed.
+// Same arithmetic, same order of selection, same final rows: bit-exact with the LDS form and the reference
+// (tests/test_softnms_gpu.py runs every golden through both).  Latency-bound: tools/bench_softnms.py quotes its
+// us per outer step against the measured floor of the bare reduction + exchange chain.
+__device__ __forceinline__ unsigned sortable_key(float s)
+{
+    unsigned u = __float_as_uint(s);
+    if (u == 0x80000000u) u = 0u;                      // -0.0 == +0.0 in the reference's float compare
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__device__ __forceinline__ unsigned dpp_max_u32(unsigned v)
+{
+    // row_shr 1, 2, 4, 8 inside the 16-lane rows, row_bcast 15 / 31 across them: lane 63 ends with the wave maximum.
+    // Lanes without a source keep their own value (old = v); max is idempotent, so no bank masks are needed.
+    unsigned o;
+#define RR_DPP_STEP(ctrl, rmask)                                                  \
+    o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, ctrl, rmask, 0xf, false); \
+    v = o > v ? o : v;
+    RR_DPP_STEP(0x111, 0xf) RR_DPP_STEP(0x112, 0xf) RR_DPP_STEP(0x114, 0xf) RR_DPP_STEP(0x118, 0xf)
+    RR_DPP_STEP(0x142, 0xa) RR_DPP_STEP(0x143, 0xc)
+#undef RR_DPP_STEP
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+struct RegCand {            // a candidate for the next selection: key = (sortable score, ~position), the box itself
+    unsigned ks, kp;
+    float x1, y1, x2, y2;
+    unsigned tied;          // more than one candidate carries the maximal score (the position decided)
+};
+
+// wave-wide best candidate (highest score, then lowest position) -> every lane holds it
+__device__ __forceinline__ RegCand wave_best(RegCand c)
+{
+    const unsigned ms = dpp_max_u32(c.ks);
+    unsigned long long tie = __ballot(c.ks == ms);
+    int src;
+    const unsigned tied = __popcll(tie) > 1;
+    if (!tied) {
+        src = __ffsll((long long)tie) - 1;
+    } else {                                        // equal scores: the lowest position (largest ~position) wins
+        const unsigned mp = dpp_max_u32(c.ks == ms ? c.kp : 0u);
+        tie = __ballot(c.ks == ms && c.kp == mp);
+        src = __ffsll((long long)tie) - 1;
+    }
+    RegCand r;
+    r.ks = ms;
+    r.tied = tied;
+    r.kp = (unsigned)__builtin_amdgcn_readlane((int)c.kp, src);
+    r.x1 = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(c.x1), src));
+    r.y1 = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(c.y1), src));
+    r.x2 = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(c.x2), src));
+    r.y2 = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(c.y2), src));
+    return r;
+}
+
+constexpr int SMALL_SEG_REG = 256;          // one box per lane of four waves
+constexpr int REG_DEAD = 0x7fffffff;         // position of a box that is out of the game (dead, or a padding slot)
+constexpr int REG_MASK_WORDS = 200;          // 32-bit words of one dead-position mask: positions < 6400
+
+// lds: [2][16] exchange slots of 8 words + [2][REG_MASK_WORDS] dead-position masks (zero on entry)
+template <int T, int NB>
+__device__ __forceinline__ void soft_nms_registers(float *b, const int stride, const int n, const float sigma, const float Nt, const float thr,
+                                   const int method, unsigned *lds, int *out_n, int *err)
+{
+    constexpr int W = T / 64;
+    unsigned *slots = lds;                       // [2][16][8]
+    unsigned *masks = lds + 2 * 16 * 8;          // [2][REG_MASK_WORDS] dead positions of the current / the previous death step
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float x1[NB], y1[NB], x2[NB], y2[NB], sc[NB], ar[NB];
+    unsigned key[NB];                            // sortable_key(sc[j]), refreshed when the score changes
+    int pos[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int p = j * T + tid;
+        if (p < n) {
+            const float *r = b + (size_t)p * stride;
+            x1[j] = r[0]; y1[j] = r[1]; x2[j] = r[2]; y2[j] = r[3]; sc[j] = r[4];
+            ar[j] = (float)(((double)(x2[j] - x1[j]) + 1.0) * ((double)(y2[j] - y1[j]) + 1.0));
+            pos[j] = p;
+            key[j] = sortable_key(sc[j]);
+        } else {
+            x1[j] = y1[j] = x2[j] = y2[j] = sc[j] = ar[j] = 0.f;
+            pos[j] = REG_DEAD;
+            key[j] = 0u;
+        }
+    }
+    int N = n, xbuf = 0, mbuf = 0;
+
+    // block-wide best candidate among the lane candidates `c`; `dead` = deaths of this lane in the current step (summed)
+    auto block_best = [&](RegCand c, int dead, int &dead_total) -> RegCand {
+        RegCand r = wave_best(c);
+        int d = 0;                                 // wave total of the lanes' death counts (0..NB each): NB ballots, no shuffles
+#pragma unroll
+        for (int q = 1; q <= NB; ++q) d += __popcll(__ballot(dead >= q));
+        if (T == 64) {
+            dead_total = d;
+            return r;
+        }
+        // slot = [score key, ~position, deaths, tied | x1, y1, x2, y2]: two 16-byte halves.  Every wave's first half is
+        // read unconditionally (W independent ds_read_b128: one LDS round trip), the winner's box in a second one.
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 *sl = reinterpret_cast<u32x4 *>(slots + (xbuf * 16 + wave) * 8);
+        if (lane == 0) {
+            sl[0] = u32x4{r.ks, r.kp, (unsigned)d, r.tied};
+            sl[1] = u32x4{__float_as_uint(r.x1), __float_as_uint(r.y1), __float_as_uint(r.x2), __float_as_uint(r.y2)};
+        }
+        __syncthreads();
+        const u32x4 *s0 = reinterpret_cast<const u32x4 *>(slots + xbuf * 16 * 8);
+        xbuf ^= 1;                                 // the other set of slots next time: no second barrier per step
+        u32x4 h[W];
+#pragma unroll
+        for (int w = 0; w < W; ++w) h[w] = s0[2 * w];
+        unsigned bs = h[0][0], bp = h[0][1], tied = h[0][3];
+        int bw = 0, tot = (int)h[0][2];
+#pragma unroll
+        for (int w = 1; w < W; ++w) {
+            const unsigned os = h[w][0], op = h[w][1];
+            tot += (int)h[w][2];
+            const bool same = os == bs && bs != 0u;                   // two waves share the maximal score
+            const bool better = os > bs || (os == bs && op > bp);
+            tied = same ? 1u : (os > bs ? h[w][3] : tied);
+            bs = better ? os : bs;
+            bp = better ? op : bp;
+            bw = better ? w : bw;
+        }
+        dead_total = tot;
+        const u32x4 box = s0[2 * bw + 1];
+        RegCand q;
+        q.ks = bs; q.kp = bp; q.tied = tied;
+        q.x1 = __uint_as_float(box[0]); q.y1 = __uint_as_float(box[1]);
+        q.x2 = __uint_as_float(box[2]); q.y2 = __uint_as_float(box[3]);
+        return q;
+    };
+    // the lane's best candidate among its boxes at positions (lo, N)
+    auto lane_best = [&](int lo) -> RegCand {
+        RegCand c;
+        c.ks = 0u; c.kp = 0u; c.x1 = c.y1 = c.x2 = c.y2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            if (pos[j] > lo && pos[j] < N) {
+                const unsigned ks = key[j], kp = ~(unsigned)pos[j];
+                if (ks > c.ks || (ks == c.ks && kp > c.kp)) {
+                    c.ks = ks; c.kp = kp; c.x1 = x1[j]; c.y1 = y1[j]; c.x2 = x2[j]; c.y2 = y2[j];
+                }
+            }
+        }
+        return c;
+    };
+
+    int dummy;
+    RegCand sel = block_best(lane_best(-1), 0, dummy);
+    int my_err = 0;
+    for (int i = 0; i < N; ++i) {
+        const int maxpos = (int)~sel.kp;
+        const float tx1 = sel.x1, ty1 = sel.y1, tx2 = sel.x2, ty2 = sel.y2;
+        const double tarea = ((double)(tx2 - tx1) + 1.0) * ((double)(ty2 - ty1) + 1.0);
+        // ---- swap i <-> maxpos (position numbers only) and the cheap half of the decay: which of my boxes in (i, N) overlap
+        // the selected one at all (iw > 0 and ih > 0)?  Typically a handful of the segment's boxes do.
+        unsigned ovl = 0u;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            int p = pos[j];
+            p = (p == maxpos) ? i : ((p == i) ? maxpos : p);
+            pos[j] = p;
+            // (float)((double)d + 1.0) == d + 1.0f (one correctly rounded add).  v_min / v_max instead of the reference's
+            // `a <= b ? a : b`: they differ only in the sign of a zero result, which the "+ 1" erases (finite inputs)
+            const float iw = (__builtin_fminf(tx2, x2[j]) - __builtin_fmaxf(tx1, x1[j])) + 1.0f;
+            const float ih = (__builtin_fminf(ty2, y2[j]) - __builtin_fmaxf(ty1, y1[j])) + 1.0f;
+            if (p > i && p < N && iw > 0.0f && ih > 0.0f) ovl |= 1u << j;
+        }
+        // ---- the expensive half (double-precision union, IEEE division, double exp) runs once per OVERLAPPING box of the
+        // busiest lane, not once per register slot that holds an overlapping box somewhere in the wave: every lane picks
+        // its lowest pending slot, gathers that box with selects (no dynamically indexed registers), updates its score
+        unsigned deadbits = 0u;
+        while (__any(ovl != 0u)) {
+            if (ovl != 0u) {
+                const int j = __ffs((int)ovl) - 1;
+                ovl &= ovl - 1u;
+                float bx1 = x1[0], by1 = y1[0], bx2 = x2[0], by2 = y2[0], bsc = sc[0], bar = ar[0];
+#pragma unroll
+                for (int jj = 1; jj < NB; ++jj) {
+                    const bool t = j == jj;
+                    bx1 = t ? x1[jj] : bx1; by1 = t ? y1[jj] : by1; bx2 = t ? x2[jj] : bx2; by2 = t ? y2[jj] : by2;
+                    bsc = t ? sc[jj] : bsc; bar = t ? ar[jj] : bar;
+                }
+                const float iw = (__builtin_fminf(tx2, bx2) - __builtin_fmaxf(tx1, bx1)) + 1.0f;
+                const float ih = (__builtin_fminf(ty2, by2) - __builtin_fmaxf(ty1, by1)) + 1.0f;
+                const float ua = (float)((tarea + (double)bar) - (double)(iw * ih));
+                if (ua == 0.0f) my_err = 1;
+                const float ov = (iw * ih) / ua;
+                float weight;
+                if (method == 1) {
+                    weight = (ov > Nt) ? (float)(1.0 - (double)ov) : 1.0f;
+                } else if (method == 2) {
+                    const float q = (-(ov * ov)) / sigma;
+                    weight = (float)exp((double)q);
+                } else {
+                    weight = (ov > Nt) ? 0.0f : 1.0f;
+                }
+                const float ns = weight * bsc;
+#pragma unroll
+                for (int jj = 0; jj < NB; ++jj) {
+                    sc[jj] = (j == jj) ? ns : sc[jj];
+                    key[jj] = (j == jj) ? sortable_key(ns) : key[jj];
+                }
+                if (ns < thr) deadbits |= 1u << j;
+            }
+        }
+        // ---- the lane's best surviving candidate for the next step
+        RegCand c;
+        c.ks = 0u; c.kp = 0u; c.x1 = c.y1 = c.x2 = c.y2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int p = pos[j];
+            if (p > i && p < N && !(deadbits & (1u << j))) {
+                const unsigned ks = key[j], kp = ~(unsigned)p;
+                if (ks > c.ks || (ks == c.ks && kp > c.kp)) {
+                    c.ks = ks; c.kp = kp; c.x1 = x1[j]; c.y1 = y1[j]; c.x2 = x2[j]; c.y2 = y2[j];
+                }
+            }
+        }
+        const int ndead = __popc(deadbits);
+        int D;
+        sel = block_best(c, ndead, D);
+        if (D == 0) continue;
+        // ---- renumbering = the reference's swap-with-last compaction: the k-th dead position from the left below the new
+        // N receives the k-th surviving box from the right end.  Dead positions of this step -> bits of an LDS mask.
+        unsigned *mk = masks + mbuf * REG_MASK_WORDS;
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+            if (deadbits & (1u << j)) atomicOr(&mk[pos[j] >> 5], 1u << (pos[j] & 31));
+        __syncthreads();
+        const int newN = N - D;
+        // new position of a survivor that sits at p in [newN, N): its rank r from the right among the survivors of that
+        // range is the index, from the left, of the dead position in (i, newN) it moves to
+        auto new_pos = [&](int p) -> int {
+            int deadabove = 0;
+            if (p + 1 < N) {
+                const int w0 = (p + 1) >> 5, w1 = (N - 1) >> 5;
+                for (int w = w0; w <= w1; ++w) {
+                    unsigned m = mk[w];
+                    if (w == w0) m &= ~0u << ((p + 1) & 31);
+                    if (w == w1 && ((N & 31) != 0)) m &= (1u << (N & 31)) - 1u;
+                    deadabove += __popc(m);
+                }
+            }
+            int r = (N - 1 - p) - deadabove;
+            const int lo = i + 1;
+            const int w0 = lo >> 5, w1 = (newN - 1) >> 5;
+            for (int w = w0; w <= w1; ++w) {
+                unsigned m = mk[w];
+                if (w == w0) m &= ~0u << (lo & 31);
+                if (w == w1 && ((newN & 31) != 0)) m &= (1u << (newN & 31)) - 1u;
+                const int cnt = __popc(m);
+                if (r < cnt) {
+                    for (int q = 0; q < r; ++q) m &= m - 1u;
+                    return (w << 5) + (__ffs((int)m) - 1);
+                }
+                r -= cnt;
+            }
+            return p;
+        };
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int p = pos[j];
+            if (deadbits & (1u << j)) pos[j] = REG_DEAD;
+            else if (p >= newN && p < N) pos[j] = new_pos(p);
+        }
+        // The next selection was made on the old numbering.  Its score is still the maximum; unless that maximum was
+        // shared (a tie is decided by position, and positions just changed: select again, rare) only its own position
+        // may have moved — every lane renumbers it for itself, no second reduction, no further barrier.
+        if (sel.tied || sel.ks == 0u) {
+            N = newN;
+            sel = block_best(lane_best(i), 0, dummy);
+        } else {
+            const int q = (int)~sel.kp;
+            if (q >= newN && q < N) sel.kp = ~(unsigned)new_pos(q);
+            N = newN;
+        }
+        // the OTHER mask (the previous death step's) is cleared now: every wave left it at least one barrier ago; this
+        // one is read until the next barrier and will be cleared by the next death step
+        mbuf ^= 1;
+        for (int w = tid; w < REG_MASK_WORDS; w += T) masks[mbuf * REG_MASK_WORDS + w] = 0u;
+    }
+    if (my_err) *err = 1;
+    // rows [0, N) in selection order = position order
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        if (pos[j] < N) {
+            float *r = b + (size_t)pos[j] * stride;
+            r[0] = x1[j]; r[1] = y1[j]; r[2] = x2[j]; r[3] = y2[j]; r[4] = sc[j];
+        }
+    }
+    if (tid == 0) *out_n = N;
+}
+
 constexpr int SMALL_SEG = 192;   // segments up to this many boxes run on one wave
 constexpr int MID_SEG = 512;     // first launch of the two-launch split: LDS for this many boxes (12.8 KB)
 
@@ -270,6 +587,37 @@ __global__ __launch_bounds__(T) void soft_nms_kernel(float *boxes, const int *se
     if (threadIdx.x == 0) n_out[seg] = nn;
 }
 
+// One workgroup per segment, boxes in registers (soft_nms_registers).  Segments of up to 192 boxes inside a launch sized for
+// longer ones run on the first wave alone (no barriers at all in their ~N steps).
+template <int T, int NB>
+__global__ __launch_bounds__(T) void soft_nms_reg_kernel(float *boxes, const int *seg_off, const int *seg_len, int stride,
+                                                         float sigma, float Nt, float thr, int method, int *n_out, int *err)
+{
+    __shared__ __align__(16) unsigned lds[2 * 16 * 8 + 2 * REG_MASK_WORDS];
+    const int seg = blockIdx.x;
+    const int off = seg_off[seg];
+    const int n = seg_len ? seg_len[seg] : seg_off[seg + 1] - off;
+    for (int w = threadIdx.x; w < 2 * 16 * 8 + 2 * REG_MASK_WORDS; w += T) lds[w] = 0u;
+    __syncthreads();
+    float *b = boxes + (size_t)off * stride;
+    if (T > 256 && n <= SMALL_SEG_REG) {         // a short segment in a launch sized for long ones: the first four waves, one box each
+        if (threadIdx.x >= 256) return;
+        soft_nms_registers<256, 1>(b, stride, n, sigma, Nt, thr, method, lds, &n_out[seg], err);
+        return;
+    }
+    soft_nms_registers<T, NB>(b, stride, n, sigma, Nt, thr, method, lds, &n_out[seg], err);
+}
+
+int softnms_reg_enabled()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("RR_SOFTNMS_REG");
+        v = (e == nullptr || atoi(e) != 0) ? 1 : 0;      // 0: the LDS-resident loop (A/B switch)
+    }
+    return v;
+}
+
 }  // namespace
 
 extern "C" size_t rr_soft_nms_workspace_bytes(int total_boxes, int max_seg_boxes)
@@ -301,6 +649,26 @@ static int soft_nms_launch(float *boxes, const int *seg_off, const int *seg_len,
                            seg_len, stride, sigma, Nt, threshold, method, (CAP), n_out, err_flag, gws, (LO), (HI)); \
     } while (0)
     constexpr int ALL = 0x7fffffff;
+    // Regime: a few segments (an image's classes at evaluation, rrnet_operator.py:246-284) are a latency problem — the
+    // register-resident kernel; a batch of more long segments than two per CU is a throughput problem, where the LDS loop's
+    // 256-thread workgroups (4 per CU) retire more segments per unit time (1280 x 1500 boxes: 5.5 against 6.0 ms)
+    const bool throughput_regime = nseg > 512 && max_seg_boxes > 256;
+    if (in_lds && softnms_reg_enabled() && !throughput_regime) {
+        // register-resident kernels: T x NB boxes per segment
+#define LAUNCH_REG(T, NB)                                                                                              \
+        hipLaunchKernelGGL((soft_nms_reg_kernel<T, NB>), dim3(nseg), dim3(T), 0, stream, boxes, seg_off, seg_len, stride, sigma, \
+                           Nt, threshold, method, n_out, err_flag)
+        // One wave alone on a SIMD issues a vector instruction every 4 cycles, two waves one every 2: the configurations put
+        // (at least) two waves on every SIMD of the CU wherever the segment is long enough to feed them
+        // (measured: 1024 x 2 for 1500 boxes, four waves per SIMD, is 30 % slower than 512 x 3: a 16-wave barrier and exchange)
+        if (max_seg_boxes <= 256) LAUNCH_REG(256, 1);
+        else if (max_seg_boxes <= 1536) LAUNCH_REG(512, 3);
+        else if (max_seg_boxes <= 3072) LAUNCH_REG(1024, 3);
+        else LAUNCH_REG(1024, 6);
+#undef LAUNCH_REG
+        RR_CHECK_LAUNCH("rr_soft_nms_segments");
+        return RR_OK;
+    }
     if (max_seg_boxes <= SMALL_SEG) LAUNCH(64, lds, cap, -1, ALL);
     else if (in_lds && max_seg_boxes > MID_SEG) {
         // The caller's bound is the LONGEST possible segment (K = 1500 at inference: 37.5 KB of LDS per workgroup = four
