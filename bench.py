@@ -268,7 +268,7 @@ def main():
                 # (tools/prof_bench.sh -> tools/pmc_traffic.py -> profiles/rNN_traffic_pmc.json); PMC counters
                 # cannot be read from inside the process, so the field names its source
                 traffic, traffic_source = None, None
-                for tag in ("r03", "r02", "r01"):
+                for tag in ("r04", "r03", "r02", "r01"):
                     tpath = os.path.join(ROOT, "profiles", "%s_traffic_pmc.json" % tag)
                     if os.path.exists(tpath) and a.backbone == "hourglass" and a.size == 1024 and a.batch == 8:
                         with open(tpath) as f:

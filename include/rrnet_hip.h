@@ -79,6 +79,11 @@ int rr_conv_dgrad(const float *dy, const float *w, float *dx, int n, int h, int 
  * rr_conv_dgrad_s1(dy [n,p,q,k], wt) = dx [n,h,w,c], p = h + 2*pad_h - r + 1.  Same result as rr_conv_dgrad
  * (different summation order inside the fp32 accumulation chain). */
 int rr_weight_flip_transpose(const float *w, float *wt, int k, int c, int r, int s, hipStream_t stream);
+/* The same for every filter of a flat parameter buffer in ONE launch (host layer: rrnet_amd/flat.py keeps the flipped copies
+ * of all stride-1 layers in a second flat buffer, refreshed once per optimizer step): table = ntiles x int4 {element offset
+ * of the filter in flat / wt_flat, (r*s) << 16 | k, c, tap << 20 | k_tile << 10 | c_tile}, one 32 x 32 tile of the (k, c)
+ * plane of one tap per workgroup.  Filters of up to 65535 output channels, 1024 tiles per side, r*s < 2048. */
+int rr_weight_flip_transpose_batch(const float *flat, float *wt_flat, const int *table, int ntiles, hipStream_t stream);
 int rr_conv_dgrad_s1(const float *dy, const float *wt, float *dx, int n, int h, int wd, int c, int k,
                      int r, int s, int pad_h, int pad_w, int accumulate, hipStream_t stream);
 /* Small-channel convolutions (the 7x7 stride-2 stem on a 3-channel image, backbones/hourglass.py:143): rr_conv_pack_taps

@@ -68,9 +68,63 @@ class FlatParams:
                 self._bucket_need.append(need)
                 start, need = end, 0
         self._index_of = {id(p): i for i, p in enumerate(params)}
+        self._offs = {id(p): o for p, o in zip(params, offs)}
+        # flipped / transposed copies of the 4-D filters for the stride-1 data gradients (rr_conv_dgrad_s1*): one flat
+        # buffer with the parameters' offsets, filled by ONE launch per optimizer step instead of one launch per layer
+        # inside backward (lazily allocated at the first data gradient; RR_WT_CACHE=0: per-layer launches as before)
+        self.wt_flat = None
+        self._wt_table = None
+        self._wt_version = None
+        self._wt_enabled = os.environ.get("RR_WT_CACHE", "1") != "0" and dev.type == "cuda"
         self.overlap = os.environ.get("RR_DP_OVERLAP", "1") != "0"
         self._pg = None
         self._begin_step()
+
+    def _build_wt_table(self):
+        import numpy as np
+        rows = []
+        for p in self.params:
+            if p.dim() != 4:
+                continue
+            k, c, r, s = p.shape
+            if k > 65535 or r * s >= 2048 or (k + 31) // 32 > 1023 or (c + 31) // 32 > 1023:
+                continue
+            o = self._offs[id(p)]
+            kt, ct = (k + 31) // 32, (c + 31) // 32
+            tap, ki, ci = np.meshgrid(np.arange(r * s), np.arange(kt), np.arange(ct), indexing="ij")
+            n = tap.size
+            t = np.empty((n, 4), dtype=np.int32)
+            t[:, 0] = o
+            t[:, 1] = ((r * s) << 16) | k
+            t[:, 2] = c
+            t[:, 3] = (tap.reshape(-1) << 20) | (ki.reshape(-1) << 10) | ci.reshape(-1)
+            rows.append(t)
+        tab = np.concatenate(rows) if rows else np.zeros((0, 4), dtype=np.int32)
+        self._wt_table = torch.from_numpy(tab).to(self.flat.device)
+
+    def refresh_wt(self):
+        """Refill the flipped-filter cache from the current parameters (one launch).  Called by FlatAdam.step right after
+        the update kernel, and by wt_view when the parameters were written some other way (load_state_dict, broadcast)."""
+        if not self._wt_enabled or self.wt_flat is None:
+            return
+        from rrnet_amd import _C
+        _C.check(_C.fn("rr_weight_flip_transpose_batch")(_C.ptr(self.flat), _C.ptr(self.wt_flat), _C.ptr(self._wt_table),
+                                                         self._wt_table.shape[0], _C.stream()), "rr_weight_flip_transpose_batch")
+        self._wt_version = self.flat._version
+
+    def wt_view(self, p):
+        """Flat fp32 tensor [k*c*r*s] holding wt[c][R-1-r][S-1-s][k] of the 4-D parameter p, or None (cache off, p not a
+        filter of this buffer)."""
+        if not self._wt_enabled or p.dim() != 4 or id(p) not in self._offs:
+            return None
+        if self.wt_flat is None:
+            self._build_wt_table()
+            self.wt_flat = torch.empty_like(self.flat)
+            self._wt_version = None
+        if self._wt_version != self.flat._version:       # parameters written since the last fill (or never filled)
+            self.refresh_wt()
+        o = self._offs[id(p)]
+        return self.wt_flat[o:o + p.numel()]
 
     def _begin_step(self):
         nb = len(self._bucket_range)
@@ -198,3 +252,4 @@ class FlatAdam(torch.optim.Optimizer):
         self.step_count += 1
         ops.adam_step(self.fp.flat, self.fp.grad, self.exp_avg, self.exp_avg_sq, g['lr'], g['betas'][0], g['betas'][1],
                       g['eps'], self.step_count, scale)
+        self.fp.refresh_wt()          # the update kernel wrote through raw pointers: refill the flipped-filter cache now

@@ -221,7 +221,7 @@ class _ConvBnAct(torch.autograd.Function):
                                  g_into=g_into)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = _input_grad(dy, wc, ctx.xshape, stride, pad, x_acc, in_link, x)
+            dx = _input_grad(dy, wc, ctx.xshape, stride, pad, x_acc, in_link, x, w)
         w_t = _grad_target(w)
         ret_dw = None
         stem = (not ctx.packed and tuple(w.shape[1:]) == (3, 7, 7) and stride == 2 and tuple(pad) == (3, 3)
@@ -254,22 +254,29 @@ class _ConvBnAct(torch.autograd.Function):
         return dx, ret_dw, ret_dg, ret_db, dres, None, None, None, None, None, None, None, None
 
 
-def _input_grad(dy, wc, xshape, stride, pad, x_acc, in_link, x):
+def _wt_of(w_param):
+    """The cached flipped / transposed copy of a filter parameter that lives in a FlatParams buffer (None otherwise)."""
+    flat = getattr(w_param, "_rr_flat", None) if w_param is not None else None
+    return flat.wt_view(w_param) if flat is not None else None
+
+
+def _input_grad(dy, wc, xshape, stride, pad, x_acc, in_link, x, w_param=None):
     """Data gradient of a convolution node -> the tensor to hand to autograd (None when it was added into the fan-in
     buffer of x's fan-out).  Where the launch can carry them it also produces the BatchNorm-backward sums of the layer
     that produced x (ops.BnLink): when x has this node as its only consumer, or when this node is the LAST registered
     contributor to the fan-in buffer of x's fan-out (the epilogue then holds the complete gradient)."""
     _wgrad_join(dy.device)        # the previous layer's weight gradient has had the HBM-bound stretch to itself
+    wt = _wt_of(w_param) if stride == 1 else None
     if x_acc is None:
         link = in_link if (in_link is not None and in_link.consumers == 1) else None
-        return ops.conv_dgrad(dy, wc, xshape, stride, pad, bnsum=link, bnsum_z=x)
+        return ops.conv_dgrad(dy, wc, xshape, stride, pad, bnsum=link, bnsum_z=x, wt=wt)
     link = x_acc.link if x_acc.pending == 1 else None
     x_acc.pending -= 1
     if x_acc.buf is not None:
         # another consumer of x already produced its gradient: add into it inside the dgrad epilogue
-        ops.conv_dgrad(dy, wc, xshape, stride, pad, out=x_acc.buf, accumulate=True, bnsum=link, bnsum_z=x)
+        ops.conv_dgrad(dy, wc, xshape, stride, pad, out=x_acc.buf, accumulate=True, bnsum=link, bnsum_z=x, wt=wt)
         return None
-    x_acc.buf = ops.conv_dgrad(dy, wc, xshape, stride, pad, bnsum=link, bnsum_z=x)
+    x_acc.buf = ops.conv_dgrad(dy, wc, xshape, stride, pad, bnsum=link, bnsum_z=x, wt=wt)
     return x_acc.buf
 
 
@@ -394,7 +401,7 @@ class _ConvBnSyncMulti(torch.autograd.Function):
                                      cnt_devs[i], msc, msh)
             if ctx.needs_input_grad[0]:
                 if x_acc is not None:
-                    r = _input_grad(dy, ws[i], xshape, stride, pad, x_acc, None, x)
+                    r = _input_grad(dy, ws[i], xshape, stride, pad, x_acc, None, x, params[3 * i])
                     dx = r if r is not None else dx
                 elif dx is None:
                     dx = ops.conv_dgrad(dy, ws[i], xshape, stride, pad)
@@ -491,7 +498,7 @@ class _ConvBias(torch.autograd.Function):
             dy = ops.sum_n([dy], y)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = _input_grad(dy, wc, ctx.xshape, stride, pad, ctx.x_acc, ctx.in_link, x)
+            dx = _input_grad(dy, wc, ctx.xshape, stride, pad, ctx.x_acc, ctx.in_link, x, w)
         w_t = _grad_target(w)
         ret_dw = None
         if w_t is not None:

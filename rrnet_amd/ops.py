@@ -266,8 +266,9 @@ _DGRAD_BNSUM = os.environ.get("RR_DGRAD_BNSUM", "1") != "0"
 _BF16_S2_DGRAD = os.environ.get("RR_BF16_S2_DGRAD", "1") != "0"     # A/B: stride-2 data gradients stay on the fp32 kernel
 
 
-def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False, bnsum=None, bnsum_z=None):
+def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False, bnsum=None, bnsum_z=None, wt=None):
     """dy [N,K,P,Q], w [K,C,R,S] -> dx [N,C,H,W]; with `out` and accumulate adds into it.
+    wt: the flipped / transposed filter (rr_weight_flip_transpose of w) when the caller keeps one (FlatParams.wt_view).
     bnsum (BnLink of the layer that produced the convolution's input): when the launch can carry them, the producer's
     BatchNorm-backward sums are computed in the epilogue and left in bnsum.sums / bnsum.dz.  bnsum_z: the
     convolution's input itself (= the producer's output), needed when bnsum.use_z."""
@@ -294,8 +295,9 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False,
                      "rr_pad_channels")
             wp = zeros_nhwc(kp, c, r, s, dy.device)
             wp[:k] = w
-        wt = torch.empty(kp * c * r * s, dtype=torch.float32, device=dy.device)
-        _C.check(_C.fn("rr_weight_flip_transpose")(_C.ptr(wp), _C.ptr(wt), kp, c, r, s, _C.stream()), "rr_weight_flip_transpose")
+        if wt is None or kp != k:
+            wt = torch.empty(kp * c * r * s, dtype=torch.float32, device=dy.device)
+            _C.check(_C.fn("rr_weight_flip_transpose")(_C.ptr(wp), _C.ptr(wt), kp, c, r, s, _C.stream()), "rr_weight_flip_transpose")
         slab = torch.empty(_C.fn("rr_conv_stat_slab_bytes")(n, h, wd, c) // 8, dtype=torch.float64, device=dy.device)
         sums = _ZEROS.take(2 * c, dy.device)
         flops_m = 2.0 * dy.shape[0] * dy.shape[2] * dy.shape[3] * k * c * r * s
@@ -312,9 +314,10 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False,
     if (stride == 1 and k % 4 == 0 and c % 4 == 0 and r * s <= 64 and pad[0] < r and pad[1] < s and _DGRAD_VIA_FPROP
             and (dy.shape[2] * dy.shape[3] >= _DGRAD_VIA_FPROP_MIN_PIXELS or _bf16_ok(k, c, r, s, dy, out))):
         # the forward kernel on dy with the flipped / transposed filter (one tiny transpose per layer and step)
-        wt = torch.empty(k * c * r * s, dtype=torch.float32, device=dy.device)
-        _C.check(_C.fn("rr_weight_flip_transpose")(_C.ptr(w), _C.ptr(wt), k, c, r, s, _C.stream()),
-                 "rr_weight_flip_transpose")
+        if wt is None:
+            wt = torch.empty(k * c * r * s, dtype=torch.float32, device=dy.device)
+            _C.check(_C.fn("rr_weight_flip_transpose")(_C.ptr(w), _C.ptr(wt), k, c, r, s, _C.stream()),
+                     "rr_weight_flip_transpose")
         bf = _bf16_ok(k, c, r, s, dy, out)
         sfx, tsfx = ("_bf16", "+bf16") if bf else ("", "")
         if (bnsum is not None and not bnsum.relu_bias and _DGRAD_BNSUM and bnsum.y is not None and c <= 1024 and out.numel() * 4 < (1 << 31)

@@ -217,9 +217,9 @@ def audit(tol=2e-5, tol_wgrad=2e-4, sample=False):
                 rec.note("fprop_stats", sig, max(e1, _rel(sums[k:2 * k], s2)), tol)
         return out
 
-    def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False, bnsum=None, bnsum_z=None):
+    def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False, bnsum=None, bnsum_z=None, wt=None):
         base = out.clone() if (out is not None and accumulate) else None
-        res = orig["conv_dgrad"](dy, w, x_shape, stride, pad, out, accumulate, bnsum, bnsum_z)
+        res = orig["conv_dgrad"](dy, w, x_shape, stride, pad, out, accumulate, bnsum, bnsum_z, wt)   # wt: the cached flipped filter
         relu_mask = None          # conv + bias + ReLU producer: this launch stored the masked gradient
         if bnsum is not None and bnsum.relu_bias and bnsum.sums is not None and bnsum.dz is res:
             relu_mask = bnsum_z
