@@ -136,7 +136,11 @@ class _ConvBnAct(torch.autograd.Function):
             if sync or not BN_FUSED_STATS or slab.numel() > 512 * 2 * k:   # SyncBN exchange: one small all-reduce of [sum, sumsq, count] (C5 in SURVEY §2.2);
                 sums = ops.bn_reduce_slab(slab, k, extra=1)
                 if sync:
-                    sums[2 * k] = count          # the global count stays on the device: no host sync per layer
+                    # the global count stays on the device.  fill_ (scalar as a kernel argument), NOT `sums[2 * k] = count`:
+                    # that indexing form copies a pageable host scalar, and a pageable H2D copy blocks the host until
+                    # the stream has drained — one host sync per SyncBN layer (found with the one-rank RCCL step: 430 ms of
+                    # host time per 487 ms step)
+                    sums[2 * k:2 * k + 1].fill_(count)
                     dptrace.record("default", "all_reduce", sums.numel(), "syncbn_fwd")
                     dist.all_reduce(sums)
                     cnt_dev = sums[2 * k:].clone()   # own storage: `sums` is a slice of a shared zero pool (version counter)
@@ -336,7 +340,7 @@ class _ConvBnSyncMulti(torch.autograd.Function):
         # one sample count per layer (layers of different stride see different numbers of pixels)
         counts = [float(y.numel() // k) for (y, _), k in zip(ys, ks)]
         for i, cnt in enumerate(counts):
-            packed[tot - L + i] = cnt
+            packed[tot - L + i:tot - L + i + 1].fill_(cnt)       # (fill_, not item assignment: see _ConvBnAct.forward)
         dptrace.record("default", "all_reduce", packed.numel(), "syncbn_fwd x%d" % L)
         dist.all_reduce(packed)
         cnt_devs = [packed[tot - L + i:tot - L + i + 1].clone() for i in range(L)]
