@@ -73,7 +73,6 @@ struct ConvArgs {
     int relu, accumulate;
     int M, wK, wC;
     int ksplit;
-    int order;         // experiment: 0 = stage before the MFMAs (default), 1 = behind them
     // strided destination (stride-2 data gradient, one output parity class per launch): logical output pixel (n, h, w) of
     // the DH x DW grid lands at physical pixel (n, h * osh + oh0, w * osw + ow0) of an OH x OW map; osh == 0: dense
     int OH, OW, osh, osw, oh0, ow0;
@@ -206,7 +205,6 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(const ConvArgs a)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     const int lr = lane & 31, lh = lane >> 5;
-    const int order = a.order;
 
     if (kc_lo < kc_hi) {
         prep();
@@ -230,14 +228,13 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(const ConvArgs a)
             for (int j = 0; j < TN; ++j)
                 fb[kk][j] = *reinterpret_cast<const bf16x8 *>(B + ((wn * TN + j) * 32 + lr) * LDK + kk * 16 + lh * 8);
         }
-        if (order == 0) {
-            // tile kc + 1 (loaded one iteration ago) -> the other LDS buffer, whose last readers passed the previous barrier;
-            // then tile kc + 2 goes out
-            store_all(buf ^ 1);
-            p_live = kc + 2 < kc_hi;
-            prep();
-            load_all();
-        }
+        // tile kc + 1 (loaded one iteration ago) -> the other LDS buffer, whose last readers passed the previous barrier;
+        // then tile kc + 2 goes out.  (Staging BEHIND the matrix instructions instead — a whole iteration for the loads to
+        // land — measured the same: the loop is bound by instruction issue, ~96 non-MFMA instructions per 8 MFMAs.)
+        store_all(buf ^ 1);
+        p_live = kc + 2 < kc_hi;
+        prep();
+        load_all();
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -245,12 +242,6 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(const ConvArgs a)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk][i], fb[kk][j], acc[i][j], 0, 0, 0);
-        if (order == 1) {          // staging behind the matrix instructions: the loads get a whole iteration to land
-            store_all(buf ^ 1);
-            p_live = kc + 2 < kc_hi;
-            prep();
-            load_all();
-        }
         __syncthreads();
     }
 
@@ -424,11 +415,6 @@ int fprop_impl(const float *x, const float *w, const float *bias, float *y, doub
     RR_CHECK_ARG(a.DH > 0 && a.DW > 0, "rr_conv_fprop_bf16: empty output");
     a.R = r; a.S = s; a.stride = stride; a.pad_h = pad_h; a.pad_w = pad_w;
     a.relu = relu; a.accumulate = accumulate; a.ksplit = 1;
-    {
-        static int order = -1;
-        if (order < 0) { const char *e = getenv("RR_BF16_ORDER"); order = e ? atoi(e) : 0; }
-        a.order = order;
-    }
     const long M = (long)n * a.DH * a.DW;
     RR_CHECK_ARG(M < (1l << 31) && (long)n * h * wd * c * 4 < (1l << 31) && (long)k * r * s * c * 4 < (1l << 31) && M * k * 4 < (1l << 31),
                  "rr_conv_fprop_bf16: tensors must stay below 2 GiB (32-bit buffer offsets)");

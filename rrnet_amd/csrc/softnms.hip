@@ -284,7 +284,7 @@ __device__ __forceinline__ RegCand wave_best(RegCand c)
 
 constexpr int SMALL_SEG_REG = 256;          // one box per lane of four waves
 constexpr int REG_DEAD = 0x7fffffff;         // position of a box that is out of the game (dead, or a padding slot)
-constexpr int REG_MASK_WORDS = 200;          // 32-bit words of one dead-position mask: positions < 6400
+constexpr int REG_MASK_WORDS = 96;           // 32-bit words of one dead-position mask: positions < 3072
 
 // lds: [2][16] exchange slots of 8 words + [2][REG_MASK_WORDS] dead-position masks (zero on entry)
 template <int T, int NB>
@@ -304,8 +304,8 @@ __device__ __forceinline__ void soft_nms_registers(float *b, const int stride, c
         if (p < n) {
             const float *r = b + (size_t)p * stride;
             x1[j] = r[0]; y1[j] = r[1]; x2[j] = r[2]; y2[j] = r[3]; sc[j] = r[4];
-            ar[j] = (float)(((double)(x2[j] - x1[j]) + 1.0) * ((double)(y2[j] - y1[j]) + 1.0));
             pos[j] = p;
+            ar[j] = (float)(((double)(x2[j] - x1[j]) + 1.0) * ((double)(y2[j] - y1[j]) + 1.0));
             key[j] = sortable_key(sc[j]);
         } else {
             x1[j] = y1[j] = x2[j] = y2[j] = sc[j] = ar[j] = 0.f;
@@ -653,7 +653,10 @@ static int soft_nms_launch(float *boxes, const int *seg_off, const int *seg_len,
     // register-resident kernel; a batch of more long segments than two per CU is a throughput problem, where the LDS loop's
     // 256-thread workgroups (4 per CU) retire more segments per unit time (1280 x 1500 boxes: 5.5 against 6.0 ms)
     const bool throughput_regime = nseg > 512 && max_seg_boxes > 256;
-    if (in_lds && softnms_reg_enabled() && !throughput_regime) {
+    // (measured, one segment: 2500 boxes 4.97 against 5.57 ms for the LDS loop; at 5000 / 9000 boxes — six / nine boxes per
+    // lane of a 1024-thread workgroup, 128 registers per lane — the register kernel spills and loses, 15.7 against 14.2 and
+    // 52 against 38 ms: it takes segments of up to 3072 boxes)
+    if (max_seg_boxes <= 3072 && softnms_reg_enabled() && !throughput_regime) {
         // register-resident kernels: T x NB boxes per segment
 #define LAUNCH_REG(T, NB)                                                                                              \
         hipLaunchKernelGGL((soft_nms_reg_kernel<T, NB>), dim3(nseg), dim3(T), 0, stream, boxes, seg_off, seg_len, stride, sigma, \
@@ -663,8 +666,7 @@ static int soft_nms_launch(float *boxes, const int *seg_off, const int *seg_len,
         // (measured: 1024 x 2 for 1500 boxes, four waves per SIMD, is 30 % slower than 512 x 3: a 16-wave barrier and exchange)
         if (max_seg_boxes <= 256) LAUNCH_REG(256, 1);
         else if (max_seg_boxes <= 1536) LAUNCH_REG(512, 3);
-        else if (max_seg_boxes <= 3072) LAUNCH_REG(1024, 3);
-        else LAUNCH_REG(1024, 6);
+        else LAUNCH_REG(1024, 3);
 #undef LAUNCH_REG
         RR_CHECK_LAUNCH("rr_soft_nms_segments");
         return RR_OK;

@@ -187,3 +187,17 @@ def test_dcn_backward_streams_equal_one_stream(tmp_path):
     _compare(one, two, "DCN heads: two streams under stress vs one stream", bound)
     for r in two[1]["repeat_vs_first"]:
         assert r["grad"][0] <= bound, r
+
+
+def test_side_stream_bf16_model_equals_one_stream(tmp_path):
+    """The same A/B for the config-4 precision (cfg.Model.bf16: every convolution on the bf16-operand kernels, incl. the
+    parity-class stride-2 data gradients and the bf16 weight-gradient kernel on the side stream), under stress."""
+    extra = ["--bf16"]
+    one = _run(tmp_path, "bf16_one", dict(DET, RR_WGRAD_STREAM="0"), 256, 2, 2, extra)
+    noise = max(r["grad"][0] for r in one[1]["repeat_vs_first"])
+    print("bf16 model, one stream run to run: %.2e" % noise)
+    assert noise <= BOUND, noise
+    side = _run(tmp_path, "bf16_side", dict(DET, RR_WGRAD_STREAM="2", RR_WGRAD_STRESS="1"), 256, 2, 3, extra)
+    _compare(one, side, "bf16 model: side stream under stress vs one stream")
+    for r in side[1]["repeat_vs_first"]:
+        assert r["grad"][0] <= BOUND, r
