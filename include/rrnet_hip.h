@@ -84,6 +84,10 @@ int rr_weight_flip_transpose(const float *w, float *wt, int k, int c, int r, int
  * of the filter in flat / wt_flat, (r*s) << 16 | k, c, tap << 20 | k_tile << 10 | c_tile}, one 32 x 32 tile of the (k, c)
  * plane of one tap per workgroup.  Filters of up to 65535 output channels, 1024 tiles per side, r*s < 2048. */
 int rr_weight_flip_transpose_batch(const float *flat, float *wt_flat, const int *table, int ntiles, hipStream_t stream);
+/* ... and, for the bf16-operand convolutions, bf16 copies of both (w16_flat: the filters as they are, wt16_flat: flipped /
+ * transposed; bf16 elements at the same element offsets; either may be NULL). */
+int rr_weight_flip_transpose_batch_bf16(const float *flat, float *wt_flat, unsigned short *w16_flat, unsigned short *wt16_flat,
+                                        const int *table, int ntiles, hipStream_t stream);
 int rr_conv_dgrad_s1(const float *dy, const float *wt, float *dx, int n, int h, int wd, int c, int k,
                      int r, int s, int pad_h, int pad_w, int accumulate, hipStream_t stream);
 /* Small-channel convolutions (the 7x7 stride-2 stem on a 3-channel image, backbones/hourglass.py:143): rr_conv_pack_taps
@@ -131,16 +135,20 @@ int rr_conv_wgrad(const float *x, const float *dy, float *dw, int n, int h, int 
  * Vector shapes only (C % 4 == 0, R*S <= 64, for rr_conv_wgrad_bf16 also K % 4 == 0; every tensor < 2 GiB): the host
  * layer keeps the fp32 entry points for the rest (stride-2 data gradients, the 17-tap WH head, the 3-channel stem's
  * unpacked form).  rr_conv_dgrad_s1*_bf16 take the flipped / transposed filter of rr_weight_flip_transpose (fp32). */
+/* w_bf16 / wt_bf16 (may be NULL): the same filter already rounded to bf16, same [k][r][s][c] element order (the host layer
+ * keeps bf16 copies of all filters, refreshed once per optimizer step: rr_weight_flip_transpose_batch).  Used when
+ * c % 8 == 0: 16-byte loads of 8 channels, no converts for the B operand; identical results. */
 int rr_conv_fprop_bf16(const float *x, const float *w, const float *bias, float *y, double *stat_slab,
                        int n, int h, int wd, int c, int k, int r, int s, int stride, int pad_h, int pad_w,
-                       int relu, hipStream_t stream);
+                       int relu, const unsigned short *w_bf16, hipStream_t stream);
 int rr_conv_dgrad_s1_bf16(const float *dy, const float *wt, float *dx, int n, int h, int wd, int c, int k,
-                          int r, int s, int pad_h, int pad_w, int accumulate, hipStream_t stream);
+                          int r, int s, int pad_h, int pad_w, int accumulate, const unsigned short *wt_bf16,
+                          hipStream_t stream);
 int rr_conv_dgrad_s1_bnsum_bf16(const float *dy, const float *wt, float *dx, int n, int h, int wd, int c, int k,
                                 int r, int s, int pad_h, int pad_w, int accumulate, const float *prod_y,
                                 const float *prod_z, const float *prod_mean, const float *prod_invstd,
                                 const float *prod_mask_scale, const float *prod_mask_shift, double *slab,
-                                double *sums, hipStream_t stream);
+                                double *sums, const unsigned short *wt_bf16, hipStream_t stream);
 int rr_conv_dgrad_s1_relubias_bf16(const float *dy, const float *wt, float *dx, int n, int h, int wd, int c, int k,
                                    int r, int s, int pad_h, int pad_w, int accumulate, const float *prod_z,
                                    double *slab, double *sums, hipStream_t stream);

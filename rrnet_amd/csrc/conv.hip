@@ -1489,7 +1489,8 @@ extern "C" int rr_weight_flip_transpose(const float *w, float *wt, int k, int c,
 // buffers, K, C, packed (tap << 20 | k-tile << 10 | c-tile)} (built once by the host layer, rrnet_amd/flat.py); the
 // flipped / transposed copy lands at the SAME offset of `wt_flat`.  Replaces one tiny launch per layer and step on the
 // critical path of backward (73 in the headline step, 153 with bf16 stride-1 data gradients at every size).
-__global__ __launch_bounds__(256) void weight_flip_transpose_batch_kernel(const float *flat, float *wt_flat, const int4 *table, int RS_unused)
+__global__ __launch_bounds__(256) void weight_flip_transpose_batch_kernel(const float *flat, float *wt_flat, const int4 *table,
+                                                                          unsigned short *w16_flat, unsigned short *wt16_flat)
 {
     __shared__ float tile[32][33];
     const int4 d = table[blockIdx.x];
@@ -1502,13 +1503,20 @@ __global__ __launch_bounds__(256) void weight_flip_transpose_batch_kernel(const 
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     for (int i = ty; i < 32; i += 8) {
         const int k = k0 + i, c = c0 + tx;
-        tile[i][tx] = (k < Kk && c < C) ? w[((long)k * RS + tap) * C + c] : 0.f;
+        const bool in = k < Kk && c < C;
+        const float v = in ? w[((long)k * RS + tap) * C + c] : 0.f;
+        tile[i][tx] = v;
+        if (in && w16_flat) w16_flat[d.x + ((long)k * RS + tap) * C + c] = __builtin_bit_cast(unsigned short, (__bf16)v);
     }
     __syncthreads();
     const int ftap = RS - 1 - tap;
     for (int i = ty; i < 32; i += 8) {
         const int c = c0 + i, k = k0 + tx;
-        if (k < Kk && c < C) wt[((long)c * RS + ftap) * Kk + k] = tile[tx][i];
+        if (k < Kk && c < C) {
+            const float v = tile[tx][i];
+            wt[((long)c * RS + ftap) * Kk + k] = v;
+            if (wt16_flat) wt16_flat[d.x + ((long)c * RS + ftap) * Kk + k] = __builtin_bit_cast(unsigned short, (__bf16)v);
+        }
     }
 }
 
@@ -1517,8 +1525,19 @@ extern "C" int rr_weight_flip_transpose_batch(const float *flat, float *wt_flat,
     RR_CHECK_ARG(flat && wt_flat && table && ntiles >= 0, "rr_weight_flip_transpose_batch: null argument");
     if (ntiles == 0) return RR_OK;
     hipLaunchKernelGGL(weight_flip_transpose_batch_kernel, dim3(ntiles), dim3(256), 0, stream, flat, wt_flat,
-                       reinterpret_cast<const int4 *>(table), 0);
+                       reinterpret_cast<const int4 *>(table), (unsigned short *)nullptr, (unsigned short *)nullptr);
     RR_CHECK_LAUNCH("rr_weight_flip_transpose_batch");
+    return RR_OK;
+}
+
+extern "C" int rr_weight_flip_transpose_batch_bf16(const float *flat, float *wt_flat, unsigned short *w16_flat,
+                                                   unsigned short *wt16_flat, const int *table, int ntiles, hipStream_t stream)
+{
+    RR_CHECK_ARG(flat && wt_flat && table && ntiles >= 0, "rr_weight_flip_transpose_batch_bf16: null argument");
+    if (ntiles == 0) return RR_OK;
+    hipLaunchKernelGGL(weight_flip_transpose_batch_kernel, dim3(ntiles), dim3(256), 0, stream, flat, wt_flat,
+                       reinterpret_cast<const int4 *>(table), w16_flat, wt16_flat);
+    RR_CHECK_LAUNCH("rr_weight_flip_transpose_batch_bf16");
     return RR_OK;
 }
 

@@ -62,6 +62,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_srd(const void *p, long b
 struct ConvArgs {
     const float *src;  // X [N,H,W,C]  (or dY for the stride-1 data gradient)
     const float *w;    // [K][R][S][C] fp32
+    const unsigned short *w16;   // the same filter already rounded to bf16 (B16 instantiation: read 8 channels per load, no converts)
     float *dst;        // Y [N,P,Q,K]
     const float *bias;
     double *stat_slab; // [mtiles][2][K] per-block column sums / sums of squares, or null
@@ -79,7 +80,10 @@ struct ConvArgs {
 };
 
 // 128 x BN output tile, 256 threads = 4 waves (BN 128: 2x2 waves of 64x64; BN 64: 4x1 waves of 32x64; BN 32: 4x1 of 32x32)
-template <int BN, bool BNS>
+// B16: the filter comes as bf16 (a.w16; C % 8 == 0): half the B loads, no converts, 16-byte LDS stores for the B image.
+// SO: strided destination (ConvArgs::osh; the stride-2 data gradient's parity-class launches) — its own instantiation: folded
+// into the plain kernel the per-element pixel arithmetic cost 20 registers and the third workgroup per CU (585 -> 524 TFLOP/s).
+template <int BN, bool BNS, bool B16 = false, bool SO = false>
 __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(const ConvArgs a)
 {
     constexpr int WN = BN / 64 ? BN / 64 : 1;
@@ -90,7 +94,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(const ConvArgs a)
     constexpr int CPR = BK / 4;                 // float4 columns per row (8)
     constexpr int RPP = 256 / CPR;              // rows per pass of the 256 threads (32)
     constexpr int AJ = BM / RPP;                // 4
-    constexpr int BJ = BN / RPP > 0 ? BN / RPP : 1;
+    constexpr int BJ = B16 ? (BN / 64 > 0 ? BN / 64 : 1) : (BN / RPP > 0 ? BN / RPP : 1);   // B16: 4 chunks of 8 channels per row, 64 rows per pass
 
     extern __shared__ __align__(16) unsigned short lds16[];
     unsigned short *As = lds16;                 // [2][A_ELEMS]
@@ -147,14 +151,15 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(const ConvArgs a)
     }
     int b_boff[BJ];
     bool b_ok[BJ];
+    const int b_row = B16 ? t / 4 : a_row, b_col = B16 ? (t % 4) * 8 : a_col, b_rpp = B16 ? 64 : RPP;
 #pragma unroll
     for (int j = 0; j < BJ; ++j) {
-        const int ko = n0 + a_row + RPP * j;
-        b_ok[j] = ko < a.wK && (a_row + RPP * j) < BN;
-        b_boff[j] = (int)(((long)ko * RS * a.wC + a_col) * 4);
+        const int ko = n0 + b_row + b_rpp * j;
+        b_ok[j] = ko < a.wK && (b_row + b_rpp * j) < BN;
+        b_boff[j] = (int)(((long)ko * RS * a.wC + b_col) * (B16 ? 2 : 4));
     }
     const __amdgpu_buffer_rsrc_t rs_src = make_srd(a.src, (long)a.N * a.SH * a.SW * a.SC * 4);
-    const __amdgpu_buffer_rsrc_t rs_w = make_srd(a.w, (long)a.wK * RS * a.wC * 4);
+    const __amdgpu_buffer_rsrc_t rs_w = B16 ? make_srd(a.w16, (long)a.wK * RS * a.wC * 2) : make_srd(a.w, (long)a.wK * RS * a.wC * 4);
     constexpr unsigned OOB = 0xFFFFFFF0u;       // beyond any (< 2 GiB) tensor: the hardware returns 0, no select on the data
 
     f32x4 ra[AJ], rb[BJ];
@@ -162,13 +167,14 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(const ConvArgs a)
     int p_cch = kc_lo / RS, p_tl = kc_lo - (kc_lo / RS) * RS;
     int p_ri = p_tl / a.S, p_si = p_tl - (p_tl / a.S) * a.S;
     int p_adelta = 0, p_wdelta = 0, p_tlc = 0;
-    bool p_cok = false, p_live = true;
+    bool p_cok = false, p_wcok = false, p_live = true;
     auto prep = [&]() {
         const int c0 = p_cch * BK;
         p_tlc = p_tl;
         p_adelta = ((p_ri * a.SW + p_si) * a.SC + c0) * 4;
         p_cok = c0 + a_col < a.SC;                          // (SC == wC: one test serves both operands)
-        p_wdelta = (p_tl * a.wC + c0) * 4;
+        p_wcok = c0 + b_col < a.wC;
+        p_wdelta = (p_tl * a.wC + c0) * (B16 ? 2 : 4);
         ++p_tl;
         if (++p_si == a.S) { p_si = 0; ++p_ri; }
         if (p_tl == RS) { p_tl = 0; p_ri = 0; p_si = 0; ++p_cch; }
@@ -182,9 +188,9 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(const ConvArgs a)
         }
 #pragma unroll
         for (int j = 0; j < BJ; ++j) {
-            const unsigned ok = (unsigned)b_ok[j] & (unsigned)p_cok & (unsigned)p_live;
+            const unsigned ok = (unsigned)b_ok[j] & (unsigned)p_wcok & (unsigned)p_live;
             const unsigned off = ok ? (unsigned)(b_boff[j] + p_wdelta) : OOB;
-            rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, off, 0, 0));
+            rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, off, 0, 0));   // B16: 8 bf16
         }
     };
     auto store_all = [&](int buf) {
@@ -192,9 +198,16 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(const ConvArgs a)
 #pragma unroll
         for (int j = 0; j < AJ; ++j)
             *reinterpret_cast<u16x4 *>(A + (a_row + RPP * j) * LDK + a_col) = f2bf4(ra[j]);
+        if constexpr (B16) {
 #pragma unroll
-        for (int j = 0; j < BJ; ++j)          // (a_row + RPP * j < BN always: BJ = BN / RPP, a_row < RPP — no guard, no exec-mask branch)
-            *reinterpret_cast<u16x4 *>(B + (a_row + RPP * j) * LDK + a_col) = f2bf4(rb[j]);
+            for (int j = 0; j < BJ; ++j)
+                if (BN >= 64 || b_row < BN)
+                    *reinterpret_cast<f32x4 *>(B + (b_row + 64 * j) * LDK + b_col) = rb[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < BJ; ++j)      // (a_row + RPP * j < BN always: BJ = BN / RPP, a_row < RPP — no guard, no exec-mask branch)
+                *reinterpret_cast<u16x4 *>(B + (a_row + RPP * j) * LDK + a_col) = f2bf4(rb[j]);
+        }
     };
 
     f32x16 acc[TM][TN];
@@ -308,7 +321,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(const ConvArgs a)
                 if (a.relu) v = v > 0.f ? v : 0.f;
                 if (m < a.M && n_ok) {
                     long pix = m;
-                    if (a.osh) {
+                    if constexpr (SO) {
                         const int n = m / hw, rem = m - n * hw;
                         const int h = rem / a.DW;
                         pix = ((long)n * a.OH + (h * a.osh + a.oh0)) * a.OW + ((rem - h * a.DW) * a.osw + a.ow0);
@@ -401,12 +414,14 @@ int launch(K kern, int blocks, int gz, size_t lds, hipStream_t stream, const Con
 
 int fprop_impl(const float *x, const float *w, const float *bias, float *y, double *stat_slab, int n, int h, int wd, int c,
                int k, int r, int s, int stride, int pad_h, int pad_w, int relu, int accumulate, hipStream_t stream,
-               const BnSumArgs *bs = nullptr, const OutMap *om = nullptr)
+               const BnSumArgs *bs = nullptr, const OutMap *om = nullptr, const unsigned short *w16 = nullptr)
 {
     RR_CHECK_ARG(n > 0 && h > 0 && wd > 0 && c > 0 && k > 0 && r > 0 && s > 0 && stride > 0, "rr_conv_fprop_bf16: bad dims");
     RR_CHECK_ARG(c % 4 == 0 && r * s <= 64, "rr_conv_fprop_bf16: C=%d must be a multiple of 4 and R*S <= 64 (fp32 path for the rest)", c);
     ConvArgs a{};
     a.src = x; a.w = w; a.dst = y; a.bias = bias; a.stat_slab = stat_slab;
+    a.w16 = (w16 != nullptr && c % 8 == 0) ? w16 : nullptr;       // 16-byte loads of 8 channels
+    RR_CHECK_ARG(w != nullptr || a.w16 != nullptr, "rr_conv_fprop_bf16: no filter");
     a.N = n; a.SH = h; a.SW = wd; a.SC = c;
     a.DH = (h + 2 * pad_h - r) / stride + 1; a.DW = (wd + 2 * pad_w - s) / stride + 1; a.DC = k;
     if (om != nullptr) {        // pads are LEADING pads; taps past the far edge are masked by the gather
@@ -447,15 +462,13 @@ int fprop_impl(const float *x, const float *w, const float *bias, float *y, doub
     }
     int rc;
     const char *name = "rr_conv_fprop_bf16";
-    if (fused) {
-        rc = bn == 128 ? launch(conv_igemm_bf16_kernel<128, true>, blocks, ks, igemm_lds(128), stream, a, name)
-           : bn == 64  ? launch(conv_igemm_bf16_kernel<64, true>, blocks, ks, igemm_lds(64), stream, a, name)
-                       : launch(conv_igemm_bf16_kernel<32, true>, blocks, ks, igemm_lds(32), stream, a, name);
-    } else {
-        rc = bn == 128 ? launch(conv_igemm_bf16_kernel<128, false>, blocks, ks, igemm_lds(128), stream, a, name)
-           : bn == 64  ? launch(conv_igemm_bf16_kernel<64, false>, blocks, ks, igemm_lds(64), stream, a, name)
-                       : launch(conv_igemm_bf16_kernel<32, false>, blocks, ks, igemm_lds(32), stream, a, name);
-    }
+#define RR_IG(BNv, BNSv, SOv)                                                                                      \
+    (a.w16 ? launch(conv_igemm_bf16_kernel<BNv, BNSv, true, SOv>, blocks, ks, igemm_lds(BNv), stream, a, name)           \
+           : launch(conv_igemm_bf16_kernel<BNv, BNSv, false, SOv>, blocks, ks, igemm_lds(BNv), stream, a, name))
+    if (fused) rc = bn == 128 ? RR_IG(128, true, false) : bn == 64 ? RR_IG(64, true, false) : RR_IG(32, true, false);
+    else if (a.osh) rc = bn == 128 ? RR_IG(128, false, true) : bn == 64 ? RR_IG(64, false, true) : RR_IG(32, false, true);
+    else rc = bn == 128 ? RR_IG(128, false, false) : bn == 64 ? RR_IG(64, false, false) : RR_IG(32, false, false);
+#undef RR_IG
     if (rc == RR_OK && bs != nullptr) {
         if (fused) return rr_bn_reduce_slab(bs->slab, (int)rr_cdiv(M, BM), k, bs->sums, stream);
         return rr_bn_bwd_reduce(y, bs->z, bs->y, bs->mean, bs->invstd, bs->msc, bs->msh, bs->sums, M, k, 1, stream);
@@ -623,25 +636,27 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradArgs a)
 
 extern "C" int rr_conv_fprop_bf16(const float *x, const float *w, const float *bias, float *y, double *stat_slab,
                                   int n, int h, int wd, int c, int k, int r, int s, int stride, int pad_h,
-                                  int pad_w, int relu, hipStream_t stream)
+                                  int pad_w, int relu, const unsigned short *w_bf16, hipStream_t stream)
 {
-    return fprop_impl(x, w, bias, y, stat_slab, n, h, wd, c, k, r, s, stride, pad_h, pad_w, relu, 0, stream);
+    return fprop_impl(x, w, bias, y, stat_slab, n, h, wd, c, k, r, s, stride, pad_h, pad_w, relu, 0, stream, nullptr, nullptr, w_bf16);
 }
 
 extern "C" int rr_conv_dgrad_s1_bf16(const float *dy, const float *wt, float *dx, int n, int h, int wd, int c, int k,
-                                     int r, int s, int pad_h, int pad_w, int accumulate, hipStream_t stream)
+                                     int r, int s, int pad_h, int pad_w, int accumulate, const unsigned short *wt_bf16,
+                                     hipStream_t stream)
 {
     RR_CHECK_ARG(pad_h < r && pad_w < s && pad_h >= 0 && pad_w >= 0, "rr_conv_dgrad_s1_bf16: pad must be in [0, kernel)");
     const int p = h + 2 * pad_h - r + 1, q = wd + 2 * pad_w - s + 1;
     RR_CHECK_ARG(p > 0 && q > 0, "rr_conv_dgrad_s1_bf16: empty dy");
-    return fprop_impl(dy, wt, nullptr, dx, nullptr, n, p, q, k, c, r, s, 1, r - 1 - pad_h, s - 1 - pad_w, 0, accumulate, stream);
+    return fprop_impl(dy, wt, nullptr, dx, nullptr, n, p, q, k, c, r, s, 1, r - 1 - pad_h, s - 1 - pad_w, 0, accumulate, stream,
+                      nullptr, nullptr, wt_bf16);
 }
 
 extern "C" int rr_conv_dgrad_s1_bnsum_bf16(const float *dy, const float *wt, float *dx, int n, int h, int wd, int c, int k,
                                            int r, int s, int pad_h, int pad_w, int accumulate, const float *prod_y,
                                            const float *prod_z, const float *prod_mean, const float *prod_invstd,
                                            const float *prod_mask_scale, const float *prod_mask_shift, double *slab,
-                                           double *sums, hipStream_t stream)
+                                           double *sums, const unsigned short *wt_bf16, hipStream_t stream)
 {
     RR_CHECK_ARG(pad_h < r && pad_w < s && pad_h >= 0 && pad_w >= 0, "rr_conv_dgrad_s1_bnsum_bf16: pad must be in [0, kernel)");
     RR_CHECK_ARG(prod_y && prod_mean && prod_invstd && slab && sums && (!prod_mask_scale == !prod_mask_shift),
@@ -650,7 +665,8 @@ extern "C" int rr_conv_dgrad_s1_bnsum_bf16(const float *dy, const float *wt, flo
     const int p = h + 2 * pad_h - r + 1, q = wd + 2 * pad_w - s + 1;
     RR_CHECK_ARG(p > 0 && q > 0, "rr_conv_dgrad_s1_bnsum_bf16: empty dy");
     const BnSumArgs bs{prod_y, prod_z, prod_mean, prod_invstd, prod_mask_scale, prod_mask_shift, slab, sums, 0};
-    return fprop_impl(dy, wt, nullptr, dx, nullptr, n, p, q, k, c, r, s, 1, r - 1 - pad_h, s - 1 - pad_w, 0, accumulate, stream, &bs);
+    return fprop_impl(dy, wt, nullptr, dx, nullptr, n, p, q, k, c, r, s, 1, r - 1 - pad_h, s - 1 - pad_w, 0, accumulate, stream, &bs,
+                      nullptr, wt_bf16);
 }
 
 extern "C" int rr_conv_dgrad_s1_relubias_bf16(const float *dy, const float *wt, float *dx, int n, int h, int wd, int c, int k,

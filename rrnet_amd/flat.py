@@ -73,6 +73,7 @@ class FlatParams:
         # buffer with the parameters' offsets, filled by ONE launch per optimizer step instead of one launch per layer
         # inside backward (lazily allocated at the first data gradient; RR_WT_CACHE=0: per-layer launches as before)
         self.wt_flat = None
+        self.w16_flat = self.wt16_flat = None       # bf16 copies (plain / flipped) for the bf16-operand kernels, on demand
         self._wt_table = None
         self._wt_version = None
         self._wt_enabled = os.environ.get("RR_WT_CACHE", "1") != "0" and dev.type == "cuda"
@@ -108,23 +109,46 @@ class FlatParams:
         if not self._wt_enabled or self.wt_flat is None:
             return
         from rrnet_amd import _C
-        _C.check(_C.fn("rr_weight_flip_transpose_batch")(_C.ptr(self.flat), _C.ptr(self.wt_flat), _C.ptr(self._wt_table),
-                                                         self._wt_table.shape[0], _C.stream()), "rr_weight_flip_transpose_batch")
+        if self.w16_flat is not None:
+            _C.check(_C.fn("rr_weight_flip_transpose_batch_bf16")(_C.ptr(self.flat), _C.ptr(self.wt_flat), _C.ptr(self.w16_flat),
+                                                                  _C.ptr(self.wt16_flat), _C.ptr(self._wt_table),
+                                                                  self._wt_table.shape[0], _C.stream()),
+                     "rr_weight_flip_transpose_batch_bf16")
+        else:
+            _C.check(_C.fn("rr_weight_flip_transpose_batch")(_C.ptr(self.flat), _C.ptr(self.wt_flat), _C.ptr(self._wt_table),
+                                                             self._wt_table.shape[0], _C.stream()), "rr_weight_flip_transpose_batch")
         self._wt_version = self.flat._version
 
-    def wt_view(self, p):
-        """Flat fp32 tensor [k*c*r*s] holding wt[c][R-1-r][S-1-s][k] of the 4-D parameter p, or None (cache off, p not a
-        filter of this buffer)."""
+    def _wt_ready(self, p, bf16):
         if not self._wt_enabled or p.dim() != 4 or id(p) not in self._offs:
-            return None
+            return False
         if self.wt_flat is None:
             self._build_wt_table()
             self.wt_flat = torch.empty_like(self.flat)
             self._wt_version = None
+        if bf16 and self.w16_flat is None:
+            self.w16_flat = torch.empty(self.numel, dtype=torch.bfloat16, device=self.flat.device)
+            self.wt16_flat = torch.empty(self.numel, dtype=torch.bfloat16, device=self.flat.device)
+            self._wt_version = None
         if self._wt_version != self.flat._version:       # parameters written since the last fill (or never filled)
             self.refresh_wt()
+        return True
+
+    def wt_view(self, p):
+        """Flat fp32 tensor [k*c*r*s] holding wt[c][R-1-r][S-1-s][k] of the 4-D parameter p, or None (cache off, p not a
+        filter of this buffer)."""
+        if not self._wt_ready(p, False):
+            return None
         o = self._offs[id(p)]
         return self.wt_flat[o:o + p.numel()]
+
+    def w16_views(self, p):
+        """(bf16 copy of the filter [k][r][s][c], bf16 copy of its flipped / transposed form) for the bf16-operand kernels,
+        or (None, None)."""
+        if not self._wt_ready(p, True):
+            return None, None
+        o = self._offs[id(p)]
+        return self.w16_flat[o:o + p.numel()], self.wt16_flat[o:o + p.numel()]
 
     def _begin_step(self):
         nb = len(self._bucket_range)

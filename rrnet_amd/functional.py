@@ -128,7 +128,7 @@ class _ConvBnAct(torch.autograd.Function):
                 y, slab, x = ops.conv_fprop_packed(x, wc, stride, pad, want_stats=True)
                 ctx.packed = True
             else:
-                y, slab = ops.conv_fprop(x, wc, None, stride, pad, False, want_stats=True)
+                y, slab = ops.conv_fprop(x, wc, None, stride, pad, False, want_stats=True, w16=_w16_of(w)[0])
             count = float(y.numel() // k)
             cnt_dev = None
             mom = bn.momentum if bn.momentum is not None else 0.1
@@ -158,7 +158,7 @@ class _ConvBnAct(torch.autograd.Function):
                 # bias (+ReLU); no separate pass over the output
                 ctx.cfg = (stride, pad, relu, count, sync, False)
                 return ops.conv_fprop(x, ops.to_nhwc(wc * scale.view(-1, 1, 1, 1)), shift, stride, pad, relu)
-            y = ops.conv_fprop(x, wc, None, stride, pad, False)
+            y = ops.conv_fprop(x, wc, None, stride, pad, False, w16=_w16_of(w)[0])
         res = ops.to_nhwc(residual) if residual is not None else None
         z = ops.bn_apply(y, scale, shift, res, relu)
         if bn.training:
@@ -264,6 +264,12 @@ def _wt_of(w_param):
     return flat.wt_view(w_param) if flat is not None else None
 
 
+def _w16_of(w_param):
+    """bf16 mode: (bf16 copy, flipped bf16 copy) of a filter parameter of a FlatParams buffer, else (None, None)."""
+    flat = getattr(w_param, "_rr_flat", None) if (w_param is not None and ops.BF16) else None
+    return flat.w16_views(w_param) if flat is not None else (None, None)
+
+
 def _input_grad(dy, wc, xshape, stride, pad, x_acc, in_link, x, w_param=None):
     """Data gradient of a convolution node -> the tensor to hand to autograd (None when it was added into the fan-in
     buffer of x's fan-out).  Where the launch can carry them it also produces the BatchNorm-backward sums of the layer
@@ -271,16 +277,17 @@ def _input_grad(dy, wc, xshape, stride, pad, x_acc, in_link, x, w_param=None):
     contributor to the fan-in buffer of x's fan-out (the epilogue then holds the complete gradient)."""
     _wgrad_join(dy.device)        # the previous layer's weight gradient has had the HBM-bound stretch to itself
     wt = _wt_of(w_param) if stride == 1 else None
+    wt16 = _w16_of(w_param)[1] if (stride == 1 and wt is not None) else None
     if x_acc is None:
         link = in_link if (in_link is not None and in_link.consumers == 1) else None
-        return ops.conv_dgrad(dy, wc, xshape, stride, pad, bnsum=link, bnsum_z=x, wt=wt)
+        return ops.conv_dgrad(dy, wc, xshape, stride, pad, bnsum=link, bnsum_z=x, wt=wt, wt16=wt16)
     link = x_acc.link if x_acc.pending == 1 else None
     x_acc.pending -= 1
     if x_acc.buf is not None:
         # another consumer of x already produced its gradient: add into it inside the dgrad epilogue
-        ops.conv_dgrad(dy, wc, xshape, stride, pad, out=x_acc.buf, accumulate=True, bnsum=link, bnsum_z=x, wt=wt)
+        ops.conv_dgrad(dy, wc, xshape, stride, pad, out=x_acc.buf, accumulate=True, bnsum=link, bnsum_z=x, wt=wt, wt16=wt16)
         return None
-    x_acc.buf = ops.conv_dgrad(dy, wc, xshape, stride, pad, bnsum=link, bnsum_z=x, wt=wt)
+    x_acc.buf = ops.conv_dgrad(dy, wc, xshape, stride, pad, bnsum=link, bnsum_z=x, wt=wt, wt16=wt16)
     return x_acc.buf
 
 
@@ -462,7 +469,7 @@ class _ConvBias(torch.autograd.Function):
         ctx.bf16 = ops.BF16
         x = ops.to_nhwc(x)
         wc = ops.to_nhwc(w)
-        y = ops.conv_fprop(x, wc, b, stride, pad, relu)
+        y = ops.conv_fprop(x, wc, b, stride, pad, relu, w16=_w16_of(w)[0])
         ctx.save_for_backward(x, wc, y if relu else None)
         ctx.cfg = (stride, pad, relu)
         ctx.params = (w, b)

@@ -157,7 +157,7 @@ def _bf16_ok(c, k, r, s, *tensors):
     return BF16 and c % 4 == 0 and k % 4 == 0 and r * s <= 64 and all(t.numel() * 4 < (1 << 31) for t in tensors)
 
 
-def conv_fprop(x, w, bias=None, stride=1, pad=(0, 0), relu=False, want_stats=False, algo_kg=None):
+def conv_fprop(x, w, bias=None, stride=1, pad=(0, 0), relu=False, want_stats=False, algo_kg=None, w16=None):
     """x [N,C,H,W] (NHWC memory), w [K,C,R,S] (OHWI memory) -> y [N,K,P,Q] (NHWC memory)
     and, if want_stats, the per-block BatchNorm partial-sum slab (see rr_conv_fprop).
     algo_kg: the useful reduction length when the operands carry zero padding (timer FLOPs stay algorithmic)."""
@@ -176,9 +176,10 @@ def conv_fprop(x, w, bias=None, stride=1, pad=(0, 0), relu=False, want_stats=Fal
     bf = _bf16_ok(c, 4, r, s, x, w, y)
     f = _C.fn("rr_conv_fprop_bf16" if bf else "rr_conv_fprop")
     flops = 2.0 * n * p * q * k * (c * r * s if algo_kg is None else algo_kg)
+    tail = (_C.ptr(w16), _C.stream()) if bf else (_C.stream(),)      # w16: the filter already rounded to bf16 (optional)
     _C.check(_timed(_igemm_name("fprop", k, c % 4 != 0, n * p * q) + ("+bf16" if bf else ""), flops,
                     lambda: f(_C.ptr(x), _C.ptr(w), _C.ptr(bias), _C.ptr(y), _C.ptr(slab), n, h, wd, c, k, r, s,
-                              stride, pad[0], pad[1], int(relu), _C.stream()),
+                              stride, pad[0], pad[1], int(relu), *tail),
                     (n, h, wd, c, k, r, s, stride), 4.0 * (x.numel() + y.numel() + w.numel())), "rr_conv_fprop")
     return (y, slab) if want_stats else y
 
@@ -266,7 +267,7 @@ _DGRAD_BNSUM = os.environ.get("RR_DGRAD_BNSUM", "1") != "0"
 _BF16_S2_DGRAD = os.environ.get("RR_BF16_S2_DGRAD", "1") != "0"     # A/B: stride-2 data gradients stay on the fp32 kernel
 
 
-def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False, bnsum=None, bnsum_z=None, wt=None):
+def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False, bnsum=None, bnsum_z=None, wt=None, wt16=None):
     """dy [N,K,P,Q], w [K,C,R,S] -> dx [N,C,H,W]; with `out` and accumulate adds into it.
     wt: the flipped / transposed filter (rr_weight_flip_transpose of w) when the caller keeps one (FlatParams.wt_view).
     bnsum (BnLink of the layer that produced the convolution's input): when the launch can carry them, the producer's
@@ -320,6 +321,7 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False,
                      "rr_weight_flip_transpose")
         bf = _bf16_ok(k, c, r, s, dy, out)
         sfx, tsfx = ("_bf16", "+bf16") if bf else ("", "")
+        tail = (_C.ptr(wt16), _C.stream()) if bf else (_C.stream(),)     # wt16: the flipped filter already in bf16 (optional)
         if (bnsum is not None and not bnsum.relu_bias and _DGRAD_BNSUM and bnsum.y is not None and c <= 1024 and out.numel() * 4 < (1 << 31)
                 and tuple(bnsum.y.shape) == tuple(out.shape)
                 and (not bnsum.use_z or (bnsum_z is not None and is_nhwc(bnsum_z) and bnsum_z.shape == out.shape))):
@@ -332,7 +334,7 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False,
                             lambda: fb(_C.ptr(dy), _C.ptr(wt), _C.ptr(out), n, h, wd, c, k, r, s, pad[0], pad[1],
                                        int(accumulate), _C.ptr(bnsum.y), _C.ptr(zt), _C.ptr(bnsum.mean),
                                        _C.ptr(bnsum.invstd), _C.ptr(bnsum.msc), _C.ptr(bnsum.msh), _C.ptr(slab),
-                                       _C.ptr(sums), _C.stream()), (n, h, wd, c, k, r, s, stride),
+                                       _C.ptr(sums), *tail), (n, h, wd, c, k, r, s, stride),
                             4.0 * (dy.numel() + out.numel() * (3 if accumulate else 2) + w.numel())),
                      "rr_conv_dgrad_s1_bnsum")
             bnsum.sums, bnsum.dz = sums, out
@@ -341,7 +343,7 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False,
         # same HIP kernel instance as a forward convolution: timed under its name
         _C.check(_timed(_igemm_name("fprop", c, False, n * h * wd) + tsfx, flops,
                         lambda: f1(_C.ptr(dy), _C.ptr(wt), _C.ptr(out), n, h, wd, c, k, r, s, pad[0], pad[1],
-                                   int(accumulate), _C.stream()), (n, h, wd, c, k, r, s, stride),
+                                   int(accumulate), *tail), (n, h, wd, c, k, r, s, stride),
                         4.0 * (dy.numel() + out.numel() * (2 if accumulate else 1) + w.numel())), "rr_conv_dgrad_s1")
         return out
     if stride == 2 and _bf16_ok(k, c, r, s, dy, out) and _BF16_S2_DGRAD:

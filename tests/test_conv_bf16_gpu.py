@@ -81,6 +81,12 @@ def test_bf16_kernels_equal_fp32_kernels_on_rounded_operands(cfg, bf16_switch):
     bf16_switch(False)
     y_ref, slab_ref = ops.conv_fprop(xr, wr, b, stride, (ph, pw), relu, want_stats=True)
     _close(y, y_ref, "fprop")
+    if c % 8 == 0:      # the filter handed over already rounded to bf16 (FlatParams' per-step copies): same numbers
+        bf16_switch(True)
+        w16 = wt.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)          # [k][r][s][c] memory order
+        y16 = ops.conv_fprop(x, wt, b, stride, (ph, pw), relu, w16=w16)
+        bf16_switch(False)
+        _close(y16, y_ref, "fprop (bf16 filter source)")
     st, st_ref = slab.view(-1, 2, k).sum(0), slab_ref.view(-1, 2, k).sum(0)
     _close(st, st_ref, "fprop statistics", 1e-4)
     # the rounding is really there: against the UNROUNDED fp32 kernel the difference is bf16-sized

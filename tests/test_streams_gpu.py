@@ -128,19 +128,23 @@ def test_side_stream_default_path_with_split_k(tmp_path, size, batch):
     g1, g2 = _load(one[0], "grad.bin"), _load(one[0], "grad2.bin")
     self_rel, _ = _rel(g2, g1, sl)
     cross_rel, _ = _rel(_load(side[0], "grad.bin"), g1, sl)
-    good = self_rel <= BOUND
+    # "well-conditioned here" = reproducible to a third of the bound in the one-stream arm itself; on those parameters the
+    # arms must agree to 1e-4 of the scale (the spread of a parameter that just made the cut is a few 1e-5; a lost or torn
+    # weight gradient is >= 1e-2).  Everywhere else the comparison is between two samples of the same noisy quantity:
+    # generous factors, they still separate "same distribution" from "a wrong gradient somewhere" (O(1) on that parameter)
+    good = self_rel <= BOUND / 3
     n_good, n = int(good.sum()), good.numel()
     worst_good = float(cross_rel[good].max())
-    print("default path: %d of %d parameters reproducible within %.0e in the one-stream arm; on those the side stream "
+    print("default path: %d of %d parameters reproducible within %.1e in the one-stream arm; on those the side stream "
           "(under stress) differs by at most %.2e; all parameters: median %.2e (one stream vs itself %.2e), above bound "
-          "%d (vs %d), worst %.2e (vs %.2e)" % (n_good, n, BOUND, worst_good, float(cross_rel.median()),
+          "%d (vs %d), worst %.2e (vs %.2e)" % (n_good, n, BOUND / 3, worst_good, float(cross_rel.median()),
                                                   float(self_rel.median()), int((cross_rel > BOUND).sum()),
                                                   int((self_rel > BOUND).sum()), float(cross_rel.max()), float(self_rel.max())))
-    assert n_good >= 20, (n_good, n)             # the last stack's heads and their feeders: downstream of the deep levels' noise
-    assert worst_good <= 3 * BOUND, worst_good
-    assert float(cross_rel.median()) <= 3 * max(float(self_rel.median()), BOUND)
-    assert int((cross_rel > BOUND).sum()) <= int(1.3 * (self_rel > BOUND).sum()) + 10
-    assert float(cross_rel.max()) <= 3 * max(float(self_rel.max()), BOUND)
+    assert n_good >= 15, (n_good, n)             # the last stack's heads and their feeders: downstream of the deep levels' noise
+    assert worst_good <= 1e-4, worst_good
+    assert float(cross_rel.median()) <= 5 * max(float(self_rel.median()), BOUND)
+    assert int((cross_rel > BOUND).sum()) <= int(1.5 * (self_rel > BOUND).sum()) + 30
+    assert float(cross_rel.max()) <= max(10 * float(self_rel.max()), 0.5) and float(cross_rel.max()) < 2.0
     la, lb = np.array(one[1]["losses"][0]), np.array(side[1]["losses"][0])
     assert np.all(np.abs(la - lb) <= 2e-5 * np.maximum(np.abs(la), 1e-3)), (la, lb)
 

@@ -43,12 +43,20 @@ for i, (n, c, h, w, k, r, st) in enumerate(SHAPES):
     dx = ops.empty_nhwc(n, c, h, w, "cuda")
     flops = 2.0 * n * p * q * k * c * r * r
     row = "N%d C%d %dx%d K%d r%d s%d |" % (n, c, h, w, k, r, st)
-    for bf in (False, True):
-        ops.BF16 = bf
-        t1 = timeit(lambda: ops.conv_fprop(x, wt, None, st, (pad, pad), False, want_stats=True))
-        t2 = timeit(lambda: ops.conv_dgrad(dy, wt, (n, c, h, w), st, (pad, pad), out=dx))
+    # the filter's bf16 copies as FlatParams keeps them (refreshed once per optimizer step): [k][r][s][c] and flipped [c][r'][s'][k]
+    w16 = wt.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)
+    wt32 = torch.empty(k * c * r * r, dtype=torch.float32, device="cuda")
+    ops._C.check(ops._C.fn("rr_weight_flip_transpose")(ops._C.ptr(wt), ops._C.ptr(wt32), k, c, r, r, ops._C.stream()), "flip")
+    wt16 = wt32.to(torch.bfloat16)
+    for bf in (False, True, "w16"):
+        ops.BF16 = bool(bf)
+        kw = dict(w16=w16) if bf == "w16" else {}
+        kd = dict(wt=wt32, wt16=wt16) if bf == "w16" else {}
+        t1 = timeit(lambda: ops.conv_fprop(x, wt, None, st, (pad, pad), False, want_stats=True, **kw))
+        t2 = timeit(lambda: ops.conv_dgrad(dy, wt, (n, c, h, w), st, (pad, pad), out=dx, **kd))
         t3 = timeit(lambda: ops.conv_wgrad(x, dy, dw, st, (pad, pad)))
         row += " %s fprop %.3f ms %.0f TF, dgrad %.3f ms %.0f TF, wgrad %.3f ms %.0f TF |" % (
-            "bf16" if bf else "fp32", t1, flops / t1 / 1e9, t2, flops / t2 / 1e9, t3, flops / t3 / 1e9)
+            {False: "fp32", True: "bf16", "w16": "bf16 + bf16 filter copies"}[bf], t1, flops / t1 / 1e9, t2, flops / t2 / 1e9,
+            t3, flops / t3 / 1e9)
     ops.BF16 = False
     print(row, flush=True)
