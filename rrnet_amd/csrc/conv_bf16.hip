@@ -182,6 +182,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(const ConvArgs a)
     auto load_all = [&]() {
 #pragma unroll
         for (int j = 0; j < AJ; ++j) {
+            // (timing experiment, round 4: without this tap-mask arithmetic — wrong at the borders — the kernel runs 6 % faster)
             const unsigned ok = (unsigned)p_cok & (unsigned)((a_mask[j] >> p_tlc) & 1ull) & (unsigned)p_live;
             const unsigned off = ok ? (unsigned)(a_boff[j] + p_adelta) : OOB;
             ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_src, off, 0, 0));
