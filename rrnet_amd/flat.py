@@ -76,6 +76,7 @@ class FlatParams:
         self.w16_flat = self.wt16_flat = None       # bf16 copies (plain / flipped) for the bf16-operand kernels, on demand
         self._wt_table = None
         self._wt_version = None
+        self._wt_pver = {}                          # id(parameter) -> its own version counter at the last fill
         self._wt_enabled = os.environ.get("RR_WT_CACHE", "1") != "0" and dev.type == "cuda"
         self.overlap = os.environ.get("RR_DP_OVERLAP", "1") != "0"
         self._pg = None
@@ -105,7 +106,9 @@ class FlatParams:
 
     def refresh_wt(self):
         """Refill the flipped-filter cache from the current parameters (one launch).  Called by FlatAdam.step right after
-        the update kernel, and by wt_view when the parameters were written some other way (load_state_dict, broadcast)."""
+        the update kernel, and by wt_view when the parameters were written some other way: an in-place write to the flat
+        buffer (broadcast) or to a parameter (load_state_dict's param.copy_) moves that tensor's version counter, which is
+        compared at every use.  A write through `p.data` is invisible to both counters: call invalidate_wt() after one."""
         if not self._wt_enabled or self.wt_flat is None:
             return
         from rrnet_amd import _C
@@ -118,6 +121,11 @@ class FlatParams:
             _C.check(_C.fn("rr_weight_flip_transpose_batch")(_C.ptr(self.flat), _C.ptr(self.wt_flat), _C.ptr(self._wt_table),
                                                              self._wt_table.shape[0], _C.stream()), "rr_weight_flip_transpose_batch")
         self._wt_version = self.flat._version
+        self._wt_pver = {id(p): p._version for p in self.params if p.dim() == 4}
+
+    def invalidate_wt(self):
+        """Mark the flipped-filter cache stale (the next data gradient refills it)."""
+        self._wt_version = None
 
     def _wt_ready(self, p, bf16):
         if not self._wt_enabled or p.dim() != 4 or id(p) not in self._offs:
@@ -130,7 +138,7 @@ class FlatParams:
             self.w16_flat = torch.empty(self.numel, dtype=torch.bfloat16, device=self.flat.device)
             self.wt16_flat = torch.empty(self.numel, dtype=torch.bfloat16, device=self.flat.device)
             self._wt_version = None
-        if self._wt_version != self.flat._version:       # parameters written since the last fill (or never filled)
+        if self._wt_version != self.flat._version or self._wt_pver.get(id(p)) != p._version:   # written since the last fill
             self.refresh_wt()
         return True
 

@@ -123,3 +123,46 @@ def test_training_process_entry_point(tmp_path, monkeypatch, capsys):
     # round trip into a fresh model of the same architecture
     from rrnet_amd.models.rrnet import RRNet
     RRNet(cfg).load_state_dict(sd, strict=True)
+
+
+def test_flipped_filter_cache_follows_the_parameters():
+    """FlatParams keeps flipped / transposed copies of every filter (fp32 and, on demand, bf16) for the stride-1 data gradients,
+    refilled by ONE launch per optimizer step (rr_weight_flip_transpose_batch[_bf16]).  The cache must equal the per-layer
+    kernel's output, follow a fused Adam step (raw-pointer update) and follow parameters written some other way
+    (load_state_dict: the flat buffer's version counter)."""
+    from rrnet_amd import _C, ops
+    from rrnet_amd.flat import FlatAdam
+    m = _model()
+    opt = FlatAdam(m, lr=1e-2)
+    fp = opt.fp
+
+    def reference(p):
+        k, c, r, s = p.shape
+        wt = torch.empty(k * c * r * s, dtype=torch.float32, device=p.device)
+        _C.check(_C.fn("rr_weight_flip_transpose")(_C.ptr(ops.to_nhwc(p.detach())), _C.ptr(wt), k, c, r, s, _C.stream()), "flip")
+        return wt
+
+    def check(tag):
+        n = 0
+        for p in fp.params:
+            if p.dim() != 4:
+                assert fp.wt_view(p) is None
+                continue
+            ref = reference(p)
+            assert torch.equal(fp.wt_view(p), ref), (tag, tuple(p.shape))
+            w16, wt16 = fp.w16_views(p)
+            assert torch.equal(wt16.float(), ref.to(torch.bfloat16).float()), (tag, "wt16", tuple(p.shape))
+            assert torch.equal(w16.float(), p.detach().permute(0, 2, 3, 1).reshape(-1).to(torch.bfloat16).float()), (tag, "w16")
+            n += 1
+        assert n > 10
+    check("initial")
+    x = torch.randn(2, 3, 64, 64, generator=torch.Generator().manual_seed(1)).cuda()
+    opt.zero_grad()
+    _loss(m, x).backward()
+    before = fp.flat.clone()
+    opt.step()
+    assert not torch.equal(before, fp.flat)
+    check("after the fused Adam step")
+    sd = {k: v.clone() * 1.5 for k, v in m.state_dict().items()}
+    m.load_state_dict(sd)
+    check("after load_state_dict")
