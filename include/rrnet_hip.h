@@ -154,6 +154,37 @@ int rr_conv_dgrad_s1_relubias_bf16(const float *dy, const float *wt, float *dx, 
                                    double *slab, double *sums, hipStream_t stream);
 int rr_conv_wgrad_bf16(const float *x, const float *dy, float *dw, int n, int h, int wd, int c, int k,
                        int r, int s, int stride, int pad_h, int pad_w, int out_h, int out_w, hipStream_t stream);
+
+/* ---- split-operand convolutions ("f16x3", cfg.Model.conv_math; csrc/conv_bf16.hip) -------------------------------
+ * fp32 in, fp32 out, fp32 accumulation, as rr_conv_fprop / rr_conv_dgrad / rr_conv_wgrad (reference: nn.Conv2d in
+ * /root/reference/backbones/hourglass.py:12-61); inside the kernel each operand is the sum of two fp16 values (22
+ * significant bits, after a power-of-two scaling taken from the tensor's largest magnitude) and the three products
+ * hi*hi + hi*lo + lo*hi run on the 16-bit matrix instructions.  amax_*: DEVICE words holding the bit pattern of
+ * max|tensor|, produced by rr_absmax_bits (atomicMax into a word the caller zeroed; several calls may share a word to
+ * take the maximum over several tensors).  Shapes as the _bf16 entry points. */
+int rr_absmax_bits(const float *x, long n, unsigned *out, hipStream_t stream);
+int rr_conv_fprop_f16x3(const float *x, const float *w, const float *bias, float *y, double *stat_slab,
+                        int n, int h, int wd, int c, int k, int r, int s, int stride, int pad_h,
+                        int pad_w, int relu, const unsigned *amax_x, const unsigned *amax_w, hipStream_t stream);
+int rr_conv_dgrad_s1_f16x3(const float *dy, const float *wt, float *dx, int n, int h, int wd, int c, int k,
+                           int r, int s, int pad_h, int pad_w, int accumulate, const unsigned *amax_dy,
+                           const unsigned *amax_w, hipStream_t stream);
+int rr_conv_dgrad_s1_bnsum_f16x3(const float *dy, const float *wt, float *dx, int n, int h, int wd, int c, int k,
+                                 int r, int s, int pad_h, int pad_w, int accumulate, const float *prod_y,
+                                 const float *prod_z, const float *prod_mean, const float *prod_invstd,
+                                 const float *prod_mask_scale, const float *prod_mask_shift, double *slab,
+                                 double *sums, const unsigned *amax_dy, const unsigned *amax_w, hipStream_t stream);
+int rr_conv_dgrad_s1_relubias_f16x3(const float *dy, const float *wt, float *dx, int n, int h, int wd, int c, int k,
+                                    int r, int s, int pad_h, int pad_w, int accumulate, const float *prod_z,
+                                    double *slab, double *sums, const unsigned *amax_dy, const unsigned *amax_w,
+                                    hipStream_t stream);
+int rr_conv_dgrad_s2_f16x3(const float *dy, const float *w, float *dx, int n, int h, int wd, int c, int k,
+                           int r, int s, int pad_h, int pad_w, int accumulate, float *wsub, const unsigned *amax_dy,
+                           const unsigned *amax_w, hipStream_t stream);
+int rr_conv_wgrad_f16x3(const float *x, const float *dy, float *dw, int n, int h, int wd, int c, int k,
+                        int r, int s, int stride, int pad_h, int pad_w, int out_h, int out_w, const unsigned *amax_x,
+                        const unsigned *amax_dy, hipStream_t stream);
+
 /* Stride-2 data gradient (rr_conv_dgrad with stride 2) on the bf16 forward kernel: one launch per output parity class
  * (h % 2, w % 2) with that class's sub-filter (1 / 2 / 2 / 4 taps of a 3x3), written to every second pixel of dx
  * [n,h,w,c]; classes no tap reaches are zeroed (unless accumulating).  w OHWI fp32; wsub: k*r*s*c floats of caller

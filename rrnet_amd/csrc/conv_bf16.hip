@@ -23,6 +23,7 @@
 // the layer moves 1.07 GB for 618.5 GFLOP (ridge at 8 TB/s: 0.13 ms; MFMA at peak: 0.25 ms).
 #include "common.h"
 #include "rrnet_hip.h"
+#include <type_traits>
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 int rr_conv_pick_ksplit(int blocks, int nk);      // csrc/conv.hip: the occupancy model shared with the fp32 kernels
@@ -35,6 +36,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
@@ -43,6 +45,54 @@ constexpr int BK = 32;
 constexpr int LDK = BK + 8;          // [row][k] image row stride in bf16 (80 bytes): conflict-free ds_read_b128
 
 __device__ __forceinline__ u16x4 f2bf4(f32x4 v) { return __builtin_bit_cast(u16x4, __builtin_convertvector(v, bf16x4)); }
+
+__device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x16 mfma16(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+
+// v = parts[0] + parts[1] (+ parts[2]) + O(2^-16 / 2^-24 |v|): each part the round-to-nearest-even bf16 of what is left
+// (the subtractions are exact in fp32).  Not for |v| >= 2^127.5 (the hi part rounds to infinity) or non-finite v.
+// F16: the parts are fp16 (11 significant bits each: two parts carry 22 bits), v pre-multiplied by the operand's power-of-two
+// scale (ConvArgs::amax_*) so that the tensor's largest magnitude sits in [2^14, 2^15) of fp16's range.
+template <int SP, bool F16 = false>
+__device__ __forceinline__ void split_bf4(f32x4 v, u16x4 (&parts)[SP], float scale = 1.f)
+{
+    if constexpr (F16) {
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        f32x2 lo2 = {v[0] * scale, v[1] * scale}, hi2 = {v[2] * scale, v[3] * scale};
+#pragma unroll
+        for (int i = 0; i < SP; ++i) {
+            const f16x2 h0 = __builtin_convertvector(lo2, f16x2), h1 = __builtin_convertvector(hi2, f16x2);
+            const u32x2 pk = {__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1)};
+            parts[i] = __builtin_bit_cast(u16x4, pk);
+            if (i + 1 < SP) {
+                lo2 -= __builtin_convertvector(h0, f32x2);
+                hi2 -= __builtin_convertvector(h1, f32x2);
+            }
+        }
+        return;
+    }
+    // pairs: one v_cvt_pk_bf16_f32 rounds two values, shift / mask widen them again (5.5 vector instructions per element for
+    // three parts; element-wise conversion, which is what __builtin_convertvector of the 4-vector compiles to, took 7.9)
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    f32x2 lo2 = {v[0], v[1]}, hi2 = {v[2], v[3]};
+#pragma unroll
+    for (int i = 0; i < SP; ++i) {
+        const unsigned p0 = __builtin_bit_cast(unsigned, __builtin_convertvector(lo2, bf16x2));
+        const unsigned p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(hi2, bf16x2));
+        const u32x2 pk = {p0, p1};
+        parts[i] = __builtin_bit_cast(u16x4, pk);
+        if (i + 1 < SP) {
+            lo2[0] -= __builtin_bit_cast(float, p0 << 16);
+            lo2[1] -= __builtin_bit_cast(float, p0 & 0xffff0000u);
+            hi2[0] -= __builtin_bit_cast(float, p1 << 16);
+            hi2[1] -= __builtin_bit_cast(float, p1 & 0xffff0000u);
+        }
+    }
+}
 
 __device__ __forceinline__ int xcd_remap(int bid, int nb)
 {
@@ -77,15 +127,39 @@ struct ConvArgs {
     // strided destination (stride-2 data gradient, one output parity class per launch): logical output pixel (n, h, w) of
     // the DH x DW grid lands at physical pixel (n, h * osh + oh0, w * osw + ow0) of an OH x OW map; osh == 0: dense
     int OH, OW, osh, osw, oh0, ow0;
+    // F16 instantiations: bit patterns of max|src| and max|w| (rr_absmax_bits), from which the kernel derives the power-of-two
+    // operand scales; null: scale 1
+    const unsigned *amax_src, *amax_w;
 };
 
 // 128 x BN output tile, 256 threads = 4 waves (BN 128: 2x2 waves of 64x64; BN 64: 4x1 waves of 32x64; BN 32: 4x1 of 32x32)
 // B16: the filter comes as bf16 (a.w16; C % 8 == 0): half the B loads, no converts, 16-byte LDS stores for the B image.
 // SO: strided destination (ConvArgs::osh; the stride-2 data gradient's parity-class launches) — its own instantiation: folded
 // into the plain kernel the per-element pixel arithmetic cost 20 registers and the third workgroup per CU (585 -> 524 TFLOP/s).
-template <int BN, bool BNS, bool B16 = false, bool SO = false>
-__global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(const ConvArgs a)
+// SP: operand split (csrc header of the split section below).  1: each operand rounded to ONE bf16 value.  2 / 3: each fp32
+// operand is written as a sum of 2 / 3 bf16 values (hi + mid [+ lo], each the round-to-nearest of what the previous ones left)
+// and the products hi*hi + (hi*mid + mid*hi) [+ hi*lo + mid*mid + lo*hi] are accumulated — 3 / 6 matrix instructions per
+// product tile instead of 1, 2^-16 / 2^-24 relative per product.  The small products go to their own accumulator (added to
+// the hi*hi one in the epilogue), so their rounding never touches the main sum.
+// WS (wave specialisation, 512 threads): waves 0-3 only read LDS and issue matrix instructions, waves 4-7 only fetch, split
+// and stage the next tile.  Each SIMD then holds one wave of each kind and overlaps them in hardware — with 3 / 6 matrix
+// instructions per product tile the loop is matrix-bound only if nothing else sits in the matrix waves' instruction stream.
+template <int BN, bool BNS, bool B16 = false, bool SO = false, int SP = 1, bool WS = false, bool F16 = false>
+__global__ __launch_bounds__(WS ? 512 : 256) void conv_igemm_bf16_kernel(const ConvArgs a)
 {
+    typedef typename std::conditional<F16, f16x8, bf16x8>::type frag_t;
+    // operand scales (F16): 2^(14 - floor(log2(max|tensor|))), exact powers of two; the product is undone in the epilogue
+    float sc_a = 1.f, sc_b = 1.f, sc_inv = 1.f;
+    if constexpr (F16) {
+        auto scale_of = [](const unsigned *p) {
+            if (p == nullptr) return 1.f;
+            const unsigned e = (__builtin_amdgcn_readfirstlane(*p) >> 23) & 0xffu;          // biased exponent of the maximum
+            return e == 0u ? 1.f : __builtin_bit_cast(float, (268u - e) << 23);                // 2^(14 - (e - 127))
+        };
+        sc_a = scale_of(a.amax_src);
+        sc_b = scale_of(a.amax_w);
+        sc_inv = 1.f / (sc_a * sc_b);
+    }
     constexpr int WN = BN / 64 ? BN / 64 : 1;
     constexpr int WM = 4 / WN;
     constexpr int TM = BM / (WM * 32);
@@ -97,10 +171,11 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(const ConvArgs a)
     constexpr int BJ = B16 ? (BN / 64 > 0 ? BN / 64 : 1) : (BN / RPP > 0 ? BN / RPP : 1);   // B16: 4 chunks of 8 channels per row, 64 rows per pass
 
     extern __shared__ __align__(16) unsigned short lds16[];
-    unsigned short *As = lds16;                 // [2][A_ELEMS]
-    unsigned short *Bs = lds16 + 2 * A_ELEMS;   // [2][B_ELEMS]
+    unsigned short *As = lds16;                      // [2][SP][A_ELEMS]
+    unsigned short *Bs = lds16 + 2 * SP * A_ELEMS;   // [2][SP][B_ELEMS]
 
-    const int t = threadIdx.x;
+    const int t = WS ? (threadIdx.x & 255) : threadIdx.x;     // index inside the thread's role group
+    const bool producer = WS && threadIdx.x >= 256;
     const int lane = t & 63, wave = t >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int ntiles = (a.DC + BN - 1) / BN;
@@ -159,10 +234,12 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(const ConvArgs a)
         b_boff[j] = (int)(((long)ko * RS * a.wC + b_col) * (B16 ? 2 : 4));
     }
     const __amdgpu_buffer_rsrc_t rs_src = make_srd(a.src, (long)a.N * a.SH * a.SW * a.SC * 4);
-    const __amdgpu_buffer_rsrc_t rs_w = B16 ? make_srd(a.w16, (long)a.wK * RS * a.wC * 2) : make_srd(a.w, (long)a.wK * RS * a.wC * 4);
+    const __amdgpu_buffer_rsrc_t rs_w = B16 ? make_srd(a.w16, (long)a.wK * RS * a.wC * 2 * SP) : make_srd(a.w, (long)a.wK * RS * a.wC * 4);
+    const int w16_image = a.wK * RS * a.wC * 2;      // B16, SP > 1: the filter's hi / mid / lo images follow each other
     constexpr unsigned OOB = 0xFFFFFFF0u;       // beyond any (< 2 GiB) tensor: the hardware returns 0, no select on the data
 
-    f32x4 ra[AJ], rb[BJ];
+    constexpr int NBI = B16 ? SP : 1;            // filter images fetched per K-step
+    f32x4 ra[AJ], rb[NBI][BJ];
     // wave-uniform state of the K-step being fetched (tap inner, channel chunk outer: the taps re-read the same lines from L2)
     int p_cch = kc_lo / RS, p_tl = kc_lo - (kc_lo / RS) * RS;
     int p_ri = p_tl / a.S, p_si = p_tl - (p_tl / a.S) * a.S;
@@ -179,7 +256,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(const ConvArgs a)
         if (++p_si == a.S) { p_si = 0; ++p_ri; }
         if (p_tl == RS) { p_tl = 0; p_ri = 0; p_si = 0; ++p_cch; }
     };
-    auto load_all = [&]() {
+    auto load_into = [&](f32x4 (&ra)[AJ], f32x4 (&rb)[NBI][BJ]) {
 #pragma unroll
         for (int j = 0; j < AJ; ++j) {
             // (timing experiment, round 4: without this tap-mask arithmetic — wrong at the borders — the kernel runs 6 % faster)
@@ -191,35 +268,182 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(const ConvArgs a)
         for (int j = 0; j < BJ; ++j) {
             const unsigned ok = (unsigned)b_ok[j] & (unsigned)p_wcok & (unsigned)p_live;
             const unsigned off = ok ? (unsigned)(b_boff[j] + p_wdelta) : OOB;
-            rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, off, 0, 0));   // B16: 8 bf16
+#pragma unroll
+            for (int sp = 0; sp < (B16 ? SP : 1); ++sp)      // (OOB + image offset stays beyond the descriptor's size)
+                rb[sp][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, off, sp * w16_image, 0));   // B16: 8 bf16
         }
     };
-    auto store_all = [&](int buf) {
-        unsigned short *A = As + buf * A_ELEMS, *B = Bs + buf * B_ELEMS;
+    auto load_all = [&]() { load_into(ra, rb); };
+    auto store_from = [&](f32x4 (&ra)[AJ], f32x4 (&rb)[NBI][BJ], int buf) {
+        unsigned short *A = As + buf * SP * A_ELEMS, *B = Bs + buf * SP * B_ELEMS;
 #pragma unroll
-        for (int j = 0; j < AJ; ++j)
-            *reinterpret_cast<u16x4 *>(A + (a_row + RPP * j) * LDK + a_col) = f2bf4(ra[j]);
+        for (int j = 0; j < AJ; ++j) {
+            u16x4 parts[SP];
+            split_bf4<SP, F16>(ra[j], parts, sc_a);
+#pragma unroll
+            for (int sp = 0; sp < SP; ++sp)
+                *reinterpret_cast<u16x4 *>(A + sp * A_ELEMS + (a_row + RPP * j) * LDK + a_col) = parts[sp];
+        }
         if constexpr (B16) {
 #pragma unroll
             for (int j = 0; j < BJ; ++j)
                 if (BN >= 64 || b_row < BN)
-                    *reinterpret_cast<f32x4 *>(B + (b_row + 64 * j) * LDK + b_col) = rb[j];
+#pragma unroll
+                    for (int sp = 0; sp < SP; ++sp)
+                        *reinterpret_cast<f32x4 *>(B + sp * B_ELEMS + (b_row + 64 * j) * LDK + b_col) = rb[sp][j];
         } else {
 #pragma unroll
-            for (int j = 0; j < BJ; ++j)      // (a_row + RPP * j < BN always: BJ = BN / RPP, a_row < RPP — no guard, no exec-mask branch)
-                *reinterpret_cast<u16x4 *>(B + (a_row + RPP * j) * LDK + a_col) = f2bf4(rb[j]);
+            for (int j = 0; j < BJ; ++j) {    // (a_row + RPP * j < BN always: BJ = BN / RPP, a_row < RPP — no guard, no exec-mask branch)
+                u16x4 parts[SP];
+                split_bf4<SP, F16>(rb[0][j], parts, sc_b);
+#pragma unroll
+                for (int sp = 0; sp < SP; ++sp)
+                    *reinterpret_cast<u16x4 *>(B + sp * B_ELEMS + (a_row + RPP * j) * LDK + a_col) = parts[sp];
+            }
         }
     };
 
-    f32x16 acc[TM][TN];
+    auto store_all = [&](int buf) { store_from(ra, rb, buf); };
+
+    f32x16 acc[TM][TN], acl[SP > 1 ? TM : 1][SP > 1 ? TN : 1];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+            for (int e = 0; e < 16; ++e) {
+                acc[i][j][e] = 0.f;
+                if constexpr (SP > 1) acl[i][j][e] = 0.f;
+            }
     const int lr = lane & 31, lh = lane >> 5;
 
+    if constexpr (WS) {
+        // LDS stores / reads of this wave retired, then the barrier: no vmcnt wait (the producers' loads of tile kc + 2 stay in
+        // flight across it, __syncthreads() would drain them).  "memory": the compiler moves no LDS access across it.
+#define RR_WS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+        if (producer) {
+            // Two tiles in flight in registers (ra / rb and ra2 / rb2 alternate): a tile's loads are issued a whole K-step before
+            // its split + LDS store needs them.  The loads are inline assembly and the waits are counted BY HAND: hipcc's own wait
+            // insertion is conservative at a loop header (registers loaded before the back edge get vmcnt(0) at their first use,
+            // whatever was issued after them), which exposed a full memory latency in every second K-step of this loop.
+            // Every load's destination is an output of its asm statement and an in/out operand of the wait that retires it, so
+            // nothing the compiler schedules can read it in between.
+            typedef int i32x4 __attribute__((ext_vector_type(4)));
+            auto srd4 = [](const void *p, long bytes) {
+                const unsigned long long u = reinterpret_cast<unsigned long long>(p);
+                i32x4 r;
+                r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)u);
+                r[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32));
+                r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+                r[3] = 0x00020000;
+                return r;
+            };
+            const i32x4 q_src = srd4(a.src, (long)a.N * a.SH * a.SW * a.SC * 4);
+            const i32x4 q_w = B16 ? srd4(a.w16, (long)a.wK * RS * a.wC * 2 * SP) : srd4(a.w, (long)a.wK * RS * a.wC * 4);
+            constexpr int NLOADS = AJ + NBI * BJ;       // loads per tile and thread
+            static_assert(NLOADS == 8 || NLOADS == 6 || NLOADS == 10, "the wait count below is a literal");
+            auto fetch = [&](f32x4 (&ra)[AJ], f32x4 (&rb)[NBI][BJ]) {
+#pragma unroll
+                for (int j = 0; j < AJ; ++j) {
+                    const unsigned ok = (unsigned)p_cok & (unsigned)((a_mask[j] >> p_tlc) & 1ull) & (unsigned)p_live;
+                    const unsigned off = ok ? (unsigned)(a_boff[j] + p_adelta) : OOB;
+                    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(ra[j]) : "v"(off), "s"(q_src) : "memory");
+                }
+#pragma unroll
+                for (int j = 0; j < BJ; ++j) {
+                    const unsigned ok = (unsigned)b_ok[j] & (unsigned)p_wcok & (unsigned)p_live;
+#pragma unroll
+                    for (int sp = 0; sp < NBI; ++sp) {
+                        const unsigned off = ok ? (unsigned)(b_boff[j] + p_wdelta + sp * w16_image) : OOB;
+                        asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(rb[sp][j]) : "v"(off), "s"(q_w) : "memory");
+                    }
+                }
+            };
+            // all but the newest NLOADS loads have landed: the tile in (ra, rb) is complete, the next one may still be in flight
+            auto landed = [&](f32x4 (&ra)[AJ], f32x4 (&rb)[NBI][BJ]) {
+                static_assert(AJ == 4, "operand list below");
+                if constexpr (NLOADS == 8) asm volatile("s_waitcnt vmcnt(8)" : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]) :: "memory");
+                else if constexpr (NLOADS == 6) asm volatile("s_waitcnt vmcnt(6)" : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]) :: "memory");
+                else asm volatile("s_waitcnt vmcnt(10)" : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]) :: "memory");
+#pragma unroll
+                for (int sp = 0; sp < NBI; ++sp)
+#pragma unroll
+                    for (int j = 0; j < BJ; ++j) asm volatile("" : "+v"(rb[sp][j]) :: "memory");   // (ordered behind the wait: both volatile)
+            };
+            f32x4 ra2[AJ], rb2[NBI][BJ];
+            prep();
+            fetch(ra, rb);                          // tile 0
+            p_live = kc_lo + 1 < kc_hi;
+            prep();
+            fetch(ra2, rb2);                        // tile 1
+            landed(ra, rb);
+            store_from(ra, rb, 0);
+            p_live = kc_lo + 2 < kc_hi;
+            prep();
+            fetch(ra, rb);                          // tile 2
+            RR_WS_BARRIER();
+            for (int kc = kc_lo; kc < kc_hi; kc += 2) {
+                landed(ra2, rb2);
+                store_from(ra2, rb2, 1);            // tile kc + 1: the readers of tile kc - 1 passed the previous barrier
+                p_live = kc + 3 < kc_hi;
+                prep();
+                fetch(ra2, rb2);
+                RR_WS_BARRIER();
+                if (kc + 1 >= kc_hi) break;
+                landed(ra, rb);
+                store_from(ra, rb, 0);              // tile kc + 2
+                p_live = kc + 4 < kc_hi;
+                prep();
+                fetch(ra, rb);
+                RR_WS_BARRIER();
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the two tiles past the end (all-zero loads) before the registers are reused
+        } else {
+            // Matrix waves, rotated by half a K-step against the barrier: the fragments of a tile's second half and of the next
+            // tile's first half are fetched while the other half's matrix instructions run, so no LDS latency is exposed.
+            //   barrier #kc+1 sits between the two halves of tile kc: by then this wave holds ALL of tile kc in registers
+            //   (its buffer is free for tile kc + 2) and the producers have finished tile kc + 1.
+            frag_t f0a[SP][TM], f0b[SP][TN], f1a[SP][TM], f1b[SP][TN];
+            auto frags = [&](frag_t (&fa)[SP][TM], frag_t (&fb)[SP][TN], int buf, int kk) {
+                const unsigned short *A = As + buf * SP * A_ELEMS, *B = Bs + buf * SP * B_ELEMS;
+#pragma unroll
+                for (int sp = 0; sp < SP; ++sp) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+                        fa[sp][i] = *reinterpret_cast<const frag_t *>(A + sp * A_ELEMS + ((wm * TM + i) * 32 + lr) * LDK + kk * 16 + lh * 8);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        fb[sp][j] = *reinterpret_cast<const frag_t *>(B + sp * B_ELEMS + ((wn * TN + j) * 32 + lr) * LDK + kk * 16 + lh * 8);
+                }
+            };
+            auto mma = [&](frag_t (&fa)[SP][TM], frag_t (&fb)[SP][TN]) {
+#define RR_MM(ACC, PA, PB)                                                                                          \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)                      \
+        ACC[i][j] = mfma16(fa[PA][i], fb[PB][j], ACC[i][j]);
+                RR_MM(acc, 0, 0)
+                if constexpr (SP >= 2) { RR_MM(acl, 0, 1) RR_MM(acl, 1, 0) }
+                if constexpr (SP == 3) { RR_MM(acl, 1, 1) RR_MM(acl, 0, 2) RR_MM(acl, 2, 0) }
+#undef RR_MM
+            };
+            __builtin_amdgcn_s_setprio(1);
+            RR_WS_BARRIER();
+            frags(f0a, f0b, 0, 0);
+            for (int kc = kc_lo; kc < kc_hi; ++kc) {
+                const int buf = (kc - kc_lo) & 1;
+                frags(f1a, f1b, buf, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(f0a, f0b);
+                __builtin_amdgcn_sched_barrier(0);
+                RR_WS_BARRIER();
+                frags(f0a, f0b, buf ^ 1, 0);        // (after the last tile: a buffer of zeros, never used)
+                __builtin_amdgcn_sched_barrier(0);
+                mma(f1a, f1b);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __builtin_amdgcn_s_setprio(0);
+        }
+#undef RR_WS_BARRIER
+    } else {
     if (kc_lo < kc_hi) {
         prep();
         load_all();
@@ -231,17 +455,19 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(const ConvArgs a)
     __syncthreads();
     for (int kc = kc_lo; kc < kc_hi; ++kc) {
         const int buf = (kc - kc_lo) & 1;
-        const unsigned short *A = As + buf * A_ELEMS, *B = Bs + buf * B_ELEMS;
-        bf16x8 fa[2][TM], fb[2][TN];
+        const unsigned short *A = As + buf * SP * A_ELEMS, *B = Bs + buf * SP * B_ELEMS;
+        frag_t fa[2][SP][TM], fb[2][SP][TN];
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+        for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-                fa[kk][i] = *reinterpret_cast<const bf16x8 *>(A + ((wm * TM + i) * 32 + lr) * LDK + kk * 16 + lh * 8);
+            for (int sp = 0; sp < SP; ++sp) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-                fb[kk][j] = *reinterpret_cast<const bf16x8 *>(B + ((wn * TN + j) * 32 + lr) * LDK + kk * 16 + lh * 8);
-        }
+                for (int i = 0; i < TM; ++i)
+                    fa[kk][sp][i] = *reinterpret_cast<const frag_t *>(A + sp * A_ELEMS + ((wm * TM + i) * 32 + lr) * LDK + kk * 16 + lh * 8);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    fb[kk][sp][j] = *reinterpret_cast<const frag_t *>(B + sp * B_ELEMS + ((wn * TN + j) * 32 + lr) * LDK + kk * 16 + lh * 8);
+            }
         // tile kc + 1 (loaded one iteration ago) -> the other LDS buffer, whose last readers passed the previous barrier;
         // then tile kc + 2 goes out.  (Staging BEHIND the matrix instructions instead — a whole iteration for the loads to
         // land — measured the same: the loop is bound by instruction issue, ~96 non-MFMA instructions per 8 MFMAs.)
@@ -250,13 +476,27 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(const ConvArgs a)
         prep();
         load_all();
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk][i], fb[kk][j], acc[i][j], 0, 0, 0);
+        for (int kk = 0; kk < 2; ++kk) {
+            // (product outermost, tiles inner: consecutive matrix instructions never share an accumulator)
+#define RR_MM(ACC, PA, PB)                                                                                          \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)                      \
+        ACC[i][j] = mfma16(fa[kk][PA][i], fb[kk][PB][j], ACC[i][j]);
+            if constexpr (SP == 3) { RR_MM(acl, 0, 2) RR_MM(acl, 2, 0) RR_MM(acl, 1, 1) }
+            if constexpr (SP >= 2) { RR_MM(acl, 0, 1) RR_MM(acl, 1, 0) }
+            RR_MM(acc, 0, 0)
+#undef RR_MM
+        }
         __syncthreads();
+    }
+    }
+    if constexpr (SP > 1) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                acc[i][j] += acl[i][j];
+                if constexpr (F16) acc[i][j] *= sc_inv;
+            }
     }
 
     // ---- epilogue (as csrc/conv.hip).  D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
@@ -265,6 +505,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(const ConvArgs a)
     const __amdgpu_buffer_rsrc_t bs_rs_y = make_srd(BNS ? a.bs_y : a.src, (long)a.M * a.DC * 4);
     const __amdgpu_buffer_rsrc_t bs_rs_z = make_srd(BNS && a.bs_z != nullptr ? a.bs_z : a.src, (long)a.M * a.DC * 4);
     const int mode_e = a.ksplit > 1 ? 2 : (a.accumulate ? 1 : 0);
+    if (!producer) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int ncol = n0 + (wn * TN + j) * 32 + lr;
@@ -350,9 +591,10 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(const ConvArgs a)
             }
         }
     }
+    }
     if (do_stats) {
         __syncthreads();
-        if (t < BN && n0 + t < a.DC) {
+        if (t < BN && n0 + t < a.DC && !producer) {
             double d1 = 0.0, d2 = 0.0;
 #pragma unroll
             for (int w = 0; w < WM; ++w) {
@@ -401,21 +643,22 @@ struct BnSumArgs {
 
 struct OutMap { int DH, DW, OH, OW, osh, osw, oh0, ow0; };   // explicit logical output grid + strided destination
 
-size_t igemm_lds(int bn) { return sizeof(unsigned short) * 2 * (size_t)(BM + bn) * LDK; }
+size_t igemm_lds(int bn, int sp = 1) { return sizeof(unsigned short) * 2 * (size_t)sp * (BM + bn) * LDK; }
 
 template <typename K>
-int launch(K kern, int blocks, int gz, size_t lds, hipStream_t stream, const ConvArgs &args, const char *name)
+int launch(K kern, int blocks, int gz, size_t lds, hipStream_t stream, const ConvArgs &args, const char *name, int threads = 256)
 {
     if (lds > 48 * 1024)
-        hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3(blocks, 1, gz), dim3(256), lds, stream, args);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3(blocks, 1, gz), dim3(threads), lds, stream, args);
     RR_CHECK_LAUNCH(name);
     return RR_OK;
 }
 
 int fprop_impl(const float *x, const float *w, const float *bias, float *y, double *stat_slab, int n, int h, int wd, int c,
                int k, int r, int s, int stride, int pad_h, int pad_w, int relu, int accumulate, hipStream_t stream,
-               const BnSumArgs *bs = nullptr, const OutMap *om = nullptr, const unsigned short *w16 = nullptr)
+               const BnSumArgs *bs = nullptr, const OutMap *om = nullptr, const unsigned short *w16 = nullptr,
+               int split = 0, const unsigned *amax_src = nullptr, const unsigned *amax_w = nullptr)
 {
     RR_CHECK_ARG(n > 0 && h > 0 && wd > 0 && c > 0 && k > 0 && r > 0 && s > 0 && stride > 0, "rr_conv_fprop_bf16: bad dims");
     RR_CHECK_ARG(c % 4 == 0 && r * s <= 64, "rr_conv_fprop_bf16: C=%d must be a multiple of 4 and R*S <= 64 (fp32 path for the rest)", c);
@@ -466,10 +709,26 @@ int fprop_impl(const float *x, const float *w, const float *bias, float *y, doub
 #define RR_IG(BNv, BNSv, SOv)                                                                                      \
     (a.w16 ? launch(conv_igemm_bf16_kernel<BNv, BNSv, true, SOv>, blocks, ks, igemm_lds(BNv), stream, a, name)           \
            : launch(conv_igemm_bf16_kernel<BNv, BNSv, false, SOv>, blocks, ks, igemm_lds(BNv), stream, a, name))
+    // split operands (rr_conv_*_f16x3): two fp16 parts per operand, three matrix instructions per product tile
+#define RR_SX(BNv, BNSv, SOv) launch(conv_igemm_bf16_kernel<BNv, BNSv, false, SOv, 2, false, true>, blocks, ks, igemm_lds(BNv, 2), stream, a, name)
+#define RR_SW(BNSv) launch(conv_igemm_bf16_kernel<128, BNSv, false, false, 2, true, true>, blocks, ks, igemm_lds(128, 2), stream, a, name, 512)
+    if (split) {
+        static int ws_env = -1;             // RR_SPLIT_WS=0: the 256-thread kernel on the 128-wide tiles too (A/B switch)
+        if (ws_env < 0) { const char *e = getenv("RR_SPLIT_WS"); ws_env = e ? atoi(e) : 1; }
+        a.w16 = nullptr;
+        a.amax_src = amax_src; a.amax_w = amax_w;
+        name = "rr_conv_fprop_f16x3";
+        if (ws_env && bn == 128 && !a.osh) rc = fused ? RR_SW(true) : RR_SW(false);
+        else if (fused) rc = bn == 128 ? RR_SX(128, true, false) : bn == 64 ? RR_SX(64, true, false) : RR_SX(32, true, false);
+        else if (a.osh) rc = bn == 128 ? RR_SX(128, false, true) : bn == 64 ? RR_SX(64, false, true) : RR_SX(32, false, true);
+        else rc = bn == 128 ? RR_SX(128, false, false) : bn == 64 ? RR_SX(64, false, false) : RR_SX(32, false, false);
+    } else
     if (fused) rc = bn == 128 ? RR_IG(128, true, false) : bn == 64 ? RR_IG(64, true, false) : RR_IG(32, true, false);
     else if (a.osh) rc = bn == 128 ? RR_IG(128, false, true) : bn == 64 ? RR_IG(64, false, true) : RR_IG(32, false, true);
     else rc = bn == 128 ? RR_IG(128, false, false) : bn == 64 ? RR_IG(64, false, false) : RR_IG(32, false, false);
 #undef RR_IG
+#undef RR_SX
+#undef RR_SW
     if (rc == RR_OK && bs != nullptr) {
         if (fused) return rr_bn_reduce_slab(bs->slab, (int)rr_cdiv(M, BM), k, bs->sums, stream);
         return rr_bn_bwd_reduce(y, bs->z, bs->y, bs->mean, bs->invstd, bs->msc, bs->msh, bs->sums, M, k, 1, stream);
@@ -495,28 +754,44 @@ struct WgradArgs {
     float *dw;
     int N, H, W, C, K, R, S, P, Q, stride, pad_h, pad_w;
     int M, chunks_per_split, mt, nt;
+    const unsigned *amax_x, *amax_dy;       // split instantiation: bit patterns of max|x|, max|dy| (rr_absmax_bits)
 };
 
-__device__ __forceinline__ bf16x8 lds_tr_frag(const unsigned short *img, int k0, int lane)
+template <typename F = bf16x8>
+__device__ __forceinline__ F lds_tr_frag(const unsigned short *img, int k0, int lane)
 {
     const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
     const unsigned short *a = img + (k0 + 8 * (g >> 1) + q) * 32 + 16 * (g & 1) + 4 * p;
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)a);
     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(a + 4 * 32));
-    union { s16x4 h[2]; bf16x8 v; } u;
+    union { s16x4 h[2]; F v; } u;
     u.h[0] = lo; u.h[1] = hi;
     return u.v;
 }
 
 // 128 (ko) x 128 (c) tile per workgroup and tap; 2x2 waves of 64x64.  K-step = 32 pixels.
+// SP = 2, F16: both operands split into two fp16 parts (see conv_igemm_bf16_kernel), three matrix instructions per tile.
+template <int SP = 1, bool F16 = false>
 __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradArgs a)
 {
+    typedef typename std::conditional<F16, f16x8, bf16x8>::type frag_t;
+    float sc_a = 1.f, sc_b = 1.f, sc_inv = 1.f;
+    if constexpr (F16) {
+        auto scale_of = [](const unsigned *p) {
+            if (p == nullptr) return 1.f;
+            const unsigned e = (__builtin_amdgcn_readfirstlane(*p) >> 23) & 0xffu;
+            return e == 0u ? 1.f : __builtin_bit_cast(float, (268u - e) << 23);
+        };
+        sc_a = scale_of(a.amax_dy);
+        sc_b = scale_of(a.amax_x);
+        sc_inv = 1.f / (sc_a * sc_b);
+    }
     constexpr int BLK = 32 * 32 + 32;            // one 32-column block of a K-step: [32 pixels][32 channels] (+64 B: the 8-byte
                                                  // stores of a 16-lane group go to two blocks, on disjoint banks)
     constexpr int IMG = 4 * BLK;                 // 128 channels
     extern __shared__ __align__(16) unsigned short lds16[];
-    unsigned short *As = lds16;                  // [2][IMG]  dY  (ko)
-    unsigned short *Bs = lds16 + 2 * IMG;        // [2][IMG]  X   (c)
+    unsigned short *As = lds16;                  // [2][SP][IMG]  dY  (ko)
+    unsigned short *Bs = lds16 + 2 * SP * IMG;   // [2][SP][IMG]  X   (c)
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -575,22 +850,31 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradArgs a)
         }
     };
     auto store_all = [&](int buf) {
-        unsigned short *A = As + buf * IMG, *B = Bs + buf * IMG;
+        unsigned short *A = As + buf * SP * IMG, *B = Bs + buf * SP * IMG;
         const int blk = (s_col >> 5) * BLK, cc = s_col & 31;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            *reinterpret_cast<u16x4 *>(A + blk + (s_row + 8 * j) * 32 + cc) = f2bf4(ra[j]);
-            *reinterpret_cast<u16x4 *>(B + blk + (s_row + 8 * j) * 32 + cc) = f2bf4(rb[j]);
+            u16x4 pa[SP], pb[SP];
+            split_bf4<SP, F16>(ra[j], pa, sc_a);
+            split_bf4<SP, F16>(rb[j], pb, sc_b);
+#pragma unroll
+            for (int sp = 0; sp < SP; ++sp) {
+                *reinterpret_cast<u16x4 *>(A + sp * IMG + blk + (s_row + 8 * j) * 32 + cc) = pa[sp];
+                *reinterpret_cast<u16x4 *>(B + sp * IMG + blk + (s_row + 8 * j) * 32 + cc) = pb[sp];
+            }
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][2], acl[SP > 1 ? 2 : 1][SP > 1 ? 2 : 1];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+            for (int e = 0; e < 16; ++e) {
+                acc[i][j][e] = 0.f;
+                if constexpr (SP > 1) acl[i][j][e] = 0.f;
+            }
 
     load_all(kc_begin);
     store_all(0);
@@ -598,25 +882,39 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradArgs a)
     __syncthreads();
     for (int kc = kc_begin; kc < kc_end; ++kc) {
         const int buf = (kc - kc_begin) & 1;
-        const unsigned short *A = As + buf * IMG, *B = Bs + buf * IMG;
-        bf16x8 fa[2][2], fb[2][2];
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) fa[kk][i] = lds_tr_frag(A + (wm * 2 + i) * BLK, kk * 16, lane);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) fb[kk][j] = lds_tr_frag(B + (wn * 2 + j) * BLK, kk * 16, lane);
-        }
-        store_all(buf ^ 1);
-        load_all(kc + 2);
+        const unsigned short *A = As + buf * SP * IMG, *B = Bs + buf * SP * IMG;
+        frag_t fa[2][SP][2], fb[2][SP][2];
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int sp = 0; sp < SP; ++sp) {
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk][i], fb[kk][j], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < 2; ++i) fa[kk][sp][i] = lds_tr_frag<frag_t>(A + sp * IMG + (wm * 2 + i) * BLK, kk * 16, lane);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) fb[kk][sp][j] = lds_tr_frag<frag_t>(B + sp * IMG + (wn * 2 + j) * BLK, kk * 16, lane);
+            }
+        store_all(buf ^ 1);
+        load_all(kc + 2);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+#define RR_MM(ACC, PA, PB)                                                                                          \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                        \
+        ACC[i][j] = mfma16(fa[kk][PA][i], fb[kk][PB][j], ACC[i][j]);
+            RR_MM(acc, 0, 0)
+            if constexpr (SP >= 2) { RR_MM(acl, 0, 1) RR_MM(acl, 1, 0) }
+            if constexpr (SP == 3) { RR_MM(acl, 1, 1) RR_MM(acl, 0, 2) RR_MM(acl, 2, 0) }
+#undef RR_MM
+        }
         __syncthreads();
+    }
+    if constexpr (SP > 1) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                acc[i][j] += acl[i][j];
+                if constexpr (F16) acc[i][j] *= sc_inv;
+            }
     }
     const int lr = lane & 31, lh = lane >> 5;
 #pragma unroll
@@ -633,7 +931,27 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradArgs a)
     }
 }
 
+__global__ __launch_bounds__(256) void absmax_bits_kernel(const f32x4 *x, long n4, unsigned *out)
+{
+    float m = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const f32x4 v = x[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __builtin_bit_cast(unsigned, m));     // non-negative floats order as their bit patterns
+}
+
 }  // namespace
+
+extern "C" int rr_absmax_bits(const float *x, long n, unsigned *out, hipStream_t stream)
+{
+    RR_CHECK_ARG(n % 4 == 0, "rr_absmax_bits: n must be a multiple of 4");
+    hipLaunchKernelGGL(absmax_bits_kernel, dim3(1024), dim3(256), 0, stream, reinterpret_cast<const f32x4 *>(x), n / 4, out);
+    RR_CHECK_LAUNCH("rr_absmax_bits");
+    return RR_OK;
+}
 
 extern "C" int rr_conv_fprop_bf16(const float *x, const float *w, const float *bias, float *y, double *stat_slab,
                                   int n, int h, int wd, int c, int k, int r, int s, int stride, int pad_h,
@@ -711,8 +1029,9 @@ __global__ __launch_bounds__(256) void weight_parity_pack_kernel(const float *w,
     }
 }
 
-extern "C" int rr_conv_dgrad_s2_bf16(const float *dy, const float *w, float *dx, int n, int h, int wd, int c, int k,
-                                     int r, int s, int pad_h, int pad_w, int accumulate, float *wsub, hipStream_t stream)
+static int dgrad_s2_impl(const float *dy, const float *w, float *dx, int n, int h, int wd, int c, int k, int r, int s, int pad_h,
+                         int pad_w, int accumulate, float *wsub, hipStream_t stream, int split, const unsigned *amax_dy,
+                         const unsigned *amax_w)
 {
     RR_CHECK_ARG(n > 0 && h > 0 && wd > 0 && c > 0 && k > 0 && r > 0 && s > 0, "rr_conv_dgrad_s2_bf16: bad dims");
     RR_CHECK_ARG(c % 4 == 0 && k % 4 == 0 && r * s <= 64 && pad_h >= 0 && pad_w >= 0 && wsub != nullptr,
@@ -746,7 +1065,7 @@ extern "C" int rr_conv_dgrad_s2_bf16(const float *dy, const float *w, float *dx,
         if (blk > 0 && Hc > 0 && Wc > 0) {
             const OutMap om{Hc, Wc, h, wd, 2, 2, ph, pw};
             const int rc = fprop_impl(dy, wsub + base, nullptr, dx, nullptr, n, p, q, k, c, Rc[cl], Sc[cl], 1, lead_h[cl], lead_w[cl], 0,
-                                      accumulate, stream, nullptr, &om);
+                                      accumulate, stream, nullptr, &om, nullptr, split, amax_dy, amax_w);
             if (rc != RR_OK) return rc;
         }
         base += blk;
@@ -754,13 +1073,21 @@ extern "C" int rr_conv_dgrad_s2_bf16(const float *dy, const float *w, float *dx,
     return RR_OK;
 }
 
-extern "C" int rr_conv_wgrad_bf16(const float *x, const float *dy, float *dw, int n, int h, int wd, int c, int k,
-                                  int r, int s, int stride, int pad_h, int pad_w, int out_h, int out_w, hipStream_t stream)
+extern "C" int rr_conv_dgrad_s2_bf16(const float *dy, const float *w, float *dx, int n, int h, int wd, int c, int k,
+                                     int r, int s, int pad_h, int pad_w, int accumulate, float *wsub, hipStream_t stream)
+{
+    return dgrad_s2_impl(dy, w, dx, n, h, wd, c, k, r, s, pad_h, pad_w, accumulate, wsub, stream, 0, nullptr, nullptr);
+}
+
+static int wgrad_impl(const float *x, const float *dy, float *dw, int n, int h, int wd, int c, int k, int r, int s, int stride,
+                      int pad_h, int pad_w, int out_h, int out_w, hipStream_t stream, int split, const unsigned *amax_x,
+                      const unsigned *amax_dy)
 {
     RR_CHECK_ARG(n > 0 && h > 0 && wd > 0 && c > 0 && k > 0 && r > 0 && s > 0 && stride > 0, "rr_conv_wgrad_bf16: bad dims");
     RR_CHECK_ARG(c % 4 == 0 && k % 4 == 0, "rr_conv_wgrad_bf16: C=%d, K=%d must be multiples of 4 (fp32 path for the rest)", c, k);
     WgradArgs a{};
     a.x = x; a.dy = dy; a.dw = dw;
+    a.amax_x = amax_x; a.amax_dy = amax_dy;
     a.N = n; a.H = h; a.W = wd; a.C = c; a.K = k; a.R = r; a.S = s;
     a.P = out_h > 0 ? out_h : (h + 2 * pad_h - r) / stride + 1;
     a.Q = out_w > 0 ? out_w : (wd + 2 * pad_w - s) / stride + 1;
@@ -772,15 +1099,104 @@ extern "C" int rr_conv_wgrad_bf16(const float *x, const float *dy, float *dw, in
     a.mt = rr_cdiv(k, 128); a.nt = rr_cdiv(c, 128);
     const int tiles = a.mt * a.nt * r * s;
     const int total_chunks = rr_cdiv(M, BK);
-    // pixel splits: fill the resident-workgroup slots (256 CUs x 4) once, never fewer than 16 K-steps per split
-    const int slots = 1024;
+    // pixel splits: fill the resident-workgroup slots (256 CUs x 4; x 2 for the split kernel's 68 KB of LDS) once, never fewer
+    // than 16 K-steps per split
+    const int slots = split ? 512 : 1024;
     int splits = tiles < slots ? slots / tiles : 1;
     if (splits > rr_cdiv(total_chunks, 16)) splits = rr_cdiv(total_chunks, 16);
     if (splits < 1) splits = 1;
     a.chunks_per_split = rr_cdiv(total_chunks, splits);
     splits = rr_cdiv(total_chunks, a.chunks_per_split);
-    const size_t lds = sizeof(unsigned short) * 4 * 4 * (32 * 32 + 32);  // 2 operands x 2 buffers x 4 blocks of 32 x 32 (+ pad)
-    hipLaunchKernelGGL(conv_wgrad_bf16_kernel, dim3(tiles * splits), dim3(256), lds, stream, a);
+    const size_t lds = sizeof(unsigned short) * 4 * 4 * (32 * 32 + 32) * (split ? 2 : 1);  // 2 operands x 2 buffers x (parts) x 4 blocks of 32 x 32 (+ pad)
+    if (split) {
+        auto kern = conv_wgrad_bf16_kernel<2, true>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3(tiles * splits), dim3(256), lds, stream, a);
+    } else {
+        hipLaunchKernelGGL((conv_wgrad_bf16_kernel<1, false>), dim3(tiles * splits), dim3(256), lds, stream, a);
+    }
     RR_CHECK_LAUNCH("rr_conv_wgrad_bf16");
     return RR_OK;
+}
+
+extern "C" int rr_conv_wgrad_bf16(const float *x, const float *dy, float *dw, int n, int h, int wd, int c, int k,
+                                  int r, int s, int stride, int pad_h, int pad_w, int out_h, int out_w, hipStream_t stream)
+{
+    return wgrad_impl(x, dy, dw, n, h, wd, c, k, r, s, stride, pad_h, pad_w, out_h, out_w, stream, 0, nullptr, nullptr);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Split-operand entry points ("f16x3"): the same convolutions with each fp32 operand written as hi + lo, two fp16 values
+// (22 significant bits), after a power-of-two scaling that puts the tensor's largest magnitude into [2^14, 2^15), and
+// hi*hi + hi*lo + lo*hi accumulated in fp32 on v_mfma_f32_32x32x16_f16 — three matrix instructions at the 16-bit rate
+// instead of eight v_mfma_f32_32x32x2_f32 for the same 32 x 32 x 16 block (the fp32 matrix rate of gfx950 is 1/16 of the
+// 16-bit one).  amax_*: device words holding the bit pattern of max|tensor| (rr_absmax_bits), read by the kernels, no host
+// synchronisation.  Error against an fp64 convolution: below the fp32-MFMA kernels' own (tests/test_conv_split_gpu.py).
+extern "C" int rr_conv_fprop_f16x3(const float *x, const float *w, const float *bias, float *y, double *stat_slab,
+                                   int n, int h, int wd, int c, int k, int r, int s, int stride, int pad_h,
+                                   int pad_w, int relu, const unsigned *amax_x, const unsigned *amax_w, hipStream_t stream)
+{
+    RR_CHECK_ARG(amax_x && amax_w, "rr_conv_fprop_f16x3: the operands' maxima are required");
+    return fprop_impl(x, w, bias, y, stat_slab, n, h, wd, c, k, r, s, stride, pad_h, pad_w, relu, 0, stream, nullptr, nullptr, nullptr,
+                      1, amax_x, amax_w);
+}
+
+extern "C" int rr_conv_dgrad_s1_f16x3(const float *dy, const float *wt, float *dx, int n, int h, int wd, int c, int k,
+                                      int r, int s, int pad_h, int pad_w, int accumulate, const unsigned *amax_dy,
+                                      const unsigned *amax_w, hipStream_t stream)
+{
+    RR_CHECK_ARG(pad_h < r && pad_w < s && pad_h >= 0 && pad_w >= 0, "rr_conv_dgrad_s1_f16x3: pad must be in [0, kernel)");
+    RR_CHECK_ARG(amax_dy && amax_w, "rr_conv_dgrad_s1_f16x3: the operands' maxima are required");
+    const int p = h + 2 * pad_h - r + 1, q = wd + 2 * pad_w - s + 1;
+    RR_CHECK_ARG(p > 0 && q > 0, "rr_conv_dgrad_s1_f16x3: empty dy");
+    return fprop_impl(dy, wt, nullptr, dx, nullptr, n, p, q, k, c, r, s, 1, r - 1 - pad_h, s - 1 - pad_w, 0, accumulate, stream,
+                      nullptr, nullptr, nullptr, 1, amax_dy, amax_w);
+}
+
+extern "C" int rr_conv_dgrad_s1_bnsum_f16x3(const float *dy, const float *wt, float *dx, int n, int h, int wd, int c, int k,
+                                            int r, int s, int pad_h, int pad_w, int accumulate, const float *prod_y,
+                                            const float *prod_z, const float *prod_mean, const float *prod_invstd,
+                                            const float *prod_mask_scale, const float *prod_mask_shift, double *slab,
+                                            double *sums, const unsigned *amax_dy, const unsigned *amax_w, hipStream_t stream)
+{
+    RR_CHECK_ARG(pad_h < r && pad_w < s && pad_h >= 0 && pad_w >= 0, "rr_conv_dgrad_s1_bnsum_f16x3: pad must be in [0, kernel)");
+    RR_CHECK_ARG(prod_y && prod_mean && prod_invstd && slab && sums && (!prod_mask_scale == !prod_mask_shift) && amax_dy && amax_w,
+                 "rr_conv_dgrad_s1_bnsum_f16x3: the producer's y / mean / invstd, the two buffers and the maxima are required");
+    RR_CHECK_ARG(c % 4 == 0 && c <= 1024, "rr_conv_dgrad_s1_bnsum_f16x3: C=%d must be a multiple of 4 and <= 1024", c);
+    const int p = h + 2 * pad_h - r + 1, q = wd + 2 * pad_w - s + 1;
+    RR_CHECK_ARG(p > 0 && q > 0, "rr_conv_dgrad_s1_bnsum_f16x3: empty dy");
+    const BnSumArgs bs{prod_y, prod_z, prod_mean, prod_invstd, prod_mask_scale, prod_mask_shift, slab, sums, 0};
+    return fprop_impl(dy, wt, nullptr, dx, nullptr, n, p, q, k, c, r, s, 1, r - 1 - pad_h, s - 1 - pad_w, 0, accumulate, stream, &bs,
+                      nullptr, nullptr, 1, amax_dy, amax_w);
+}
+
+extern "C" int rr_conv_dgrad_s1_relubias_f16x3(const float *dy, const float *wt, float *dx, int n, int h, int wd, int c, int k,
+                                               int r, int s, int pad_h, int pad_w, int accumulate, const float *prod_z,
+                                               double *slab, double *sums, const unsigned *amax_dy, const unsigned *amax_w,
+                                               hipStream_t stream)
+{
+    RR_CHECK_ARG(pad_h < r && pad_w < s && pad_h >= 0 && pad_w >= 0, "rr_conv_dgrad_s1_relubias_f16x3: pad must be in [0, kernel)");
+    RR_CHECK_ARG(prod_z && slab && sums && amax_dy && amax_w, "rr_conv_dgrad_s1_relubias_f16x3: the producer's output, the two buffers and the maxima are required");
+    RR_CHECK_ARG(c % 4 == 0 && k % 4 == 0 && c <= 1024, "rr_conv_dgrad_s1_relubias_f16x3: C=%d, K=%d must be multiples of 4", c, k);
+    const int p = h + 2 * pad_h - r + 1, q = wd + 2 * pad_w - s + 1;
+    RR_CHECK_ARG(p > 0 && q > 0, "rr_conv_dgrad_s1_relubias_f16x3: empty dy");
+    const BnSumArgs bs{prod_z, prod_z, nullptr, nullptr, nullptr, nullptr, slab, sums, 1};
+    return fprop_impl(dy, wt, nullptr, dx, nullptr, n, p, q, k, c, r, s, 1, r - 1 - pad_h, s - 1 - pad_w, 0, accumulate, stream, &bs,
+                      nullptr, nullptr, 1, amax_dy, amax_w);
+}
+
+extern "C" int rr_conv_dgrad_s2_f16x3(const float *dy, const float *w, float *dx, int n, int h, int wd, int c, int k,
+                                      int r, int s, int pad_h, int pad_w, int accumulate, float *wsub, const unsigned *amax_dy,
+                                      const unsigned *amax_w, hipStream_t stream)
+{
+    RR_CHECK_ARG(amax_dy && amax_w, "rr_conv_dgrad_s2_f16x3: the operands' maxima are required");
+    return dgrad_s2_impl(dy, w, dx, n, h, wd, c, k, r, s, pad_h, pad_w, accumulate, wsub, stream, 1, amax_dy, amax_w);
+}
+
+extern "C" int rr_conv_wgrad_f16x3(const float *x, const float *dy, float *dw, int n, int h, int wd, int c, int k,
+                                   int r, int s, int stride, int pad_h, int pad_w, int out_h, int out_w, const unsigned *amax_x,
+                                   const unsigned *amax_dy, hipStream_t stream)
+{
+    RR_CHECK_ARG(amax_x && amax_dy, "rr_conv_wgrad_f16x3: the operands' maxima are required");
+    return wgrad_impl(x, dy, dw, n, h, wd, c, k, r, s, stride, pad_h, pad_w, out_h, out_w, stream, 1, amax_x, amax_dy);
 }

@@ -266,7 +266,7 @@ def _wt_of(w_param):
 
 def _w16_of(w_param):
     """bf16 mode: (bf16 copy, flipped bf16 copy) of a filter parameter of a FlatParams buffer, else (None, None)."""
-    flat = getattr(w_param, "_rr_flat", None) if (w_param is not None and ops.BF16) else None
+    flat = getattr(w_param, "_rr_flat", None) if (w_param is not None and ops.BF16 == ops.MATH_BF16) else None
     return flat.w16_views(w_param) if flat is not None else (None, None)
 
 

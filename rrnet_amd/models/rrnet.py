@@ -67,7 +67,8 @@ class RRNet(nn.Module):
         # builder-defined (BASELINE configs[3] "bf16"; the reference is fp32-only): bf16 matrix operands with fp32
         # accumulation in every convolution of the backbone and the heads (csrc/conv_bf16.hip); activations, weights,
         # BatchNorm statistics, losses and the optimizer stay fp32
-        self.bf16 = bool(getattr(cfg.Model, "bf16", False))
+        # cfg.Model.conv_math = "f16x3": split-operand kernels (two fp16 parts per operand, fp32-level accuracy; ops.math_mode)
+        self.bf16 = ops.math_mode(cfg.Model)
 
     def forward(self, x, k=1500):
         with ops.bf16_scope(self.bf16):

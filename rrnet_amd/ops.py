@@ -130,17 +130,34 @@ def out_hw(h, w, r, s, stride, ph, pw):
 # bf16 matrix operands for the convolutions (BASELINE config 4; csrc/conv_bf16.hip).  A process-wide switch set by the
 # model (cfg.Model.bf16 -> rrnet_amd.models.rrnet) for the duration of its forward / backward: same tensors (fp32 in
 # HBM), same autograd graph, only the kernels the launches go to differ.  The headline configuration never sets it.
-_BF16_ENV = os.environ.get("RR_CONV_BF16", "0") == "1"      # force it on for everything (experiments)
+#
+# The switch has three positions (cfg.Model.conv_math, math_mode()):
+#   0 / False  "f32"    v_mfma_f32_32x32x2_f32 (csrc/conv.hip) — the reference's arithmetic
+#   1 / True   "bf16"   operands rounded to bf16 (config 4)
+#   2          "f16x3"  operands split into two fp16 parts, three products: fp32-level accuracy at the 16-bit matrix rate
+MATH_F32, MATH_BF16, MATH_F16X3 = 0, 1, 2
+_MATH_NAMES = {"f32": MATH_F32, "fp32": MATH_F32, "bf16": MATH_BF16, "f16x3": MATH_F16X3}
+_BF16_ENV = MATH_BF16 if os.environ.get("RR_CONV_BF16", "0") == "1" else _MATH_NAMES.get(os.environ.get("RR_CONV_MATH", "f32"), MATH_F32)
 BF16 = _BF16_ENV
 
 
+def math_mode(model_cfg):
+    """cfg.Model -> the switch position: conv_math ("f32" | "bf16" | "f16x3") if present, else the older bf16 flag."""
+    name = getattr(model_cfg, "conv_math", None)
+    if name:
+        if name not in _MATH_NAMES:
+            raise ValueError("cfg.Model.conv_math must be one of %s, got %r" % (sorted(_MATH_NAMES), name))
+        return _MATH_NAMES[name]
+    return MATH_BF16 if getattr(model_cfg, "bf16", False) else MATH_F32
+
+
 class bf16_scope:
-    """`with ops.bf16_scope(flag):` — the convolutions launched inside take the bf16-operand kernels when `flag`.
-    RRNet.forward opens it for a model built with cfg.Model.bf16; every convolution node remembers the setting of its
-    forward and re-opens it around its backward (rrnet_amd/functional.py)."""
+    """`with ops.bf16_scope(mode):` — the convolutions launched inside take the bf16-operand (1 / True) or split-operand
+    (2) kernels.  RRNet.forward opens it for a model built with cfg.Model.bf16 / conv_math; every convolution node
+    remembers the setting of its forward and re-opens it around its backward (rrnet_amd/functional.py)."""
 
     def __init__(self, on):
-        self.on = bool(on) or _BF16_ENV
+        self.on = int(on) or _BF16_ENV
 
     def __enter__(self):
         global BF16
@@ -152,9 +169,39 @@ class bf16_scope:
 
 
 
-def _bf16_ok(c, k, r, s, *tensors):
-    """Shapes csrc/conv_bf16.hip takes: vector path (C and K multiples of 4, <= 64 taps), tensors below 2 GiB."""
-    return BF16 and c % 4 == 0 and k % 4 == 0 and r * s <= 64 and all(t.numel() * 4 < (1 << 31) for t in tensors)
+def _bf16_ok(c, k, r, s, *tensors, pixels=None):
+    """Shapes csrc/conv_bf16.hip takes: vector path (C and K multiples of 4, <= 64 taps), tensors below 2 GiB.
+    -> 0 (fp32 kernels) or the switch position (MATH_BF16 / MATH_F16X3)."""
+    ok = BF16 and c % 4 == 0 and k % 4 == 0 and r * s <= 64 and all(t.numel() * 4 < (1 << 31) for t in tensors)
+    if ok and BF16 == MATH_F16X3:
+        # the split kernels pay two small reductions (the operands' maxima) per launch and three matrix instructions per tile:
+        # they beat the fp32-MFMA kernels on the large 3x3 layers only; the rest stays on csrc/conv.hip — same accuracy class
+        if pixels is None or pixels < _SPLIT_MIN_PIXELS or c * r * s < _SPLIT_MIN_K or k < 64 or c < 64:
+            return 0
+    return int(BF16) if ok else 0
+
+
+_SPLIT_MIN_PIXELS = int(os.environ.get("RR_SPLIT_MIN_PIXELS", "16384"))    # N*P*Q below which a layer stays on the fp32 kernels
+_SPLIT_MIN_K = int(os.environ.get("RR_SPLIT_MIN_K", "1024"))               # C*R*S (reduction length) likewise
+
+
+def amax_of(t):
+    """Device word holding the bit pattern of max|t| (rr_absmax_bits) for the split-operand kernels, computed on the
+    current stream and remembered on the tensor object (same version, same stream): a gradient serves its data
+    gradient and its weight gradient with one reduction."""
+    sid = torch.cuda.current_stream(t.device).cuda_stream
+    hit = getattr(t, "_rr_amax", None)
+    if hit is not None and hit[0] == t._version and hit[1] == sid:
+        return hit[2]
+    word = _ZEROS.take(1, t.device)                   # 8 zeroed bytes; the kernels read the first 4
+    n = t.numel()
+    assert n % 4 == 0 and t.dtype == torch.float32
+    _C.check(_C.fn("rr_absmax_bits")(_C.ptr(t), n, _C.ptr(word), _C.stream()), "rr_absmax_bits")
+    try:
+        t._rr_amax = (t._version, sid, word)
+    except AttributeError:
+        pass
+    return word
 
 
 def conv_fprop(x, w, bias=None, stride=1, pad=(0, 0), relu=False, want_stats=False, algo_kg=None, w16=None):
@@ -173,11 +220,12 @@ def conv_fprop(x, w, bias=None, stride=1, pad=(0, 0), relu=False, want_stats=Fal
     if want_stats:
         nbytes = _C.fn("rr_conv_stat_slab_bytes")(n, p, q, k)
         slab = torch.empty(nbytes // 8, dtype=torch.float64, device=x.device)
-    bf = _bf16_ok(c, 4, r, s, x, w, y)
-    f = _C.fn("rr_conv_fprop_bf16" if bf else "rr_conv_fprop")
+    bf = _bf16_ok(c, 4 if BF16 != MATH_F16X3 else k, r, s, x, w, y, pixels=n * p * q)
+    f = _C.fn(("rr_conv_fprop", "rr_conv_fprop_bf16", "rr_conv_fprop_f16x3")[bf])
     flops = 2.0 * n * p * q * k * (c * r * s if algo_kg is None else algo_kg)
-    tail = (_C.ptr(w16), _C.stream()) if bf else (_C.stream(),)      # w16: the filter already rounded to bf16 (optional)
-    _C.check(_timed(_igemm_name("fprop", k, c % 4 != 0, n * p * q) + ("+bf16" if bf else ""), flops,
+    # w16: the filter already rounded to bf16 (optional); split operands: the two tensors' maxima
+    tail = ((_C.stream(),), (_C.ptr(w16), _C.stream()), None)[bf] if bf != MATH_F16X3 else (_C.ptr(amax_of(x)), _C.ptr(amax_of(w)), _C.stream())
+    _C.check(_timed(_igemm_name("fprop", k, c % 4 != 0, n * p * q) + ("", "+bf16", "+f16x3")[bf], flops,
                     lambda: f(_C.ptr(x), _C.ptr(w), _C.ptr(bias), _C.ptr(y), _C.ptr(slab), n, h, wd, c, k, r, s,
                               stride, pad[0], pad[1], int(relu), *tail),
                     (n, h, wd, c, k, r, s, stride), 4.0 * (x.numel() + y.numel() + w.numel())), "rr_conv_fprop")
@@ -302,26 +350,28 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False,
         slab = torch.empty(_C.fn("rr_conv_stat_slab_bytes")(n, h, wd, c) // 8, dtype=torch.float64, device=dy.device)
         sums = _ZEROS.take(2 * c, dy.device)
         flops_m = 2.0 * dy.shape[0] * dy.shape[2] * dy.shape[3] * k * c * r * s
-        bf = _bf16_ok(kp, c, r, s, dyp, out)
-        fr = _C.fn("rr_conv_dgrad_s1_relubias_bf16" if bf else "rr_conv_dgrad_s1_relubias")
-        _C.check(_timed(_igemm_name("fprop", c, False, n * h * wd) + "+relubias" + ("+bf16" if bf else ""), flops_m,
+        bf = _bf16_ok(kp, c, r, s, dyp, out, pixels=n * h * wd)
+        fr = _C.fn("rr_conv_dgrad_s1_relubias" + ("", "_bf16", "_f16x3")[bf])
+        rtail = (_C.ptr(amax_of(dyp)), _C.ptr(amax_of(wp)), _C.stream()) if bf == MATH_F16X3 else (_C.stream(),)
+        _C.check(_timed(_igemm_name("fprop", c, False, n * h * wd) + "+relubias" + ("", "+bf16", "+f16x3")[bf], flops_m,
                         lambda: fr(_C.ptr(dyp), _C.ptr(wt), _C.ptr(out), n, h, wd, c, kp, r, s, pad[0], pad[1], int(accumulate),
-                                   _C.ptr(bnsum_z), _C.ptr(slab), _C.ptr(sums), _C.stream()), (n, h, wd, c, k, r, s, stride)),
+                                   _C.ptr(bnsum_z), _C.ptr(slab), _C.ptr(sums), *rtail), (n, h, wd, c, k, r, s, stride)),
                  "rr_conv_dgrad_s1_relubias")
         bnsum.sums, bnsum.dz = sums, out
         return out
     flops = 2.0 * dy.shape[0] * dy.shape[2] * dy.shape[3] * k * c * r * s
     # (bf16 operands: the forward kernel at every size — its split-K covers the small maps, and the dgrad kernel is fp32-only)
     if (stride == 1 and k % 4 == 0 and c % 4 == 0 and r * s <= 64 and pad[0] < r and pad[1] < s and _DGRAD_VIA_FPROP
-            and (dy.shape[2] * dy.shape[3] >= _DGRAD_VIA_FPROP_MIN_PIXELS or _bf16_ok(k, c, r, s, dy, out))):
+            and (dy.shape[2] * dy.shape[3] >= _DGRAD_VIA_FPROP_MIN_PIXELS or _bf16_ok(k, c, r, s, dy, out, pixels=n * h * wd))):
         # the forward kernel on dy with the flipped / transposed filter (one tiny transpose per layer and step)
         if wt is None:
             wt = torch.empty(k * c * r * s, dtype=torch.float32, device=dy.device)
             _C.check(_C.fn("rr_weight_flip_transpose")(_C.ptr(w), _C.ptr(wt), k, c, r, s, _C.stream()),
                      "rr_weight_flip_transpose")
-        bf = _bf16_ok(k, c, r, s, dy, out)
-        sfx, tsfx = ("_bf16", "+bf16") if bf else ("", "")
-        tail = (_C.ptr(wt16), _C.stream()) if bf else (_C.stream(),)     # wt16: the flipped filter already in bf16 (optional)
+        bf = _bf16_ok(k, c, r, s, dy, out, pixels=n * h * wd)
+        sfx, tsfx = (("", ""), ("_bf16", "+bf16"), ("_f16x3", "+f16x3"))[bf]
+        # wt16: the flipped filter already in bf16 (optional); split operands: the maxima of dy and of the filter
+        tail = ((_C.stream(),), (_C.ptr(wt16), _C.stream()), None)[bf] if bf != MATH_F16X3 else (_C.ptr(amax_of(dy)), _C.ptr(amax_of(w)), _C.stream())
         if (bnsum is not None and not bnsum.relu_bias and _DGRAD_BNSUM and bnsum.y is not None and c <= 1024 and out.numel() * 4 < (1 << 31)
                 and tuple(bnsum.y.shape) == tuple(out.shape)
                 and (not bnsum.use_z or (bnsum_z is not None and is_nhwc(bnsum_z) and bnsum_z.shape == out.shape))):
@@ -346,13 +396,15 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False,
                                    int(accumulate), *tail), (n, h, wd, c, k, r, s, stride),
                         4.0 * (dy.numel() + out.numel() * (2 if accumulate else 1) + w.numel())), "rr_conv_dgrad_s1")
         return out
-    if stride == 2 and _bf16_ok(k, c, r, s, dy, out) and _BF16_S2_DGRAD:
+    if stride == 2 and _bf16_ok(k, c, r, s, dy, out, pixels=n * h * wd // 4) and _BF16_S2_DGRAD:
         # bf16 operands: one launch of the forward kernel per output parity class on its packed sub-filter
         wsub = torch.empty(k * c * r * s, dtype=torch.float32, device=dy.device)
-        f2 = _C.fn("rr_conv_dgrad_s2_bf16")
-        _C.check(_timed("conv_dgrad_s2+bf16", flops,
+        sx = _bf16_ok(k, c, r, s, dy, out, pixels=n * h * wd // 4) == MATH_F16X3
+        f2 = _C.fn("rr_conv_dgrad_s2_f16x3" if sx else "rr_conv_dgrad_s2_bf16")
+        stail = (_C.ptr(amax_of(dy)), _C.ptr(amax_of(w)), _C.stream()) if sx else (_C.stream(),)
+        _C.check(_timed("conv_dgrad_s2" + ("+f16x3" if sx else "+bf16"), flops,
                         lambda: f2(_C.ptr(dy), _C.ptr(w), _C.ptr(out), n, h, wd, c, k, r, s, pad[0], pad[1], int(accumulate),
-                                   _C.ptr(wsub), _C.stream()), (n, h, wd, c, k, r, s, stride)), "rr_conv_dgrad_s2_bf16")
+                                   _C.ptr(wsub), *stail), (n, h, wd, c, k, r, s, stride)), "rr_conv_dgrad_s2_bf16")
         return out
     f = _C.fn("rr_conv_dgrad")
     _C.check(_timed(_igemm_name("dgrad", c, (k % 4 != 0) or (c % 4 != 0), n * h * wd, stride), flops,
@@ -369,13 +421,14 @@ def conv_wgrad(x, dy, dw, stride=1, pad=(0, 0), explicit_out=False, algo_c=None)
     n, c, h, wd = x.shape
     k, c2, r, s = dw.shape
     assert c == c2 and dy.shape[1] == k
-    bf = _bf16_ok(c, k, r, s, x, dy) and c > 32 and k > 32
-    f = _C.fn("rr_conv_wgrad_bf16" if bf else "rr_conv_wgrad")
+    bf = _bf16_ok(c, k, r, s, x, dy, pixels=dy.shape[0] * dy.shape[2] * dy.shape[3]) if (c > 32 and k > 32) else 0
+    f = _C.fn(("rr_conv_wgrad", "rr_conv_wgrad_bf16", "rr_conv_wgrad_f16x3")[bf])
     flops = 2.0 * dy.shape[0] * dy.shape[2] * dy.shape[3] * k * (c * r * s if algo_c is None else algo_c)
-    _C.check(_timed("conv_wgrad<BN=%d>%s" % (128 if c > 32 else 32, "+bf16" if bf else ""), flops,
+    wtail = (_C.ptr(amax_of(x)), _C.ptr(amax_of(dy)), _C.stream()) if bf == MATH_F16X3 else (_C.stream(),)
+    _C.check(_timed("conv_wgrad<BN=%d>%s" % (128 if c > 32 else 32, ("", "+bf16", "+f16x3")[bf]), flops,
                     lambda: f(_C.ptr(x), _C.ptr(dy), _C.ptr(dw), n, h, wd, c, k, r, s, stride, pad[0], pad[1],
                               dy.shape[2] if explicit_out else 0, dy.shape[3] if explicit_out else 0,
-                              _C.stream()), (n, h, wd, c, k, r, s, stride)), "rr_conv_wgrad")
+                              *wtail), (n, h, wd, c, k, r, s, stride)), "rr_conv_wgrad")
     return dw
 
 

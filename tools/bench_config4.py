@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def run(batch=8, size=1024, steps=5, dcn=True, backbone="hourglass", bf16=None):
+def run(batch=8, size=1024, steps=5, dcn=True, backbone="hourglass", bf16=None, conv_math=None):
     """bf16 (default: with the DCN heads): cfg.Model.bf16 — bf16 matrix operands in EVERY convolution of the backbone and
     the heads (csrc/conv_bf16.hip), not only in the six deformable layers."""
     bf16 = dcn if bf16 is None else bf16
@@ -28,6 +28,8 @@ def run(batch=8, size=1024, steps=5, dcn=True, backbone="hourglass", bf16=None):
              getattr(cfg.Model, "dcn_bf16", False), getattr(cfg.Model, "bf16", False))
     cfg.Train.batch_size, cfg.Train.crop_size, cfg.Model.backbone = batch, (size, size), backbone
     cfg.Model.dcn_heads, cfg.Model.dcn_bf16, cfg.Model.bf16 = dcn, dcn, bf16
+    saved_math = getattr(cfg.Model, "conv_math", None)
+    cfg.Model.conv_math = conv_math          # "f16x3": split-operand kernels on the large layers (ops.math_mode)
     if cfg.Distributed.gpu_id < 0:
         cfg.Distributed.gpu_id, cfg.Distributed.rank, cfg.Distributed.world_size = 0, 0, 1
     try:
@@ -57,20 +59,22 @@ def run(batch=8, size=1024, steps=5, dcn=True, backbone="hourglass", bf16=None):
         torch.cuda.synchronize()
         t = (time.perf_counter() - t0) / steps
         out = {"value": round(batch / t, 4), "unit": "images/sec", "ms_per_step": round(t * 1e3, 2), "steps": steps,
-               "dcn_layers": n_dcn, "dtype": "bf16 matrix operands, fp32 accumulation / storage" if bf16 else "f32",
+               "dcn_layers": n_dcn, "dtype": ("f32 (large layers: operands split into two fp16 parts, three MFMA products, fp32 accumulation)"
+                                              if conv_math == "f16x3" else "bf16 matrix operands, fp32 accumulation / storage" if bf16 else "f32"),
                "workload": (("RRNet hourglass-104 + %d DCN head layers (offsets ~ N(0,1)) train step, B=%d, %dx%d"
                              % (n_dcn, batch, size, size)) if dcn else
                             "RRNet hourglass-104 train step, B=%d, %dx%d (no DCN heads)" % (batch, size, size))
-                           + (", bf16 operands in every convolution" if bf16 else "")}
+                           + (", bf16 operands in every convolution" if bf16 else "") + (", conv_math f16x3" if conv_math == "f16x3" else "")}
         if backbone == "hourglass" and size == 1024:
             # 7.02 TFLOP of convolution per image; the six DCN layers replace plain 3x3 layers of the same FLOPs
-            peak = 2500.0 if bf16 else 157.3
+            peak = 2500.0 if (bf16 or conv_math == "f16x3") else 157.3
             out["step_mfma_frac"] = round(out["value"] * 7.02 / peak, 4)
             out["mfma_peak_tflops"] = peak
         return out
     finally:
         (cfg.Train.batch_size, cfg.Train.crop_size, cfg.Model.backbone, cfg.Model.dcn_heads, cfg.Model.dcn_bf16,
          cfg.Model.bf16) = saved
+        cfg.Model.conv_math = saved_math
 
 
 if __name__ == "__main__":
@@ -82,7 +86,8 @@ if __name__ == "__main__":
     ap.add_argument("--plain", action="store_true", help="no DCN heads")
     ap.add_argument("--fp32", action="store_true", help="fp32 convolutions (round 3's config-4 definition: only the DCN layers in bf16)")
     ap.add_argument("--bf16", action="store_true", help="bf16 convolutions even with --plain")
+    ap.add_argument("--math", default=None, help="cfg.Model.conv_math: f32 | bf16 | f16x3")
     a = ap.parse_args()
     torch.cuda.set_device(0)
     bf16 = True if a.bf16 else (False if a.fp32 else None)
-    print(json.dumps(run(a.batch, a.size, a.steps, not a.plain, a.backbone, bf16)))
+    print(json.dumps(run(a.batch, a.size, a.steps, not a.plain, a.backbone, bf16, a.math)))
