@@ -232,6 +232,11 @@ int rr_bn_eval_coeffs(const float *gamma, const float *beta, const float *runnin
 int rr_bn_apply(const float *y, const float *scale, const float *shift, const float *res,
                 const float *res_scale, const float *res_shift, float *out, long total, int c, int relu,
                 hipStream_t stream);
+/* rr_bn_apply that also leaves max |out| (bit pattern, atomicMax into the zeroed word *amax_out): the operand scale of
+ * the split-operand convolution that consumes `out` (rr_conv_*_f16x3) without a pass of rr_absmax_bits. */
+int rr_bn_apply_amax(const float *y, const float *scale, const float *shift, const float *res,
+                     const float *res_scale, const float *res_shift, float *out, long total, int c, int relu,
+                     unsigned *amax_out, hipStream_t stream);
 int rr_bn_bwd_reduce(const float *dz, const float *z, const float *y, const float *mean,
                      const float *invstd, const float *mask_scale, const float *mask_shift, double *sums,
                      long npix, int c, int sums_zeroed, hipStream_t stream);

@@ -145,7 +145,7 @@ struct ConvArgs {
 // and stage the next tile.  Each SIMD then holds one wave of each kind and overlaps them in hardware — with 3 / 6 matrix
 // instructions per product tile the loop is matrix-bound only if nothing else sits in the matrix waves' instruction stream.
 template <int BN, bool BNS, bool B16 = false, bool SO = false, int SP = 1, bool WS = false, bool F16 = false>
-__global__ __launch_bounds__(WS ? 512 : 256) void conv_igemm_bf16_kernel(const ConvArgs a)
+__global__ __launch_bounds__(WS ? 512 : 256, (!WS && SP == 2) ? 2 : 1) void conv_igemm_bf16_kernel(const ConvArgs a)
 {
     typedef typename std::conditional<F16, f16x8, bf16x8>::type frag_t;
     // operand scales (F16): 2^(14 - floor(log2(max|tensor|))), exact powers of two; the product is undone in the epilogue
@@ -456,18 +456,33 @@ __global__ __launch_bounds__(WS ? 512 : 256) void conv_igemm_bf16_kernel(const C
     for (int kc = kc_lo; kc < kc_hi; ++kc) {
         const int buf = (kc - kc_lo) & 1;
         const unsigned short *A = As + buf * SP * A_ELEMS, *B = Bs + buf * SP * B_ELEMS;
-        frag_t fa[2][SP][TM], fb[2][SP][TN];
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
+        // SP == 1: the fragments of both 16-wide halves up front (as tuned).  SP > 1: one half at a time — half the fragment
+        // registers, which keeps the split kernel within 256 registers (two workgroups per CU)
+        constexpr int NKK = SP > 1 ? 1 : 2;
+        frag_t fa[NKK][SP][TM], fb[NKK][SP][TN];
+        auto frags = [&](int slot, int kk) {
 #pragma unroll
             for (int sp = 0; sp < SP; ++sp) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
-                    fa[kk][sp][i] = *reinterpret_cast<const frag_t *>(A + sp * A_ELEMS + ((wm * TM + i) * 32 + lr) * LDK + kk * 16 + lh * 8);
+                    fa[slot][sp][i] = *reinterpret_cast<const frag_t *>(A + sp * A_ELEMS + ((wm * TM + i) * 32 + lr) * LDK + kk * 16 + lh * 8);
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    fb[kk][sp][j] = *reinterpret_cast<const frag_t *>(B + sp * B_ELEMS + ((wn * TN + j) * 32 + lr) * LDK + kk * 16 + lh * 8);
+                    fb[slot][sp][j] = *reinterpret_cast<const frag_t *>(B + sp * B_ELEMS + ((wn * TN + j) * 32 + lr) * LDK + kk * 16 + lh * 8);
             }
+        };
+        auto mma = [&](int slot) {
+            // (product outermost, tiles inner: consecutive matrix instructions never share an accumulator)
+#define RR_MM(ACC, PA, PB)                                                                                          \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)                      \
+        ACC[i][j] = mfma16(fa[slot][PA][i], fb[slot][PB][j], ACC[i][j]);
+            if constexpr (SP == 3) { RR_MM(acl, 0, 2) RR_MM(acl, 2, 0) RR_MM(acl, 1, 1) }
+            if constexpr (SP >= 2) { RR_MM(acl, 0, 1) RR_MM(acl, 1, 0) }
+            RR_MM(acc, 0, 0)
+#undef RR_MM
+        };
+        frags(0, 0);
+        if constexpr (SP == 1) frags(1, 1);
         // tile kc + 1 (loaded one iteration ago) -> the other LDS buffer, whose last readers passed the previous barrier;
         // then tile kc + 2 goes out.  (Staging BEHIND the matrix instructions instead — a whole iteration for the loads to
         // land — measured the same: the loop is bound by instruction issue, ~96 non-MFMA instructions per 8 MFMAs.)
@@ -475,16 +490,12 @@ __global__ __launch_bounds__(WS ? 512 : 256) void conv_igemm_bf16_kernel(const C
         p_live = kc + 2 < kc_hi;
         prep();
         load_all();
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            // (product outermost, tiles inner: consecutive matrix instructions never share an accumulator)
-#define RR_MM(ACC, PA, PB)                                                                                          \
-    _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)                      \
-        ACC[i][j] = mfma16(fa[kk][PA][i], fb[kk][PB][j], ACC[i][j]);
-            if constexpr (SP == 3) { RR_MM(acl, 0, 2) RR_MM(acl, 2, 0) RR_MM(acl, 1, 1) }
-            if constexpr (SP >= 2) { RR_MM(acl, 0, 1) RR_MM(acl, 1, 0) }
-            RR_MM(acc, 0, 0)
-#undef RR_MM
+        mma(0);
+        if constexpr (SP == 1) {
+            mma(1);
+        } else {
+            frags(0, 1);
+            mma(0);
         }
         __syncthreads();
     }
@@ -713,8 +724,12 @@ int fprop_impl(const float *x, const float *w, const float *bias, float *y, doub
 #define RR_SX(BNv, BNSv, SOv) launch(conv_igemm_bf16_kernel<BNv, BNSv, false, SOv, 2, false, true>, blocks, ks, igemm_lds(BNv, 2), stream, a, name)
 #define RR_SW(BNSv) launch(conv_igemm_bf16_kernel<128, BNSv, false, false, 2, true, true>, blocks, ks, igemm_lds(128, 2), stream, a, name, 512)
     if (split) {
-        static int ws_env = -1;             // RR_SPLIT_WS=0: the 256-thread kernel on the 128-wide tiles too (A/B switch)
-        if (ws_env < 0) { const char *e = getenv("RR_SPLIT_WS"); ws_env = e ? atoi(e) : 1; }
+        // RR_SPLIT_WS=1: the wave-specialised 512-thread kernel on the 128-wide tiles (A/B switch).  Measured at 256 -> 256 3x3 on
+        // 8 x 256 x 256: 2.84 ms against 2.27 ms for two 256-thread workgroups per CU — a SIMD does not overlap one wave's matrix
+        // instructions with another wave's vector instructions (tools/coissue_probe.hip), so separating the roles buys nothing
+        // and the second workgroup's independent barrier phase does.
+        static int ws_env = -1;
+        if (ws_env < 0) { const char *e = getenv("RR_SPLIT_WS"); ws_env = e ? atoi(e) : 0; }
         a.w16 = nullptr;
         a.amax_src = amax_src; a.amax_w = amax_w;
         name = "rr_conv_fprop_f16x3";
@@ -772,7 +787,7 @@ __device__ __forceinline__ F lds_tr_frag(const unsigned short *img, int k0, int 
 // 128 (ko) x 128 (c) tile per workgroup and tap; 2x2 waves of 64x64.  K-step = 32 pixels.
 // SP = 2, F16: both operands split into two fp16 parts (see conv_igemm_bf16_kernel), three matrix instructions per tile.
 template <int SP = 1, bool F16 = false>
-__global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradArgs a)
+__global__ __launch_bounds__(256, SP > 1 ? 2 : 1) void conv_wgrad_bf16_kernel(const WgradArgs a)
 {
     typedef typename std::conditional<F16, f16x8, bf16x8>::type frag_t;
     float sc_a = 1.f, sc_b = 1.f, sc_inv = 1.f;
@@ -883,27 +898,48 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradArgs a)
     for (int kc = kc_begin; kc < kc_end; ++kc) {
         const int buf = (kc - kc_begin) & 1;
         const unsigned short *A = As + buf * SP * IMG, *B = Bs + buf * SP * IMG;
-        frag_t fa[2][SP][2], fb[2][SP][2];
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
+        // fragments of one 16-pixel half at a time (SP > 1: 32 registers instead of 64 — the split kernel must stay within 256
+        // registers for its second workgroup per CU)
+        frag_t fa[SP][2], fb[SP][2];
+        auto frags = [&](int kk) {
 #pragma unroll
             for (int sp = 0; sp < SP; ++sp) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) fa[kk][sp][i] = lds_tr_frag<frag_t>(A + sp * IMG + (wm * 2 + i) * BLK, kk * 16, lane);
+                for (int i = 0; i < 2; ++i) fa[sp][i] = lds_tr_frag<frag_t>(A + sp * IMG + (wm * 2 + i) * BLK, kk * 16, lane);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) fb[kk][sp][j] = lds_tr_frag<frag_t>(B + sp * IMG + (wn * 2 + j) * BLK, kk * 16, lane);
+                for (int j = 0; j < 2; ++j) fb[sp][j] = lds_tr_frag<frag_t>(B + sp * IMG + (wn * 2 + j) * BLK, kk * 16, lane);
             }
-        store_all(buf ^ 1);
-        load_all(kc + 2);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+        };
+        auto mma = [&]() {
 #define RR_MM(ACC, PA, PB)                                                                                          \
     _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                        \
-        ACC[i][j] = mfma16(fa[kk][PA][i], fb[kk][PB][j], ACC[i][j]);
+        ACC[i][j] = mfma16(fa[PA][i], fb[PB][j], ACC[i][j]);
             RR_MM(acc, 0, 0)
             if constexpr (SP >= 2) { RR_MM(acl, 0, 1) RR_MM(acl, 1, 0) }
             if constexpr (SP == 3) { RR_MM(acl, 1, 1) RR_MM(acl, 0, 2) RR_MM(acl, 2, 0) }
 #undef RR_MM
+        };
+        if constexpr (SP == 1) {
+            frag_t ga[2], gb[2];       // (one part: both halves up front, as the kernel was tuned)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) ga[i] = lds_tr_frag<frag_t>(A + (wm * 2 + i) * BLK, 16, lane);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) gb[j] = lds_tr_frag<frag_t>(B + (wn * 2 + j) * BLK, 16, lane);
+            frags(0);
+            store_all(buf ^ 1);
+            load_all(kc + 2);
+            mma();
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(ga[i], gb[j], acc[i][j]);
+        } else {
+            frags(0);
+            store_all(buf ^ 1);
+            load_all(kc + 2);
+            mma();
+            frags(1);
+            mma();
         }
         __syncthreads();
     }

@@ -126,11 +126,15 @@ __global__ void bn_eval_coeffs_kernel(const float *gamma, const float *beta, con
 }
 
 // out = relu?( y*scale+shift  [+ res | + res*res_scale+res_shift] )
+// AMAX: also max |out| -> *amax as a bit pattern (one atomicMax per wave) — the next convolution's operand scale when it
+// runs on the split-operand kernels (rr_conv_*_f16x3), saved a pass of rr_absmax_bits over the tensor
+template <bool AMAX>
 __global__ __launch_bounds__(EW_THREADS) void bn_apply_kernel(const f32x4 *y, const float *scale, const float *shift,
                                                               const f32x4 *res, const float *res_scale,
                                                               const float *res_shift, f32x4 *out, long n4, int C4,
-                                                              int relu)
+                                                              int relu, unsigned *amax)
 {
+    float vmax = 0.f;
     for (long i = (long)blockIdx.x * EW_THREADS + threadIdx.x; i < n4; i += (long)gridDim.x * EW_THREADS) {
         const int c = (int)(i % C4) * 4;
         f32x4 v = y[i];
@@ -150,6 +154,12 @@ __global__ __launch_bounds__(EW_THREADS) void bn_apply_kernel(const f32x4 *y, co
             for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
         }
         out[i] = v;
+        if constexpr (AMAX) vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    }
+    if constexpr (AMAX) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
+        if ((threadIdx.x & 63) == 0) atomicMax(amax, __builtin_bit_cast(unsigned, vmax));
     }
 }
 
@@ -662,9 +672,21 @@ extern "C" int rr_bn_apply(const float *y, const float *scale, const float *shif
 {
     RR_CHECK_ARG(c % 4 == 0 && total % c == 0, "rr_bn_apply: C=%d must be a multiple of 4", c);
     const long n4 = total / 4;
-    EW_LAUNCH(bn_apply_kernel, n4, stream, (const f32x4 *)y, scale, shift, (const f32x4 *)res, res_scale, res_shift,
-              (f32x4 *)out, n4, c / 4, relu);
+    EW_LAUNCH(bn_apply_kernel<false>, n4, stream, (const f32x4 *)y, scale, shift, (const f32x4 *)res, res_scale, res_shift,
+              (f32x4 *)out, n4, c / 4, relu, (unsigned *)nullptr);
     RR_CHECK_LAUNCH("rr_bn_apply");
+    return RR_OK;
+}
+
+extern "C" int rr_bn_apply_amax(const float *y, const float *scale, const float *shift, const float *res,
+                                const float *res_scale, const float *res_shift, float *out, long total, int c, int relu,
+                                unsigned *amax_out, hipStream_t stream)
+{
+    RR_CHECK_ARG(c % 4 == 0 && total % c == 0 && amax_out != nullptr, "rr_bn_apply_amax: C=%d must be a multiple of 4, amax_out required", c);
+    const long n4 = total / 4;
+    EW_LAUNCH(bn_apply_kernel<true>, n4, stream, (const f32x4 *)y, scale, shift, (const f32x4 *)res, res_scale, res_shift,
+              (f32x4 *)out, n4, c / 4, relu, amax_out);
+    RR_CHECK_LAUNCH("rr_bn_apply_amax");
     return RR_OK;
 }
 

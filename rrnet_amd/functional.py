@@ -167,6 +167,7 @@ class _ConvBnAct(torch.autograd.Function):
             remask = relu and residual is None
             ctx.save_for_backward(x, wc, y, z if (relu and not remask) else None, mean, invstd, gamma, cnt_dev,
                                   scale if remask else None, shift if remask else None)
+            ctx.x_amax = ops.amax_carry(x)      # (split-operand kernels: the weight gradient reuses the forward's reduction)
             if out_link is not None:
                 # what a consumer's data gradient needs to produce this layer's BatchNorm-backward sums in its epilogue
                 out_link.y, out_link.mean, out_link.invstd = y, mean, invstd
@@ -185,6 +186,7 @@ class _ConvBnAct(torch.autograd.Function):
     @staticmethod
     def _backward(ctx, dz):
         x, wc, y, z, mean, invstd, gamma, cnt_dev, msc, msh = ctx.saved_tensors
+        ops.amax_restore(x, getattr(ctx, "x_amax", None))
         stride, pad, relu, count, sync, has_res = ctx.cfg
         w, gamma_p, beta_p = ctx.params
         dz = ops.to_nhwc(dz)
@@ -471,6 +473,7 @@ class _ConvBias(torch.autograd.Function):
         wc = ops.to_nhwc(w)
         y = ops.conv_fprop(x, wc, b, stride, pad, relu, w16=_w16_of(w)[0])
         ctx.save_for_backward(x, wc, y if relu else None)
+        ctx.x_amax = ops.amax_carry(x)
         ctx.cfg = (stride, pad, relu)
         ctx.params = (w, b)
         ctx.xshape = tuple(x.shape)
@@ -484,6 +487,7 @@ class _ConvBias(torch.autograd.Function):
     @staticmethod
     def _backward(ctx, dy):
         x, wc, y = ctx.saved_tensors
+        ops.amax_restore(x, getattr(ctx, "x_amax", None))
         stride, pad, relu = ctx.cfg
         w, b = ctx.params
         dy = ops.to_nhwc(dy)

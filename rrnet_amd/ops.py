@@ -185,13 +185,26 @@ _SPLIT_MIN_PIXELS = int(os.environ.get("RR_SPLIT_MIN_PIXELS", "16384"))    # N*P
 _SPLIT_MIN_K = int(os.environ.get("RR_SPLIT_MIN_K", "1024"))               # C*R*S (reduction length) likewise
 
 
+def amax_carry(t):
+    """The remembered maximum of t (or None), to be kept by an autograd node next to the tensor it saves: saved tensors
+    come back as new Python objects.  amax_restore() hands it to the unpacked tensor in backward."""
+    hit = getattr(t, "_rr_amax", None)
+    return hit[2] if (hit is not None and hit[0] == t._version) else None
+
+
+def amax_restore(t, word):
+    """Backward: the maximum computed in forward (complete long before: valid on every stream)."""
+    if word is not None and t is not None:
+        t._rr_amax = (t._version, None, word)
+
+
 def amax_of(t):
     """Device word holding the bit pattern of max|t| (rr_absmax_bits) for the split-operand kernels, computed on the
     current stream and remembered on the tensor object (same version, same stream): a gradient serves its data
     gradient and its weight gradient with one reduction."""
     sid = torch.cuda.current_stream(t.device).cuda_stream
     hit = getattr(t, "_rr_amax", None)
-    if hit is not None and hit[0] == t._version and hit[1] == sid:
+    if hit is not None and hit[0] == t._version and (hit[1] == sid or hit[1] is None):
         return hit[2]
     word = _ZEROS.take(1, t.device)                   # 8 zeroed bytes; the kernels read the first 4
     n = t.numel()
@@ -517,6 +530,14 @@ def bn_apply(y, scale, shift, residual=None, relu=False, res_scale=None, res_shi
     assert is_nhwc(y) and (residual is None or (is_nhwc(residual) and residual.shape == y.shape))
     n, c, h, w = y.shape
     out = empty_nhwc(n, c, h, w, y.device)
+    if BF16 == MATH_F16X3 and y.is_cuda and n * h * w >= _SPLIT_MIN_PIXELS:
+        # split-operand convolutions: the consumer's operand scale comes out of this pass (see amax_of)
+        word = _ZEROS.take(1, y.device)
+        _C.check(_C.fn("rr_bn_apply_amax")(_C.ptr(y), _C.ptr(scale), _C.ptr(shift), _C.ptr(residual), _C.ptr(res_scale),
+                                           _C.ptr(res_shift), _C.ptr(out), y.numel(), c, int(relu), _C.ptr(word), _C.stream()),
+                 "rr_bn_apply_amax")
+        out._rr_amax = (out._version, torch.cuda.current_stream(y.device).cuda_stream, word)
+        return out
     _C.check(_C.fn("rr_bn_apply")(_C.ptr(y), _C.ptr(scale), _C.ptr(shift), _C.ptr(residual), _C.ptr(res_scale),
                                   _C.ptr(res_shift), _C.ptr(out), y.numel(), c, int(relu), _C.stream()), "rr_bn_apply")
     return out
