@@ -176,12 +176,13 @@ def _bf16_ok(c, k, r, s, *tensors, pixels=None):
     if ok and BF16 == MATH_F16X3:
         # the split kernels pay two small reductions (the operands' maxima) per launch and three matrix instructions per tile:
         # they beat the fp32-MFMA kernels on the large 3x3 layers only; the rest stays on csrc/conv.hip — same accuracy class
-        if pixels is None or pixels < _SPLIT_MIN_PIXELS or c * r * s < _SPLIT_MIN_K or k < 64 or c < 64:
+        if pixels is None or pixels < _SPLIT_MIN_PIXELS or c * r * s < _SPLIT_MIN_K or k < _SPLIT_MIN_CH or c < _SPLIT_MIN_CH:
             return 0
     return int(BF16) if ok else 0
 
 
 _SPLIT_MIN_PIXELS = int(os.environ.get("RR_SPLIT_MIN_PIXELS", "16384"))    # N*P*Q below which a layer stays on the fp32 kernels
+_SPLIT_MIN_CH = 64                                                         # narrower layers (either side) likewise
 _SPLIT_MIN_K = int(os.environ.get("RR_SPLIT_MIN_K", "1024"))               # C*R*S (reduction length) likewise
 
 

@@ -57,6 +57,8 @@ def main():
     ap.add_argument("--step", type=int, default=0, help="step number handed to train_step (>= 2000 switches the stage-2 loss on)")
     ap.add_argument("--dcn", action="store_true", help="config 4: DCN heads with bf16 operands")
     ap.add_argument("--bf16", action="store_true", help="config 4: bf16 matrix operands in every convolution (cfg.Model.bf16)")
+    ap.add_argument("--math", default=None, help="cfg.Model.conv_math (f16x3: split-operand kernels; the size thresholds are dropped "
+                    "so that every eligible layer of a small model takes them)")
     ap.add_argument("--perturb", type=float, default=0.0, help="repeats 2.. see the images multiplied by (1 + perturb * N(0,1)): "
                     "the conditioning of the gradient w.r.t. rounding-sized input noise")
     ap.add_argument("--sabotage", action="store_true", help="drop every wait ON a side stream (the joins): the test's own "
@@ -72,6 +74,10 @@ def main():
         cfg.Model.dcn_heads = True
         cfg.Model.dcn_bf16 = True
     cfg.Model.bf16 = bool(a.bf16)
+    cfg.Model.conv_math = a.math
+    if a.math == "f16x3":
+        from rrnet_amd import ops
+        ops._SPLIT_MIN_PIXELS = ops._SPLIT_MIN_K = ops._SPLIT_MIN_CH = 0
     cfg.Distributed.gpu_id, cfg.Distributed.rank, cfg.Distributed.world_size = 0, 0, 1
     torch.cuda.set_device(0)
     if os.environ.get("RR_DP_FORCE") == "1":

@@ -1,0 +1,200 @@
+"""GPU: the model on the split-operand convolutions (cfg.Model.conv_math = "f16x3"; csrc/conv_bf16.hip rr_conv_*_f16x3).
+
+Same contract as the fp32 model (the reference's arithmetic: backbones/hourglass.py:12-61 -> nn.Conv2d in fp32), checked
+the same way: against the fp64 oracle (oracle/model.py) the split model is not further away than the fp32-MFMA model; a
+block's gradients agree with the fp32 kernels' to 2e-4 (not bf16's 6e-2); the tiny RRNet over-fits one batch; and every
+distinct kernel call of a full-size train step matches a host fp64 recomputation at the fp32 audit's tolerances.
+The size thresholds of the layer policy (ops._SPLIT_MIN_PIXELS / _SPLIT_MIN_K) are dropped in the small-model tests so
+that every eligible layer really takes the split kernels."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+CL = torch.channels_last
+
+
+@pytest.fixture()
+def all_layers_split():
+    from rrnet_amd import ops
+    saved = (ops._SPLIT_MIN_PIXELS, ops._SPLIT_MIN_K, ops._SPLIT_MIN_CH)
+    ops._SPLIT_MIN_PIXELS = ops._SPLIT_MIN_K = ops._SPLIT_MIN_CH = 0
+    yield
+    ops._SPLIT_MIN_PIXELS, ops._SPLIT_MIN_K, ops._SPLIT_MIN_CH = saved
+
+
+class _Calls:
+    """Counts the C-ABI entry points fetched by name (rrnet_amd._C.fn) while active."""
+
+    def __enter__(self):
+        from rrnet_amd import _C
+        self.C, self.orig, self.n = _C, _C.fn, {}
+
+        def fn(name, *a, **kw):
+            self.n[name] = self.n.get(name, 0) + 1
+            return self.orig(name, *a, **kw)
+        _C.fn = fn
+        return self
+
+    def __exit__(self, *exc):
+        self.C.fn = self.orig
+
+    def split(self):
+        return sum(v for k, v in self.n.items() if k.endswith("_f16x3"))
+
+
+def _cfg(backbone, math):
+    return SimpleNamespace(num_classes=10, Model=SimpleNamespace(num_stacks=2, backbone=backbone, nms_type_for_stage1="nms",
+                           nms_per_class_for_stage1=True, bf16=False, conv_math=math), Train=SimpleNamespace(scale_factor=4))
+
+
+def _maxdiff(a, b):
+    return float((a.detach().double().cpu() - b.detach().double().cpu()).abs().max())
+
+
+@pytest.mark.parametrize("backbone,size,bs,training", [("hourglass_tiny", 128, 2, True), ("hourglass", 256, 1, False)])
+def test_split_model_is_as_close_to_the_fp64_oracle_as_the_fp32_model(backbone, size, bs, training, all_layers_split):
+    from oracle import model as om
+    from helpers import host_synth_batch as synth_batch
+    from rrnet_amd import ops
+    from rrnet_amd.models.rrnet import RRNet
+    torch.manual_seed(219)
+    model = RRNet(_cfg(backbone, "f16x3"))
+    assert model.bf16 == ops.MATH_F16X3
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    imgs = synth_batch(bs, size, size, boxes_per_image=8, seed=219)[0]
+    P = om.Params({k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}, training=training)
+    with torch.no_grad():
+        plain = om.stage1(P, om.hourglass_net(P, imgs.double()))
+    outs = {}
+    for math in ("f16x3", "f32"):
+        m = RRNet(_cfg(backbone, math))
+        m.load_state_dict(sd)
+        m = m.cuda().to(memory_format=CL)
+        m.train(training)
+        with _Calls() as calls, torch.no_grad():
+            outs[math] = m(imgs.cuda(), k=50)
+        assert (calls.split() > 20) == (math == "f16x3"), (math, calls.n)
+    for name, idx in (("heat-map logits", 0), ("wh", 1), ("offset", 2)):
+        for s in range(2):
+            scale = float(plain[idx][s].abs().max())
+            d_split, d_f32 = _maxdiff(outs["f16x3"][idx][s], plain[idx][s]), _maxdiff(outs["f32"][idx][s], plain[idx][s])
+            print("%s stack %d (%s %dx%d %s): |HIP - fp64 oracle| f16x3 %.3e, fp32 MFMA %.3e (scale %.3g)" % (
+                name, s, backbone, size, size, "train" if training else "eval", d_split, d_f32, scale))
+            assert d_split <= 2.0 * d_f32 + 2e-6 * scale, (name, s, d_split, d_f32)
+            assert d_split <= 1e-3 * scale                       # BASELINE north_star: within 1e-3
+
+
+def test_split_block_gradients_match_fp32(all_layers_split):
+    """ResidualBlock (conv-bn-relu-conv-bn + projection skip, train-mode BN) + a head convolution with bias + ReLU,
+    forward and backward on both kernel families from the same weights and cotangent.  The outputs agree to 2e-5 of their
+    scale.  The gradients agree except where one of the ~1e6 ReLU inputs sits within that 1e-6 of zero and its mask flips
+    (measured: about one flip per run — the same happens between two summation orders of the fp32 kernels): an O(1)
+    change of ONE gradient element, seen as ~3e-3 of the maximum in the sums that contain it.  Bound: 2e-3 in relative L2
+    norm, 2e-2 of the maximum (bf16 operands: 6e-2 median — tests/test_bf16_model_gpu.py); a wrong operand scale shows as
+    a power of two.  The kernels themselves are pinned at 4e-6 in tests/test_conv_split_gpu.py."""
+    import torch.nn as nn
+    from rrnet_amd import functional as RF, ops
+    from rrnet_amd.backbones.hourglass import ResidualBlock
+    from rrnet_amd.flat import FlatParams
+    res = {}
+    x0 = torch.randn(4, 128, 64, 64, generator=torch.Generator().manual_seed(3))
+    g0 = (torch.randn(4, 256, 32, 32, generator=torch.Generator().manual_seed(4)) * 1e-3).cuda().to(memory_format=CL)
+    for math in (ops.MATH_F32, ops.MATH_F16X3):
+        torch.manual_seed(5)
+        blk = ResidualBlock(128, 256, stride=2).cuda().to(memory_format=CL).train()
+        head = nn.Conv2d(256, 256, 3, padding=1).cuda().to(memory_format=CL)
+        fp = FlatParams(nn.ModuleList([blk, head]))
+        fp.zero_grad()
+        x = x0.cuda().to(memory_format=CL).requires_grad_()
+        with _Calls() as calls, ops.bf16_scope(math):
+            y = RF.conv_bias(blk(x), head, relu=True)
+            (y * g0).sum().backward()
+        torch.cuda.synchronize()
+        assert (calls.split() >= 9) == (math == ops.MATH_F16X3), calls.n
+        res[math] = (y.detach().clone(), x.grad.clone(), fp.grad.clone(),
+                     [((p._rr_grad.data_ptr() - fp.grad.data_ptr()) // 4, p.numel()) for p in fp.params])
+    a, b = res[ops.MATH_F16X3], res[ops.MATH_F32]
+
+    def rel(u, v):
+        return float((u - v).abs().max() / v.abs().max())
+
+    def l2(u, v):
+        return float((u.double() - v.double()).norm() / v.double().norm())
+    dy, dx = rel(a[0], b[0]), rel(a[1], b[1])
+    dp = [rel(a[2][o:o + n], b[2][o:o + n]) for o, n in b[3]]
+    lx, lp = l2(a[1], b[1]), [l2(a[2][o:o + n], b[2][o:o + n]) for o, n in b[3]]
+    print("ResidualBlock + head, f16x3 vs fp32 kernels: output %.2e; input gradient max %.2e L2 %.2e; parameter gradients worst max "
+          "%.2e L2 %.2e" % (dy, dx, lx, max(dp), max(lp)))
+    assert dy <= 2e-5, dy
+    assert dx <= 2e-2 and max(dp) <= 2e-2, (dx, dp)
+    assert lx <= 2e-3 and max(lp) <= 2e-3, (lx, lp)
+    assert not torch.equal(a[2], b[2])
+
+
+def test_split_rrnet_tiny_overfits_one_batch(all_layers_split):
+    from rrnet_amd.configs.rrnet_config import Config as cfg
+    from rrnet_amd.operators.rrnet_operator import RRNetOperator
+    saved = (cfg.Train.batch_size, cfg.Train.crop_size, cfg.Model.backbone, getattr(cfg.Model, "conv_math", None))
+    cfg.Train.batch_size, cfg.Train.crop_size, cfg.Model.backbone, cfg.Model.conv_math = 2, (256, 256), "hourglass_tiny", "f16x3"
+    cfg.Distributed.gpu_id, cfg.Distributed.rank, cfg.Distributed.world_size = 0, 0, 1
+    try:
+        torch.manual_seed(219)
+        op = RRNetOperator(cfg)
+        op.model.train()
+        b = op.training_loader.get_batch()
+        hist = []
+        with _Calls() as calls:
+            for step in range(60):
+                _, losses = op.train_step(step, (b[0], b[1].clone()) + tuple(b[2:]))
+                hist.append([float(v.detach()) for v in losses])
+        assert calls.split() > 60 * 20, calls.n
+    finally:
+        cfg.Train.batch_size, cfg.Train.crop_size, cfg.Model.backbone, cfg.Model.conv_math = saved
+    hist = np.array(hist)
+    assert np.isfinite(hist).all()
+    first, last = hist[:5, 0].mean(), hist[-5:, 0].mean()
+    print("f16x3 overfit: loss %.3f -> %.3f, heat-map focal %.3f -> %.3f" % (first, last, hist[:5, 1].mean(), hist[-5:, 1].mean()))
+    assert last < 0.6 * first, (first, last)
+    assert hist[-5:, 1].mean() < hist[:5, 1].mean()
+
+
+def test_config2_f16x3_full_size_train_step_every_kernel_call_sampled():
+    """One train step at B=8, 1024x1024, hourglass-104 with conv_math f16x3 and the PRODUCT's layer policy (large 3x3
+    layers on the split kernels, the rest on csrc/conv.hip), every distinct kernel call audited against a host fp64
+    recomputation from the inputs the call received at the fp32 audit's tolerances (2e-5; wgrad 2e-4 of the output scale:
+    tests/test_configs_gpu.py::test_config2_full_size_train_step_every_kernel_call_sampled) — the operands are NOT rounded
+    in the recomputation: the split kernels carry the fp32 contract."""
+    import time
+    from kernel_audit import audit
+    from rrnet_amd.configs.rrnet_config import Config as cfg
+    from rrnet_amd.operators.rrnet_operator import RRNetOperator
+    saved = (cfg.Train.batch_size, cfg.Train.crop_size, cfg.Model.backbone, getattr(cfg.Model, "conv_math", None))
+    cfg.Train.batch_size, cfg.Train.crop_size, cfg.Model.backbone, cfg.Model.conv_math = 8, (1024, 1024), "hourglass", "f16x3"
+    cfg.Distributed.gpu_id, cfg.Distributed.rank, cfg.Distributed.world_size = 0, 0, 1
+    try:
+        torch.manual_seed(cfg.seed)
+        op = RRNetOperator(cfg)
+        op.model.train()
+        b = op.training_loader.get_batch()
+        t0 = time.perf_counter()
+        with _Calls() as calls, audit(sample=True) as rec:
+            _, losses = op.train_step(0, b)
+            torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    finally:
+        cfg.Train.batch_size, cfg.Train.crop_size, cfg.Model.backbone, cfg.Model.conv_math = saved
+    assert all(np.isfinite(float(v.detach())) for v in losses)
+    kinds = {}
+    for key, err in rec.seen.items():
+        kinds.setdefault(key[0], []).append(err)
+    print("f16x3 audit %.0f s: " % dt + "  ".join("%s:%d (max %.1e)" % (kk, len(v), max(v)) for kk, v in sorted(kinds.items())))
+    n = {k: v for k, v in calls.n.items() if k.endswith("_f16x3")}
+    print("split-operand launches:", n)
+    assert not rec.bad, rec.bad[:10]
+    assert len(rec.seen) > 150
+    # (the 3x3 layers of the 256^2 .. 64^2 levels and the heads: 68 forward launches, as many data and weight gradients)
+    assert n.get("rr_conv_fprop_f16x3", 0) >= 60 and n.get("rr_conv_wgrad_f16x3", 0) >= 60, n
+    assert sum(v for k, v in n.items() if "dgrad" in k) >= 60, n

@@ -205,3 +205,19 @@ def test_side_stream_bf16_model_equals_one_stream(tmp_path):
     _compare(one, side, "bf16 model: side stream under stress vs one stream")
     for r in side[1]["repeat_vs_first"]:
         assert r["grad"][0] <= BOUND, r
+
+
+def test_side_stream_f16x3_model_equals_one_stream(tmp_path):
+    """The same A/B with cfg.Model.conv_math = "f16x3": the split-operand kernels read device words holding their operands'
+    maxima (ops.amax_of: reduced on the stream that first needs them, remembered on the tensor, carried from the forward
+    to the weight gradient on the side stream).  A maximum read before its reduction has finished gives a wrong operand
+    scale — gradients off by powers of two or overflowing to inf — which this comparison and the finite check catch."""
+    extra = ["--math", "f16x3"]
+    one = _run(tmp_path, "split_one", dict(DET, RR_WGRAD_STREAM="0"), 256, 2, 2, extra)
+    noise = max(r["grad"][0] for r in one[1]["repeat_vs_first"])
+    print("f16x3 model, one stream run to run: %.2e" % noise)
+    assert noise <= BOUND, noise
+    side = _run(tmp_path, "split_side", dict(DET, RR_WGRAD_STREAM="2", RR_WGRAD_STRESS="1"), 256, 2, 3, extra)
+    _compare(one, side, "f16x3 model: side stream under stress vs one stream")
+    for r in side[1]["repeat_vs_first"]:
+        assert r["grad"][0] <= BOUND, r
