@@ -253,6 +253,13 @@ int rr_bn_bwd_apply_gacc(const float *dz, const float *z, const float *y, const 
                     const double *sums, double count,
                     const double *count_dev, float *dx, float *g_acc, float *dgamma, float *dbeta, long total,
                     int c, hipStream_t stream);
+/* rr_bn_bwd_apply / rr_bn_bwd_apply_gacc (g_accumulate) that also leave max |dx| in the zeroed word *amax_dx (see
+ * rr_bn_apply_amax): dx is the operand of the data / weight gradients of the convolution in front of the BatchNorm. */
+int rr_bn_bwd_apply_amax(const float *dz, const float *z, const float *y, const float *mean,
+                         const float *invstd, const float *gamma, const float *mask_scale, const float *mask_shift,
+                         const double *sums, double count, const double *count_dev, float *dx, float *g_out,
+                         int g_accumulate, float *dgamma, float *dbeta, long total, int c, unsigned *amax_dx,
+                         hipStream_t stream);
 int rr_relu_fwd(const float *x, float *out, long total, hipStream_t stream);
 /* [npix][k] -> [npix][kp], channels k..kp-1 zero (kp a multiple of 4): the 10- / 2-channel gradients of the hm / offset
  * heads' last 1x1 convolutions (detectors/centernet_detector.py:14-16) enter the vector data-gradient kernel as 12 / 4

@@ -976,7 +976,8 @@ __global__ __launch_bounds__(256) void absmax_bits_kernel(const f32x4 *x, long n
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    if ((threadIdx.x & 63) == 0) atomicMax(out, __builtin_bit_cast(unsigned, m));     // non-negative floats order as their bit patterns
+    // non-negative floats order as their bit patterns; look before the same-address atomic (see bn_apply_kernel)
+    if ((threadIdx.x & 63) == 0 && __builtin_bit_cast(unsigned, m) > *(volatile unsigned *)out) atomicMax(out, __builtin_bit_cast(unsigned, m));
 }
 
 }  // namespace
@@ -984,7 +985,10 @@ __global__ __launch_bounds__(256) void absmax_bits_kernel(const f32x4 *x, long n
 extern "C" int rr_absmax_bits(const float *x, long n, unsigned *out, hipStream_t stream)
 {
     RR_CHECK_ARG(n % 4 == 0, "rr_absmax_bits: n must be a multiple of 4");
-    hipLaunchKernelGGL(absmax_bits_kernel, dim3(1024), dim3(256), 0, stream, reinterpret_cast<const f32x4 *>(x), n / 4, out);
+    if (n == 0) return RR_OK;
+    long blocks = (n / 4 + 256 * 8 - 1) / (256 * 8);       // >= 8 float4 per thread; a filter takes a few workgroups, not 1024
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(absmax_bits_kernel, dim3((int)blocks), dim3(256), 0, stream, reinterpret_cast<const f32x4 *>(x), n / 4, out);
     RR_CHECK_LAUNCH("rr_absmax_bits");
     return RR_OK;
 }

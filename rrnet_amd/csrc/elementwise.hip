@@ -159,7 +159,9 @@ __global__ __launch_bounds__(EW_THREADS) void bn_apply_kernel(const f32x4 *y, co
     if constexpr (AMAX) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
-        if ((threadIdx.x & 63) == 0) atomicMax(amax, __builtin_bit_cast(unsigned, vmax));
+        // (look first: once the word holds the tensor's maximum, or nearly, almost every wave skips the same-address atomic —
+        // 16 k of them per launch serialise at ~15 ns each)
+        if ((threadIdx.x & 63) == 0 && __builtin_bit_cast(unsigned, vmax) > *(volatile unsigned *)amax) atomicMax(amax, __builtin_bit_cast(unsigned, vmax));
     }
 }
 
@@ -228,13 +230,18 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_kernel(const float *
 
 // dx = gamma*invstd*(dy - sum_dy/count - xhat*sum_dy_xhat/count); optional g_out = dy (the masked
 // gradient, for the residual branch); workgroup 0 also accumulates dgamma / dbeta.
+// AMAX: also max |dx| -> *amax (bit pattern): dx is the output gradient of the convolution in front of this BatchNorm, i.e.
+// an operand of its data and weight gradients (rr_conv_*_f16x3 scale their operands by the tensor's maximum)
+template <bool AMAX>
 __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(const f32x4 *dz, const f32x4 *z, const f32x4 *y,
                                                                   const float *mean, const float *invstd,
                                                                   const float *gamma, const float *mscale, const float *mshift,
                                                                   const double *sums, double count_h,
                                                                   const double *count_d, f32x4 *dx, f32x4 *g_out,
-                                                                  float *dgamma, float *dbeta, long n4, int C, int g_acc)
+                                                                  float *dgamma, float *dbeta, long n4, int C, int g_acc,
+                                                                  unsigned *amax)
 {
+    float vmax = 0.f;
     const int C4 = C / 4;
     const double count = count_d ? *count_d : count_h;
     if (blockIdx.x == 0 && dgamma) {
@@ -268,6 +275,14 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(const f32x4 *d
             o[e] = ga[e] * is[e] * (g[e] - sdy - xh[e] * sdx);
         }
         dx[i] = o;
+        if constexpr (AMAX) vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
+    }
+    if constexpr (AMAX) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
+        // (look first: once the word holds the tensor's maximum, or nearly, almost every wave skips the same-address atomic —
+        // 16 k of them per launch serialise at ~15 ns each)
+        if ((threadIdx.x & 63) == 0 && __builtin_bit_cast(unsigned, vmax) > *(volatile unsigned *)amax) atomicMax(amax, __builtin_bit_cast(unsigned, vmax));
     }
 }
 
@@ -714,14 +729,30 @@ static int bn_bwd_apply_impl(const float *dz, const float *z, const float *y, co
                              const float *invstd, const float *gamma, const float *mask_scale,
                              const float *mask_shift, const double *sums, double count,
                              const double *count_dev, float *dx, float *g_out, float *dgamma, float *dbeta,
-                             long total, int c, int g_acc, hipStream_t stream)
+                             long total, int c, int g_acc, hipStream_t stream, unsigned *amax = nullptr)
 {
     RR_CHECK_ARG(c % 4 == 0 && total % c == 0, "rr_bn_bwd_apply: C=%d must be a multiple of 4", c);
     const long n4 = total / 4;
-    EW_LAUNCH(bn_bwd_apply_kernel, n4, stream, (const f32x4 *)dz, (const f32x4 *)z, (const f32x4 *)y, mean, invstd, gamma,
-              mask_scale, mask_shift, sums, count, count_dev, (f32x4 *)dx, (f32x4 *)g_out, dgamma, dbeta, n4, c, g_acc);
+    if (amax != nullptr)
+        EW_LAUNCH(bn_bwd_apply_kernel<true>, n4, stream, (const f32x4 *)dz, (const f32x4 *)z, (const f32x4 *)y, mean, invstd, gamma,
+                  mask_scale, mask_shift, sums, count, count_dev, (f32x4 *)dx, (f32x4 *)g_out, dgamma, dbeta, n4, c, g_acc, amax);
+    else
+        EW_LAUNCH(bn_bwd_apply_kernel<false>, n4, stream, (const f32x4 *)dz, (const f32x4 *)z, (const f32x4 *)y, mean, invstd, gamma,
+                  mask_scale, mask_shift, sums, count, count_dev, (f32x4 *)dx, (f32x4 *)g_out, dgamma, dbeta, n4, c, g_acc,
+                  (unsigned *)nullptr);
     RR_CHECK_LAUNCH("rr_bn_bwd_apply");
     return RR_OK;
+}
+
+extern "C" int rr_bn_bwd_apply_amax(const float *dz, const float *z, const float *y, const float *mean,
+                                    const float *invstd, const float *gamma, const float *mask_scale,
+                                    const float *mask_shift, const double *sums, double count,
+                                    const double *count_dev, float *dx, float *g_out, int g_accumulate, float *dgamma,
+                                    float *dbeta, long total, int c, unsigned *amax_dx, hipStream_t stream)
+{
+    RR_CHECK_ARG(amax_dx != nullptr && (!g_accumulate || g_out != nullptr), "rr_bn_bwd_apply_amax: amax_dx (and the fan-in buffer when accumulating) required");
+    return bn_bwd_apply_impl(dz, z, y, mean, invstd, gamma, mask_scale, mask_shift, sums, count, count_dev, dx, g_out, dgamma,
+                             dbeta, total, c, g_accumulate ? 1 : 0, stream, amax_dx);
 }
 
 extern "C" int rr_bn_bwd_apply(const float *dz, const float *z, const float *y, const float *mean,

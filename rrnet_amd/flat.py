@@ -75,6 +75,8 @@ class FlatParams:
         self.wt_flat = None
         self.w16_flat = self.wt16_flat = None       # bf16 copies (plain / flipped) for the bf16-operand kernels, on demand
         self._wt_table = None
+        self.epoch = 0                              # optimizer steps taken through the flat buffer (FlatAdam.step): cache key for
+                                                    # per-step quantities derived from the parameters (functional._wamax_attach)
         self._wt_version = None
         self._wt_pver = {}                          # id(parameter) -> its own version counter at the last fill
         self._wt_enabled = os.environ.get("RR_WT_CACHE", "1") != "0" and dev.type == "cuda"
@@ -284,4 +286,5 @@ class FlatAdam(torch.optim.Optimizer):
         self.step_count += 1
         ops.adam_step(self.fp.flat, self.fp.grad, self.exp_avg, self.exp_avg_sq, g['lr'], g['betas'][0], g['betas'][1],
                       g['eps'], self.step_count, scale)
+        self.fp.epoch += 1
         self.fp.refresh_wt()          # the update kernel wrote through raw pointers: refill the flipped-filter cache now

@@ -115,6 +115,7 @@ class _ConvBnAct(torch.autograd.Function):
         ctx.bf16 = ops.BF16
         x = ops.to_nhwc(x)
         wc = ops.to_nhwc(w)
+        _wamax_attach(w, wc)
         n, _, h, wd = x.shape
         k = w.shape[0]
         sync = _is_sync(bn)
@@ -272,12 +273,27 @@ def _w16_of(w_param):
     return flat.w16_views(w_param) if flat is not None else (None, None)
 
 
+def _wamax_attach(w_param, wc):
+    """Split-operand kernels: hand the filter's maximum (one small reduction per parameter and optimizer step, remembered on
+    the parameter) to the NHWC view `wc` the launch receives — forward and data gradient see different view objects."""
+    if ops.BF16 != ops.MATH_F16X3 or w_param is None or not wc.is_cuda:
+        return
+    flat = getattr(w_param, "_rr_flat", None)
+    key = (flat.epoch if flat is not None else -1, w_param._version, w_param.data_ptr())
+    hit = getattr(w_param, "_rr_wamax", None)
+    if hit is None or hit[0] != key:
+        hit = (key, ops.amax_of(wc))
+        w_param._rr_wamax = hit
+    ops.amax_restore(wc, hit[1])
+
+
 def _input_grad(dy, wc, xshape, stride, pad, x_acc, in_link, x, w_param=None):
     """Data gradient of a convolution node -> the tensor to hand to autograd (None when it was added into the fan-in
     buffer of x's fan-out).  Where the launch can carry them it also produces the BatchNorm-backward sums of the layer
     that produced x (ops.BnLink): when x has this node as its only consumer, or when this node is the LAST registered
     contributor to the fan-in buffer of x's fan-out (the epilogue then holds the complete gradient)."""
     _wgrad_join(dy.device)        # the previous layer's weight gradient has had the HBM-bound stretch to itself
+    _wamax_attach(w_param, wc)
     wt = _wt_of(w_param) if stride == 1 else None
     wt16 = _w16_of(w_param)[1] if (stride == 1 and wt is not None) else None
     if x_acc is None:
@@ -471,6 +487,7 @@ class _ConvBias(torch.autograd.Function):
         ctx.bf16 = ops.BF16
         x = ops.to_nhwc(x)
         wc = ops.to_nhwc(w)
+        _wamax_attach(w, wc)
         y = ops.conv_fprop(x, wc, b, stride, pad, relu, w16=_w16_of(w)[0])
         ctx.save_for_backward(x, wc, y if relu else None)
         ctx.x_amax = ops.amax_carry(x)

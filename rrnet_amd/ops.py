@@ -182,6 +182,8 @@ def _bf16_ok(c, k, r, s, *tensors, pixels=None):
 
 
 _SPLIT_MIN_PIXELS = int(os.environ.get("RR_SPLIT_MIN_PIXELS", "16384"))    # N*P*Q below which a layer stays on the fp32 kernels
+_FUSED_AMAX_FWD = os.environ.get("RR_SPLIT_FUSED_AMAX_FWD", "1") != "0"    # bn_apply leaves max |out| for the next convolution
+_FUSED_AMAX_BWD = os.environ.get("RR_SPLIT_FUSED_AMAX_BWD", "1") != "0"    # bn_bwd_apply leaves max |dx| for the data / weight gradient
 _SPLIT_MIN_CH = 64                                                         # narrower layers (either side) likewise
 _SPLIT_MIN_K = int(os.environ.get("RR_SPLIT_MIN_K", "1024"))               # C*R*S (reduction length) likewise
 
@@ -531,7 +533,7 @@ def bn_apply(y, scale, shift, residual=None, relu=False, res_scale=None, res_shi
     assert is_nhwc(y) and (residual is None or (is_nhwc(residual) and residual.shape == y.shape))
     n, c, h, w = y.shape
     out = empty_nhwc(n, c, h, w, y.device)
-    if BF16 == MATH_F16X3 and y.is_cuda and n * h * w >= _SPLIT_MIN_PIXELS:
+    if BF16 == MATH_F16X3 and y.is_cuda and n * h * w >= _SPLIT_MIN_PIXELS and _FUSED_AMAX_FWD:
         # split-operand convolutions: the consumer's operand scale comes out of this pass (see amax_of)
         word = _ZEROS.take(1, y.device)
         _C.check(_C.fn("rr_bn_apply_amax")(_C.ptr(y), _C.ptr(scale), _C.ptr(shift), _C.ptr(residual), _C.ptr(res_scale),
@@ -563,6 +565,16 @@ def bn_bwd_apply(dz, z, y, mean, invstd, gamma, sums, count, want_g=False, dgamm
         g = g_into
     else:
         g = empty_nhwc(n, c, h, w, y.device) if want_g else None
+    if BF16 == MATH_F16X3 and y.is_cuda and n * h * w >= _SPLIT_MIN_PIXELS and _FUSED_AMAX_BWD:
+        # split-operand convolutions: dx is the operand of the data / weight gradient launched next — its maximum comes out
+        # of this pass.  (dx is a fresh tensor that nothing adds into later: the remembered maximum cannot go stale.)
+        word = _ZEROS.take(1, y.device)
+        _C.check(_C.fn("rr_bn_bwd_apply_amax")(_C.ptr(dz), _C.ptr(z), _C.ptr(y), _C.ptr(mean), _C.ptr(invstd), _C.ptr(gamma),
+                                               _C.ptr(mask_scale), _C.ptr(mask_shift), _C.ptr(sums), float(count), _C.ptr(count_dev),
+                                               _C.ptr(dx), _C.ptr(g), int(g_into is not None), _C.ptr(dgamma), _C.ptr(dbeta),
+                                               y.numel(), c, _C.ptr(word), _C.stream()), "rr_bn_bwd_apply_amax")
+        dx._rr_amax = (dx._version, torch.cuda.current_stream(y.device).cuda_stream, word)
+        return dx, g
     _C.check(_C.fn("rr_bn_bwd_apply_gacc" if g_into is not None else "rr_bn_bwd_apply")(_C.ptr(dz), _C.ptr(z), _C.ptr(y), _C.ptr(mean), _C.ptr(invstd), _C.ptr(gamma),
                                       _C.ptr(mask_scale), _C.ptr(mask_shift), _C.ptr(sums), float(count), _C.ptr(count_dev), _C.ptr(dx), _C.ptr(g), _C.ptr(dgamma), _C.ptr(dbeta),
                                       y.numel(), c, _C.stream()), "rr_bn_bwd_apply")
