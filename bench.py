@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--extra-pool", type=int, default=512, help="distinct resident frames of the config-5 pass (4 batches of 128)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--time-every", type=int, default=4, help="HIP-event pair around every n-th launch of the dominant kernel")
+    ap.add_argument("--math", default="f32", choices=["f32", "f16x3"], help="cfg.Model.conv_math of the timed train step (f16x3: "
+                    "split-operand kernels on the large layers; the default line stays on the fp32 matrix instruction)")
     ap.add_argument("--detail", action="store_true", help="print a per-layer-shape conv time table to stderr")
     return ap.parse_args()
 
@@ -148,7 +150,35 @@ def extras(a):
     except Exception as e:
         out["config4"] = {"value": None, "error": repr(e)}
     torch.cuda.empty_cache()
+    if a.backbone == "hourglass" and a.size == 1024 and a.math == "f32":
+        try:
+            out["config2_f16x3"] = config2_split(a)
+        except Exception as e:
+            out["config2_f16x3"] = {"value": None, "error": repr(e)}
+        torch.cuda.empty_cache()
     return out
+
+
+def config2_split(a, steps=5):
+    """The HEADLINE workload (configs[1], same model, batch, loop) with cfg.Model.conv_math = "f16x3": the large 3x3
+    convolutions on the split-operand kernels (csrc/conv_bf16.hip rr_conv_*_f16x3: each fp32 operand as two fp16 parts,
+    three matrix products, fp32 accumulation), the rest on the fp32-MFMA kernels.  Reported NEXT to the headline, not as
+    it: the headline stays on v_mfma_f32_32x32x2_f32.  Evidence that the arithmetic is fp32-class rides along: the error
+    of one layer against an fp64 convolution under both kernels (tests/test_conv_split_gpu.py, tests/test_split_model_gpu.py
+    hold the bounds)."""
+    import bench_config4
+    import bench_conv_split
+    r = bench_config4.run(a.batch, a.size, steps, False, a.backbone, False, "f16x3")
+    r["vs_headline_arithmetic"] = "same tensors, same autograd graph, same launches except the convolutions with >= 2048 output " \
+                                  "pixels, >= 64 channels and a reduction length >= 1024 (ops._bf16_ok)"
+    r["error_vs_fp64_one_layer"] = bench_conv_split.accuracy(verbose=False)
+    rates = bench_conv_split.layer_rates()
+    r["dominant_layer"] = {"shape": "N8 C256 256x256 K256 3x3", **rates}
+    # matrix-pipe ceiling of this arithmetic: three v_mfma_f32_32x32x16_f16 per product tile at the 16-bit dense peak
+    r["mfma_peak_tflops"] = round(2500.0 / 3.0, 1)
+    r["step_mfma_frac"] = round(r["value"] * ALGO_TFLOP_PER_IMAGE / (2500.0 / 3.0), 4)
+    r["fprop_frac_of_peak"] = round(rates["f16x3"]["fprop"]["tflops"] / (2500.0 / 3.0), 4)
+    return r
 
 
 def config4_train_step(a, steps=5):
@@ -194,6 +224,7 @@ def main():
     cfg.Train.batch_size = a.batch
     cfg.Train.crop_size = (a.size, a.size)
     cfg.Model.backbone = a.backbone
+    cfg.Model.conv_math = a.math if a.math != "f32" else None
     cfg.Distributed.gpu_id = local
     cfg.Distributed.rank = rank
     cfg.Distributed.world_size = world
@@ -249,7 +280,9 @@ def main():
         out = {
             "metric": "images/sec (train step)", "value": round(images / elapsed, 4), "unit": "images/sec",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if a.math == "f32" else "f32 storage / accumulation; large convolutions multiply fp16 hi+lo operand pairs (f16x3)",
+            "data": "synthetic",
             # the batches are resident in HBM before the timed region (tier contract); the reference's loader would pay a
             # ~100 MB host-to-device image copy per step inside it
             "input_residency": "device",

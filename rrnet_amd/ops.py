@@ -181,7 +181,7 @@ def _bf16_ok(c, k, r, s, *tensors, pixels=None):
     return int(BF16) if ok else 0
 
 
-_SPLIT_MIN_PIXELS = int(os.environ.get("RR_SPLIT_MIN_PIXELS", "16384"))    # N*P*Q below which a layer stays on the fp32 kernels
+_SPLIT_MIN_PIXELS = int(os.environ.get("RR_SPLIT_MIN_PIXELS", "2048"))    # N*P*Q below which a layer stays on the fp32 kernels
 _FUSED_AMAX_FWD = os.environ.get("RR_SPLIT_FUSED_AMAX_FWD", "1") != "0"    # bn_apply leaves max |out| for the next convolution
 _FUSED_AMAX_BWD = os.environ.get("RR_SPLIT_FUSED_AMAX_BWD", "1") != "0"    # bn_bwd_apply leaves max |dx| for the data / weight gradient
 _SPLIT_MIN_CH = 64                                                         # narrower layers (either side) likewise

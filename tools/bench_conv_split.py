@@ -29,7 +29,7 @@ def timeit(fn, iters=10, warm=3):
     return s.elapsed_time(e) / iters
 
 
-def accuracy():
+def accuracy(verbose=True):
     torch.manual_seed(0)
     n, c, h, k, r = 2, 256, 128, 256, 3
     x = torch.randn(n, c, h, h, device="cuda") * torch.rand(n, c, 1, 1, device="cuda") * 3
@@ -37,13 +37,39 @@ def accuracy():
     cols = torch.nn.functional.unfold(x.double(), r, padding=1)
     ref = (w.double().reshape(k, -1) @ cols).reshape(n, k, h, h)
     rms = ref.pow(2).mean().sqrt()
+    out = {}
+    saved = ops.BF16
     for name, mode in MODES:
-        with ops.bf16_scope(mode):
-            ops.BF16 = mode
-            y = ops.conv_fprop(ops.to_nhwc(x), ops.to_nhwc(w), None, 1, (1, 1), False).double()
-        print("%-6s forward error vs fp64 (n2 c256 128x128 k256 3x3): rms %.3e of rms y, max %.3e of max |y|" % (
-            name, float((y - ref).pow(2).mean().sqrt() / rms), float((y - ref).abs().max() / ref.abs().max())))
-    ops.BF16 = ops.MATH_F32
+        ops.BF16 = mode
+        y = ops.conv_fprop(ops.to_nhwc(x), ops.to_nhwc(w), None, 1, (1, 1), False).double()
+        out[name] = {"rms_err_over_rms_y": float((y - ref).pow(2).mean().sqrt() / rms),
+                     "max_err_over_max_y": float((y - ref).abs().max() / ref.abs().max())}
+        if verbose:
+            print("%-6s forward error vs fp64 (n2 c256 128x128 k256 3x3): rms %.3e of rms y, max %.3e of max |y|" % (
+                name, out[name]["rms_err_over_rms_y"], out[name]["max_err_over_max_y"]))
+    ops.BF16 = saved
+    return out
+
+
+def layer_rates(shape=(8, 256, 256, 256, 3), iters=10):
+    """fprop / dgrad / wgrad of one layer shape under the three arithmetics -> {math: {op: {"ms", "tflops"}}} (the operand
+    maxima of the split kernels are reduced inside the timed calls, as in a train step without a fused producer)."""
+    n, c, h, k, r = shape
+    pad = r // 2
+    x = ops.to_nhwc(torch.randn(n, c, h, h, device="cuda"))
+    w = ops.to_nhwc(torch.randn(k, c, r, r, device="cuda") * 0.02)
+    dy = ops.to_nhwc(torch.randn(n, k, h, h, device="cuda") * 1e-3)
+    dw = torch.zeros((k, r, r, c), device="cuda").permute(0, 3, 1, 2)
+    flops = 2.0 * n * h * h * k * c * r * r
+    saved, out = ops.BF16, {}
+    for name, mode in MODES:
+        ops.BF16 = mode
+        t = {"fprop": timeit(lambda: ops.conv_fprop(x.view_as(x), w.view_as(w), None, 1, (pad, pad), False), iters),
+             "dgrad": timeit(lambda: ops.conv_dgrad(dy.view_as(dy), w.view_as(w), (n, c, h, h), 1, (pad, pad)), iters),
+             "wgrad": timeit(lambda: ops.conv_wgrad(x.view_as(x), dy.view_as(dy), dw, 1, (pad, pad)), iters)}
+        out[name] = {kk: {"ms": round(v, 4), "tflops": round(flops / v / 1e9, 1)} for kk, v in t.items()}
+    ops.BF16 = saved
+    return out
 
 
 def main():
