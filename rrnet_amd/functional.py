@@ -73,6 +73,8 @@ def _wgrad_async(fn, device, *tensors):
     cur = torch.cuda.current_stream(device)
     side = _side_stream(device, "wgrad")
     side.wait_stream(cur)
+    for t in tensors:                     # maxima reduced on the current stream so far are complete for the side stream too
+        ops.amax_publish(t)
     with torch.cuda.stream(side):
         _stress_delay()
         fn()
@@ -657,8 +659,11 @@ def fanout_shared(x, n):
     if acc is None:
         acc = GradAcc()
         acc.link = getattr(x, "_rr_bnlink", None)
+    amax = getattr(x, "_rr_amax", None)     # (split-operand kernels: the views ARE x — its remembered maximum travels with them)
     for o in outs:
         o._rr_acc = acc
+        if amax is not None and amax[0] == x._version:
+            o._rr_amax = (o._version, amax[1], amax[2])
     return outs + (acc,)
 
 

@@ -201,6 +201,14 @@ def amax_restore(t, word):
         t._rr_amax = (t._version, None, word)
 
 
+def amax_publish(t):
+    """The caller has just ordered another stream behind the current one (wait_stream): a maximum remembered on t from the
+    current stream may be read there."""
+    hit = getattr(t, "_rr_amax", None) if t is not None else None
+    if hit is not None and hit[1] == torch.cuda.current_stream(t.device).cuda_stream:
+        t._rr_amax = (hit[0], None, hit[2])
+
+
 def amax_of(t):
     """Device word holding the bit pattern of max|t| (rr_absmax_bits) for the split-operand kernels, computed on the
     current stream and remembered on the tensor object (same version, same stream): a gradient serves its data

@@ -129,7 +129,7 @@ def test_side_stream_default_path_with_split_k(tmp_path, size, batch):
     self_rel, _ = _rel(g2, g1, sl)
     cross_rel, _ = _rel(_load(side[0], "grad.bin"), g1, sl)
     # "well-conditioned here" = reproducible to a third of the bound in the one-stream arm itself; on those parameters the
-    # arms must agree to 1e-4 of the scale (the spread of a parameter that just made the cut is a few 1e-5; a lost or torn
+    # arms must agree to 2e-3 of the scale (the spread of a parameter that just made the cut is 1e-5 ... 5e-4; a lost or torn
     # weight gradient is >= 1e-2).  Everywhere else the comparison is between two samples of the same noisy quantity:
     # generous factors, they still separate "same distribution" from "a wrong gradient somewhere" (O(1) on that parameter)
     good = self_rel <= BOUND / 3
@@ -141,7 +141,8 @@ def test_side_stream_default_path_with_split_k(tmp_path, size, batch):
                                                   float(self_rel.median()), int((cross_rel > BOUND).sum()),
                                                   int((self_rel > BOUND).sum()), float(cross_rel.max()), float(self_rel.max())))
     assert n_good >= 15, (n_good, n)             # the last stack's heads and their feeders: downstream of the deep levels' noise
-    assert worst_good <= 1e-4, worst_good
+    # (two one-stream samples can agree to 3e-6 by chance on a parameter whose real spread is a few 1e-4: measured 4.9e-4)
+    assert worst_good <= 2e-3, worst_good
     assert float(cross_rel.median()) <= 5 * max(float(self_rel.median()), BOUND)
     assert int((cross_rel > BOUND).sum()) <= int(1.5 * (self_rel > BOUND).sum()) + 30
     assert float(cross_rel.max()) <= max(10 * float(self_rel.max()), 0.5) and float(cross_rel.max()) < 2.0
