@@ -267,10 +267,11 @@ __global__ __launch_bounds__(WS ? 512 : 256, (!WS && SP == 2) ? 2 : 1) void conv
 #pragma unroll
         for (int j = 0; j < BJ; ++j) {
             const unsigned ok = (unsigned)b_ok[j] & (unsigned)p_wcok & (unsigned)p_live;
-            const unsigned off = ok ? (unsigned)(b_boff[j] + p_wdelta) : OOB;
 #pragma unroll
-            for (int sp = 0; sp < (B16 ? SP : 1); ++sp)      // (OOB + image offset stays beyond the descriptor's size)
-                rb[sp][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, off, sp * w16_image, 0));   // B16: 8 bf16
+            for (int sp = 0; sp < (B16 ? SP : 1); ++sp) {
+                const unsigned off = ok ? (unsigned)(b_boff[j] + p_wdelta + sp * w16_image) : OOB;
+                rb[sp][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, off, 0, 0));   // B16: 8 values of 16 bits
+            }
         }
     };
     auto load_all = [&]() { load_into(ra, rb); };
@@ -654,6 +655,21 @@ struct BnSumArgs {
 
 struct OutMap { int DH, DW, OH, OW, osh, osw, oh0, ow0; };   // explicit logical output grid + strided destination
 
+// filter [K][R][S][C] fp32 -> its two fp16 parts, scaled by the power of two the convolution kernel derives from the same word:
+// image 0 = hi, image 1 = lo (each K*R*S*C halves).  A 2.4 MB filter: ~5 us, against 48 of the 149 vector instructions per
+// K-step and thread that splitting the filter tile inside the convolution costs.
+__global__ __launch_bounds__(256) void weight_split_f16_kernel(const f32x4 *w, const unsigned *amax, unsigned short *out, long n4)
+{
+    const unsigned e = (*amax >> 23) & 0xffu;
+    const float scale = e == 0u ? 1.f : __builtin_bit_cast(float, (268u - e) << 23);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        u16x4 parts[2];
+        split_bf4<2, true>(w[i], parts, scale);
+        *reinterpret_cast<u16x4 *>(out + 4 * i) = parts[0];
+        *reinterpret_cast<u16x4 *>(out + 4 * (n4 + i)) = parts[1];
+    }
+}
+
 size_t igemm_lds(int bn, int sp = 1) { return sizeof(unsigned short) * 2 * (size_t)sp * (BM + bn) * LDK; }
 
 template <typename K>
@@ -669,7 +685,8 @@ int launch(K kern, int blocks, int gz, size_t lds, hipStream_t stream, const Con
 int fprop_impl(const float *x, const float *w, const float *bias, float *y, double *stat_slab, int n, int h, int wd, int c,
                int k, int r, int s, int stride, int pad_h, int pad_w, int relu, int accumulate, hipStream_t stream,
                const BnSumArgs *bs = nullptr, const OutMap *om = nullptr, const unsigned short *w16 = nullptr,
-               int split = 0, const unsigned *amax_src = nullptr, const unsigned *amax_w = nullptr)
+               int split = 0, const unsigned *amax_src = nullptr, const unsigned *amax_w = nullptr,
+               unsigned short *w_split = nullptr)
 {
     RR_CHECK_ARG(n > 0 && h > 0 && wd > 0 && c > 0 && k > 0 && r > 0 && s > 0 && stride > 0, "rr_conv_fprop_bf16: bad dims");
     RR_CHECK_ARG(c % 4 == 0 && r * s <= 64, "rr_conv_fprop_bf16: C=%d must be a multiple of 4 and R*S <= 64 (fp32 path for the rest)", c);
@@ -733,6 +750,18 @@ int fprop_impl(const float *x, const float *w, const float *bias, float *y, doub
         a.w16 = nullptr;
         a.amax_src = amax_src; a.amax_w = amax_w;
         name = "rr_conv_fprop_f16x3";
+        if (w_split != nullptr && c % 8 == 0 && bn == 128) {
+            // the filter split once per launch into caller scratch (k*r*s*c floats = the two fp16 images), read by the B16 instantiation
+            const long n4 = (long)k * r * s * c / 4;
+            long sb = (n4 + 255) / 256;
+            if (sb > 1024) sb = 1024;
+            hipLaunchKernelGGL(weight_split_f16_kernel, dim3((int)sb), dim3(256), 0, stream, reinterpret_cast<const f32x4 *>(w), amax_w, w_split, n4);
+            RR_CHECK_LAUNCH("rr_conv_fprop_f16x3(filter split)");
+            a.w16 = w_split;
+#define RR_SB(BNSv, SOv) launch(conv_igemm_bf16_kernel<128, BNSv, true, SOv, 2, false, true>, blocks, ks, igemm_lds(128, 2), stream, a, name)
+            rc = fused ? RR_SB(true, false) : (a.osh ? RR_SB(false, true) : RR_SB(false, false));
+#undef RR_SB
+        } else
         if (ws_env && bn == 128 && !a.osh) rc = fused ? RR_SW(true) : RR_SW(false);
         else if (fused) rc = bn == 128 ? RR_SX(128, true, false) : bn == 64 ? RR_SX(64, true, false) : RR_SX(32, true, false);
         else if (a.osh) rc = bn == 128 ? RR_SX(128, false, true) : bn == 64 ? RR_SX(64, false, true) : RR_SX(32, false, true);
@@ -1174,30 +1203,32 @@ extern "C" int rr_conv_wgrad_bf16(const float *x, const float *dy, float *dw, in
 // synchronisation.  Error against an fp64 convolution: below the fp32-MFMA kernels' own (tests/test_conv_split_gpu.py).
 extern "C" int rr_conv_fprop_f16x3(const float *x, const float *w, const float *bias, float *y, double *stat_slab,
                                    int n, int h, int wd, int c, int k, int r, int s, int stride, int pad_h,
-                                   int pad_w, int relu, const unsigned *amax_x, const unsigned *amax_w, hipStream_t stream)
+                                   int pad_w, int relu, const unsigned *amax_x, const unsigned *amax_w, float *w_split_scratch,
+                                   hipStream_t stream)
 {
     RR_CHECK_ARG(amax_x && amax_w, "rr_conv_fprop_f16x3: the operands' maxima are required");
     return fprop_impl(x, w, bias, y, stat_slab, n, h, wd, c, k, r, s, stride, pad_h, pad_w, relu, 0, stream, nullptr, nullptr, nullptr,
-                      1, amax_x, amax_w);
+                      1, amax_x, amax_w, reinterpret_cast<unsigned short *>(w_split_scratch));
 }
 
 extern "C" int rr_conv_dgrad_s1_f16x3(const float *dy, const float *wt, float *dx, int n, int h, int wd, int c, int k,
                                       int r, int s, int pad_h, int pad_w, int accumulate, const unsigned *amax_dy,
-                                      const unsigned *amax_w, hipStream_t stream)
+                                      const unsigned *amax_w, float *w_split_scratch, hipStream_t stream)
 {
     RR_CHECK_ARG(pad_h < r && pad_w < s && pad_h >= 0 && pad_w >= 0, "rr_conv_dgrad_s1_f16x3: pad must be in [0, kernel)");
     RR_CHECK_ARG(amax_dy && amax_w, "rr_conv_dgrad_s1_f16x3: the operands' maxima are required");
     const int p = h + 2 * pad_h - r + 1, q = wd + 2 * pad_w - s + 1;
     RR_CHECK_ARG(p > 0 && q > 0, "rr_conv_dgrad_s1_f16x3: empty dy");
     return fprop_impl(dy, wt, nullptr, dx, nullptr, n, p, q, k, c, r, s, 1, r - 1 - pad_h, s - 1 - pad_w, 0, accumulate, stream,
-                      nullptr, nullptr, nullptr, 1, amax_dy, amax_w);
+                      nullptr, nullptr, nullptr, 1, amax_dy, amax_w, reinterpret_cast<unsigned short *>(w_split_scratch));
 }
 
 extern "C" int rr_conv_dgrad_s1_bnsum_f16x3(const float *dy, const float *wt, float *dx, int n, int h, int wd, int c, int k,
                                             int r, int s, int pad_h, int pad_w, int accumulate, const float *prod_y,
                                             const float *prod_z, const float *prod_mean, const float *prod_invstd,
                                             const float *prod_mask_scale, const float *prod_mask_shift, double *slab,
-                                            double *sums, const unsigned *amax_dy, const unsigned *amax_w, hipStream_t stream)
+                                            double *sums, const unsigned *amax_dy, const unsigned *amax_w, float *w_split_scratch,
+                                            hipStream_t stream)
 {
     RR_CHECK_ARG(pad_h < r && pad_w < s && pad_h >= 0 && pad_w >= 0, "rr_conv_dgrad_s1_bnsum_f16x3: pad must be in [0, kernel)");
     RR_CHECK_ARG(prod_y && prod_mean && prod_invstd && slab && sums && (!prod_mask_scale == !prod_mask_shift) && amax_dy && amax_w,
@@ -1207,7 +1238,7 @@ extern "C" int rr_conv_dgrad_s1_bnsum_f16x3(const float *dy, const float *wt, fl
     RR_CHECK_ARG(p > 0 && q > 0, "rr_conv_dgrad_s1_bnsum_f16x3: empty dy");
     const BnSumArgs bs{prod_y, prod_z, prod_mean, prod_invstd, prod_mask_scale, prod_mask_shift, slab, sums, 0};
     return fprop_impl(dy, wt, nullptr, dx, nullptr, n, p, q, k, c, r, s, 1, r - 1 - pad_h, s - 1 - pad_w, 0, accumulate, stream, &bs,
-                      nullptr, nullptr, 1, amax_dy, amax_w);
+                      nullptr, nullptr, 1, amax_dy, amax_w, reinterpret_cast<unsigned short *>(w_split_scratch));
 }
 
 extern "C" int rr_conv_dgrad_s1_relubias_f16x3(const float *dy, const float *wt, float *dx, int n, int h, int wd, int c, int k,

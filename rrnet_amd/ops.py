@@ -184,6 +184,16 @@ def _bf16_ok(c, k, r, s, *tensors, pixels=None):
 _SPLIT_MIN_PIXELS = int(os.environ.get("RR_SPLIT_MIN_PIXELS", "2048"))    # N*P*Q below which a layer stays on the fp32 kernels
 _FUSED_AMAX_FWD = os.environ.get("RR_SPLIT_FUSED_AMAX_FWD", "1") != "0"    # bn_apply leaves max |out| for the next convolution
 _FUSED_AMAX_BWD = os.environ.get("RR_SPLIT_FUSED_AMAX_BWD", "1") != "0"    # bn_bwd_apply leaves max |dx| for the data / weight gradient
+_SPLIT_PRESPLIT_PIXELS = int(os.environ.get("RR_SPLIT_PRESPLIT_PIXELS", "65536"))   # from here on the filter is split once per launch
+
+
+def _split_scratch(w, pixels):
+    """Scratch for the per-launch filter split of the f16x3 kernels (k*r*s*c floats), or None below the size where it pays."""
+    if pixels < _SPLIT_PRESPLIT_PIXELS or w.shape[1] % 8 != 0 or w.shape[0] <= 64:
+        return None
+    return torch.empty(w.numel(), dtype=torch.float32, device=w.device)
+
+
 _SPLIT_MIN_CH = 64                                                         # narrower layers (either side) likewise
 _SPLIT_MIN_K = int(os.environ.get("RR_SPLIT_MIN_K", "1024"))               # C*R*S (reduction length) likewise
 
@@ -248,7 +258,8 @@ def conv_fprop(x, w, bias=None, stride=1, pad=(0, 0), relu=False, want_stats=Fal
     f = _C.fn(("rr_conv_fprop", "rr_conv_fprop_bf16", "rr_conv_fprop_f16x3")[bf])
     flops = 2.0 * n * p * q * k * (c * r * s if algo_kg is None else algo_kg)
     # w16: the filter already rounded to bf16 (optional); split operands: the two tensors' maxima
-    tail = ((_C.stream(),), (_C.ptr(w16), _C.stream()), None)[bf] if bf != MATH_F16X3 else (_C.ptr(amax_of(x)), _C.ptr(amax_of(w)), _C.stream())
+    tail = ((_C.stream(),), (_C.ptr(w16), _C.stream()), None)[bf] if bf != MATH_F16X3 else \
+        (_C.ptr(amax_of(x)), _C.ptr(amax_of(w)), _C.ptr(_split_scratch(w, n * p * q)), _C.stream())
     _C.check(_timed(_igemm_name("fprop", k, c % 4 != 0, n * p * q) + ("", "+bf16", "+f16x3")[bf], flops,
                     lambda: f(_C.ptr(x), _C.ptr(w), _C.ptr(bias), _C.ptr(y), _C.ptr(slab), n, h, wd, c, k, r, s,
                               stride, pad[0], pad[1], int(relu), *tail),
@@ -395,7 +406,8 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False,
         bf = _bf16_ok(k, c, r, s, dy, out, pixels=n * h * wd)
         sfx, tsfx = (("", ""), ("_bf16", "+bf16"), ("_f16x3", "+f16x3"))[bf]
         # wt16: the flipped filter already in bf16 (optional); split operands: the maxima of dy and of the filter
-        tail = ((_C.stream(),), (_C.ptr(wt16), _C.stream()), None)[bf] if bf != MATH_F16X3 else (_C.ptr(amax_of(dy)), _C.ptr(amax_of(w)), _C.stream())
+        tail = ((_C.stream(),), (_C.ptr(wt16), _C.stream()), None)[bf] if bf != MATH_F16X3 else \
+            (_C.ptr(amax_of(dy)), _C.ptr(amax_of(w)), _C.ptr(_split_scratch(w, n * h * wd)), _C.stream())
         if (bnsum is not None and not bnsum.relu_bias and _DGRAD_BNSUM and bnsum.y is not None and c <= 1024 and out.numel() * 4 < (1 << 31)
                 and tuple(bnsum.y.shape) == tuple(out.shape)
                 and (not bnsum.use_z or (bnsum_z is not None and is_nhwc(bnsum_z) and bnsum_z.shape == out.shape))):
