@@ -259,13 +259,19 @@ def main():
     ops.SYNC_WAIT_S = 0.0
     host_s = 0.0
     t0 = time.perf_counter()
+    last = None
     for _ in range(a.steps):
         h0 = time.perf_counter()
-        op.train_step(step_no, fresh(batches[step_no % len(batches)]))
+        last = op.train_step(step_no, fresh(batches[step_no % len(batches)]))[1]
         host_s += time.perf_counter() - h0
         step_no += 1
     sync_all()
     elapsed = time.perf_counter() - t0
+    # a timing on non-finite numbers is not a timing (NaN arithmetic draws less power: every kernel runs faster)
+    finite = bool(all(torch.isfinite(v.detach()).all() for v in last)) and bool(torch.isfinite(op.optimizer.fp.grad).all()) \
+        and bool(torch.isfinite(op.optimizer.fp.flat).all())
+    if not finite:
+        raise RuntimeError("bench.py: non-finite losses / gradients / parameters after the timed steps")
     # host side of a step: time inside train_step() minus the time blocked in its one device->host read (RoI count)
     host_enqueue_ms = (host_s - ops.SYNC_WAIT_S) / a.steps * 1e3
     ops.TIMER = None
@@ -285,7 +291,7 @@ def main():
             "data": "synthetic",
             # the batches are resident in HBM before the timed region (tier contract); the reference's loader would pay a
             # ~100 MB host-to-device image copy per step inside it
-            "input_residency": "device",
+            "input_residency": "device", "finite_after_timed_steps": finite,
             "config": {"workload": "RRNet %s (2 stacks) train step, %dx%d synthetic VisDrone frames, fp32" %
                                    ("hourglass-104" if a.backbone == "hourglass" else "hourglass-tiny", a.size, a.size),
                        "per_gpu_batch": a.batch, "global_batch": a.batch * world, "k": 1500,

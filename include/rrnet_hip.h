@@ -161,24 +161,25 @@ int rr_conv_wgrad_bf16(const float *x, const float *dy, float *dw, int n, int h,
  * significant bits, after a power-of-two scaling taken from the tensor's largest magnitude) and the three products
  * hi*hi + hi*lo + lo*hi run on the 16-bit matrix instructions.  amax_*: DEVICE words holding the bit pattern of
  * max|tensor|, produced by rr_absmax_bits (atomicMax into a word the caller zeroed; several calls may share a word to
- * take the maximum over several tensors).  Shapes as the _bf16 entry points.  w_split_scratch (optional, k*r*s*c floats of
- * caller scratch; C % 8 == 0, K > 64): the filter is split into its two fp16 parts ONCE per launch by a small kernel
- * instead of tile by tile inside the convolution (48 of its 149 vector instructions per K-step); worth it from ~16 k
- * output pixels. */
+ * take the maximum over several tensors).  Shapes as the _bf16 entry points.  w_split / wt_split (optional; C % 8 == 0,
+ * K > 64): the filter (for the data gradients: the flipped / transposed one) already split into its two fp16 parts by
+ * rr_weight_split_f16 with the SAME amax word — 2*k*r*s*c halves, hi image then lo image — instead of tile by tile inside
+ * the convolution (48 of its 149 vector instructions per K-step and thread). */
+int rr_weight_split_f16(const float *w, long n, const unsigned *amax_w, unsigned short *out, hipStream_t stream);
 int rr_absmax_bits(const float *x, long n, unsigned *out, hipStream_t stream);
 int rr_conv_fprop_f16x3(const float *x, const float *w, const float *bias, float *y, double *stat_slab,
                         int n, int h, int wd, int c, int k, int r, int s, int stride, int pad_h,
-                        int pad_w, int relu, const unsigned *amax_x, const unsigned *amax_w, float *w_split_scratch,
-                        hipStream_t stream);
+                        int pad_w, int relu, const unsigned *amax_x, const unsigned *amax_w,
+                        const unsigned short *w_split, hipStream_t stream);
 int rr_conv_dgrad_s1_f16x3(const float *dy, const float *wt, float *dx, int n, int h, int wd, int c, int k,
                            int r, int s, int pad_h, int pad_w, int accumulate, const unsigned *amax_dy,
-                           const unsigned *amax_w, float *w_split_scratch, hipStream_t stream);
+                           const unsigned *amax_w, const unsigned short *wt_split, hipStream_t stream);
 int rr_conv_dgrad_s1_bnsum_f16x3(const float *dy, const float *wt, float *dx, int n, int h, int wd, int c, int k,
                                  int r, int s, int pad_h, int pad_w, int accumulate, const float *prod_y,
                                  const float *prod_z, const float *prod_mean, const float *prod_invstd,
                                  const float *prod_mask_scale, const float *prod_mask_shift, double *slab,
-                                 double *sums, const unsigned *amax_dy, const unsigned *amax_w, float *w_split_scratch,
-                                 hipStream_t stream);
+                                 double *sums, const unsigned *amax_dy, const unsigned *amax_w,
+                                 const unsigned short *wt_split, hipStream_t stream);
 int rr_conv_dgrad_s1_relubias_f16x3(const float *dy, const float *wt, float *dx, int n, int h, int wd, int c, int k,
                                     int r, int s, int pad_h, int pad_w, int accumulate, const float *prod_z,
                                     double *slab, double *sums, const unsigned *amax_dy, const unsigned *amax_w,

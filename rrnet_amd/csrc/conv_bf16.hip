@@ -130,6 +130,10 @@ struct ConvArgs {
     // F16 instantiations: bit patterns of max|src| and max|w| (rr_absmax_bits), from which the kernel derives the power-of-two
     // operand scales; null: scale 1
     const unsigned *amax_src, *amax_w;
+    // workgroup -> tile map: 1 = every XCD works on ONE column tile (n_tile = xcd % ntiles): the filter rows an XCD re-reads for
+    // every row tile (2.4 MB of fp16 hi + lo for 128 of 256 output channels) then stay in its 4 MiB L2; with the column tiles
+    // interleaved on every XCD (4.7 MB) they do not, and every re-read goes to the memory side
+    int xcd_n;
 };
 
 // 128 x BN output tile, 256 threads = 4 waves (BN 128: 2x2 waves of 64x64; BN 64: 4x1 waves of 32x64; BN 32: 4x1 of 32x32)
@@ -179,8 +183,16 @@ __global__ __launch_bounds__(WS ? 512 : 256, (!WS && SP == 2) ? 2 : 1) void conv
     const int lane = t & 63, wave = t >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int ntiles = (a.DC + BN - 1) / BN;
-    const int logical = xcd_remap(blockIdx.x, gridDim.x);
-    const int n_tile = logical % ntiles, m_tile = logical / ntiles;
+    int n_tile, m_tile;
+    if (a.xcd_n) {
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, groups = 8 / ntiles;
+        n_tile = xcd % ntiles;
+        m_tile = (xcd / ntiles) * ((int)gridDim.x / ntiles / groups) + idx;
+    } else {
+        const int logical = xcd_remap(blockIdx.x, gridDim.x);
+        n_tile = logical % ntiles;
+        m_tile = logical / ntiles;
+    }
     const int m0 = m_tile * BM, n0 = n_tile * BN;
     const int RS = a.R * a.S;
     const int cpt = (a.SC + BK - 1) / BK;
@@ -686,7 +698,7 @@ int fprop_impl(const float *x, const float *w, const float *bias, float *y, doub
                int k, int r, int s, int stride, int pad_h, int pad_w, int relu, int accumulate, hipStream_t stream,
                const BnSumArgs *bs = nullptr, const OutMap *om = nullptr, const unsigned short *w16 = nullptr,
                int split = 0, const unsigned *amax_src = nullptr, const unsigned *amax_w = nullptr,
-               unsigned short *w_split = nullptr)
+               const unsigned short *w_split = nullptr)
 {
     RR_CHECK_ARG(n > 0 && h > 0 && wd > 0 && c > 0 && k > 0 && r > 0 && s > 0 && stride > 0, "rr_conv_fprop_bf16: bad dims");
     RR_CHECK_ARG(c % 4 == 0 && r * s <= 64, "rr_conv_fprop_bf16: C=%d must be a multiple of 4 and R*S <= 64 (fp32 path for the rest)", c);
@@ -716,6 +728,12 @@ int fprop_impl(const float *x, const float *w, const float *bias, float *y, doub
     if (bn == 128 && rr_cdiv(M, BM) * rr_cdiv(k, 128) <= rr_conv_small_tiles()) bn = 32;
     else if (bn == 128 && rr_cdiv(M, BM) * rr_cdiv(k, 128) <= rr_conv_mid_tiles()) bn = 64;
     const int blocks = rr_cdiv(M, BM) * rr_cdiv(k, bn);
+    {
+        static int xcd_env = -1;            // RR_CONV_XCD_N=0: column tiles interleaved on every XCD (A/B switch)
+        if (xcd_env < 0) { const char *e = getenv("RR_CONV_XCD_N"); xcd_env = e ? atoi(e) : 1; }
+        const int nt = rr_cdiv(k, bn), mt = rr_cdiv(M, BM);
+        a.xcd_n = (xcd_env && nt > 1 && 8 % nt == 0 && mt % (8 / nt) == 0) ? 1 : 0;
+    }
     const int nk = rr_cdiv(c, BK) * r * s;
     int ks = (bias == nullptr && !relu && k % 4 == 0 && k <= 1024) ? rr_conv_pick_ksplit(blocks, nk) : 1;
     if (bs != nullptr && bs->relu_bias) ks = 1;
@@ -751,12 +769,7 @@ int fprop_impl(const float *x, const float *w, const float *bias, float *y, doub
         a.amax_src = amax_src; a.amax_w = amax_w;
         name = "rr_conv_fprop_f16x3";
         if (w_split != nullptr && c % 8 == 0 && bn == 128) {
-            // the filter split once per launch into caller scratch (k*r*s*c floats = the two fp16 images), read by the B16 instantiation
-            const long n4 = (long)k * r * s * c / 4;
-            long sb = (n4 + 255) / 256;
-            if (sb > 1024) sb = 1024;
-            hipLaunchKernelGGL(weight_split_f16_kernel, dim3((int)sb), dim3(256), 0, stream, reinterpret_cast<const f32x4 *>(w), amax_w, w_split, n4);
-            RR_CHECK_LAUNCH("rr_conv_fprop_f16x3(filter split)");
+            // the filter's two fp16 images, made by rr_weight_split_f16 (once per optimizer step, outside the backward pass): the B16 instantiation
             a.w16 = w_split;
 #define RR_SB(BNSv, SOv) launch(conv_igemm_bf16_kernel<128, BNSv, true, SOv, 2, false, true>, blocks, ks, igemm_lds(128, 2), stream, a, name)
             rc = fused ? RR_SB(true, false) : (a.osh ? RR_SB(false, true) : RR_SB(false, false));
@@ -1201,34 +1214,45 @@ extern "C" int rr_conv_wgrad_bf16(const float *x, const float *dy, float *dw, in
 // instead of eight v_mfma_f32_32x32x2_f32 for the same 32 x 32 x 16 block (the fp32 matrix rate of gfx950 is 1/16 of the
 // 16-bit one).  amax_*: device words holding the bit pattern of max|tensor| (rr_absmax_bits), read by the kernels, no host
 // synchronisation.  Error against an fp64 convolution: below the fp32-MFMA kernels' own (tests/test_conv_split_gpu.py).
+extern "C" int rr_weight_split_f16(const float *w, long n, const unsigned *amax_w, unsigned short *out, hipStream_t stream)
+{
+    RR_CHECK_ARG(w && amax_w && out && n > 0 && n % 4 == 0, "rr_weight_split_f16: n must be a positive multiple of 4, pointers non-null");
+    const long n4 = n / 4;
+    long sb = (n4 + 255) / 256;
+    if (sb > 1024) sb = 1024;
+    hipLaunchKernelGGL(weight_split_f16_kernel, dim3((int)sb), dim3(256), 0, stream, reinterpret_cast<const f32x4 *>(w), amax_w, out, n4);
+    RR_CHECK_LAUNCH("rr_weight_split_f16");
+    return RR_OK;
+}
+
 extern "C" int rr_conv_fprop_f16x3(const float *x, const float *w, const float *bias, float *y, double *stat_slab,
                                    int n, int h, int wd, int c, int k, int r, int s, int stride, int pad_h,
-                                   int pad_w, int relu, const unsigned *amax_x, const unsigned *amax_w, float *w_split_scratch,
-                                   hipStream_t stream)
+                                   int pad_w, int relu, const unsigned *amax_x, const unsigned *amax_w,
+                                   const unsigned short *w_split, hipStream_t stream)
 {
     RR_CHECK_ARG(amax_x && amax_w, "rr_conv_fprop_f16x3: the operands' maxima are required");
     return fprop_impl(x, w, bias, y, stat_slab, n, h, wd, c, k, r, s, stride, pad_h, pad_w, relu, 0, stream, nullptr, nullptr, nullptr,
-                      1, amax_x, amax_w, reinterpret_cast<unsigned short *>(w_split_scratch));
+                      1, amax_x, amax_w, w_split);
 }
 
 extern "C" int rr_conv_dgrad_s1_f16x3(const float *dy, const float *wt, float *dx, int n, int h, int wd, int c, int k,
                                       int r, int s, int pad_h, int pad_w, int accumulate, const unsigned *amax_dy,
-                                      const unsigned *amax_w, float *w_split_scratch, hipStream_t stream)
+                                      const unsigned *amax_w, const unsigned short *wt_split, hipStream_t stream)
 {
     RR_CHECK_ARG(pad_h < r && pad_w < s && pad_h >= 0 && pad_w >= 0, "rr_conv_dgrad_s1_f16x3: pad must be in [0, kernel)");
     RR_CHECK_ARG(amax_dy && amax_w, "rr_conv_dgrad_s1_f16x3: the operands' maxima are required");
     const int p = h + 2 * pad_h - r + 1, q = wd + 2 * pad_w - s + 1;
     RR_CHECK_ARG(p > 0 && q > 0, "rr_conv_dgrad_s1_f16x3: empty dy");
     return fprop_impl(dy, wt, nullptr, dx, nullptr, n, p, q, k, c, r, s, 1, r - 1 - pad_h, s - 1 - pad_w, 0, accumulate, stream,
-                      nullptr, nullptr, nullptr, 1, amax_dy, amax_w, reinterpret_cast<unsigned short *>(w_split_scratch));
+                      nullptr, nullptr, nullptr, 1, amax_dy, amax_w, wt_split);
 }
 
 extern "C" int rr_conv_dgrad_s1_bnsum_f16x3(const float *dy, const float *wt, float *dx, int n, int h, int wd, int c, int k,
                                             int r, int s, int pad_h, int pad_w, int accumulate, const float *prod_y,
                                             const float *prod_z, const float *prod_mean, const float *prod_invstd,
                                             const float *prod_mask_scale, const float *prod_mask_shift, double *slab,
-                                            double *sums, const unsigned *amax_dy, const unsigned *amax_w, float *w_split_scratch,
-                                            hipStream_t stream)
+                                            double *sums, const unsigned *amax_dy, const unsigned *amax_w,
+                                            const unsigned short *wt_split, hipStream_t stream)
 {
     RR_CHECK_ARG(pad_h < r && pad_w < s && pad_h >= 0 && pad_w >= 0, "rr_conv_dgrad_s1_bnsum_f16x3: pad must be in [0, kernel)");
     RR_CHECK_ARG(prod_y && prod_mean && prod_invstd && slab && sums && (!prod_mask_scale == !prod_mask_shift) && amax_dy && amax_w,
@@ -1238,7 +1262,7 @@ extern "C" int rr_conv_dgrad_s1_bnsum_f16x3(const float *dy, const float *wt, fl
     RR_CHECK_ARG(p > 0 && q > 0, "rr_conv_dgrad_s1_bnsum_f16x3: empty dy");
     const BnSumArgs bs{prod_y, prod_z, prod_mean, prod_invstd, prod_mask_scale, prod_mask_shift, slab, sums, 0};
     return fprop_impl(dy, wt, nullptr, dx, nullptr, n, p, q, k, c, r, s, 1, r - 1 - pad_h, s - 1 - pad_w, 0, accumulate, stream, &bs,
-                      nullptr, nullptr, 1, amax_dy, amax_w, reinterpret_cast<unsigned short *>(w_split_scratch));
+                      nullptr, nullptr, 1, amax_dy, amax_w, wt_split);
 }
 
 extern "C" int rr_conv_dgrad_s1_relubias_f16x3(const float *dy, const float *wt, float *dx, int n, int h, int wd, int c, int k,

@@ -187,13 +187,20 @@ _FUSED_AMAX_BWD = os.environ.get("RR_SPLIT_FUSED_AMAX_BWD", "1") != "0"    # bn_
 _SPLIT_PRESPLIT_PIXELS = int(os.environ.get("RR_SPLIT_PRESPLIT_PIXELS", "65536"))   # from here on the filter is split once per launch
 
 
-def _split_scratch(w, pixels):
-    """Scratch for the per-launch filter split of the f16x3 kernels (k*r*s*c floats), or None below the size where it pays."""
-    if pixels < _SPLIT_PRESPLIT_PIXELS or w.shape[1] % 8 != 0 or w.shape[0] <= 64:
+def split_filter(w, amax_word, pixels, flat=None):
+    """The two fp16 images of a filter for the f16x3 kernels (rr_weight_split_f16: hi, then lo; scaled by the power of two
+    the kernels derive from `amax_word`), or None below the layer size where a ready-made split pays.  w: the OHWI filter
+    (forward) — or, with `flat`, the flat flipped / transposed copy of it (data gradients), whose K and C trade places."""
+    k, c = (w.shape[0], w.shape[1])
+    if pixels < _SPLIT_PRESPLIT_PIXELS or c % 8 != 0 or k % 8 != 0 or min(k, c) <= 64:
         return None
-    return torch.empty(w.numel(), dtype=torch.float32, device=w.device)
+    src = w if flat is None else flat
+    out = torch.empty(2 * src.numel(), dtype=torch.float16, device=src.device)
+    _C.check(_C.fn("rr_weight_split_f16")(_C.ptr(src), src.numel(), _C.ptr(amax_word), _C.ptr(out), _C.stream()), "rr_weight_split_f16")
+    return out
 
 
+_SPLIT_PER_LAUNCH = os.environ.get("RR_SPLIT_PER_LAUNCH", "1") == "1"     # the filter split at every large launch into a fresh temporary (0: in-tile split)
 _SPLIT_MIN_CH = 64                                                         # narrower layers (either side) likewise
 _SPLIT_MIN_K = int(os.environ.get("RR_SPLIT_MIN_K", "1024"))               # C*R*S (reduction length) likewise
 
@@ -238,7 +245,7 @@ def amax_of(t):
     return word
 
 
-def conv_fprop(x, w, bias=None, stride=1, pad=(0, 0), relu=False, want_stats=False, algo_kg=None, w16=None):
+def conv_fprop(x, w, bias=None, stride=1, pad=(0, 0), relu=False, want_stats=False, algo_kg=None, w16=None, w_split=None):
     """x [N,C,H,W] (NHWC memory), w [K,C,R,S] (OHWI memory) -> y [N,K,P,Q] (NHWC memory)
     and, if want_stats, the per-block BatchNorm partial-sum slab (see rr_conv_fprop).
     algo_kg: the useful reduction length when the operands carry zero padding (timer FLOPs stay algorithmic)."""
@@ -258,8 +265,13 @@ def conv_fprop(x, w, bias=None, stride=1, pad=(0, 0), relu=False, want_stats=Fal
     f = _C.fn(("rr_conv_fprop", "rr_conv_fprop_bf16", "rr_conv_fprop_f16x3")[bf])
     flops = 2.0 * n * p * q * k * (c * r * s if algo_kg is None else algo_kg)
     # w16: the filter already rounded to bf16 (optional); split operands: the two tensors' maxima
+    if bf == MATH_F16X3 and w_split is None and _SPLIT_PER_LAUNCH:
+        # a LOCAL that lives until the launch below has been enqueued: built inside the argument tuple the temporary was
+        # released before the launch, the caching allocator handed its block to the next zero-filled scratch, and the
+        # data gradients read a filter of zeros / garbage — non-finite gradients, and a step that ran 10 % FASTER
+        w_split = split_filter(w, amax_of(w), n * p * q)
     tail = ((_C.stream(),), (_C.ptr(w16), _C.stream()), None)[bf] if bf != MATH_F16X3 else \
-        (_C.ptr(amax_of(x)), _C.ptr(amax_of(w)), _C.ptr(_split_scratch(w, n * p * q)), _C.stream())
+        (_C.ptr(amax_of(x)), _C.ptr(amax_of(w)), _C.ptr(w_split), _C.stream())
     _C.check(_timed(_igemm_name("fprop", k, c % 4 != 0, n * p * q) + ("", "+bf16", "+f16x3")[bf], flops,
                     lambda: f(_C.ptr(x), _C.ptr(w), _C.ptr(bias), _C.ptr(y), _C.ptr(slab), n, h, wd, c, k, r, s,
                               stride, pad[0], pad[1], int(relu), *tail),
@@ -350,7 +362,8 @@ _DGRAD_BNSUM = os.environ.get("RR_DGRAD_BNSUM", "1") != "0"
 _BF16_S2_DGRAD = os.environ.get("RR_BF16_S2_DGRAD", "1") != "0"     # A/B: stride-2 data gradients stay on the fp32 kernel
 
 
-def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False, bnsum=None, bnsum_z=None, wt=None, wt16=None):
+def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False, bnsum=None, bnsum_z=None, wt=None, wt16=None,
+               wt_split=None):
     """dy [N,K,P,Q], w [K,C,R,S] -> dx [N,C,H,W]; with `out` and accumulate adds into it.
     wt: the flipped / transposed filter (rr_weight_flip_transpose of w) when the caller keeps one (FlatParams.wt_view).
     bnsum (BnLink of the layer that produced the convolution's input): when the launch can carry them, the producer's
@@ -406,8 +419,10 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False,
         bf = _bf16_ok(k, c, r, s, dy, out, pixels=n * h * wd)
         sfx, tsfx = (("", ""), ("_bf16", "+bf16"), ("_f16x3", "+f16x3"))[bf]
         # wt16: the flipped filter already in bf16 (optional); split operands: the maxima of dy and of the filter
+        if bf == MATH_F16X3 and wt_split is None and _SPLIT_PER_LAUNCH:
+            wt_split = split_filter(w, amax_of(w), n * h * wd, flat=wt)
         tail = ((_C.stream(),), (_C.ptr(wt16), _C.stream()), None)[bf] if bf != MATH_F16X3 else \
-            (_C.ptr(amax_of(dy)), _C.ptr(amax_of(w)), _C.ptr(_split_scratch(w, n * h * wd)), _C.stream())
+            (_C.ptr(amax_of(dy)), _C.ptr(amax_of(w)), _C.ptr(wt_split), _C.stream())
         if (bnsum is not None and not bnsum.relu_bias and _DGRAD_BNSUM and bnsum.y is not None and c <= 1024 and out.numel() * 4 < (1 << 31)
                 and tuple(bnsum.y.shape) == tuple(out.shape)
                 and (not bnsum.use_z or (bnsum_z is not None and is_nhwc(bnsum_z) and bnsum_z.shape == out.shape))):

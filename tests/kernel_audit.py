@@ -172,8 +172,8 @@ def audit(tol=2e-5, tol_wgrad=2e-4, sample=False):
             rec.note("wgrad_packed", sig, float((got[ks] - ref).abs().max() / max(float(ref.abs().max()), 1e-30)), tol_wgrad)
         return res
 
-    def conv_fprop(x, w, bias=None, stride=1, pad=(0, 0), relu=False, want_stats=False, algo_kg=None, w16=None):
-        out = orig["conv_fprop"](x, w, bias, stride, pad, relu, want_stats, algo_kg, w16)      # w16: the cached bf16 copy of w
+    def conv_fprop(x, w, bias=None, stride=1, pad=(0, 0), relu=False, want_stats=False, algo_kg=None, w16=None, w_split=None):
+        out = orig["conv_fprop"](x, w, bias, stride, pad, relu, want_stats, algo_kg, w16, w_split)   # w16 / w_split: cached copies of w
         y = out[0] if want_stats else out
         sig = (tuple(x.shape), tuple(w.shape), stride, tuple(pad), bias is not None, relu, want_stats)
         flops = 2.0 * y.numel() * w.shape[1] * w.shape[2] * w.shape[3]
@@ -217,9 +217,10 @@ def audit(tol=2e-5, tol_wgrad=2e-4, sample=False):
                 rec.note("fprop_stats", sig, max(e1, _rel(sums[k:2 * k], s2)), tol)
         return out
 
-    def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False, bnsum=None, bnsum_z=None, wt=None, wt16=None):
+    def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False, bnsum=None, bnsum_z=None, wt=None, wt16=None,
+                   wt_split=None):
         base = out.clone() if (out is not None and accumulate) else None
-        res = orig["conv_dgrad"](dy, w, x_shape, stride, pad, out, accumulate, bnsum, bnsum_z, wt, wt16)   # the cached flipped filters
+        res = orig["conv_dgrad"](dy, w, x_shape, stride, pad, out, accumulate, bnsum, bnsum_z, wt, wt16, wt_split)   # the cached flipped filters
         relu_mask = None          # conv + bias + ReLU producer: this launch stored the masked gradient
         if bnsum is not None and bnsum.relu_bias and bnsum.sums is not None and bnsum.dz is res:
             relu_mask = bnsum_z

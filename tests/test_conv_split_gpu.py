@@ -184,3 +184,40 @@ def test_absmax_bits_is_the_maximum_magnitude():
         _C.check(_C.fn("rr_absmax_bits")(_C.ptr(x), n, _C.ptr(word), _C.stream()), "rr_absmax_bits")
         assert word[:1].view(torch.float32).item() == x.abs().max().item()
         assert int(word[1]) == 0
+
+
+def test_ready_made_filter_split_gives_the_same_numbers(math_switch):
+    """rr_weight_split_f16 + the B16 instantiation (the filter split once per optimizer step instead of tile by tile inside the
+    convolution): forward, data gradient with BN sums, on the flipped copy — identical products, so the results agree with
+    the in-kernel split to fp32 summation noise, and with the fp32 kernels as everywhere else."""
+    from rrnet_amd import _C, ops
+    n, c, h, w, k = 2, 256, 96, 96, 256
+    x = ops.to_nhwc(_mk((n, c, h, w), 31).cuda())
+    wt = ops.to_nhwc((_mk((k, c, 3, 3), 32) * 0.02).cuda())
+    gy = ops.to_nhwc((_mk((n, k, h, w), 33) * 1e-4).cuda())
+    math_switch(ops.MATH_F16X3)
+    saved = ops._SPLIT_PRESPLIT_PIXELS
+    ops._SPLIT_PRESPLIT_PIXELS = 0
+    try:
+        word = ops.amax_of(wt)
+        ws = ops.split_filter(wt, word, n * h * w)
+        assert ws is not None and ws.numel() == 2 * wt.numel()
+        # the images: hi + lo reproduce the scaled filter to 2^-22
+        scale = 2.0 ** (14 - int(np.floor(np.log2(float(wt.abs().max())))))
+        flat = wt.permute(0, 2, 3, 1).reshape(-1)
+        rec = (ws[:flat.numel()].double() + ws[flat.numel():].double()) / scale
+        assert float((rec - flat.double()).abs().max()) <= 2.0 ** -21 * float(flat.abs().max())
+        y1 = ops.conv_fprop(x, wt, None, 1, (1, 1), False, w_split=ws)
+        y0 = ops.conv_fprop(x, wt, None, 1, (1, 1), False)
+        flip = torch.empty(wt.numel(), dtype=torch.float32, device="cuda")
+        _C.check(_C.fn("rr_weight_flip_transpose")(_C.ptr(wt), _C.ptr(flip), k, c, 3, 3, _C.stream()), "flip")
+        wts = ops.split_filter(wt, word, n * h * w, flat=flip)
+        d1 = ops.conv_dgrad(gy, wt, (n, c, h, w), 1, (1, 1), wt=flip, wt_split=wts)
+        d0 = ops.conv_dgrad(gy, wt, (n, c, h, w), 1, (1, 1), wt=flip)
+    finally:
+        ops._SPLIT_PRESPLIT_PIXELS = saved
+    math_switch(ops.MATH_F32)
+    _close(y1, y0, "fprop, ready-made split vs in-kernel split", 1e-6)
+    _close(d1, d0, "dgrad, ready-made split vs in-kernel split", 1e-6)
+    _close(y1, ops.conv_fprop(x, wt, None, 1, (1, 1), False), "fprop vs fp32 kernel")
+    _close(d1, ops.conv_dgrad(gy, wt, (n, c, h, w), 1, (1, 1)), "dgrad vs fp32 kernel")

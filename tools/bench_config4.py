@@ -46,10 +46,12 @@ def run(batch=8, size=1024, steps=5, dcn=True, backbone="hourglass", bf16=None, 
         batches = [op.training_loader.get_batch() for _ in range(len(op.training_loader))]
         step_no = 2000                                   # past the stage-2 warm-up: all four losses on
 
+        last = [None]
+
         def one():
             nonlocal step_no
             b = batches[step_no % len(batches)]
-            op.train_step(step_no, (b[0], b[1].clone()) + tuple(b[2:]))
+            last[0] = op.train_step(step_no, (b[0], b[1].clone()) + tuple(b[2:]))[1]
             step_no += 1
         one()
         torch.cuda.synchronize()
@@ -58,13 +60,23 @@ def run(batch=8, size=1024, steps=5, dcn=True, backbone="hourglass", bf16=None, 
             one()
         torch.cuda.synchronize()
         t = (time.perf_counter() - t0) / steps
-        out = {"value": round(batch / t, 4), "unit": "images/sec", "ms_per_step": round(t * 1e3, 2), "steps": steps,
+        # a timing on non-finite numbers is not a timing (NaN arithmetic draws less power: everything runs faster)
+        finite = bool(all(torch.isfinite(v.detach()).all() for v in last[0])) and bool(torch.isfinite(op.optimizer.fp.grad).all()) \
+            and bool(torch.isfinite(op.optimizer.fp.flat).all())
+        if not finite:
+            raise RuntimeError("bench_config4: non-finite losses / gradients / parameters after the timed steps")
+        out = {"finite_after_timed_steps": finite, "value": round(batch / t, 4), "unit": "images/sec", "ms_per_step": round(t * 1e3, 2), "steps": steps,
                "dcn_layers": n_dcn, "dtype": ("f32 (large layers: operands split into two fp16 parts, three MFMA products, fp32 accumulation)"
                                               if conv_math == "f16x3" else "bf16 matrix operands, fp32 accumulation / storage" if bf16 else "f32"),
                "workload": (("RRNet hourglass-104 + %d DCN head layers (offsets ~ N(0,1)) train step, B=%d, %dx%d"
                              % (n_dcn, batch, size, size)) if dcn else
                             "RRNet hourglass-104 train step, B=%d, %dx%d (no DCN heads)" % (batch, size, size))
                            + (", bf16 operands in every convolution" if bf16 else "") + (", conv_math f16x3" if conv_math == "f16x3" else "")}
+        ms_ = torch.cuda.memory_stats()
+        out["allocator"] = {"reserved_GiB": round(ms_["reserved_bytes.all.current"] / 2 ** 30, 2),
+                            "allocated_peak_GiB": round(ms_["allocated_bytes.all.peak"] / 2 ** 30, 2),
+                            "segments": ms_["segment.all.current"], "hipMallocs": ms_["num_device_alloc"],
+                            "hipFrees": ms_["num_device_free"], "alloc_retries": ms_["num_alloc_retries"]}
         if backbone == "hourglass" and size == 1024:
             # 7.02 TFLOP of convolution per image; the six DCN layers replace plain 3x3 layers of the same FLOPs
             peak = 2500.0 if (bf16 or conv_math == "f16x3") else 157.3
