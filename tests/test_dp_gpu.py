@@ -263,3 +263,24 @@ def test_rccl_single_rank_step_matches_non_distributed(tmp_path):
     assert float(cross.max()) <= 3 * max(float(sens.max()), 1e-3)
     r = forced[1]["repeat_vs_first"][0]
     assert r["grad"][0] <= 1e-5 and r["buffers"] <= 2e-5, r
+
+
+def test_rccl_single_rank_f16x3_step_runs_and_matches(tmp_path):
+    """The data-parallel path (SyncBN nodes `_ConvBnSyncMulti`, bucketed gradient all-reduce from the side stream) with
+    cfg.Model.conv_math = "f16x3": the split-operand kernels take their operands' maxima from device words whatever node
+    launches them (ops.amax_of); the one-rank RCCL step must give the non-distributed f16x3 step's losses and — on the
+    well-conditioned parameters — its gradients, and stay finite."""
+    from test_streams_gpu import DET, _load, _rel, _run
+    extra = ["--math", "f16x3"]
+    plain = _run(tmp_path, "plain_split", dict(DET, RR_WGRAD_STREAM="2"), 256, 2, 2, extra + ["--perturb", "1e-7"])
+    forced = _run(tmp_path, "rccl1_split", dict(DET, RR_WGRAD_STREAM="2", RR_DP_FORCE="1", RR_WGRAD_STRESS="1"), 256, 2, 1, extra)
+    assert forced[1]["collectives"][0]["grads"] == forced[1]["buckets"]
+    la, lb = np.array(plain[1]["losses"][0]), np.array(forced[1]["losses"][0])
+    assert np.all(np.abs(la - lb) <= 1e-4 * np.maximum(np.abs(la), 1e-3)), (la, lb)
+    sl = plain[1]["slices"]
+    g0 = _load(plain[0], "grad.bin")
+    sens, _ = _rel(_load(plain[0], "grad2.bin"), g0, sl)
+    cross, _ = _rel(_load(forced[0], "grad.bin"), g0, sl)
+    good = sens <= 1e-5
+    print("f16x3, one-rank RCCL vs non-distributed: %d well-conditioned parameters, worst difference %.2e" % (int(good.sum()), float(cross[good].max())))
+    assert int(good.sum()) >= 10 and float(cross[good].max()) <= 1e-4
