@@ -1,5 +1,9 @@
-// bf16-operand NHWC convolutions on the gfx950 matrix cores (v_mfma_f32_32x32x16_bf16, fp32 accumulation) — BASELINE
-// config 4 ("RRNet ... bf16"), selected by cfg.Model.bf16; the headline configuration stays on csrc/conv.hip (fp32).
+// 16-bit-operand NHWC convolutions on the gfx950 matrix cores, fp32 accumulation.  Two arithmetics share the kernels:
+//   bf16   (rr_conv_*_bf16, cfg.Model.bf16 — BASELINE config 4): each operand rounded to ONE bf16 value;
+//   f16x3  (rr_conv_*_f16x3, cfg.Model.conv_math — an fp32-class arithmetic): each operand the sum of TWO fp16 values after a
+//          power-of-two scaling by the tensor's maximum, three products per tile (template parameters SP = 2, F16; the
+//          entry points and their contract: the "Split-operand entry points" section at the end of this file).
+// The headline configuration stays on csrc/conv.hip (v_mfma_f32_32x32x2_f32).  What follows describes the bf16 form.
 //
 // The reference is fp32-only (/root/reference/backbones/hourglass.py:12-61,127-199 through nn.Conv2d / cuDNN), so this
 // precision is builder-defined: activations, weights, gradients and every BatchNorm / loss / optimizer quantity stay

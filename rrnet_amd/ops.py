@@ -245,6 +245,16 @@ def amax_of(t):
     return word
 
 
+def _math_tail(mode, filter16, src, flt, filter_split):
+    """The trailing arguments of a forward-kernel launch under the three arithmetics: fp32 (stream), bf16 (the filter's cached
+    bf16 copy or NULL, stream), f16x3 (the two operands' maxima, the filter's ready-made fp16 split or NULL, stream)."""
+    if mode == MATH_F16X3:
+        return (_C.ptr(amax_of(src)), _C.ptr(amax_of(flt)), _C.ptr(filter_split), _C.stream())
+    if mode == MATH_BF16:
+        return (_C.ptr(filter16), _C.stream())
+    return (_C.stream(),)
+
+
 def conv_fprop(x, w, bias=None, stride=1, pad=(0, 0), relu=False, want_stats=False, algo_kg=None, w16=None, w_split=None):
     """x [N,C,H,W] (NHWC memory), w [K,C,R,S] (OHWI memory) -> y [N,K,P,Q] (NHWC memory)
     and, if want_stats, the per-block BatchNorm partial-sum slab (see rr_conv_fprop).
@@ -270,8 +280,7 @@ def conv_fprop(x, w, bias=None, stride=1, pad=(0, 0), relu=False, want_stats=Fal
         # released before the launch, the caching allocator handed its block to the next zero-filled scratch, and the
         # data gradients read a filter of zeros / garbage — non-finite gradients, and a step that ran 10 % FASTER
         w_split = split_filter(w, amax_of(w), n * p * q)
-    tail = ((_C.stream(),), (_C.ptr(w16), _C.stream()), None)[bf] if bf != MATH_F16X3 else \
-        (_C.ptr(amax_of(x)), _C.ptr(amax_of(w)), _C.ptr(w_split), _C.stream())
+    tail = _math_tail(bf, w16, x, w, w_split)
     _C.check(_timed(_igemm_name("fprop", k, c % 4 != 0, n * p * q) + ("", "+bf16", "+f16x3")[bf], flops,
                     lambda: f(_C.ptr(x), _C.ptr(w), _C.ptr(bias), _C.ptr(y), _C.ptr(slab), n, h, wd, c, k, r, s,
                               stride, pad[0], pad[1], int(relu), *tail),
@@ -421,8 +430,7 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False,
         # wt16: the flipped filter already in bf16 (optional); split operands: the maxima of dy and of the filter
         if bf == MATH_F16X3 and wt_split is None and _SPLIT_PER_LAUNCH:
             wt_split = split_filter(w, amax_of(w), n * h * wd, flat=wt)
-        tail = ((_C.stream(),), (_C.ptr(wt16), _C.stream()), None)[bf] if bf != MATH_F16X3 else \
-            (_C.ptr(amax_of(dy)), _C.ptr(amax_of(w)), _C.ptr(wt_split), _C.stream())
+        tail = _math_tail(bf, wt16, dy, w, wt_split)
         if (bnsum is not None and not bnsum.relu_bias and _DGRAD_BNSUM and bnsum.y is not None and c <= 1024 and out.numel() * 4 < (1 << 31)
                 and tuple(bnsum.y.shape) == tuple(out.shape)
                 and (not bnsum.use_z or (bnsum_z is not None and is_nhwc(bnsum_z) and bnsum_z.shape == out.shape))):
