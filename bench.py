@@ -251,7 +251,8 @@ def main():
     timer = None
     if not a.no_kernel_timing:
         # HIP events around every launch of the dominant kernel (the roofline leg); --detail times all conv kernels
-        timer = ops.KernelTimer(None if a.detail else {"conv_fprop<BN=128,vec4>"}, every=1 if a.detail else a.time_every)
+        timer = ops.KernelTimer(None if a.detail else {"conv_fprop<BN=128,vec4>" + ("+f16x3" if a.math == "f16x3" else "")},
+                                every=1 if a.detail else a.time_every)
         ops.TIMER = timer
     sync_all()
     from rrnet_amd import dptrace
@@ -292,14 +293,17 @@ def main():
             # the batches are resident in HBM before the timed region (tier contract); the reference's loader would pay a
             # ~100 MB host-to-device image copy per step inside it
             "input_residency": "device", "finite_after_timed_steps": finite,
-            "config": {"workload": "RRNet %s (2 stacks) train step, %dx%d synthetic VisDrone frames, fp32" %
-                                   ("hourglass-104" if a.backbone == "hourglass" else "hourglass-tiny", a.size, a.size),
+            "config": {"workload": "RRNet %s (2 stacks) train step, %dx%d synthetic VisDrone frames, %s" %
+                                   ("hourglass-104" if a.backbone == "hourglass" else "hourglass-tiny", a.size, a.size,
+                                    "fp32" if a.math == "f32" else "fp32 tensors, conv_math f16x3"),
                        "per_gpu_batch": a.batch, "global_batch": a.batch * world, "k": 1500,
                        "parallelism": "dp%d" % world},
         }
         if timer is not None:
             summ = timer.summary()
-            dom = "conv_fprop<BN=128,vec4>"
+            split = a.math == "f16x3"
+            dom = "conv_fprop<BN=128,vec4>" + ("+f16x3" if split else "")
+            peak = 2500.0 / 3.0 if split else FP32_MFMA_PEAK_TFLOPS      # f16x3: three 16-bit matrix instructions per product tile
             if dom in summ:
                 d = summ[dom]
                 achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
@@ -319,11 +323,15 @@ def main():
                         traffic_source = "profiles/%s_traffic_pmc.json (rocprofv3 FETCH_SIZE + WRITE_SIZE passes of this command at commit %s)" % (
                             tag, tj.get("_commit", "bb2459f" if tag == "r01" else "unrecorded"))
                         break
-                out["roofline"] = {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
-                                   "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+                if split:
+                    traffic, traffic_source = None, None        # (the committed PMC passes are of the fp32 kernel)
+                out["roofline"] = {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1),
+                                   "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                                    "traffic": traffic, "traffic_source": traffic_source,
                                    "algorithmic_bytes_per_launch": round(timer.bytes.get(dom, 0.0) / d["launches"]),
-                                   "kernel": "conv_igemm_kernel<128, 0, false, 32, 2, false, false> (implicit-GEMM forward kernel, v_mfma_f32_32x32x2_f32; "
+                                   "kernel": ("conv_igemm_bf16_kernel<128, *, *, false, 2, false, true> (split-operand implicit-GEMM forward kernel, three "
+                                              "v_mfma_f32_32x32x16_f16 per product tile: peak = 2500 / 3; fprop and stride-1 dgrad)") if split else
+                                             "conv_igemm_kernel<128, 0, false, 32, 2, false, false> (implicit-GEMM forward kernel, v_mfma_f32_32x32x2_f32; "
                                              "launched for fprop and for stride-1 dgrad on flipped weights; the dgrad launches that also "
                                              "reduce the producer's BatchNorm-backward sums are the <..., true> instantiation)",
                                    "launches": d["launches"], "launches_timed": "every %d-th launch of the timed region (systematic sample)" % a.time_every,
@@ -350,7 +358,7 @@ def main():
             out["dp_force"] = "one-rank %s process group: SyncBN exchanges + bucketed gradient all-reduce issued for real" % \
                               dist.get_backend()
         if a.backbone == "hourglass" and a.size == 1024:
-            out["step_mfma_frac"] = round(out["value"] / world * ALGO_TFLOP_PER_IMAGE / FP32_MFMA_PEAK_TFLOPS, 4)
+            out["step_mfma_frac"] = round(out["value"] / world * ALGO_TFLOP_PER_IMAGE / (2500.0 / 3.0 if a.math == "f16x3" else FP32_MFMA_PEAK_TFLOPS), 4)
         if world == 1 and not a.no_extras:
             del op, batches
             import gc
