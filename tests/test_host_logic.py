@@ -61,3 +61,39 @@ def test_gradient_link_defaults():
     assert link.sums is None and link.dz is None and link.consumers == 0 and not link.use_z and not link.relu_bias
     acc = RF.GradAcc()
     assert acc.buf is None and acc.pending == 0 and acc.link is None
+
+
+def test_conv_math_switch_and_split_layer_policy():
+    """cfg.Model.conv_math -> ops.math_mode, and the layer policy of the split-operand arithmetic (ops._bf16_ok): host logic
+    only — no kernel is launched."""
+    from types import SimpleNamespace
+    import pytest
+    import torch
+    from rrnet_amd import ops
+    assert ops.math_mode(SimpleNamespace()) == ops.MATH_F32
+    assert ops.math_mode(SimpleNamespace(bf16=True)) == ops.MATH_BF16
+    assert ops.math_mode(SimpleNamespace(bf16=True, conv_math="f16x3")) == ops.MATH_F16X3      # conv_math wins
+    assert ops.math_mode(SimpleNamespace(conv_math="f32")) == ops.MATH_F32
+    assert ops.math_mode(SimpleNamespace(conv_math=None, bf16=False)) == ops.MATH_F32
+    with pytest.raises(ValueError):
+        ops.math_mode(SimpleNamespace(conv_math="fp8"))
+    t = torch.empty(4)
+    saved = ops.BF16
+    try:
+        ops.BF16 = ops.MATH_F32
+        assert ops._bf16_ok(256, 256, 3, 3, t, pixels=1 << 20) == 0
+        ops.BF16 = ops.MATH_BF16
+        assert ops._bf16_ok(256, 256, 3, 3, t) == ops.MATH_BF16
+        assert ops._bf16_ok(254, 256, 3, 3, t) == 0                        # C not a multiple of 4: fp32 kernels
+        ops.BF16 = ops.MATH_F16X3
+        assert ops._bf16_ok(256, 256, 3, 3, t, pixels=8 * 256 * 256) == ops.MATH_F16X3
+        assert ops._bf16_ok(384, 384, 3, 3, t, pixels=8 * 16 * 16) == ops.MATH_F16X3
+        assert ops._bf16_ok(512, 512, 3, 3, t, pixels=8 * 8 * 8) == 0      # 512 output pixels: stays on the fp32-MFMA kernel
+        assert ops._bf16_ok(256, 256, 1, 1, t, pixels=8 * 256 * 256) == 0  # reduction length 256 < 1024
+        assert ops._bf16_ok(256, 36, 3, 3, t, pixels=8 * 256 * 256) == 0   # narrow output (WH head)
+        assert ops._bf16_ok(256, 256, 3, 3, t) == 0                        # a caller that does not state its size
+        with ops.bf16_scope(ops.MATH_BF16):
+            assert ops.BF16 == ops.MATH_BF16
+        assert ops.BF16 == ops.MATH_F16X3
+    finally:
+        ops.BF16 = saved
