@@ -221,3 +221,38 @@ def test_ready_made_filter_split_gives_the_same_numbers(math_switch):
     _close(d1, d0, "dgrad, ready-made split vs in-kernel split", 1e-6)
     _close(y1, ops.conv_fprop(x, wt, None, 1, (1, 1), False), "fprop vs fp32 kernel")
     _close(d1, ops.conv_dgrad(gy, wt, (n, c, h, w), 1, (1, 1)), "dgrad vs fp32 kernel")
+
+
+def test_kernels_follow_the_oracle_of_the_split_arithmetic(math_switch):
+    """oracle/split.py models the contract step by step (scale from the maximum's exponent, round-to-nearest fp16 hi / lo,
+    three exact products, exact accumulation): rr_absmax_bits and rr_weight_split_f16 reproduce it BIT FOR BIT, and the
+    convolution differs from it only by its fp32 accumulation (<= 4e-7 of the output scale at a reduction length of 576;
+    against the fp32-MFMA kernels the bound is 4e-6)."""
+    from oracle import split as osp
+    from rrnet_amd import _C, ops
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(2, 64, 24, 24, generator=g) * torch.rand(2, 64, 1, 1, generator=g) * 3 * 1e-3)
+    w = torch.randn(64, 64, 3, 3, generator=g) * 0.05
+    xd, wd = ops.to_nhwc(x.cuda()), ops.to_nhwc(w.cuda())
+    # the maximum, as a bit pattern
+    word = ops.amax_of(wd)
+    assert int(word.view(torch.int32)[0]) == osp.absmax_bits(w.numpy())
+    # the filter's two images
+    saved = (ops._SPLIT_PRESPLIT_PIXELS, ops._SPLIT_MIN_PIXELS, ops._SPLIT_MIN_K, ops._SPLIT_MIN_CH)
+    ops._SPLIT_PRESPLIT_PIXELS = ops._SPLIT_MIN_PIXELS = ops._SPLIT_MIN_K = ops._SPLIT_MIN_CH = 0
+    try:
+        img = torch.empty(2 * wd.numel(), dtype=torch.float16, device="cuda")
+        _C.check(_C.fn("rr_weight_split_f16")(_C.ptr(wd), wd.numel(), _C.ptr(word), _C.ptr(img), _C.stream()), "split")
+        hi, lo = osp.split(w.permute(0, 2, 3, 1).reshape(-1).numpy(), osp.scale_of(osp.absmax_bits(w.numpy())))
+        got = img.cpu().numpy()
+        assert np.array_equal(got[:hi.size].view(np.uint16), hi.view(np.uint16))
+        assert np.array_equal(got[hi.size:].view(np.uint16), lo.view(np.uint16))
+        math_switch(ops.MATH_F16X3)
+        for stride in (1, 2):
+            y = ops.conv_fprop(xd, wd, None, stride, (1, 1), False).double().cpu().numpy()
+            ref = osp.conv2d(x.numpy(), w.numpy(), stride, (1, 1))
+            err = np.abs(y - ref).max() / np.abs(ref).max()
+            print("stride %d: kernel vs oracle of the split arithmetic %.2e" % (stride, err))
+            assert err <= 4e-7, (stride, err)
+    finally:
+        ops._SPLIT_PRESPLIT_PIXELS, ops._SPLIT_MIN_PIXELS, ops._SPLIT_MIN_K, ops._SPLIT_MIN_CH = saved
