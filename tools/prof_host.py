@@ -6,10 +6,12 @@ sys.path.insert(0, ROOT)
 import torch
 ap = argparse.ArgumentParser(); ap.add_argument("--size", type=int, default=1024); ap.add_argument("--batch", type=int, default=8)
 ap.add_argument("--top", type=int, default=35)
+ap.add_argument("--math", default=None, help="cfg.Model.conv_math")
 a = ap.parse_args()
 from rrnet_amd.configs.rrnet_config import Config as cfg
 from rrnet_amd.operators.rrnet_operator import RRNetOperator
 cfg.Train.batch_size, cfg.Train.crop_size, cfg.Model.backbone = a.batch, (a.size, a.size), "hourglass"
+cfg.Model.conv_math = a.math
 cfg.Distributed.gpu_id, cfg.Distributed.rank, cfg.Distributed.world_size = 0, 0, 1
 torch.manual_seed(cfg.seed)
 op = RRNetOperator(cfg); op.model.train()
