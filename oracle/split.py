@@ -21,11 +21,10 @@ def absmax_bits(t):
 
 
 def scale_of(bits):
-    """The kernels' scale from the maximum's bit pattern: 2^(14 - (e - 127)), e the biased exponent; 1 for a zero / denormal
-    maximum (conv_igemm_bf16_kernel, F16 branch: `(268 - e) << 23`)."""
-    e = (bits >> 23) & 0xff
-    if e == 0:
-        return np.float32(1.0)
+    """The kernels' scale from the maximum's bit pattern: 2^(14 - (e - 127)), e the biased exponent clamped to >= 15 — below that
+    (a maximum under 2^-112, zero and denormals included) `(268 - e) << 23` would run into the Inf / NaN encodings
+    (csrc/conv_bf16.hip: split_scale_from_bits)."""
+    e = max((bits >> 23) & 0xff, 15)
     return np.array([(268 - e) << 23], dtype=np.uint32).view(np.float32)[0]
 
 

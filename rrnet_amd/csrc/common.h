@@ -29,6 +29,16 @@ void rr_set_error(const char *fmt, ...);
         }                                                                  \
     } while (0)
 
+// a HIP runtime call whose failure must surface through the C ABI's error code (memsets, function attributes)
+#define RR_CHECK_HIP(call, name)                                           \
+    do {                                                                   \
+        hipError_t e_ = (call);                                            \
+        if (e_ != hipSuccess) {                                            \
+            rr_set_error("%s: %s failed: %s", name, #call, hipGetErrorString(e_)); \
+            return RR_ERR_LAUNCH;                                          \
+        }                                                                  \
+    } while (0)
+
 static inline int rr_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // y*scale + shift of a BatchNorm layer as ONE explicit fma.  The forward (bn_apply), the two backward passes that recompute

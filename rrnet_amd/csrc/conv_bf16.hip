@@ -140,6 +140,19 @@ struct ConvArgs {
     int xcd_n;
 };
 
+// Operand scale of the split-operand (f16x3) arithmetic from the word holding the bit pattern of max|tensor|: 2^(14 - floor(log2 max)),
+// an exact power of two that places the maximum in [2^14, 2^15).  Exponents below 15 (max < 2^-112, zero and denormals included)
+// are clamped: (268 - e) << 23 would otherwise reach the Inf / NaN encodings (e <= 13) — such a tensor is scaled by 2^126 at most
+// and simply keeps fewer than 22 bits.  The epilogue undoes the two scales one after the other (each factor an exact power of two:
+// their PRODUCT overflows / its inverse underflows for tiny operands).
+__device__ __forceinline__ float split_scale_from_bits(unsigned bits)
+{
+    unsigned e = (bits >> 23) & 0xffu;
+    e = e < 15u ? 15u : e;
+    return __builtin_bit_cast(float, (268u - e) << 23);
+}
+__device__ __forceinline__ float split_scale_inv(float sc) { return __builtin_bit_cast(float, (254u << 23) - __builtin_bit_cast(unsigned, sc)); }
+
 // 128 x BN output tile, 256 threads = 4 waves (BN 128: 2x2 waves of 64x64; BN 64: 4x1 waves of 32x64; BN 32: 4x1 of 32x32)
 // B16: the filter comes as bf16 (a.w16; C % 8 == 0): half the B loads, no converts, 16-byte LDS stores for the B image.
 // SO: strided destination (ConvArgs::osh; the stride-2 data gradient's parity-class launches) — its own instantiation: folded
@@ -157,16 +170,16 @@ __global__ __launch_bounds__(WS ? 512 : 256, (!WS && SP == 2) ? 2 : 1) void conv
 {
     typedef typename std::conditional<F16, f16x8, bf16x8>::type frag_t;
     // operand scales (F16): 2^(14 - floor(log2(max|tensor|))), exact powers of two; the product is undone in the epilogue
-    float sc_a = 1.f, sc_b = 1.f, sc_inv = 1.f;
+    float sc_a = 1.f, sc_b = 1.f, sc_ia = 1.f, sc_ib = 1.f;
     if constexpr (F16) {
         auto scale_of = [](const unsigned *p) {
             if (p == nullptr) return 1.f;
-            const unsigned e = (__builtin_amdgcn_readfirstlane(*p) >> 23) & 0xffu;          // biased exponent of the maximum
-            return e == 0u ? 1.f : __builtin_bit_cast(float, (268u - e) << 23);                // 2^(14 - (e - 127))
+            return split_scale_from_bits(__builtin_amdgcn_readfirstlane(*p));                // 2^(14 - (e - 127))
         };
         sc_a = scale_of(a.amax_src);
         sc_b = scale_of(a.amax_w);
-        sc_inv = 1.f / (sc_a * sc_b);
+        sc_ia = split_scale_inv(sc_a);
+        sc_ib = split_scale_inv(sc_b);
     }
     constexpr int WN = BN / 64 ? BN / 64 : 1;
     constexpr int WM = 4 / WN;
@@ -523,7 +536,7 @@ __global__ __launch_bounds__(WS ? 512 : 256, (!WS && SP == 2) ? 2 : 1) void conv
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 acc[i][j] += acl[i][j];
-                if constexpr (F16) acc[i][j] *= sc_inv;
+                if constexpr (F16) acc[i][j] = acc[i][j] * sc_ia * sc_ib;
             }
     }
 
@@ -676,8 +689,7 @@ struct OutMap { int DH, DW, OH, OW, osh, osw, oh0, ow0; };   // explicit logical
 // K-step and thread that splitting the filter tile inside the convolution costs.
 __global__ __launch_bounds__(256) void weight_split_f16_kernel(const f32x4 *w, const unsigned *amax, unsigned short *out, long n4)
 {
-    const unsigned e = (*amax >> 23) & 0xffu;
-    const float scale = e == 0u ? 1.f : __builtin_bit_cast(float, (268u - e) << 23);
+    const float scale = split_scale_from_bits(*amax);
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         u16x4 parts[2];
         split_bf4<2, true>(w[i], parts, scale);
@@ -692,7 +704,7 @@ template <typename K>
 int launch(K kern, int blocks, int gz, size_t lds, hipStream_t stream, const ConvArgs &args, const char *name, int threads = 256)
 {
     if (lds > 48 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        RR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), name);
     hipLaunchKernelGGL(kern, dim3(blocks, 1, gz), dim3(threads), lds, stream, args);
     RR_CHECK_LAUNCH(name);
     return RR_OK;
@@ -744,7 +756,7 @@ int fprop_impl(const float *x, const float *w, const float *bias, float *y, doub
     if (om != nullptr) ks = 1;       // (the zero fill of a split-K destination would wipe the other parity classes)
     if (ks > 1) {
         a.ksplit = ks;
-        if (!accumulate) hipMemsetAsync(y, 0, sizeof(float) * (size_t)M * k, stream);
+        if (!accumulate) RR_CHECK_HIP(hipMemsetAsync(y, 0, sizeof(float) * (size_t)M * k, stream), "rr_conv_fprop_bf16");
     }
     const bool tiles_full = M % BM == 0;
     RR_CHECK_ARG(bs == nullptr || !bs->relu_bias || tiles_full, "rr_conv_dgrad_s1_relubias_bf16: N*H*W = %ld must be a multiple of 128", M);
@@ -795,7 +807,7 @@ int fprop_impl(const float *x, const float *w, const float *bias, float *y, doub
         return rr_bn_bwd_reduce(y, bs->z, bs->y, bs->mean, bs->invstd, bs->msc, bs->msh, bs->sums, M, k, 1, stream);
     }
     if (rc == RR_OK && ks > 1 && stat_slab != nullptr) {
-        hipMemsetAsync(stat_slab, 0, rr_conv_stat_slab_bytes(n, a.DH, a.DW, k), stream);
+        RR_CHECK_HIP(hipMemsetAsync(stat_slab, 0, rr_conv_stat_slab_bytes(n, a.DH, a.DW, k), stream), "rr_conv_fprop_bf16");
         const int lanes = 256 / (k / 4);
         int sblocks = rr_cdiv(M, (long)lanes * 8);
         if (sblocks > 256) sblocks = 256;
@@ -836,16 +848,16 @@ template <int SP = 1, bool F16 = false>
 __global__ __launch_bounds__(256, SP > 1 ? 2 : 1) void conv_wgrad_bf16_kernel(const WgradArgs a)
 {
     typedef typename std::conditional<F16, f16x8, bf16x8>::type frag_t;
-    float sc_a = 1.f, sc_b = 1.f, sc_inv = 1.f;
+    float sc_a = 1.f, sc_b = 1.f, sc_ia = 1.f, sc_ib = 1.f;
     if constexpr (F16) {
         auto scale_of = [](const unsigned *p) {
             if (p == nullptr) return 1.f;
-            const unsigned e = (__builtin_amdgcn_readfirstlane(*p) >> 23) & 0xffu;
-            return e == 0u ? 1.f : __builtin_bit_cast(float, (268u - e) << 23);
+            return split_scale_from_bits(__builtin_amdgcn_readfirstlane(*p));
         };
         sc_a = scale_of(a.amax_dy);
         sc_b = scale_of(a.amax_x);
-        sc_inv = 1.f / (sc_a * sc_b);
+        sc_ia = split_scale_inv(sc_a);
+        sc_ib = split_scale_inv(sc_b);
     }
     constexpr int BLK = 32 * 32 + 32;            // one 32-column block of a K-step: [32 pixels][32 channels] (+64 B: the 8-byte
                                                  // stores of a 16-lane group go to two blocks, on disjoint banks)
@@ -995,7 +1007,7 @@ __global__ __launch_bounds__(256, SP > 1 ? 2 : 1) void conv_wgrad_bf16_kernel(co
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 acc[i][j] += acl[i][j];
-                if constexpr (F16) acc[i][j] *= sc_inv;
+                if constexpr (F16) acc[i][j] = acc[i][j] * sc_ia * sc_ib;
             }
     }
     const int lr = lane & 31, lh = lane >> 5;
@@ -1142,7 +1154,7 @@ static int dgrad_s2_impl(const float *dy, const float *w, float *dx, int n, int 
         RR_CHECK_ARG(Rc[cl] * Sc[cl] == 0 || (lead_h[cl] >= 0 && lead_w[cl] >= 0), "rr_conv_dgrad_s2_bf16: unsupported padding %d,%d", pad_h, pad_w);
     }
     // parity classes no tap reaches (a 1x1 stride 2: three of four) are zero
-    if (any_empty && !accumulate) hipMemsetAsync(dx, 0, sizeof(float) * (size_t)n * h * wd * c, stream);
+    if (any_empty && !accumulate) RR_CHECK_HIP(hipMemsetAsync(dx, 0, sizeof(float) * (size_t)n * h * wd * c, stream), "rr_conv_dgrad_s2_bf16");
     long base = 0;
     for (int cl = 0; cl < 4; ++cl) {
         const int ph = cl >> 1, pw = cl & 1;
@@ -1196,7 +1208,7 @@ static int wgrad_impl(const float *x, const float *dy, float *dw, int n, int h, 
     const size_t lds = sizeof(unsigned short) * 4 * 4 * (32 * 32 + 32) * (split ? 2 : 1);  // 2 operands x 2 buffers x (parts) x 4 blocks of 32 x 32 (+ pad)
     if (split) {
         auto kern = conv_wgrad_bf16_kernel<2, true>;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        RR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "rr_conv_wgrad_f16x3");
         hipLaunchKernelGGL(kern, dim3(tiles * splits), dim3(256), lds, stream, a);
     } else {
         hipLaunchKernelGGL((conv_wgrad_bf16_kernel<1, false>), dim3(tiles * splits), dim3(256), lds, stream, a);

@@ -75,6 +75,7 @@ class FlatParams:
         self.wt_flat = None
         self.w16_flat = self.wt16_flat = None       # bf16 copies (plain / flipped) for the bf16-operand kernels, on demand
         self._wt_table = None
+        self._wt_tabled = set()
         self.epoch = 0                              # optimizer steps taken through the flat buffer (FlatAdam.step): cache key for
                                                     # per-step quantities derived from the parameters (functional._wamax_attach)
         self._wt_version = None
@@ -87,12 +88,14 @@ class FlatParams:
     def _build_wt_table(self):
         import numpy as np
         rows = []
+        self._wt_tabled = set()             # ids of the filters the table covers; the rest keep the per-layer launch
         for p in self.params:
             if p.dim() != 4:
                 continue
             k, c, r, s = p.shape
             if k > 65535 or r * s >= 2048 or (k + 31) // 32 > 1023 or (c + 31) // 32 > 1023:
                 continue
+            self._wt_tabled.add(id(p))
             o = self._offs[id(p)]
             kt, ct = (k + 31) // 32, (c + 31) // 32
             tap, ki, ci = np.meshgrid(np.arange(r * s), np.arange(kt), np.arange(ct), indexing="ij")
@@ -126,8 +129,11 @@ class FlatParams:
         self._wt_pver = {id(p): p._version for p in self.params if p.dim() == 4}
 
     def invalidate_wt(self):
-        """Mark the flipped-filter cache stale (the next data gradient refills it)."""
+        """Mark every per-step quantity derived from the parameters stale: the flipped-filter cache (the next data gradient
+        refills it) and, through `epoch`, what the autograd nodes remember per optimizer step (the split-operand kernels'
+        filter maxima, functional._wamax_attach).  The one call to make after writing parameters through `p.data`."""
         self._wt_version = None
+        self.epoch += 1
 
     def _wt_ready(self, p, bf16):
         if not self._wt_enabled or p.dim() != 4 or id(p) not in self._offs:
@@ -140,6 +146,8 @@ class FlatParams:
             self.w16_flat = torch.empty(self.numel, dtype=torch.bfloat16, device=self.flat.device)
             self.wt16_flat = torch.empty(self.numel, dtype=torch.bfloat16, device=self.flat.device)
             self._wt_version = None
+        if id(p) not in self._wt_tabled:      # a shape the batch kernel's table cannot encode: nothing ever fills its slice
+            return False
         if self._wt_version != self.flat._version or self._wt_pver.get(id(p)) != p._version:   # written since the last fill
             self.refresh_wt()
         return True

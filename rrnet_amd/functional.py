@@ -281,7 +281,10 @@ def _wamax_attach(w_param, wc):
     if ops.BF16 != ops.MATH_F16X3 or w_param is None or not wc.is_cuda:
         return
     flat = getattr(w_param, "_rr_flat", None)
-    key = (flat.epoch if flat is not None else -1, w_param._version, w_param.data_ptr())
+    # (flat.flat._version: FlatParams.broadcast / any in-place write of the flat buffer; epoch: optimizer steps and
+    # FlatParams.invalidate_wt(), the documented call after a write through `p.data`)
+    key = (flat.epoch if flat is not None else -1, flat.flat._version if flat is not None else -1, w_param._version,
+           w_param.data_ptr())
     hit = getattr(w_param, "_rr_wamax", None)
     if hit is None or hit[0] != key:
         hit = (key, ops.amax_of(wc))

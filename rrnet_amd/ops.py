@@ -2,6 +2,9 @@
 tensors used purely as device-memory handles: logical shape NCHW with channels_last strides,
 i.e. NHWC in memory; conv weights logical [K,C,R,S] with channels_last strides = OHWI."""
 import os
+import sys
+import threading
+import types
 
 import torch
 
@@ -137,8 +140,33 @@ def out_hw(h, w, r, s, stride, ph, pw):
 #   2          "f16x3"  operands split into two fp16 parts, three products: fp32-level accuracy at the 16-bit matrix rate
 MATH_F32, MATH_BF16, MATH_F16X3 = 0, 1, 2
 _MATH_NAMES = {"f32": MATH_F32, "fp32": MATH_F32, "bf16": MATH_BF16, "f16x3": MATH_F16X3}
-_BF16_ENV = MATH_BF16 if os.environ.get("RR_CONV_BF16", "0") == "1" else _MATH_NAMES.get(os.environ.get("RR_CONV_MATH", "f32"), MATH_F32)
-BF16 = _BF16_ENV
+
+
+def _env_mode():
+    if os.environ.get("RR_CONV_BF16", "0") == "1":
+        return MATH_BF16
+    name = os.environ.get("RR_CONV_MATH", "f32")
+    if name not in _MATH_NAMES:
+        raise ValueError("RR_CONV_MATH must be one of %s, got %r" % (sorted(_MATH_NAMES), name))
+    return _MATH_NAMES[name]
+
+
+_BF16_ENV = _env_mode()
+
+
+# The switch is per THREAD (two models of different conv_math driven from two threads, or a backward on an autograd worker
+# while another thread runs a forward, must not see each other's setting); a thread that never set it reads the
+# environment's default.  `ops.BF16` stays readable / assignable as a module attribute (the module class below).
+class _Mode(threading.local):
+    def __init__(self):
+        self.value = _BF16_ENV
+
+
+_MODE = _Mode()
+
+
+def _mode():
+    return _MODE.value
 
 
 def math_mode(model_cfg):
@@ -152,33 +180,32 @@ def math_mode(model_cfg):
 
 
 class bf16_scope:
-    """`with ops.bf16_scope(mode):` — the convolutions launched inside take the bf16-operand (1 / True) or split-operand
-    (2) kernels.  RRNet.forward opens it for a model built with cfg.Model.bf16 / conv_math; every convolution node
-    remembers the setting of its forward and re-opens it around its backward (rrnet_amd/functional.py)."""
+    """`with ops.bf16_scope(mode):` — the convolutions launched inside (by this thread) take the fp32 (0 / None: the
+    environment's default, RR_CONV_MATH), bf16-operand (1 / True) or split-operand (2) kernels; `force=True` takes `mode`
+    literally, so that 0 means the fp32 kernels whatever the environment says.  RRNet.forward opens it for a model built
+    with cfg.Model.bf16 / conv_math; every convolution node remembers the setting of its forward and re-opens it around
+    its backward (rrnet_amd/functional.py)."""
 
-    def __init__(self, on):
-        self.on = int(on) or _BF16_ENV
+    def __init__(self, on, force=False):
+        self.on = int(on or 0) if force else (int(on or 0) or _BF16_ENV)
 
     def __enter__(self):
-        global BF16
-        self.prev, BF16 = BF16, self.on
+        self.prev, _MODE.value = _MODE.value, self.on
 
     def __exit__(self, *exc):
-        global BF16
-        BF16 = self.prev
-
+        _MODE.value = self.prev
 
 
 def _bf16_ok(c, k, r, s, *tensors, pixels=None):
     """Shapes csrc/conv_bf16.hip takes: vector path (C and K multiples of 4, <= 64 taps), tensors below 2 GiB.
     -> 0 (fp32 kernels) or the switch position (MATH_BF16 / MATH_F16X3)."""
-    ok = BF16 and c % 4 == 0 and k % 4 == 0 and r * s <= 64 and all(t.numel() * 4 < (1 << 31) for t in tensors)
-    if ok and BF16 == MATH_F16X3:
+    ok = _mode() and c % 4 == 0 and k % 4 == 0 and r * s <= 64 and all(t.numel() * 4 < (1 << 31) for t in tensors)
+    if ok and _mode() == MATH_F16X3:
         # the split kernels pay two small reductions (the operands' maxima) per launch and three matrix instructions per tile:
         # they beat the fp32-MFMA kernels on the large 3x3 layers only; the rest stays on csrc/conv.hip — same accuracy class
         if pixels is None or pixels < _SPLIT_MIN_PIXELS or c * r * s < _SPLIT_MIN_K or k < _SPLIT_MIN_CH or c < _SPLIT_MIN_CH:
             return 0
-    return int(BF16) if ok else 0
+    return int(_mode()) if ok else 0
 
 
 _SPLIT_MIN_PIXELS = int(os.environ.get("RR_SPLIT_MIN_PIXELS", "2048"))    # N*P*Q below which a layer stays on the fp32 kernels
@@ -226,23 +253,51 @@ def amax_publish(t):
         t._rr_amax = (hit[0], None, hit[2])
 
 
-def amax_of(t):
-    """Device word holding the bit pattern of max|t| (rr_absmax_bits) for the split-operand kernels, computed on the
-    current stream and remembered on the tensor object (same version, same stream): a gradient serves its data
-    gradient and its weight gradient with one reduction."""
-    sid = torch.cuda.current_stream(t.device).cuda_stream
-    hit = getattr(t, "_rr_amax", None)
-    if hit is not None and hit[0] == t._version and (hit[1] == sid or hit[1] is None):
-        return hit[2]
+_AMAX_CHECK = os.environ.get("RR_AMAX_CHECK", "0") == "1"     # recompute every remembered maximum when it is used; raise on mismatch
+
+
+def amax_drop(t):
+    """`t` is about to be (or has just been) written through its raw pointer by a kernel — an accumulate-form data gradient,
+    bn_bwd_apply's g_into, any `out=` argument: such writes never move `t._version`, so a maximum remembered on the tensor
+    object would look valid and be stale (too low: the fp16 parts overflow; too high: bits are dropped silently)."""
+    if t is not None and getattr(t, "_rr_amax", None) is not None:
+        t._rr_amax = None
+
+
+def _absmax_word(t):
     word = _ZEROS.take(1, t.device)                   # 8 zeroed bytes; the kernels read the first 4
     n = t.numel()
     assert n % 4 == 0 and t.dtype == torch.float32
     _C.check(_C.fn("rr_absmax_bits")(_C.ptr(t), n, _C.ptr(word), _C.stream()), "rr_absmax_bits")
+    return word
+
+
+def amax_of(t):
+    """Device word holding the bit pattern of max|t| (rr_absmax_bits) for the split-operand kernels, computed on the
+    current stream and remembered on the tensor object (same version, same stream): a gradient serves its data
+    gradient and its weight gradient with one reduction.  RR_AMAX_CHECK=1 (tests): every remembered word is checked
+    against a fresh reduction at the moment it is used."""
+    sid = torch.cuda.current_stream(t.device).cuda_stream
+    hit = getattr(t, "_rr_amax", None)
+    if hit is not None and hit[0] == t._version and (hit[1] == sid or hit[1] is None):
+        if _AMAX_CHECK:
+            fresh = int(_absmax_word(t).view(torch.int32)[0].item())
+            kept = int(hit[2].view(torch.int32)[0].item())
+            if fresh != kept:
+                raise RuntimeError("ops.amax_of: stale remembered maximum on a tensor of shape %s: remembered bits 0x%08x, "
+                                   "actual 0x%08x (a kernel wrote it through its raw pointer without ops.amax_drop)"
+                                   % (tuple(t.shape), kept & 0xffffffff, fresh & 0xffffffff))
+            AMAX_CHECKED[0] += 1
+        return hit[2]
+    word = _absmax_word(t)
     try:
         t._rr_amax = (t._version, sid, word)
     except AttributeError:
         pass
     return word
+
+
+AMAX_CHECKED = [0]       # remembered maxima verified under RR_AMAX_CHECK=1 (the audit asserts that the check really ran)
 
 
 def _math_tail(mode, filter16, src, flt, filter_split):
@@ -271,7 +326,7 @@ def conv_fprop(x, w, bias=None, stride=1, pad=(0, 0), relu=False, want_stats=Fal
     if want_stats:
         nbytes = _C.fn("rr_conv_stat_slab_bytes")(n, p, q, k)
         slab = torch.empty(nbytes // 8, dtype=torch.float64, device=x.device)
-    bf = _bf16_ok(c, 4 if BF16 != MATH_F16X3 else k, r, s, x, w, y, pixels=n * p * q)
+    bf = _bf16_ok(c, 4 if _mode() != MATH_F16X3 else k, r, s, x, w, y, pixels=n * p * q)
     f = _C.fn(("rr_conv_fprop", "rr_conv_fprop_bf16", "rr_conv_fprop_f16x3")[bf])
     flops = 2.0 * n * p * q * k * (c * r * s if algo_kg is None else algo_kg)
     # w16: the filter already rounded to bf16 (optional); split operands: the two tensors' maxima
@@ -371,6 +426,19 @@ _DGRAD_BNSUM = os.environ.get("RR_DGRAD_BNSUM", "1") != "0"
 _BF16_S2_DGRAD = os.environ.get("RR_BF16_S2_DGRAD", "1") != "0"     # A/B: stride-2 data gradients stay on the fp32 kernel
 
 
+def _s2_parity_pads_ok(r, s, pad):
+    """The parity-class launches of rr_conv_dgrad_s2_bf16 / _f16x3 need a non-negative leading pad in every class that has
+    taps (csrc/conv_bf16.hip, dgrad_s2_impl: lead = taps - 1 - (parity + pad - first tap) // 2); e.g. 3x3 stride 2 pad 2 has
+    none — such a layer takes rr_conv_dgrad like every other unsupported shape instead of raising."""
+    for size, pd in ((r, pad[0]), (s, pad[1])):
+        for par in (0, 1):
+            t0 = (par + pd) & 1
+            taps = (size - t0 + 1) // 2 if t0 < size else 0
+            if taps and (taps - 1) - (par + pd - t0) // 2 < 0:
+                return False
+    return True
+
+
 def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False, bnsum=None, bnsum_z=None, wt=None, wt16=None,
                wt_split=None):
     """dy [N,K,P,Q], w [K,C,R,S] -> dx [N,C,H,W]; with `out` and accumulate adds into it.
@@ -386,6 +454,8 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False,
     if out is None:
         out = empty_nhwc(n, c, h, wd, dy.device)
         accumulate = False
+    else:
+        amax_drop(out)                # an existing tensor rewritten / added into through its pointer
     assert is_nhwc(out)
     if (bnsum is not None and bnsum.relu_bias and _DGRAD_BNSUM and stride == 1 and c % 4 == 0
             and bnsum_z is not None and is_nhwc(bnsum_z) and bnsum_z.shape == out.shape and out.numel() * 4 < (1 << 31)
@@ -455,7 +525,8 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False,
                                    int(accumulate), *tail), (n, h, wd, c, k, r, s, stride),
                         4.0 * (dy.numel() + out.numel() * (2 if accumulate else 1) + w.numel())), "rr_conv_dgrad_s1")
         return out
-    if stride == 2 and _bf16_ok(k, c, r, s, dy, out, pixels=n * h * wd // 4) and _BF16_S2_DGRAD:
+    if (stride == 2 and _s2_parity_pads_ok(r, s, pad) and _bf16_ok(k, c, r, s, dy, out, pixels=n * h * wd // 4)
+            and _BF16_S2_DGRAD):
         # bf16 operands: one launch of the forward kernel per output parity class on its packed sub-filter
         wsub = torch.empty(k * c * r * s, dtype=torch.float32, device=dy.device)
         sx = _bf16_ok(k, c, r, s, dy, out, pixels=n * h * wd // 4) == MATH_F16X3
@@ -576,7 +647,7 @@ def bn_apply(y, scale, shift, residual=None, relu=False, res_scale=None, res_shi
     assert is_nhwc(y) and (residual is None or (is_nhwc(residual) and residual.shape == y.shape))
     n, c, h, w = y.shape
     out = empty_nhwc(n, c, h, w, y.device)
-    if BF16 == MATH_F16X3 and y.is_cuda and n * h * w >= _SPLIT_MIN_PIXELS and _FUSED_AMAX_FWD:
+    if _mode() == MATH_F16X3 and y.is_cuda and n * h * w >= _SPLIT_MIN_PIXELS and _FUSED_AMAX_FWD:
         # split-operand convolutions: the consumer's operand scale comes out of this pass (see amax_of)
         word = _ZEROS.take(1, y.device)
         _C.check(_C.fn("rr_bn_apply_amax")(_C.ptr(y), _C.ptr(scale), _C.ptr(shift), _C.ptr(residual), _C.ptr(res_scale),
@@ -605,10 +676,11 @@ def bn_bwd_apply(dz, z, y, mean, invstd, gamma, sums, count, want_g=False, dgamm
     dx = empty_nhwc(n, c, h, w, y.device)
     if g_into is not None:
         assert is_nhwc(g_into) and g_into.shape == y.shape
+        amax_drop(g_into)             # added into through its pointer
         g = g_into
     else:
         g = empty_nhwc(n, c, h, w, y.device) if want_g else None
-    if BF16 == MATH_F16X3 and y.is_cuda and n * h * w >= _SPLIT_MIN_PIXELS and _FUSED_AMAX_BWD:
+    if _mode() == MATH_F16X3 and y.is_cuda and n * h * w >= _SPLIT_MIN_PIXELS and _FUSED_AMAX_BWD:
         # split-operand convolutions: dx is the operand of the data / weight gradient launched next — its maximum comes out
         # of this pass.  (dx is a fresh tensor that nothing adds into later: the remembered maximum cannot go stale.)
         word = _ZEROS.take(1, y.device)
@@ -1112,3 +1184,18 @@ def dcn_psroi_bwd(dout, x, rois, trans, count, no_trans, spatial_scale, output_d
                                        part_size, sample_per_part, float(trans_std), tc, _C.ptr(dx), _C.ptr(dtrans),
                                        _C.stream()), "rr_dcn_psroi_bwd")
     return dx, dtrans
+
+
+class _OpsModule(types.ModuleType):
+    """`ops.BF16` (read / assign) = this thread's arithmetic switch."""
+
+    @property
+    def BF16(self):
+        return _MODE.value
+
+    @BF16.setter
+    def BF16(self, v):
+        _MODE.value = int(v or 0)
+
+
+sys.modules[__name__].__class__ = _OpsModule

@@ -97,3 +97,64 @@ def test_conv_math_switch_and_split_layer_policy():
         assert ops.BF16 == ops.MATH_F16X3
     finally:
         ops.BF16 = saved
+
+
+def test_conv_math_switch_is_per_thread_and_checked():
+    """The arithmetic switch lives in a threading.local: another thread reads the environment's default whatever
+    this one set; bf16_scope(0, force=True) means the fp32 kernels; an unknown RR_CONV_MATH raises instead of meaning f32."""
+    import subprocess
+    import sys
+    import threading
+    from rrnet_amd import ops
+    saved = ops.BF16
+    seen = {}
+    try:
+        ops.BF16 = ops.MATH_F16X3
+
+        def other():
+            seen["default"] = ops.BF16
+            with ops.bf16_scope(ops.MATH_BF16):
+                seen["inside"] = ops.BF16
+            seen["after"] = ops.BF16
+        th = threading.Thread(target=other)
+        th.start()
+        th.join()
+        assert seen == {"default": ops._BF16_ENV, "inside": ops.MATH_BF16, "after": ops._BF16_ENV}
+        assert ops.BF16 == ops.MATH_F16X3                       # untouched by the other thread's scope
+        with ops.bf16_scope(0, force=True):
+            assert ops.BF16 == ops.MATH_F32
+        assert ops.BF16 == ops.MATH_F16X3
+    finally:
+        ops.BF16 = saved
+    r = subprocess.run([sys.executable, "-c", "import rrnet_amd.ops"], env={**__import__("os").environ, "RR_CONV_MATH": "fp8"},
+                       capture_output=True, text=True, cwd=__import__("os").path.dirname(__import__("os").path.dirname(__file__)))
+    assert r.returncode != 0 and "RR_CONV_MATH" in r.stderr
+
+
+def test_stride2_parity_class_padding_rule():
+    """ops._s2_parity_pads_ok mirrors dgrad_s2_impl's lead >= 0 test (csrc/conv_bf16.hip): the hourglass shapes pass, a 3x3
+    stride-2 pad-2 layer falls back to rr_conv_dgrad instead of raising."""
+    from rrnet_amd import ops
+    assert ops._s2_parity_pads_ok(3, 3, (1, 1)) and ops._s2_parity_pads_ok(1, 1, (0, 0)) and ops._s2_parity_pads_ok(7, 7, (3, 3))
+    assert not ops._s2_parity_pads_ok(3, 3, (2, 2)) and not ops._s2_parity_pads_ok(3, 3, (1, 2))
+    assert not ops._s2_parity_pads_ok(1, 1, (1, 1))
+
+
+def test_profiles_index_names_only_files_that_exist():
+    """profiles/README.md is the evidence index DESIGN.md and the commit titles point to: every file name it quotes must be
+    tracked under profiles/ (round 4 indexed two files that only existed in the untracked gpurun_out/)."""
+    import itertools
+    import os
+    import re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+    text = open(os.path.join(root, "README.md")).read()
+    names = set()
+    for quoted in re.findall(r"`([^`\n]+)`", text):
+        if not re.fullmatch(r"[\w{},.\-]+\.(json|csv|txt|log)", quoted) or quoted.startswith("."):
+            continue                                   # commands, kernel names, `..._suffix` continuations, `r04_infer_*` globs
+        parts = re.split(r"\{([^}]*)\}", quoted)      # r04_config4_bf16_{dcn,plain}_bench.json -> both names
+        alts = [p.split(",") if i % 2 else [p] for i, p in enumerate(parts)]
+        names.update("".join(c) for c in itertools.product(*alts))
+    assert len(names) >= 25, sorted(names)
+    missing = sorted(n for n in names if not os.path.exists(os.path.join(root, n)))
+    assert not missing, "profiles/README.md indexes files that are not in profiles/: %s" % missing

@@ -14,7 +14,12 @@ def test_scale_places_the_maximum_in_fp16_range():
         m = np.abs(t).max() * s
         assert 2.0 ** 14 <= m < 2.0 ** 15, (gain, m)
         assert np.log2(float(s)) == np.round(np.log2(float(s)))            # a power of two: scaling and unscaling are exact
-    assert osp.scale_of(osp.absmax_bits(np.zeros(4, np.float32))) == 1.0
+    # maxima below 2^-112 (zero, denormals): the exponent is clamped — a finite power of two, never the Inf / NaN encodings
+    for tiny in (0.0, 1e-45, 1e-39, 2.0 ** -120, 2.0 ** -113):
+        s = osp.scale_of(osp.absmax_bits(np.full(4, tiny, np.float32)))
+        assert np.isfinite(s) and s == 2.0 ** 126, (tiny, s)
+    assert osp.scale_of(osp.absmax_bits(np.full(4, 2.0 ** -112, np.float32))) == 2.0 ** 126
+    assert osp.scale_of(osp.absmax_bits(np.full(4, 2.0 ** -111, np.float32))) == 2.0 ** 125
 
 
 def test_split_reconstructs_to_22_bits():
