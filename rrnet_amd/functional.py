@@ -58,6 +58,14 @@ def _stress_delay():
         torch.cuda._sleep(_STRESS_CYCLES)
 
 
+def branch_stress(device):
+    """RR_WGRAD_STRESS: the same spin kernel in front of the work of an hourglass branch stream (called at the head of a
+    branch's forward and of every convolution node's backward that runs on one), so that a branch falls far behind the
+    stream it will hand its result to."""
+    if _STRESS_CYCLES > 0 and device.type == "cuda" and torch.cuda.current_stream(device).cuda_stream in _BRANCH_IDS:
+        torch.cuda._sleep(_STRESS_CYCLES)
+
+
 def _wgrad_join(device):
     """Main stream waits for the weight gradients in flight on the side stream (before the next MFMA-bound kernel)."""
     if _WG_STATE["pending"] and not _WGRAD_FREE:
@@ -144,8 +152,9 @@ class _ConvBnAct(torch.autograd.Function):
                     # the stream has drained — one host sync per SyncBN layer (found with the one-rank RCCL step: 430 ms of
                     # host time per 487 ms step)
                     sums[2 * k:2 * k + 1].fill_(count)
-                    dptrace.record("default", "all_reduce", sums.numel(), "syncbn_fwd")
-                    dist.all_reduce(sums)
+                    pg, pgname = sync_group()
+                    dptrace.record(pgname, "all_reduce", sums.numel(), "syncbn_fwd")
+                    dist.all_reduce(sums, group=pg)
                     cnt_dev = sums[2 * k:].clone()   # own storage: `sums` is a slice of a shared zero pool (version counter)
                 mean, invstd, scale, shift = ops.bn_finalize(sums, count, gamma, beta, bn.running_mean, bn.running_var,
                                                              mom, bn.eps, cnt_dev, bn.num_batches_tracked)
@@ -189,6 +198,7 @@ class _ConvBnAct(torch.autograd.Function):
     @staticmethod
     def _backward(ctx, dz):
         x, wc, y, z, mean, invstd, gamma, cnt_dev, msc, msh = ctx.saved_tensors
+        branch_stress(dz.device)
         ops.amax_restore(x, getattr(ctx, "x_amax", None))
         stride, pad, relu, count, sync, has_res = ctx.cfg
         w, gamma_p, beta_p = ctx.params
@@ -217,17 +227,22 @@ class _ConvBnAct(torch.autograd.Function):
             else:
                 ret_dg, ret_db = dg, db
         if sync:
-            dptrace.record("default", "all_reduce", sums.numel(), "syncbn_bwd")
-            dist.all_reduce(sums)
+            pg, pgname = sync_group()
+            dptrace.record(pgname, "all_reduce", sums.numel(), "syncbn_bwd")
+            dist.all_reduce(sums, group=pg)
         want_g = has_res and relu
         x_acc, res_acc = ctx.accs
         # the residual's fan-in buffer already holds another consumer's gradient: add the masked gradient into it
         # inside this kernel (no separate g tensor, no add pass)
         g_into = res_acc.buf if (want_g and res_acc is not None and res_acc.buf is not None and ctx.needs_input_grad[4]
                                  and _G_INTO) else None
+        if g_into is not None:
+            res_acc.begin(dz.device)
         dy, g = ops.bn_bwd_apply(dz, z, y, mean, invstd, gamma, sums, count, want_g,
                                  dg_t if fused_affine else None, db_t if fused_affine else None, cnt_dev, msc, msh,
                                  g_into=g_into)
+        if g_into is not None:
+            res_acc.end(dz.device)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = _input_grad(dy, wc, ctx.xshape, stride, pad, x_acc, in_link, x, w)
@@ -256,9 +271,12 @@ class _ConvBnAct(torch.autograd.Function):
                 res_acc.pending -= 1
                 if res_acc.buf is None:
                     res_acc.buf = g
+                    res_acc.end(dz.device)
                 else:
                     if g_into is None:
+                        res_acc.begin(dz.device)
                         res_acc.buf.add_(g)
+                        res_acc.end(dz.device)
                     dres = None
         return dx, ret_dw, ret_dg, ret_db, dres, None, None, None, None, None, None, None, None
 
@@ -308,9 +326,12 @@ def _input_grad(dy, wc, xshape, stride, pad, x_acc, in_link, x, w_param=None):
     x_acc.pending -= 1
     if x_acc.buf is not None:
         # another consumer of x already produced its gradient: add into it inside the dgrad epilogue
+        x_acc.begin(dy.device)
         ops.conv_dgrad(dy, wc, xshape, stride, pad, out=x_acc.buf, accumulate=True, bnsum=link, bnsum_z=x, wt=wt, wt16=wt16)
+        x_acc.end(dy.device)
         return None
     x_acc.buf = ops.conv_dgrad(dy, wc, xshape, stride, pad, bnsum=link, bnsum_z=x, wt=wt, wt16=wt16)
+    x_acc.end(dy.device)
     return x_acc.buf
 
 
@@ -371,8 +392,9 @@ class _ConvBnSyncMulti(torch.autograd.Function):
         counts = [float(y.numel() // k) for (y, _), k in zip(ys, ks)]
         for i, cnt in enumerate(counts):
             packed[tot - L + i:tot - L + i + 1].fill_(cnt)       # (fill_, not item assignment: see _ConvBnAct.forward)
-        dptrace.record("default", "all_reduce", packed.numel(), "syncbn_fwd x%d" % L)
-        dist.all_reduce(packed)
+        pg, pgname = sync_group()
+        dptrace.record(pgname, "all_reduce", packed.numel(), "syncbn_fwd x%d" % L)
+        dist.all_reduce(packed, group=pg)
         cnt_devs = [packed[tot - L + i:tot - L + i + 1].clone() for i in range(L)]
         outs, saved, off = [], [], 0
         for i, ((bn, stride, pad, relu), (y, _), k) in enumerate(zip(specs, ys, ks)):
@@ -422,8 +444,9 @@ class _ConvBnSyncMulti(torch.autograd.Function):
         local = None
         if any(_grad_target(params[3 * i + 1]) is None for i in range(L)):
             local = packed.clone()
-        dptrace.record("default", "all_reduce", packed.numel(), "syncbn_bwd x%d" % L)
-        dist.all_reduce(packed)
+        pg, pgname = sync_group()
+        dptrace.record(pgname, "all_reduce", packed.numel(), "syncbn_bwd x%d" % L)
+        dist.all_reduce(packed, group=pg)
         if x_acc is not None:
             x_acc.pending += L - 1                 # this node contributes L data gradients to the fan-in buffer
         grads, dx, off = [], None, 0
@@ -614,11 +637,16 @@ class _FanOut(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, n):
         ctx.n = n
+        ctx.acc = None                     # the shared GradAcc of the views (fanout_shared), for its stream events
         ctx.set_materialize_grads(False)   # a consumer that accumulated into a shared GradAcc hands back None
         return tuple(x.view_as(x) for _ in range(n))
 
     @staticmethod
     def backward(ctx, *grads):
+        if ctx.acc is not None:
+            dev = next((g.device for g in grads if g is not None), None)
+            if dev is not None:
+                ctx.acc.begin(dev)         # contributors that added into the buffer from other streams
         gs = [ops.to_nhwc(g) if g.dim() == 4 else g.contiguous() for g in grads if g is not None]
         if not gs:
             return None, None
@@ -635,6 +663,49 @@ def fanout(x, n):
 
 _SHARED_ACC = os.environ.get("RR_SHARED_ACC", "1") != "0"
 
+# Hourglass branches on their own HIP streams.  The two branches of an hourglass module — up1 at the module's resolution, and
+# low1 -> low2 -> low3 one level down (backbones/hourglass.py:104-124 of the reference) — are independent between the fan-out of
+# the module's input and the up-sample-add that joins them.  The lower levels (32x32 and below at 1024x1024 input) launch too few
+# workgroups to fill 256 CUs and are chains of short kernels; with up1 of the RR_BRANCH_STREAMS outermost modules on streams of
+# their own, the large MFMA-bound kernels of those branches run beside the under-filled chain instead of in front of it, in
+# the forward and (autograd runs every node's backward on the stream of its forward) in the backward; under data parallelism each
+# branch exchanges its SyncBN statistics on a communicator of its own, so one branch's all-reduce latency sits under the other
+# branch's convolutions (sync_group).  What autograd cannot see — the shared fan-in buffers written through raw pointers — is
+# ordered by GradAcc.begin / end; tensors that cross streams are record_stream'ed at the crossing (Hourglass.forward).
+# 0 = every kernel of the model on the caller's stream (plus the weight-gradient side stream).
+_BRANCH_LEVELS = int(os.environ.get("RR_BRANCH_STREAMS", "0") or 0)
+_BRANCH_IDS = {}      # HIP stream handle -> "branch<slot>" (the name of its SyncBN communicator in rrnet_amd.dptrace)
+_BRANCH_PG = {}       # "branch<slot>" -> process group
+
+
+def branch_stream(device, slot):
+    """The stream of the `slot`-th outermost hourglass module's up1 branch (slot 0 = the module at full feature-map
+    resolution), or None: switched off, not a GPU tensor, or a module deeper than RR_BRANCH_STREAMS."""
+    if device.type != "cuda" or slot >= _BRANCH_LEVELS or _BRANCH_LEVELS <= 0:
+        return None
+    st = _side_stream(device, "branch%d" % slot)
+    _BRANCH_IDS[st.cuda_stream] = "branch%d" % slot
+    return st
+
+
+def sync_group():
+    """-> (communicator, its name in dptrace) for a SyncBN statistics exchange issued now: the default one on the caller's
+    stream, one of its own for every branch stream (created at the first use — every rank reaches that point at the same
+    place of the program; the first collective of a new RCCL communicator is run right there, as FlatParams._group does)."""
+    if not _BRANCH_IDS:
+        return None, "default"
+    name = _BRANCH_IDS.get(torch.cuda.current_stream().cuda_stream)
+    if name is None:
+        return None, "default"
+    pg = _BRANCH_PG.get(name)
+    if pg is None:
+        pg = dist.new_group()
+        warm = torch.zeros(1, dtype=torch.float32, device=torch.device("cuda", torch.cuda.current_device()))
+        dptrace.record(name, "all_reduce", 1, "communicator warm-up")
+        dist.all_reduce(warm, group=pg)
+        _BRANCH_PG[name] = pg
+    return pg, name
+
 
 class GradAcc:
     """Fan-in target shared by the consumers of one fan-out: the first consumer to run its backward publishes its
@@ -642,12 +713,33 @@ class GradAcc:
     fan-out's backward finds one complete gradient and launches no sum kernel.  The views a fan-out returns carry
     the accumulator as `_rr_acc`; convolution nodes pick it up from their input, and a nested fan-out of such a view
     (a residual block at the head of an hourglass branch) joins the same accumulator."""
-    __slots__ = ("buf", "pending", "link")
+    __slots__ = ("buf", "pending", "link", "events")
 
     def __init__(self):
         self.buf = None
         self.pending = 0        # registered contributors that have not run their backward yet
         self.link = None        # ops.BnLink of the fanned-out tensor when a conv -> bn layer produced it
+        self.events = None      # branch streams: [(stream id, event)] of the kernels that wrote `buf` so far
+
+    # The buffer is written through raw pointers, which autograd's own stream hand-over never sees.  With the hourglass
+    # branches on their own HIP streams (branch_stream) the contributors of one fan-in may run on different streams: every
+    # contributor waits for the writes of the others before it touches the buffer (begin) and leaves an event behind its own
+    # (end); the fan-out's backward waits for all of them.  Without branch streams both are no-ops.
+    def begin(self, device):
+        if self.events:
+            cur = torch.cuda.current_stream(device)
+            for sid, ev in self.events:
+                if sid != cur.cuda_stream:
+                    cur.wait_event(ev)
+
+    def end(self, device):
+        if _BRANCH_LEVELS > 0 and device.type == "cuda":
+            cur = torch.cuda.current_stream(device)
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            if self.events is None:
+                self.events = []
+            self.events.append((cur.cuda_stream, ev))
 
 
 def fanout_shared(x, n):
@@ -662,6 +754,7 @@ def fanout_shared(x, n):
     if acc is None:
         acc = GradAcc()
         acc.link = getattr(x, "_rr_bnlink", None)
+    outs[0].grad_fn.acc = acc               # (the node object is the ctx its backward receives)
     amax = getattr(x, "_rr_amax", None)     # (split-operand kernels: the views ARE x — its remembered maximum travels with them)
     for o in outs:
         o._rr_acc = acc

@@ -21,6 +21,22 @@ import contextlib
 import torch
 import torch.nn.functional as F
 
+# Where the fp64 reference arithmetic runs.  "cpu": the host (torch CPU kernels) — the default, used at the small sizes.
+# "cuda": torch's own fp64 kernels on the device (ATen element-wise / reduction kernels; double-precision conv2d / its
+# gradients through ATen's slow_conv2d = unfold + rocBLAS dgemm — MIOpen has no fp64): an implementation that shares
+# nothing with csrc/, ~50x faster than 8 host cores and without the 0.5-1 GB device->host copies.  The three full-size
+# audits (B=8, 1024x1024) run with it: on the host they took 150 s EACH of the driver's 1200 s GPU-test limit.
+REF = {"dev": "cpu"}
+
+
+def _to_ref(t):
+    return t.detach().to(REF["dev"])
+
+
+def _zeros64(n):
+    return torch.zeros(n, dtype=torch.float64, device=REF["dev"])
+
+
 SAMPLE_FLOPS = 2.0e10          # host-reference cost above which a call is sampled (sample=True only)
 FULL_FP32_WGRAD_FLOPS = 2.5e11   # sampled wgrad calls at least this large also get a full-dw fp32 host reference
 
@@ -40,23 +56,23 @@ class Record:
 
 
 def _rel(a, b):
-    a = a.detach().cpu().double()
-    b = b.detach().cpu().double()
+    a = a.detach().to(REF["dev"]).double()
+    b = b.detach().to(REF["dev"]).double()
     return float((a - b).abs().max() / max(float(b.abs().max()), 1e-30))
 
 
 def _V(t):
-    return t.detach().cpu().double().view(1, -1, 1, 1)
+    return t.detach().to(REF["dev"]).double().view(1, -1, 1, 1)
 
 
 def _c64(t):
-    return t.detach().cpu().double()
+    return t.detach().to(REF["dev"]).double()
 
 
 def _q64(t, on):
     """fp64 copy of a convolution operand; with `on` rounded to bf16 first — the contract of the bf16-operand kernels
     (csrc/conv_bf16.hip: both operands of every product rounded to nearest even, fp32 accumulation)."""
-    t = t.detach().cpu()
+    t = t.detach().to(REF["dev"])
     return (t.to(torch.bfloat16).to(torch.float32) if on else t).double()
 
 
@@ -85,7 +101,7 @@ def _dgrad_band(dy, w64, x_shape, stride, pad, n0, h0, h1, quant=False):
     p, q = dy.shape[2], dy.shape[3]
     pa = max(0, -((-(h0 + pad[0] - r + 1)) // stride))
     pb = min(p, (h1 - 1 + pad[0]) // stride + 1)
-    ref = torch.zeros((1, c, h1 - h0, wd), dtype=torch.float64)
+    ref = torch.zeros((1, c, h1 - h0, wd), dtype=torch.float64, device=REF["dev"])
     if pb <= pa:
         return ref
     opw = wd - ((q - 1) * stride - 2 * pad[1] + s)
@@ -113,12 +129,13 @@ def _img_sample(n):
 
 def _colsum64(t):
     """Per-channel sum over (N,H,W) of a logical NCHW tensor, fp64 accumulation, without an fp64 copy of the tensor."""
-    return t.detach().cpu().sum((0, 2, 3), dtype=torch.float64)
+    return t.detach().to(REF["dev"]).sum((0, 2, 3), dtype=torch.float64)
 
 
 @contextlib.contextmanager
-def audit(tol=2e-5, tol_wgrad=2e-4, sample=False):
+def audit(tol=2e-5, tol_wgrad=2e-4, sample=False, ref_device="cpu"):
     from rrnet_amd import ops
+    REF["dev"] = ref_device
     rec = Record()
     rec.sampled = set()
     names = ("conv_fprop", "conv_dgrad", "conv_wgrad", "stem_wgrad_s2d", "conv_fprop_packed", "conv_wgrad_packed", "bn_apply", "bn_bwd_reduce", "bn_bwd_apply",
@@ -193,11 +210,11 @@ def audit(tol=2e-5, tol_wgrad=2e-4, sample=False):
             rec.note("fprop", sig, err, tol)
             if want_stats:      # the statistics are a function of y (checked above): compare with fp64 sums of y itself
                 k = w.shape[0]
-                sums = ops.bn_reduce_slab(out[1], k).cpu()
-                yc = y.detach().cpu()
+                sums = ops.bn_reduce_slab(out[1], k).to(REF["dev"])
+                yc = y.detach().to(REF["dev"])
                 s1 = yc.sum((0, 2, 3), dtype=torch.float64)
-                s2 = torch.zeros(k, dtype=torch.float64)
-                sa = torch.zeros(k, dtype=torch.float64)
+                s2 = _zeros64(k)
+                sa = _zeros64(k)
                 for i in range(yc.shape[0]):
                     yi = yc[i].double()
                     s2 += (yi * yi).sum((1, 2))
@@ -205,13 +222,13 @@ def audit(tol=2e-5, tol_wgrad=2e-4, sample=False):
                 e1 = float((sums[:k] - s1).abs().max() / max(float(sa.max()), 1e-30))
                 rec.note("fprop_stats", sig, max(e1, float((sums[k:2 * k] - s2).abs().max() / float(s2.max()))), tol)
         elif ("fprop",) + sig not in rec.seen:
-            ref = F.conv2d(_q64(x, qq), _q64(w, qq), None if bias is None else bias.cpu().double(), stride, pad)
+            ref = F.conv2d(_q64(x, qq), _q64(w, qq), None if bias is None else bias.to(REF["dev"]).double(), stride, pad)
             if relu:
                 ref = ref.relu()
             rec.note("fprop", sig, _rel(y, ref), tol)
             if want_stats:
                 k = w.shape[0]
-                sums = ops.bn_reduce_slab(out[1], k).cpu()
+                sums = ops.bn_reduce_slab(out[1], k).to(REF["dev"])
                 s1, s2 = ref.sum((0, 2, 3)), (ref * ref).sum((0, 2, 3))
                 e1 = float((sums[:k] - s1).abs().max() / max(float(ref.abs().sum((0, 2, 3)).max()), 1e-30))
                 rec.note("fprop_stats", sig, max(e1, _rel(sums[k:2 * k], s2)), tol)
@@ -228,8 +245,8 @@ def audit(tol=2e-5, tol_wgrad=2e-4, sample=False):
             if ("dgrad_relubias",) + bsig not in rec.seen:
                 c = res.shape[1]
                 tot = _colsum64(res)
-                mag = res.detach().cpu().abs().sum((0, 2, 3), dtype=torch.float64)
-                o = bnsum.sums.cpu()
+                mag = res.detach().to(REF["dev"]).abs().sum((0, 2, 3), dtype=torch.float64)
+                o = bnsum.sums.to(REF["dev"])
                 e = float((o[:c] - tot).abs().max() / max(float(mag.max()), 1e-30))
                 # nothing may survive where the producer's output is zero
                 e = max(e, float((res * (relu_mask <= 0)).abs().max()))
@@ -241,14 +258,14 @@ def audit(tol=2e-5, tol_wgrad=2e-4, sample=False):
             bsig = (tuple(res.shape), zt is not None, bnsum.msc is not None, bool(accumulate))
             if ("dgrad_bnsum",) + bsig not in rec.seen:
                 c = res.shape[1]
-                s1, s2, a1, a2 = (torch.zeros(c, dtype=torch.float64) for _ in range(4))
+                s1, s2, a1, a2 = (_zeros64(c) for _ in range(4))
                 for i in range(res.shape[0]):
                     d = _masked(res[i:i + 1], None if zt is None else zt[i:i + 1], bnsum.y[i:i + 1], bnsum.msc, bnsum.msh)
                     xh = (_c64(bnsum.y[i:i + 1]) - _V(bnsum.mean)) * _V(bnsum.invstd)
                     s1 += d.sum((0, 2, 3)); a1 += d.abs().sum((0, 2, 3))
                     d = d * xh
                     s2 += d.sum((0, 2, 3)); a2 += d.abs().sum((0, 2, 3))
-                o = bnsum.sums.cpu()
+                o = bnsum.sums.to(REF["dev"])
                 e1 = float((o[:c] - s1).abs().max() / max(float(a1.max()), 1e-30))
                 e2 = float((o[c:2 * c] - s2).abs().max() / max(float(a2.max()), 1e-30))
                 rec.note("dgrad_bnsum", bsig, max(e1, e2), tol)
@@ -270,15 +287,15 @@ def audit(tol=2e-5, tol_wgrad=2e-4, sample=False):
                 if base is not None:
                     ref = ref + _c64(base[n0:n0 + 1, :, h0:h1, :])
                 if relu_mask is not None:
-                    ref = ref * (relu_mask[n0:n0 + 1, :, h0:h1, :].detach().cpu() > 0)
+                    ref = ref * (relu_mask[n0:n0 + 1, :, h0:h1, :].detach().to(REF["dev"]) > 0)
                 err = max(err, _rel(res[n0:n0 + 1, :, h0:h1, :], ref))
             rec.note("dgrad", sig, err, tol)
         elif ("dgrad",) + sig not in rec.seen:
             ref = torch.nn.grad.conv2d_input(tuple(x_shape), _q64(w, qq), _q64(dy, qq), stride, pad)
             if base is not None:
-                ref = ref + base.cpu().double()
+                ref = ref + base.to(REF["dev"]).double()
             if relu_mask is not None:
-                ref = ref * (relu_mask.detach().cpu() > 0)
+                ref = ref * (relu_mask.detach().to(REF["dev"]) > 0)
             rec.note("dgrad", sig, _rel(res, ref), tol)
         return res
 
@@ -302,13 +319,15 @@ def audit(tol=2e-5, tol_wgrad=2e-4, sample=False):
             err = float((got[ks] - ref).abs().max() / scale)
             rec.note("wgrad", sig, err, tol_wgrad)
             if flops >= FULL_FP32_WGRAD_FLOPS:
-                full = torch.nn.grad.conv2d_weight(_q64(x, qq).float().contiguous(), tuple(dw.shape),
-                                                   _q64(dy, qq).float().contiguous(), stride, pad).double()
-                rec.note("wgrad_full_fp32", sig, float((got - full).abs().max() / max(float(full.abs().max()), 1e-30)),
+                # always on the HOST: an fp32 convolution on the device would go through MIOpen, whose first use of a shape
+                # compiles kernels for ~100 s on a fresh box (and is not the independent implementation wanted here)
+                full = torch.nn.grad.conv2d_weight(_q64(x, qq).float().cpu().contiguous(), tuple(dw.shape),
+                                                   _q64(dy, qq).float().cpu().contiguous(), stride, pad).double()
+                rec.note("wgrad_full_fp32", sig, float((got.cpu() - full).abs().max() / max(float(full.abs().max()), 1e-30)),
                          tol_wgrad)
         elif check:
             ref = torch.nn.grad.conv2d_weight(_q64(x, qq), tuple(dw.shape), _q64(dy, qq), stride, pad)
-            rec.note("wgrad", sig, _rel(res.cpu().double() - base.cpu().double(), ref), tol_wgrad)
+            rec.note("wgrad", sig, _rel(res.to(REF["dev"]).double() - base.to(REF["dev"]).double(), ref), tol_wgrad)
         return res
 
     def stem_wgrad_s2d(x, dy, dw):
@@ -333,11 +352,11 @@ def audit(tol=2e-5, tol_wgrad=2e-4, sample=False):
         return res
 
     def _masked(dz, z, y, mask_scale, mask_shift):
-        d = dz.detach().cpu().double()
+        d = dz.detach().to(REF["dev"]).double()
         if z is not None:
-            d = d * (z.detach().cpu() > 0)
+            d = d * (z.detach().to(REF["dev"]) > 0)
         elif mask_scale is not None:
-            d = d * ((y.detach().cpu().double() * _V(mask_scale) + _V(mask_shift)) > 0)
+            d = d * ((y.detach().to(REF["dev"]).double() * _V(mask_scale) + _V(mask_shift)) > 0)
         return d
 
     def bn_apply(y, scale, shift, residual=None, relu=False, res_scale=None, res_shift=None):
@@ -360,14 +379,14 @@ def audit(tol=2e-5, tol_wgrad=2e-4, sample=False):
         sig = (tuple(y.shape), z is not None, mask_scale is not None)
         if ("bn_bwd_reduce",) + sig not in rec.seen:
             c = y.shape[1]
-            s1, s2, a1, a2 = (torch.zeros(c, dtype=torch.float64) for _ in range(4))
+            s1, s2, a1, a2 = (_zeros64(c) for _ in range(4))
             for i in range(y.shape[0]):                   # whole tensor, one image at a time (memory)
                 d = _masked(dz[i:i + 1], None if z is None else z[i:i + 1], y[i:i + 1], mask_scale, mask_shift)
                 xh = (_c64(y[i:i + 1]) - _V(mean)) * _V(invstd)
                 s1 += d.sum((0, 2, 3)); a1 += d.abs().sum((0, 2, 3))
                 d = d * xh
                 s2 += d.sum((0, 2, 3)); a2 += d.abs().sum((0, 2, 3))
-            o = out.cpu()
+            o = out.to(REF["dev"])
             # column sums: error relative to the sum of magnitudes (the quantity the rounding scales with)
             e1 = float((o[:c] - s1).abs().max() / max(float(a1.max()), 1e-30))
             e2 = float((o[c:2 * c] - s2).abs().max() / max(float(a2.max()), 1e-30))
@@ -406,7 +425,7 @@ def audit(tol=2e-5, tol_wgrad=2e-4, sample=False):
                 rec.sampled.add(("sum_n",) + sig)
             ref = sum(_c64(g[ns]) for g in grads)
             if z is not None:
-                ref = ref * (z[ns].detach().cpu() > 0)
+                ref = ref * (z[ns].detach().to(REF["dev"]) > 0)
             rec.note("sum_n", sig, _rel(out[ns], ref), tol)
         return out
 
@@ -426,7 +445,7 @@ def audit(tol=2e-5, tol_wgrad=2e-4, sample=False):
         if ("upsample_add_bwd",) + sig not in rec.seen:
             ns = _img_sample(dout.shape[0]) if big_elems(dout) else list(range(dout.shape[0]))
             with torch.enable_grad():                 # we are inside autograd's backward: grad mode is off here
-                low = torch.zeros((len(ns),) + tuple(low_shape[1:]), dtype=torch.float64, requires_grad=True)
+                low = torch.zeros((len(ns),) + tuple(low_shape[1:]), dtype=torch.float64, device=REF["dev"], requires_grad=True)
                 u = F.interpolate(F.interpolate(low, scale_factor=2), size=tuple(dout.shape[2:]), mode="bilinear",
                                   align_corners=True)
                 u.backward(_c64(dout[ns]))
@@ -439,18 +458,18 @@ def audit(tol=2e-5, tol_wgrad=2e-4, sample=False):
         c = dbias.numel()
         sig = (tuple(dy.shape), z is not None, c)
         if ("bias_relu_bwd",) + sig not in rec.seen:
-            tot, mag, e = torch.zeros(c, dtype=torch.float64), torch.zeros(c, dtype=torch.float64), 0.0
+            tot, mag, e = _zeros64(c), _zeros64(c), 0.0
             chunks = range(dy.shape[0]) if (dy.dim() == 4 and big_elems(dy)) else [slice(None)]
             for i in chunks:                              # whole tensor, one image at a time when it is large
                 sl = slice(i, i + 1) if isinstance(i, int) else i
                 d = _c64(dy[sl])
                 if z is not None:
-                    d = d * (z[sl].detach().cpu() > 0)
+                    d = d * (z[sl].detach().to(REF["dev"]) > 0)
                     e = max(e, float((_c64(out[sl]) - d).abs().max()))
                 flat = d.permute(0, 2, 3, 1).reshape(-1, c) if d.dim() == 4 else d.reshape(-1, c)
                 tot += flat.sum(0); mag += flat.abs().sum(0)
             e = e / max(float(dy.abs().max()), 1e-30)
-            e = max(e, float(((dbias - base).cpu().double() - tot).abs().max() / max(float(mag.max()), 1e-30)))
+            e = max(e, float(((dbias - base).to(REF["dev"]).double() - tot).abs().max() / max(float(mag.max()), 1e-30)))
             rec.note("bias_relu_bwd", sig, e, tol)
         return out
 
@@ -486,7 +505,7 @@ def audit(tol=2e-5, tol_wgrad=2e-4, sample=False):
         got = orig["bn_finalize"](sums, count, gamma, beta, running_mean, running_var, momentum, eps, count_dev,
                                   num_batches_tracked)
         if check:
-            ref = _finalize_ref(sums.detach().cpu().double(), count, gamma, beta, rm0, rv0, momentum, eps)
+            ref = _finalize_ref(sums.detach().to(REF["dev"]).double(), count, gamma, beta, rm0, rv0, momentum, eps)
             e = _finalize_err(got, ref, running_mean, running_var)
             if nb0 is not None and int(num_batches_tracked) != nb0 + 1:
                 e = float("inf")
@@ -502,7 +521,7 @@ def audit(tol=2e-5, tol_wgrad=2e-4, sample=False):
         got = orig["bn_stats_finalize"](slab, count, gamma, beta, running_mean, running_var, momentum, eps,
                                         num_batches_tracked)
         if check:
-            sums = slab.detach().cpu().view(-1, 2 * c).sum(0)
+            sums = slab.detach().to(REF["dev"]).view(-1, 2 * c).sum(0)
             ref = _finalize_ref(sums, count, gamma, beta, rm0, rv0, momentum, eps)
             rec.note("bn_stats_finalize", sig, _finalize_err(got, ref, running_mean, running_var), 1e-5)
         return got
@@ -517,5 +536,6 @@ def audit(tol=2e-5, tol_wgrad=2e-4, sample=False):
     try:
         yield rec
     finally:
+        REF["dev"] = "cpu"
         for n, f in orig.items():
             setattr(ops, n, f)

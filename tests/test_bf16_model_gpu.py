@@ -169,7 +169,7 @@ def test_config4_bf16_full_size_train_step_every_kernel_call_sampled():
         op.model.train()
         b = op.training_loader.get_batch()
         t0 = time.perf_counter()
-        with audit(sample=True) as rec:
+        with audit(sample=True, ref_device="cuda") as rec:
             _, losses = op.train_step(0, b)
             torch.cuda.synchronize()
         dt = time.perf_counter() - t0

@@ -145,7 +145,7 @@ def test_config2_full_size_train_step_every_kernel_call_sampled():
     op.model.train()
     b = op.training_loader.get_batch()
     t0 = time.perf_counter()
-    with audit(sample=True) as rec:
+    with audit(sample=True, ref_device="cuda") as rec:      # fp64 reference arithmetic by torch's own device kernels (kernel_audit.REF)
         _, losses = op.train_step(0, b)
         torch.cuda.synchronize()
     dt = time.perf_counter() - t0

@@ -180,10 +180,19 @@ def test_config2_f16x3_full_size_train_step_every_kernel_call_sampled():
         op.model.train()
         b = op.training_loader.get_batch()
         t0 = time.perf_counter()
-        with _Calls() as calls, audit(sample=True) as rec:
-            _, losses = op.train_step(0, b)
-            torch.cuda.synchronize()
+        # RR_AMAX_CHECK: every REMEMBERED operand maximum (ops.amax_of) is recomputed at the moment it is used and must
+        # equal the remembered word — kernels write through raw pointers, which never move a tensor's version counter
+        from rrnet_amd import ops
+        saved_chk, ops._AMAX_CHECK, ops.AMAX_CHECKED[0] = ops._AMAX_CHECK, True, 0
+        try:
+            with _Calls() as calls, audit(sample=True, ref_device="cuda") as rec:
+                _, losses = op.train_step(0, b)
+                torch.cuda.synchronize()
+        finally:
+            ops._AMAX_CHECK = saved_chk
         dt = time.perf_counter() - t0
+        print("remembered maxima verified against a fresh reduction: %d" % ops.AMAX_CHECKED[0])
+        assert ops.AMAX_CHECKED[0] >= 100, ops.AMAX_CHECKED[0]
     finally:
         cfg.Train.batch_size, cfg.Train.crop_size, cfg.Model.backbone, cfg.Model.conv_math = saved
     assert all(np.isfinite(float(v.detach())) for v in losses)

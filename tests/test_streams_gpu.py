@@ -22,7 +22,14 @@ exactly such rounding-sized noise, so two runs of the DEFAULT one-stream step al
     hundreds of milliseconds behind and its operands have long been released by the main stream when they are read.  A
     lifetime / ordering bug turns into a wrong gradient instead of passing by luck;
   * the test's own sensitivity: with the joins dropped the comparison fails;
-  * the same pair for the DCN backward's two streams (RR_DCN_BWD_STREAMS) at model level (config 4 heads)."""
+  * the same pair for the DCN backward's two streams (RR_DCN_BWD_STREAMS) at model level (config 4 heads).
+
+Round 5: the up1 branch of the three outermost hourglass modules of each stack runs on a stream of its own beside the
+low1 -> low2 -> low3 branch (RR_BRANCH_STREAMS, rrnet_amd/functional.py: branch_stream; autograd runs every node's
+backward on the stream of its forward).  What autograd's own hand-over cannot see is the shared fan-in buffer the two
+branches' first blocks add their input gradients into through raw pointers (GradAcc.begin / end: events).  "Side stream"
+below means BOTH mechanisms (the product default); at 256x256 each also runs alone; the stress switch delays the branch
+streams as well (branch_stress), and the sabotage arm drops the waits on them too."""
 import json
 import os
 import subprocess
@@ -46,7 +53,9 @@ BOUND = 1e-5
 # gradient of ~0 flip sign with the atomics' rounding; a gradient that has not landed when Adam runs moves whole tensors
 MOVED = 1e-3
 DET = {"RR_CONV_SPLITK": "0"}          # deterministic forward / data gradients (no split-K atomics)
-KEYS = ("RR_WGRAD_STREAM", "RR_WGRAD_STRESS", "RR_DCN_BWD_STREAMS", "RR_CONV_SPLITK", "RR_DP_FORCE")
+KEYS = ("RR_WGRAD_STREAM", "RR_WGRAD_STRESS", "RR_DCN_BWD_STREAMS", "RR_CONV_SPLITK", "RR_DP_FORCE", "RR_BRANCH_STREAMS")
+ONE = {"RR_WGRAD_STREAM": "0", "RR_BRANCH_STREAMS": "0"}      # the reference's shape: every kernel on one ordered stream
+MANY = {"RR_WGRAD_STREAM": "2", "RR_BRANCH_STREAMS": "3"}     # the product's default: wgrad side stream + three hourglass branch streams
 
 
 def _run(tmp, tag, env, size, batch, repeats, extra=()):
@@ -101,19 +110,26 @@ def _compare(ref, other, tag, bound=BOUND):
 
 @pytest.mark.parametrize("size,batch", [(256, 2), (1024, 8)])
 def test_side_stream_wgrad_equals_one_stream(tmp_path, size, batch):
-    one = _run(tmp_path, "one_stream", dict(DET, RR_WGRAD_STREAM="0"), size, batch, 2)
+    one = _run(tmp_path, "one_stream", dict(DET, **ONE), size, batch, 2)
     noise = max(r["grad"][0] for r in one[1]["repeat_vs_first"])
     print("one stream, deterministic forward, run to run: %.2e" % noise)
     assert noise <= BOUND, noise
-    side = _run(tmp_path, "side_stream", dict(DET, RR_WGRAD_STREAM="2"), size, batch, 5)
-    assert side[1]["env"]["RR_WGRAD_STREAM"] == "2"
+    side = _run(tmp_path, "side_stream", dict(DET, **MANY), size, batch, 5)
+    assert side[1]["env"]["RR_WGRAD_STREAM"] == "2" and side[1]["env"]["RR_BRANCH_STREAMS"] == "3"
     _compare(one, side, "side stream vs one stream (%dx%d, B=%d)" % (size, size, batch))
     for i, r in enumerate(side[1]["repeat_vs_first"]):
         assert r["grad"][0] <= BOUND and r["param"] <= MOVED and r["buffers"] <= 2e-5, (i, r)
     print("side stream, 5 runs: worst run-to-run %.2e" % max(r["grad"][0] for r in side[1]["repeat_vs_first"]))
-    stress = _run(tmp_path, "stress", dict(DET, RR_WGRAD_STREAM="2", RR_WGRAD_STRESS="1"), size, batch, 2)
-    _compare(one, stress, "side stream under stress vs one stream")
+    stress = _run(tmp_path, "stress", dict(DET, **MANY, RR_WGRAD_STRESS="1"), size, batch, 2)
+    _compare(one, stress, "side + branch streams under stress vs one stream")
     assert stress[1]["repeat_vs_first"][0]["grad"][0] <= BOUND
+    if size == 256:
+        # each mechanism alone, under stress: the branch streams without the weight-gradient stream, and the reverse
+        br = _run(tmp_path, "branch_only", dict(DET, RR_WGRAD_STREAM="0", RR_BRANCH_STREAMS="5", RR_WGRAD_STRESS="1"), size, batch, 2)
+        _compare(one, br, "five branch streams alone under stress vs one stream")
+        assert br[1]["repeat_vs_first"][0]["grad"][0] <= BOUND
+        wg = _run(tmp_path, "wgrad_only", dict(DET, RR_WGRAD_STREAM="2", RR_BRANCH_STREAMS="0", RR_WGRAD_STRESS="1"), size, batch, 2)
+        _compare(one, wg, "weight-gradient side stream alone under stress vs one stream")
 
 
 @pytest.mark.parametrize("size,batch", [(1024, 8)])
@@ -122,8 +138,8 @@ def test_side_stream_default_path_with_split_k(tmp_path, size, batch):
     layers (module docstring), so: parameters whose one-stream run-to-run spread is within BOUND must match within
     3 x BOUND between the arms; over ALL parameters the side-stream arm's distance to the one-stream arm must look like
     the one-stream arm's distance to itself (median and count above BOUND), not worse."""
-    one = _run(tmp_path, "one_default", {"RR_WGRAD_STREAM": "0"}, size, batch, 2)
-    side = _run(tmp_path, "side_default", {"RR_WGRAD_STREAM": "2", "RR_WGRAD_STRESS": "1"}, size, batch, 2)
+    one = _run(tmp_path, "one_default", dict(ONE), size, batch, 2)
+    side = _run(tmp_path, "side_default", dict(MANY, RR_WGRAD_STRESS="1"), size, batch, 2)
     sl = one[1]["slices"]
     g1, g2 = _load(one[0], "grad.bin"), _load(one[0], "grad2.bin")
     self_rel, _ = _rel(g2, g1, sl)
@@ -154,8 +170,8 @@ def test_stress_mode_detects_a_missing_join(tmp_path):
     """The test's own sensitivity: with every wait ON the side stream dropped (the worker patches
     torch.cuda.Stream.wait_stream; the product code is untouched) and the side stream delayed, Adam reads the gradient
     buffer before the weight gradients have landed — the comparison above must FAIL, i.e. it can see an ordering bug."""
-    one = _run(tmp_path, "one_stream", dict(DET, RR_WGRAD_STREAM="0"), 256, 2, 1)
-    bad = _run(tmp_path, "nojoin", dict(DET, RR_WGRAD_STREAM="2", RR_WGRAD_STRESS="1"), 256, 2, 1, ["--sabotage"])
+    one = _run(tmp_path, "one_stream", dict(DET, **ONE), 256, 2, 1)
+    bad = _run(tmp_path, "nojoin", dict(DET, **MANY, RR_WGRAD_STRESS="1"), 256, 2, 1, ["--sabotage"])
     p = _moved(_load(bad[0], "param.bin"), _load(one[0], "param.bin"))
     print("joins removed: %.1f %% of the parameter elements got a different Adam update" % (100 * p))
     assert p > 10 * MOVED, p
@@ -167,7 +183,7 @@ def test_gradient_conditioning_at_initialisation(tmp_path):
     gradient THROUGH them, so do most parameters of the network (the stem included); only the layers downstream of the
     last hourglass (the last stack's heads) respond at rounding size.  This is a property of the reference's network at its
     random initialisation (BatchNorm over few samples in the deep levels, 100+ layers), not of the kernels."""
-    out, meta = _run(tmp_path, "perturb", dict(DET, RR_WGRAD_STREAM="0"), 256, 2, 2, ["--perturb", "1e-7"])
+    out, meta = _run(tmp_path, "perturb", dict(DET, **ONE), 256, 2, 2, ["--perturb", "1e-7"])
     rel, _ = _rel(_load(out, "grad2.bin"), _load(out, "grad.bin"), meta["slices"])
     names = meta["names"]
     worst = int(rel.argmax())
@@ -183,9 +199,9 @@ def test_gradient_conditioning_at_initialisation(tmp_path):
 def test_dcn_backward_streams_equal_one_stream(tmp_path):
     """config 4 heads (six DCN layers, bf16 operands): wgrad beside dgrad on two streams vs one after the other."""
     extra = ["--dcn", "--backbone", "hourglass_tiny"]
-    one = _run(tmp_path, "dcn_one", dict(DET, RR_WGRAD_STREAM="0", RR_DCN_BWD_STREAMS="0"), 256, 2, 2, extra)
+    one = _run(tmp_path, "dcn_one", dict(DET, **ONE, RR_DCN_BWD_STREAMS="0"), 256, 2, 2, extra)
     noise = max(r["grad"][0] for r in one[1]["repeat_vs_first"])
-    two = _run(tmp_path, "dcn_two", dict(DET, RR_WGRAD_STREAM="2", RR_DCN_BWD_STREAMS="1", RR_WGRAD_STRESS="1"), 256, 2, 3, extra)
+    two = _run(tmp_path, "dcn_two", dict(DET, **MANY, RR_DCN_BWD_STREAMS="1", RR_WGRAD_STRESS="1"), 256, 2, 3, extra)
     # the DCN data gradient pre-sums d input in fixed point on chip and adds with float atomics: same spread in both arms
     bound = max(BOUND, 4 * noise)
     print("DCN heads, one stream run to run: %.2e" % noise)
@@ -198,11 +214,11 @@ def test_side_stream_bf16_model_equals_one_stream(tmp_path):
     """The same A/B for the config-4 precision (cfg.Model.bf16: every convolution on the bf16-operand kernels, incl. the
     parity-class stride-2 data gradients and the bf16 weight-gradient kernel on the side stream), under stress."""
     extra = ["--bf16"]
-    one = _run(tmp_path, "bf16_one", dict(DET, RR_WGRAD_STREAM="0"), 256, 2, 2, extra)
+    one = _run(tmp_path, "bf16_one", dict(DET, **ONE), 256, 2, 2, extra)
     noise = max(r["grad"][0] for r in one[1]["repeat_vs_first"])
     print("bf16 model, one stream run to run: %.2e" % noise)
     assert noise <= BOUND, noise
-    side = _run(tmp_path, "bf16_side", dict(DET, RR_WGRAD_STREAM="2", RR_WGRAD_STRESS="1"), 256, 2, 3, extra)
+    side = _run(tmp_path, "bf16_side", dict(DET, **MANY, RR_WGRAD_STRESS="1"), 256, 2, 3, extra)
     _compare(one, side, "bf16 model: side stream under stress vs one stream")
     for r in side[1]["repeat_vs_first"]:
         assert r["grad"][0] <= BOUND, r
@@ -214,11 +230,11 @@ def test_side_stream_f16x3_model_equals_one_stream(tmp_path):
     to the weight gradient on the side stream).  A maximum read before its reduction has finished gives a wrong operand
     scale — gradients off by powers of two or overflowing to inf — which this comparison and the finite check catch."""
     extra = ["--math", "f16x3"]
-    one = _run(tmp_path, "split_one", dict(DET, RR_WGRAD_STREAM="0"), 256, 2, 2, extra)
+    one = _run(tmp_path, "split_one", dict(DET, **ONE), 256, 2, 2, extra)
     noise = max(r["grad"][0] for r in one[1]["repeat_vs_first"])
     print("f16x3 model, one stream run to run: %.2e" % noise)
     assert noise <= BOUND, noise
-    side = _run(tmp_path, "split_side", dict(DET, RR_WGRAD_STREAM="2", RR_WGRAD_STRESS="1"), 256, 2, 3, extra)
+    side = _run(tmp_path, "split_side", dict(DET, **MANY, RR_WGRAD_STRESS="1"), 256, 2, 3, extra)
     _compare(one, side, "f16x3 model: side stream under stress vs one stream")
     for r in side[1]["repeat_vs_first"]:
         assert r["grad"][0] <= BOUND, r
