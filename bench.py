@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--math", default="f32", choices=["f32", "f16x3"], help="cfg.Model.conv_math of the timed train step (f16x3: "
                     "split-operand kernels on the large layers; the default line stays on the fp32 matrix instruction)")
     ap.add_argument("--detail", action="store_true", help="print a per-layer-shape conv time table to stderr")
+    ap.add_argument("--no-host-fed", action="store_true", help="skip the host-fed variant of the headline (pinned host pool -> "
+                    "copy stream -> device slots; reported as the extra key `input_residency_host`)")
     return ap.parse_args()
 
 
@@ -186,6 +188,28 @@ def config4_train_step(a, steps=5):
     convolutions replaced by DCN layers (bf16 matrix operands, non-degenerate offsets), same batch, same loop."""
     import bench_config4
     return bench_config4.run(a.batch, a.size, steps, True, a.backbone)
+
+
+def host_fed_steps(op, cfg, a, step_no):
+    """`a.steps` timed train steps of the SAME operator fed from pinned host memory (one ~100 MB H2D copy per step on a
+    copy stream, one batch ahead) -> {"value", "ms_per_step", ...}.  Reported next to the device-resident headline."""
+    from rrnet_amd.datasets.synthetic import HostFedDronesDET
+    ld = HostFedDronesDET(cfg, a.batch, a.size, a.size, rank=0, pool=2)
+    for _ in range(2):
+        op.train_step(step_no, ld.get_batch()); step_no += 1
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(a.steps):
+        last = op.train_step(step_no, ld.get_batch())[1]; step_no += 1
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    finite = bool(all(torch.isfinite(v.detach()).all() for v in last))
+    nbytes = sum(t.numel() * t.element_size() for t in ld.host[0][:3])
+    return {"value": round(a.batch * a.steps / dt, 4), "unit": "images/sec", "ms_per_step": round(dt / a.steps * 1e3, 3),
+            "steps": a.steps, "h2d_bytes_per_step": nbytes, "finite": finite,
+            "how": "pinned host pool -> copy stream (one batch ahead) -> two device slots, event-ordered hand-over; targets "
+                   "built on the device from the copied annotations inside the timed region"}
 
 
 def main():
@@ -359,6 +383,13 @@ def main():
                               dist.get_backend()
         if a.backbone == "hourglass" and a.size == 1024:
             out["step_mfma_frac"] = round(out["value"] / world * ALGO_TFLOP_PER_IMAGE / (2500.0 / 3.0 if a.math == "f16x3" else FP32_MFMA_PEAK_TFLOPS), 4)
+        if world == 1 and not a.no_host_fed and a.math == "f32":
+            # the reference's hand-over: host batches, one PCIe crossing per step (rrnet_amd/datasets/synthetic.py:
+            # HostFedDronesDET: pinned pool, copy stream one batch ahead, event-ordered).  Same operator, same steps.
+            try:
+                out["input_residency_host"] = host_fed_steps(op, cfg, a, step_no)
+            except Exception as e:
+                out["input_residency_host"] = {"value": None, "error": repr(e)}
         if world == 1 and not a.no_extras:
             del op, batches
             import gc

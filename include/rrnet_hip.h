@@ -155,6 +155,25 @@ int rr_conv_dgrad_s1_relubias_bf16(const float *dy, const float *wt, float *dx, 
 int rr_conv_wgrad_bf16(const float *x, const float *dy, float *dw, int n, int h, int wd, int c, int k,
                        int r, int s, int stride, int pad_h, int pad_w, int out_h, int out_w, hipStream_t stream);
 
+/* ---- convolutions on 16-bit ACTIVATIONS (round 5; config 4, cfg.Model.bf16; csrc/conv16.hip) ------------------------
+ * Same convolutions (reference: nn.Conv2d of /root/reference/backbones/hourglass.py:12-61,127-199,
+ * detectors/centernet_detector.py:80-93), same arithmetic contract as the *_bf16 entry points above (result == the fp32
+ * entry point on bf16-rounded operands up to the summation order; fp32 accumulation) — but both operands are bf16 tensors
+ * IN HBM: x / dy as written by their producers (rr_bn_apply_b16, rr_bn_bwd_apply_b16, rr_to_bf16), the filter's bf16
+ * copy (rr_weight_flip_transpose_batch_bf16: plain for the forward, flipped / transposed for the data gradient).  They
+ * reach LDS by LDS-DMA; 256 channels x 256 pixels per workgroup on v_mfma_f32_16x16x32_bf16.
+ * Shapes: rr_conv16_supported (C % 64 == 0, K % 256 == 0, R*S <= 16, stride 1 or 2; input < 2 GiB); the host layer keeps
+ * the *_bf16 entry points for the rest.  y / dx (fp32) and y16 / dx16 (the same values rounded to bf16, for a consumer
+ * that is again a convolution): either may be NULL, not both.  stat_slab: [ceil(M / 256)][2][K] doubles
+ * (rr_conv16_stat_slab_bytes), reduced by rr_bn_reduce_slab / rr_bn_stats_finalize like the fp32 kernel's. */
+int rr_conv16_supported(int c, int k, int r, int s, int stride);
+size_t rr_conv16_stat_slab_bytes(int n, int p, int q, int k);
+int rr_conv16_fprop(const unsigned short *x, const unsigned short *w, const float *bias, float *y, unsigned short *y16,
+                    double *stat_slab, int n, int h, int wd, int c, int k, int r, int s, int stride, int pad_h, int pad_w,
+                    int relu, hipStream_t stream);
+int rr_conv16_dgrad_s1(const unsigned short *dy, const unsigned short *wt, float *dx, unsigned short *dx16, int n, int h,
+                       int wd, int c, int k, int r, int s, int pad_h, int pad_w, int accumulate, hipStream_t stream);
+
 /* ---- split-operand convolutions ("f16x3", cfg.Model.conv_math; csrc/conv_bf16.hip) -------------------------------
  * fp32 in, fp32 out, fp32 accumulation, as rr_conv_fprop / rr_conv_dgrad / rr_conv_wgrad (reference: nn.Conv2d in
  * /root/reference/backbones/hourglass.py:12-61); inside the kernel each operand is the sum of two fp16 values (22

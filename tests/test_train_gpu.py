@@ -166,3 +166,29 @@ def test_flipped_filter_cache_follows_the_parameters():
     sd = {k: v.clone() * 1.5 for k, v in m.state_dict().items()}
     m.load_state_dict(sd)
     check("after load_state_dict")
+
+
+def test_host_fed_loader_hands_over_the_same_batches():
+    """The reference's loader hands HOST batches to the step (operators/rrnet_operator.py:121).  HostFedDronesDET (pinned
+    pool, copy stream one batch ahead, event hand-over, two device slots) must deliver, bit for bit, the batches the
+    device-resident SyntheticDronesDET holds — also while the compute stream is busy and the slots are being recycled."""
+    from types import SimpleNamespace
+    from rrnet_amd.datasets.synthetic import HostFedDronesDET, synth_batch
+    cfg = SimpleNamespace(seed=219, num_classes=10, Train=SimpleNamespace(scale_factor=4))
+    ld = HostFedDronesDET(cfg, 2, 256, 320, boxes_per_image=40, pool=3)
+    ref = [synth_batch(2, 256, 320, 40, 219 + 1000 * i, 0, 4, 10, "cuda") for i in range(3)]
+    keep = []
+    for step in range(7):                               # wraps around the pool and around the two slots several times
+        b = ld.get_batch()
+        r = ref[step % 3]
+        # work on the compute stream that READS the batch late: a spin, then a reduction of the frames
+        torch.cuda._sleep(2_000_000)
+        keep.append((b[0].double().sum(), r[0].double().sum()))
+        for got, want in zip(b[:7], r[:7]):
+            assert got.shape == want.shape and got.dtype == want.dtype
+            assert torch.equal(got, want), step
+        assert b[0].is_contiguous(memory_format=torch.channels_last)
+        assert b[7] == r[7]
+    torch.cuda.synchronize()
+    for a, c in keep:
+        assert float(a) == float(c)
