@@ -173,6 +173,25 @@ int rr_conv16_fprop(const unsigned short *x, const unsigned short *w, const floa
                     int relu, hipStream_t stream);
 int rr_conv16_dgrad_s1(const unsigned short *dy, const unsigned short *wt, float *dx, unsigned short *dx16, int n, int h,
                        int wd, int c, int k, int r, int s, int pad_h, int pad_w, int accumulate, hipStream_t stream);
+/* dw [k][r][s][c] fp32 += x (*) dy, both bf16 (rr_conv_wgrad's contract on bf16-rounded operands; fp32 atomics).
+ * Shapes: rr_conv16_wgrad_supported (K % 256 == 0, C % 128 == 0, stride 1 or 2; tensors < 2 GiB). */
+int rr_conv16_wgrad_supported(int c, int k, int r, int s, int stride);
+int rr_conv16_wgrad(const unsigned short *x, const unsigned short *dy, float *dw, int n, int h, int wd, int c, int k,
+                    int r, int s, int stride, int pad_h, int pad_w, hipStream_t stream);
+
+/* Producers of the bf16 images (csrc/elementwise.hip): rr_bn_apply / rr_bn_bwd_apply (reference: nn.BatchNorm2d + ReLU + residual
+ * add of backbones/hourglass.py:31-40 and their autograd backward) with a second, bf16 output holding the same values
+ * rounded to nearest even — written in the same pass, so the convolution that consumes the tensor never reads the fp32
+ * one.  out / dx (fp32) may be NULL when nothing else reads them.  rr_to_bf16: the plain conversion, for operands that
+ * come from elsewhere (fan-in sums, the up-sample add, head gradients). */
+int rr_bn_apply_b16(const float *y, const float *scale, const float *shift, const float *res, const float *res_scale,
+                    const float *res_shift, float *out, unsigned short *out16, long total, int c, int relu,
+                    hipStream_t stream);
+int rr_bn_bwd_apply_b16(const float *dz, const float *z, const float *y, const float *mean, const float *invstd,
+                        const float *gamma, const float *mask_scale, const float *mask_shift, const double *sums,
+                        double count, const double *count_dev, float *dx, unsigned short *dx16, float *g_out,
+                        int g_accumulate, float *dgamma, float *dbeta, long total, int c, hipStream_t stream);
+int rr_to_bf16(const float *x, unsigned short *out, long total, hipStream_t stream);
 
 /* ---- split-operand convolutions ("f16x3", cfg.Model.conv_math; csrc/conv_bf16.hip) -------------------------------
  * fp32 in, fp32 out, fp32 accumulation, as rr_conv_fprop / rr_conv_dgrad / rr_conv_wgrad (reference: nn.Conv2d in

@@ -32,6 +32,7 @@
 // wgrad (conv16_wgrad_kernel): see below.
 #include "common.h"
 #include "rrnet_hip.h"
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 namespace {
 
@@ -269,6 +270,155 @@ int launch_igemm(const Args &a, hipStream_t stream, const char *name)
     return RR_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// wgrad (conv16_wgrad_kernel).  dW[ko][tap][c] += sum over a slice of the N*P*Q pixels of dY[m][ko] * X[pix(m,tap)][c]: per tap a
+// GEMM with M = K (ko), N = C and the PIXELS as the reduction.  Both operands are reduction-major in memory ([pixel][channel]); they
+// are kept that way in LDS — 32-channel blocks of [32 pixels][32 channels] bf16 (64-byte rows: the conflict-free shape for the
+// transposing read) — and the fragments come out of ds_read_b64_tr_b16, which hands every lane the 8 consecutive pixels of its
+// channel (csrc/conv_bf16.hip: lds_tr_frag, checked lane by lane by tools/tr_probe.hip).
+//   tile      256 (ko) x NT (c, 256 or 128) per workgroup and tap, 512 threads = 8 waves as 4 (ko) x 2 (c); v_mfma_f32_32x32x16_bf16
+//   K-step    32 pixels; 16 KiB of dY + NT/16 KiB of X per step, by LDS-DMA (a 1-KiB piece = 16 pixels x 32 channels: lane l reads
+//             pixel l/4, 16-byte chunk l%4), FOUR buffers: the pieces of K-step k+2 are issued before the MFMAs of step k, a counted
+//             s_waitcnt vmcnt leaves one step in flight across the (one) barrier per step
+//   split     the pixel range is cut so that taps x tiles x splits fills the chip; partial sums are added with fp32 atomics
+// Taps outside the image, pixels beyond M: out-of-range buffer offset -> zeros.
+struct WArgs {
+    const unsigned short *x, *dy;
+    float *dw;
+    int N, H, W, C, K, R, S, P, Q, stride, pad_h, pad_w;
+    int M, steps_per_split, kt, nt;
+};
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char *blk, int k0, int lane)
+{   // blk: one [32 pixels][32 channels] block; -> the 32x32x16 operand fragment of pixels k0 .. k0+15
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    const unsigned char *a = blk + ((k0 + 8 * (g >> 1) + q) * 32 + 16 * (g & 1) + 4 * p) * 2;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)a);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(a + 4 * 32 * 2));
+    union { s16x4 h[2]; bf16x8 v; } u;
+    u.h[0] = lo; u.h[1] = hi;
+    return u.v;
+}
+
+template <int NT>
+__global__ __launch_bounds__(512, 1) void conv16_wgrad_kernel(const WArgs a)
+{
+    constexpr int NB = NT / 32;                 // X blocks per K-step
+    constexpr int A_BYTES = 8 * 2048, B_BYTES = NB * 2048, STAGE = A_BYTES + B_BYTES;
+    constexpr int TN = NT / 64;                 // 32-wide c tiles per wave (wave tile 64 ko x NT/2 c)
+    extern __shared__ __align__(16) unsigned char lds[];     // [4 stages][dY blocks | X blocks]
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wk = wave >> 1, wn = wave & 1;
+    const int RS = a.R * a.S;
+    int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int tap = logical % RS; logical /= RS;
+    const int n_tile = logical % a.nt; logical /= a.nt;
+    const int k_tile = logical % a.kt;
+    const int split = logical / a.kt;
+    const int r = tap / a.S, s = tap - r * a.S;
+    const int ko0 = k_tile * 256, c0 = n_tile * NT;
+    const int total_steps = (a.M + 31) / 32;
+    const int st_begin = split * a.steps_per_split;
+    int st_end = st_begin + a.steps_per_split;
+    if (st_end > total_steps) st_end = total_steps;
+    if (st_begin >= st_end) return;
+
+    // this lane's two pixel rows of a K-step (lane/4 and 16 + lane/4) and its 16-byte chunk of a block row
+    const int chunk = lane & 3;
+    int pn[2], pp[2], pq[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const long m = (long)st_begin * 32 + j * 16 + (lane >> 2);
+        const int PQ = a.P * a.Q;
+        pn[j] = (int)(m / PQ);
+        const int rem = (int)(m - (long)pn[j] * PQ);
+        pp[j] = rem / a.Q;
+        pq[j] = rem - pp[j] * a.Q;
+    }
+    const __amdgpu_buffer_rsrc_t rs_dy = make_srd(a.dy, (long)a.M * a.K * 2);
+    const __amdgpu_buffer_rsrc_t rs_x = make_srd(a.x, (long)a.N * a.H * a.W * a.C * 2);
+    // pieces of a K-step and wave — NT = 256: dY block `wave` and X blocks wave, wave + 8, both pixel halves (6 instructions);
+    // NT = 128: dY block `wave` both halves, X block wave % 4 of pixel half wave / 4 (3 instructions).  Every wave issues the same
+    // number per step: the counted wait below relies on it.
+    constexpr int PIECES = NB >= 8 ? 2 + 2 * (NB / 8) : 3;
+    static_assert(NB == 8 || NB == 4, "piece schedule: NT is 256 or 128");
+    auto issue = [&](int st, int stage) {
+        unsigned char *A = lds + stage * STAGE, *B = A + A_BYTES;
+        const bool live = st < st_end;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const long m = (long)st * 32 + j * 16 + (lane >> 2);
+            const unsigned okm = (unsigned)live & (unsigned)(m < a.M);
+            const unsigned offa = okm ? (unsigned)((m * a.K + ko0 + wave * 32 + chunk * 8) * 2) : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_dy, (lds_void *)(A + wave * 2048 + j * 1024), 16, offa, 0, 0, 0);
+            const int ih = pp[j] * a.stride - a.pad_h + r, iw = pq[j] * a.stride - a.pad_w + s;
+            const unsigned okx = okm & (unsigned)((unsigned)ih < (unsigned)a.H) & (unsigned)((unsigned)iw < (unsigned)a.W);
+            const long pix = ((long)pn[j] * a.H + ih) * a.W + iw;
+            if constexpr (NB == 8) {
+                const unsigned offx = okx ? (unsigned)((pix * a.C + c0 + wave * 32 + chunk * 8) * 2) : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void *)(B + wave * 2048 + j * 1024), 16, offx, 0, 0, 0);
+            } else if ((wave >> 2) == j) {              // wave-uniform
+                const int blk = wave & 3;
+                const unsigned offx = okx ? (unsigned)((pix * a.C + c0 + blk * 32 + chunk * 8) * 2) : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void *)(B + blk * 2048 + j * 1024), 16, offx, 0, 0, 0);
+            }
+            pq[j] += 32;
+            while (pq[j] >= a.Q) {
+                pq[j] -= a.Q;
+                if (++pp[j] == a.P) { pp[j] = 0; ++pn[j]; }
+            }
+        }
+    };
+
+    f32x16 acc[2][TN];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    issue(st_begin, 0);
+    issue(st_begin + 1, 1);
+    for (int st = st_begin; st < st_end; ++st) {
+        const int stage = (st - st_begin) & 3;
+        issue(st + 2, (stage + 2) & 3);              // (its buffer was last read in step st-2: two barriers ago)
+        // step st's pieces have landed when at most the 2 x PIECES newer ones are outstanding
+        if constexpr (PIECES == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const unsigned char *A = lds + stage * STAGE, *B = A + A_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 fa[2], fb[TN];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = tr_frag(A + (wk * 2 + i) * 2048, kk * 16, lane);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = tr_frag(B + (wn * TN + j) * 2048, kk * 16, lane);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    const int lr = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int c = c0 + (wn * TN + j) * 32 + lr;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int ko = ko0 + (wk * 2 + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                unsafeAtomicAdd(a.dw + ((long)ko * RS + tap) * a.C + c, acc[i][j][e]);
+            }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -312,6 +462,55 @@ int rr_conv16_dgrad_s1(const unsigned short *dy, const unsigned short *wt, float
     a.M = n * h * wd;
     a.accumulate = accumulate;
     return launch_igemm(a, stream, "rr_conv16_dgrad_s1");
+}
+
+int rr_conv16_wgrad_supported(int c, int k, int r, int s, int stride)
+{
+    return k % 256 == 0 && c % 128 == 0 && r * s <= 64 && (stride == 1 || stride == 2);
+}
+
+int rr_conv16_wgrad(const unsigned short *x, const unsigned short *dy, float *dw, int n, int h, int wd, int c, int k,
+                    int r, int s, int stride, int pad_h, int pad_w, hipStream_t stream)
+{
+    RR_CHECK_ARG(n > 0 && h > 0 && wd > 0 && x && dy && dw, "rr_conv16_wgrad: bad arguments");
+    RR_CHECK_ARG(rr_conv16_wgrad_supported(c, k, r, s, stride), "rr_conv16_wgrad: unsupported shape c=%d k=%d %dx%d stride %d", c, k, r, s, stride);
+    WArgs a{};
+    a.x = x; a.dy = dy; a.dw = dw;
+    a.N = n; a.H = h; a.W = wd; a.C = c; a.K = k; a.R = r; a.S = s; a.stride = stride; a.pad_h = pad_h; a.pad_w = pad_w;
+    a.P = (h + 2 * pad_h - r) / stride + 1;
+    a.Q = (wd + 2 * pad_w - s) / stride + 1;
+    RR_CHECK_ARG(a.P > 0 && a.Q > 0, "rr_conv16_wgrad: empty output");
+    a.M = n * a.P * a.Q;
+    RR_CHECK_ARG((long)a.M * k * 2 < (1l << 31) && (long)n * h * wd * c * 2 < (1l << 31), "rr_conv16_wgrad: tensor beyond 2 GiB");
+    const int nt_w = c % 256 == 0 ? 256 : 128;
+    a.kt = k / 256;
+    a.nt = c / nt_w;
+    const int tiles = a.kt * a.nt * r * s;
+    const int total_steps = rr_cdiv(a.M, 32);
+    // pixel splits: fill the 256 CUs (one 512-thread workgroup each) about twice, never fewer than 32 K-steps per split
+    int splits = tiles < 512 ? 512 / tiles : 1;
+    if (splits > rr_cdiv(total_steps, 32)) splits = rr_cdiv(total_steps, 32);
+    if (splits < 1) splits = 1;
+    a.steps_per_split = rr_cdiv(total_steps, splits);
+    splits = rr_cdiv(total_steps, a.steps_per_split);
+    const size_t ldsb = 4 * (size_t)(8 * 2048 + (nt_w / 32) * 2048);
+    if (nt_w == 256) {
+        static bool attr = false;
+        if (!attr) {
+            RR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv16_wgrad_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb), "rr_conv16_wgrad");
+            attr = true;
+        }
+        hipLaunchKernelGGL(conv16_wgrad_kernel<256>, dim3(tiles * splits), dim3(512), ldsb, stream, a);
+    } else {
+        static bool attr = false;
+        if (!attr) {
+            RR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv16_wgrad_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb), "rr_conv16_wgrad");
+            attr = true;
+        }
+        hipLaunchKernelGGL(conv16_wgrad_kernel<128>, dim3(tiles * splits), dim3(512), ldsb, stream, a);
+    }
+    RR_CHECK_LAUNCH("rr_conv16_wgrad");
+    return RR_OK;
 }
 
 }  // extern "C"

@@ -15,6 +15,10 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+// four fp32 -> four bf16 (round to nearest even, v_cvt_pk_bf16_f32; NaN stays NaN)
+__device__ __forceinline__ u16x4 to_bf16x4(f32x4 v) { return __builtin_bit_cast(u16x4, __builtin_convertvector(v, bf16x4)); }
 
 constexpr int EW_THREADS = 256;
 inline int ew_blocks(long n4) { long b = (n4 + EW_THREADS - 1) / EW_THREADS; return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b)); }
@@ -132,7 +136,7 @@ template <bool AMAX>
 __global__ __launch_bounds__(EW_THREADS) void bn_apply_kernel(const f32x4 *y, const float *scale, const float *shift,
                                                               const f32x4 *res, const float *res_scale,
                                                               const float *res_shift, f32x4 *out, long n4, int C4,
-                                                              int relu, unsigned *amax)
+                                                              int relu, unsigned *amax, u16x4 *out16 = nullptr)
 {
     float vmax = 0.f;
     for (long i = (long)blockIdx.x * EW_THREADS + threadIdx.x; i < n4; i += (long)gridDim.x * EW_THREADS) {
@@ -153,7 +157,8 @@ __global__ __launch_bounds__(EW_THREADS) void bn_apply_kernel(const f32x4 *y, co
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
         }
-        out[i] = v;
+        if (out) out[i] = v;
+        if (out16) out16[i] = to_bf16x4(v);      // the bf16 image the next convolution reads (csrc/conv16.hip)
         if constexpr (AMAX) vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
     }
     if constexpr (AMAX) {
@@ -239,7 +244,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(const f32x4 *d
                                                                   const double *sums, double count_h,
                                                                   const double *count_d, f32x4 *dx, f32x4 *g_out,
                                                                   float *dgamma, float *dbeta, long n4, int C, int g_acc,
-                                                                  unsigned *amax)
+                                                                  unsigned *amax, u16x4 *dx16 = nullptr)
 {
     float vmax = 0.f;
     const int C4 = C / 4;
@@ -274,7 +279,8 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(const f32x4 *d
             const float sdy = (float)sums[c + e] * inv_count, sdx = (float)sums[C + c + e] * inv_count;
             o[e] = ga[e] * is[e] * (g[e] - sdy - xh[e] * sdx);
         }
-        dx[i] = o;
+        if (dx) dx[i] = o;
+        if (dx16) dx16[i] = to_bf16x4(o);        // the bf16 image the data / weight gradient read (csrc/conv16.hip)
         if constexpr (AMAX) vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
     }
     if constexpr (AMAX) {
@@ -693,6 +699,31 @@ extern "C" int rr_bn_apply(const float *y, const float *scale, const float *shif
     return RR_OK;
 }
 
+extern "C" int rr_bn_apply_b16(const float *y, const float *scale, const float *shift, const float *res,
+                               const float *res_scale, const float *res_shift, float *out, unsigned short *out16, long total,
+                               int c, int relu, hipStream_t stream)
+{
+    RR_CHECK_ARG(c % 4 == 0 && total % c == 0 && (out != nullptr || out16 != nullptr), "rr_bn_apply_b16: C=%d must be a multiple of 4, one output required", c);
+    const long n4 = total / 4;
+    EW_LAUNCH(bn_apply_kernel<false>, n4, stream, (const f32x4 *)y, scale, shift, (const f32x4 *)res, res_scale, res_shift,
+              (f32x4 *)out, n4, c / 4, relu, (unsigned *)nullptr, (u16x4 *)out16);
+    RR_CHECK_LAUNCH("rr_bn_apply_b16");
+    return RR_OK;
+}
+
+__global__ __launch_bounds__(EW_THREADS) void to_bf16_kernel(const f32x4 *x, u16x4 *out, long n4)
+{
+    for (long i = (long)blockIdx.x * EW_THREADS + threadIdx.x; i < n4; i += (long)gridDim.x * EW_THREADS) out[i] = to_bf16x4(x[i]);
+}
+
+extern "C" int rr_to_bf16(const float *x, unsigned short *out, long total, hipStream_t stream)
+{
+    RR_CHECK_ARG(total % 4 == 0 && x != nullptr && out != nullptr, "rr_to_bf16: element count must be a multiple of 4");
+    EW_LAUNCH(to_bf16_kernel, total / 4, stream, (const f32x4 *)x, (u16x4 *)out, total / 4);
+    RR_CHECK_LAUNCH("rr_to_bf16");
+    return RR_OK;
+}
+
 extern "C" int rr_bn_apply_amax(const float *y, const float *scale, const float *shift, const float *res,
                                 const float *res_scale, const float *res_shift, float *out, long total, int c, int relu,
                                 unsigned *amax_out, hipStream_t stream)
@@ -729,11 +760,15 @@ static int bn_bwd_apply_impl(const float *dz, const float *z, const float *y, co
                              const float *invstd, const float *gamma, const float *mask_scale,
                              const float *mask_shift, const double *sums, double count,
                              const double *count_dev, float *dx, float *g_out, float *dgamma, float *dbeta,
-                             long total, int c, int g_acc, hipStream_t stream, unsigned *amax = nullptr)
+                             long total, int c, int g_acc, hipStream_t stream, unsigned *amax = nullptr, unsigned short *dx16 = nullptr)
 {
     RR_CHECK_ARG(c % 4 == 0 && total % c == 0, "rr_bn_bwd_apply: C=%d must be a multiple of 4", c);
     const long n4 = total / 4;
-    if (amax != nullptr)
+    if (dx16 != nullptr)
+        EW_LAUNCH(bn_bwd_apply_kernel<false>, n4, stream, (const f32x4 *)dz, (const f32x4 *)z, (const f32x4 *)y, mean, invstd, gamma,
+                  mask_scale, mask_shift, sums, count, count_dev, (f32x4 *)dx, (f32x4 *)g_out, dgamma, dbeta, n4, c, g_acc,
+                  (unsigned *)nullptr, (u16x4 *)dx16);
+    else if (amax != nullptr)
         EW_LAUNCH(bn_bwd_apply_kernel<true>, n4, stream, (const f32x4 *)dz, (const f32x4 *)z, (const f32x4 *)y, mean, invstd, gamma,
                   mask_scale, mask_shift, sums, count, count_dev, (f32x4 *)dx, (f32x4 *)g_out, dgamma, dbeta, n4, c, g_acc, amax);
     else
@@ -742,6 +777,17 @@ static int bn_bwd_apply_impl(const float *dz, const float *z, const float *y, co
                   (unsigned *)nullptr);
     RR_CHECK_LAUNCH("rr_bn_bwd_apply");
     return RR_OK;
+}
+
+extern "C" int rr_bn_bwd_apply_b16(const float *dz, const float *z, const float *y, const float *mean,
+                                   const float *invstd, const float *gamma, const float *mask_scale,
+                                   const float *mask_shift, const double *sums, double count,
+                                   const double *count_dev, float *dx, unsigned short *dx16, float *g_out, int g_accumulate,
+                                   float *dgamma, float *dbeta, long total, int c, hipStream_t stream)
+{
+    RR_CHECK_ARG(dx16 != nullptr && (!g_accumulate || g_out != nullptr), "rr_bn_bwd_apply_b16: dx16 (and the fan-in buffer when accumulating) required");
+    return bn_bwd_apply_impl(dz, z, y, mean, invstd, gamma, mask_scale, mask_shift, sums, count, count_dev, dx, g_out, dgamma,
+                             dbeta, total, c, g_accumulate ? 1 : 0, stream, nullptr, dx16);
 }
 
 extern "C" int rr_bn_bwd_apply_amax(const float *dz, const float *z, const float *y, const float *mean,

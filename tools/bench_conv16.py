@@ -83,6 +83,20 @@ def run_shape(n, c, h, w, k, r, stride, reps=20, check=True):
                 ms = timed(lambda: _C.check(fd(_C.ptr(dy16), _C.ptr(wflip16), _C.ptr(dx), None, n, h, w, c, k, r, r, pad[0], pad[1], 0,
                                                _C.stream()), "dgrad"), reps)
                 out["dgrad_ms"], out["dgrad_tflops"] = round(ms, 4), round(flops / ms / 1e9, 1)
+    if _C.fn("rr_conv16_wgrad_supported")(c, k, r, r, stride):
+        dy = ops.to_nhwc(torch.randn((n, k, p, q), device=dev, generator=g))
+        dy16 = to_bf16_nhwc(dy)
+        dw = ops.zeros_nhwc(k, c, r, r, dev)
+        fw = _C.fn("rr_conv16_wgrad")
+
+        def wgrad():
+            _C.check(fw(_C.ptr(x16), _C.ptr(dy16), _C.ptr(dw), n, h, w, c, k, r, r, stride, pad[0], pad[1], _C.stream()), "rr_conv16_wgrad")
+        if check:
+            wgrad()
+            refw = ops.conv_wgrad(x16.float(), dy16.float(), ops.zeros_nhwc(k, c, r, r, dev), stride, pad)
+            out["wgrad_err"] = float((dw - refw).abs().max()) / float(refw.abs().max())
+        ms = timed(wgrad, reps)
+        out["wgrad_ms"], out["wgrad_tflops"] = round(ms, 4), round(flops / ms / 1e9, 1)
     ms = timed(lambda: fprop(True), reps)
     out["fprop_ms"], out["fprop_tflops"] = round(ms, 4), round(flops / ms / 1e9, 1)
     ms = timed(lambda: fprop(False), reps)
