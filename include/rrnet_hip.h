@@ -193,6 +193,15 @@ int rr_bn_bwd_apply_b16(const float *dz, const float *z, const float *y, const f
                         int g_accumulate, float *dgamma, float *dbeta, long total, int c, hipStream_t stream);
 int rr_to_bf16(const float *x, unsigned short *out, long total, hipStream_t stream);
 
+/* Data gradient of a head's narrow 1x1 convolution (K = 10 / 2 / 34 output channels behind a 3x3 conv + bias + ReLU:
+ * /root/reference/detectors/centernet_detector.py:62,73,85-93), the producer's ReLU mask and bias gradient in the same
+ * pass — rr_conv_dgrad_s1_relubias's contract for r = s = 1 without the channel padding:
+ *   dx[m][c] = (prod_z[m][c] > 0) * ([dx[m][c] +] sum_k dy[m][k] * w[k][c]);  sums[c] += sum_m dx[m][c]  (doubles, pre-zeroed).
+ * dy [m][k], w [k][c] (the layer's own OHWI filter), k <= 36, c a divisor of 1024; dx16 (may be NULL): bf16 image of dx.
+ * HBM-bound element-wise kernel (csrc/elementwise.hip). */
+int rr_head_dgrad_relubias(const float *dy, const float *w, float *dx, unsigned short *dx16, const float *prod_z,
+                           double *sums, long m, int c, int k, int accumulate, hipStream_t stream);
+
 /* ---- split-operand convolutions ("f16x3", cfg.Model.conv_math; csrc/conv_bf16.hip) -------------------------------
  * fp32 in, fp32 out, fp32 accumulation, as rr_conv_fprop / rr_conv_dgrad / rr_conv_wgrad (reference: nn.Conv2d in
  * /root/reference/backbones/hourglass.py:12-61); inside the kernel each operand is the sum of two fp16 values (22

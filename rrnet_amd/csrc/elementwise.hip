@@ -699,6 +699,98 @@ extern "C" int rr_bn_apply(const float *y, const float *scale, const float *shif
     return RR_OK;
 }
 
+// ---- data gradient of a head's narrow 1x1 convolution, fused with the producer's ReLU mask and bias gradient ---------------
+// dx[m][c] = (z[m][c] > 0) * ( [dx[m][c] +] sum_{k < K} dy[m][k] * w[k][c] ),  sums[c] += sum_m dx[m][c]      (K = 10 / 2 / 34: the
+// hm / offset / WH heads' 1x1 layers behind a 3x3 conv + bias + ReLU, /root/reference/detectors/centernet_detector.py:62,73,85-93).
+// As a GEMM this is 12 / 4 / 36 reduction indices wide: on the implicit-GEMM kernel (rr_conv_dgrad_s1_relubias) one launch took
+// ~1.0 ms at 8 x 256 x 256 pixels — prologue / epilogue bound, 0.2 of what the bytes need.  Here it is what it is: an HBM-bound
+// element-wise pass (read dy 21 MB + z 537 MB, write dx 537 MB: ~0.2 ms), K FMAs per output from a filter held in LDS; no channel
+// padding of dy or w (rr_pad_channels), optional bf16 image of dx for the 3x3 layer's data / weight gradients (csrc/conv16.hip).
+// KMAX: K rounded up to a compile-time bound (4 / 12 / 36): the thread's K x 4 filter values live in registers (zero beyond K).
+// UNI: C == 256 — a wave is the 64 channel quads of ONE pixel, so dy[pix][0..K) is wave-uniform and comes through scalar loads.
+template <int KMAX, bool UNI>
+__global__ __launch_bounds__(EW_THREADS) void head_dgrad_relubias_kernel(const float *__restrict__ dy, const float *__restrict__ w,
+                                                                         f32x4 *__restrict__ dx, u16x4 *__restrict__ dx16,
+                                                                         const f32x4 *__restrict__ z, double *__restrict__ sums, long m, int C, int K,
+                                                                         int accumulate)
+{
+    extern __shared__ __align__(16) double red[];          // [PL][C]
+    const int C4 = C / 4, cq = threadIdx.x % C4, PL = EW_THREADS / C4;
+    int pl = threadIdx.x / C4;
+    if constexpr (UNI) pl = __builtin_amdgcn_readfirstlane(pl);
+    f32x4 wv[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) wv[k] = k < K ? *reinterpret_cast<const f32x4 *>(w + (long)k * C + cq * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    // software pipeline: the next pixel's dy row (scalar registers when UNI), mask and old gradient are fetched before the current
+    // pixel's K x 4 FMAs — with 144 filter registers per lane only two waves fit a SIMD, and one exposed HBM latency per pixel
+    // made the K = 34 layer 0.59 ms
+    const long stride = (long)gridDim.x * PL;
+    long pix = (long)blockIdx.x * PL + pl;
+    float dcur[KMAX];
+    f32x4 zcur = {0.f, 0.f, 0.f, 0.f}, ocur = {0.f, 0.f, 0.f, 0.f};
+    auto fetch = [&](long p, float (&d)[KMAX], f32x4 &zz, f32x4 &old) {
+        const long q = p < m ? p : m - 1;                      // (past the end: a valid pixel, never stored)
+        const float *row = dy + q * K;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) d[k] = row[k < K ? k : K - 1];      // beyond K the filter is zero: stay inside the row
+        zz = z[q * C4 + cq];
+        if (accumulate) old = dx[q * C4 + cq];
+    };
+    fetch(pix, dcur, zcur, ocur);
+    while (pix < m) {
+        float dnext[KMAX];
+        f32x4 znext, onext = {0.f, 0.f, 0.f, 0.f};
+        fetch(pix + stride, dnext, znext, onext);
+        f32x4 acc = ocur;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = __builtin_fmaf(dcur[k], wv[k][e], acc[e]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            acc[e] = zcur[e] > 0.f ? acc[e] : 0.f;
+            s[e] += (double)acc[e];
+        }
+        const long o = pix * C4 + cq;
+        dx[o] = acc;
+        if (dx16) dx16[o] = to_bf16x4(acc);
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) dcur[k] = dnext[k];
+        zcur = znext; ocur = onext;
+        pix += stride;
+    }
+    // column sums: over the workgroup's pixel lanes in LDS, one double atomic per channel and workgroup
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[pl * C + cq * 4 + e] = s[e];
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += EW_THREADS) {
+        double v = 0.0;
+        for (int p = 0; p < PL; ++p) v += red[p * C + c];
+        unsafeAtomicAdd(sums + c, v);
+    }
+}
+
+extern "C" int rr_head_dgrad_relubias(const float *dy, const float *w, float *dx, unsigned short *dx16, const float *prod_z, double *sums,
+                                      long m, int c, int k, int accumulate, hipStream_t stream)
+{
+    RR_CHECK_ARG(m > 0 && k > 0 && k <= 36 && c % 4 == 0 && c >= 4 && EW_THREADS % (c / 4) == 0 && dy && w && dx && prod_z && sums,
+                 "rr_head_dgrad_relubias: K=%d (<= 36), C=%d (a divisor of %d x 4)", k, c, EW_THREADS);
+    const int pl = EW_THREADS / (c / 4);
+    const size_t ldsb = sizeof(double) * (size_t)pl * c;
+    long blocks = (m + pl * 16 - 1) / (pl * 16);
+    if (blocks > 2048) blocks = 2048;
+#define RR_HD(KM, U) hipLaunchKernelGGL((head_dgrad_relubias_kernel<KM, U>), dim3((int)blocks), dim3(EW_THREADS), ldsb, stream, dy, w, \
+                                        (f32x4 *)dx, (u16x4 *)dx16, (const f32x4 *)prod_z, sums, m, c, k, accumulate)
+    const bool uni = c == 256;
+    if (k <= 4) { if (uni) RR_HD(4, true); else RR_HD(4, false); }
+    else if (k <= 12) { if (uni) RR_HD(12, true); else RR_HD(12, false); }
+    else { if (uni) RR_HD(36, true); else RR_HD(36, false); }
+#undef RR_HD
+    RR_CHECK_LAUNCH("rr_head_dgrad_relubias");
+    return RR_OK;
+}
+
 extern "C" int rr_bn_apply_b16(const float *y, const float *scale, const float *shift, const float *res,
                                const float *res_scale, const float *res_shift, float *out, unsigned short *out16, long total,
                                int c, int relu, hipStream_t stream)

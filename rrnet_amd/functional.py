@@ -81,14 +81,18 @@ def _wgrad_async(fn, device, *tensors):
     cur = torch.cuda.current_stream(device)
     side = _side_stream(device, "wgrad")
     side.wait_stream(cur)
-    for t in tensors:                     # maxima reduced on the current stream so far are complete for the side stream too
+    for t in tensors:                     # maxima reduced / bf16 images written on the current stream so far are complete for the side stream too
         ops.amax_publish(t)
+        ops.b16_publish(t)
     with torch.cuda.stream(side):
         _stress_delay()
         fn()
     for t in tensors:
         if t is not None:
             t.record_stream(side)
+            img = ops.b16_carry(t)
+            if img is not None:
+                img.record_stream(side)
     _WG_STATE["pending"] = True
     task = torch._C._current_graph_task_id()       # one join per backward pass (a pass that raised leaves no stale flag)
     if task < 0:                                   # not inside a backward pass (a backward called by hand): join right away
@@ -180,6 +184,7 @@ class _ConvBnAct(torch.autograd.Function):
             ctx.save_for_backward(x, wc, y, z if (relu and not remask) else None, mean, invstd, gamma, cnt_dev,
                                   scale if remask else None, shift if remask else None)
             ctx.x_amax = ops.amax_carry(x)      # (split-operand kernels: the weight gradient reuses the forward's reduction)
+            ctx.x_b16 = ops.b16_carry(x)        # (conv16 kernels: the weight gradient reads the forward's bf16 image of x)
             if out_link is not None:
                 # what a consumer's data gradient needs to produce this layer's BatchNorm-backward sums in its epilogue
                 out_link.y, out_link.mean, out_link.invstd = y, mean, invstd
@@ -200,6 +205,7 @@ class _ConvBnAct(torch.autograd.Function):
         x, wc, y, z, mean, invstd, gamma, cnt_dev, msc, msh = ctx.saved_tensors
         branch_stress(dz.device)
         ops.amax_restore(x, getattr(ctx, "x_amax", None))
+        ops.b16_restore(x, getattr(ctx, "x_b16", None))
         stride, pad, relu, count, sync, has_res = ctx.cfg
         w, gamma_p, beta_p = ctx.params
         dz = ops.to_nhwc(dz)
@@ -519,6 +525,7 @@ class _ConvBias(torch.autograd.Function):
         y = ops.conv_fprop(x, wc, b, stride, pad, relu, w16=_w16_of(w)[0])
         ctx.save_for_backward(x, wc, y if relu else None)
         ctx.x_amax = ops.amax_carry(x)
+        ctx.x_b16 = ops.b16_carry(x)
         ctx.cfg = (stride, pad, relu)
         ctx.params = (w, b)
         ctx.xshape = tuple(x.shape)
@@ -533,6 +540,7 @@ class _ConvBias(torch.autograd.Function):
     def _backward(ctx, dy):
         x, wc, y = ctx.saved_tensors
         ops.amax_restore(x, getattr(ctx, "x_amax", None))
+        ops.b16_restore(x, getattr(ctx, "x_b16", None))
         stride, pad, relu = ctx.cfg
         w, b = ctx.params
         dy = ops.to_nhwc(dy)
@@ -655,10 +663,28 @@ class _FanOut(torch.autograd.Function):
         return ops.sum_n(gs), None
 
 
+def _share_b16(x, views):
+    """conv16 kernels: the fan-out views ARE x — its bf16 image (written by x's producer, or converted once here so that the
+    n consumers do not convert n times) travels with them."""
+    if ops.BF16 != ops.MATH_BF16 or not x.is_cuda or x.dim() != 4 or x.dtype != torch.float32:
+        return
+    hit = getattr(x, "_rr_b16", None)
+    if hit is None or hit[0] != x._version:
+        if not (ops._CONV16 and (x.shape[1] % 256 == 0 or x.shape[1] == 128)
+                and x.shape[0] * x.shape[2] * x.shape[3] >= ops._CONV16_MIN_PIXELS and ops.is_nhwc(x)):
+            return
+        ops.bf16_of(x)
+        hit = x._rr_b16
+    for o in views:
+        o._rr_b16 = (o._version, hit[1], hit[2])
+
+
 def fanout(x, n):
     if n == 1 or not x.requires_grad:
         return (x,) * n
-    return _FanOut.apply(x, n)
+    outs = _FanOut.apply(x, n)
+    _share_b16(x, outs)
+    return outs
 
 
 _SHARED_ACC = os.environ.get("RR_SHARED_ACC", "1") != "0"
@@ -760,6 +786,7 @@ def fanout_shared(x, n):
         o._rr_acc = acc
         if amax is not None and amax[0] == x._version:
             o._rr_amax = (o._version, amax[1], amax[2])
+    _share_b16(x, outs)
     return outs + (acc,)
 
 

@@ -262,6 +262,63 @@ def amax_drop(t):
     object would look valid and be stale (too low: the fp16 parts overflow; too high: bits are dropped silently)."""
     if t is not None and getattr(t, "_rr_amax", None) is not None:
         t._rr_amax = None
+    if t is not None and getattr(t, "_rr_b16", None) is not None:
+        t._rr_b16 = None                       # (the bf16 image is as stale as the maximum)
+
+
+# ---- bf16 images of fp32 tensors (csrc/conv16.hip reads both operands of a convolution as bf16 tensors) -----------------
+# Under cfg.Model.bf16 the producers of a convolution's operands (bn_apply, bn_bwd_apply) write a bf16 image next to the fp32
+# tensor in the same pass; it rides on the tensor OBJECT as `_rr_b16 = (version, stream id | None, image)`.  An operand
+# without one (a fan-in sum, the up-sample add, a head's masked gradient) is converted on first use (rr_to_bf16) and
+# remembered the same way.  Like the remembered maxima it must be dropped when a kernel rewrites the tensor through its
+# raw pointer (amax_drop does both), is valid on the stream that made it, and on every stream once published.
+_CONV16 = os.environ.get("RR_CONV16", "1") != "0"               # 0: the round-4 kernels (fp32 tensors, converted inside every launch)
+_CONV16_MIN_PIXELS = int(os.environ.get("RR_CONV16_MIN_PIXELS", "16384"))    # output pixels below which 256-pixel tiles cannot fill the chip
+
+
+def b16_attach(t, image):
+    t._rr_b16 = (t._version, torch.cuda.current_stream(t.device).cuda_stream, image)
+
+
+def b16_carry(t):
+    """The bf16 image riding on t (or None) — for an autograd node to keep next to a tensor it saves (saved tensors come
+    back as new Python objects); b16_restore hands it to the unpacked tensor."""
+    hit = getattr(t, "_rr_b16", None)
+    return hit[2] if (hit is not None and hit[0] == t._version) else None
+
+
+def b16_restore(t, image):
+    if image is not None and t is not None:
+        t._rr_b16 = (t._version, None, image)          # made in the forward: complete on every stream by now
+
+
+def b16_publish(t):
+    hit = getattr(t, "_rr_b16", None) if t is not None else None
+    if hit is not None and hit[1] == torch.cuda.current_stream(t.device).cuda_stream:
+        t._rr_b16 = (hit[0], None, hit[2])
+
+
+def bf16_of(t):
+    """bf16 image of the fp32 NHWC tensor t (same logical shape, same memory order)."""
+    sid = torch.cuda.current_stream(t.device).cuda_stream
+    hit = getattr(t, "_rr_b16", None)
+    if hit is not None and hit[0] == t._version and (hit[1] is None or hit[1] == sid):
+        return hit[2]
+    assert t.dtype == torch.float32 and t.numel() % 4 == 0
+    img = torch.empty_like(t, dtype=torch.bfloat16)
+    assert img.stride() == t.stride()
+    _C.check(_C.fn("rr_to_bf16")(_C.ptr(t), _C.ptr(img), t.numel(), _C.stream()), "rr_to_bf16")
+    try:
+        t._rr_b16 = (t._version, sid, img)
+    except AttributeError:
+        pass
+    return img
+
+
+def conv16_ok(c, k, r, s, stride, pixels, *tensors):
+    """-> True when a forward-kernel launch of this shape goes to csrc/conv16.hip (bf16 mode only)."""
+    return bool(_CONV16 and _mode() == MATH_BF16 and pixels >= _CONV16_MIN_PIXELS and all(t is None or t.is_cuda for t in tensors)
+                and _C.fn("rr_conv16_supported")(c, k, r, s, stride) and all(t is None or t.numel() * 2 < (1 << 31) for t in tensors))
 
 
 def _absmax_word(t):
@@ -323,6 +380,20 @@ def conv_fprop(x, w, bias=None, stride=1, pad=(0, 0), relu=False, want_stats=Fal
     p, q = out_hw(h, wd, r, s, stride, pad[0], pad[1])
     y = empty_nhwc(n, k, p, q, x.device)
     slab = None
+    if conv16_ok(c, k, r, s, stride, n * p * q, x, y):
+        # both operands as bf16 tensors (csrc/conv16.hip): x's image from its producer (or converted once), the filter's from
+        # the flat cache
+        x16 = bf16_of(x)
+        if w16 is None:
+            w16 = bf16_of(w)
+        if want_stats:
+            slab = torch.empty(_C.fn("rr_conv16_stat_slab_bytes")(n, p, q, k) // 8, dtype=torch.float64, device=x.device)
+        flops = 2.0 * n * p * q * k * (c * r * s if algo_kg is None else algo_kg)
+        _C.check(_timed("conv16_fprop", flops,
+                        lambda: _C.fn("rr_conv16_fprop")(_C.ptr(x16), _C.ptr(w16), _C.ptr(bias), _C.ptr(y), None, _C.ptr(slab), n, h, wd, c, k,
+                                                         r, s, stride, pad[0], pad[1], int(relu), _C.stream()),
+                        (n, h, wd, c, k, r, s, stride), 2.0 * (x.numel() + w.numel()) + 4.0 * y.numel()), "rr_conv16_fprop")
+        return (y, slab) if want_stats else y
     if want_stats:
         nbytes = _C.fn("rr_conv_stat_slab_bytes")(n, p, q, k)
         slab = torch.empty(nbytes // 8, dtype=torch.float64, device=x.device)
@@ -423,6 +494,10 @@ class BnLink:
 
 
 _DGRAD_BNSUM = os.environ.get("RR_DGRAD_BNSUM", "1") != "0"
+# measured at 8 x 256 x 256 x 256 (tools/bench_head_dgrad.py): K = 10: 0.23 ms against 0.40, K = 2: 0.22 against 0.39; K = 34 (the WH head: 144 filter
+# registers per lane, two waves per SIMD): 0.58 against 0.48 — that layer stays on the implicit-GEMM kernel
+_HEAD_DGRAD_MAX_K = int(os.environ.get("RR_HEAD_DGRAD_MAX_K", "12"))
+_HEAD_DGRAD = os.environ.get("RR_HEAD_DGRAD", "1") != "0"      # 0: the heads' narrow 1x1 data gradients on the implicit-GEMM kernel (round 3)
 _BF16_S2_DGRAD = os.environ.get("RR_BF16_S2_DGRAD", "1") != "0"     # A/B: stride-2 data gradients stay on the fp32 kernel
 
 
@@ -461,6 +536,18 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False,
             and bnsum_z is not None and is_nhwc(bnsum_z) and bnsum_z.shape == out.shape and out.numel() * 4 < (1 << 31)
             and r * s <= 64 and pad[0] < r and pad[1] < s and dy.shape[2] * dy.shape[3] >= _DGRAD_VIA_FPROP_MIN_PIXELS
             and (n * h * wd) % 128 == 0):      # whole 128-row tiles only (see fprop_impl in csrc/conv.hip)
+        if r == 1 and s == 1 and k <= _HEAD_DGRAD_MAX_K and 1024 % c == 0 and _HEAD_DGRAD and dy.is_cuda:
+            # a head's narrow 1x1 layer (K = 10 / 2 / 34 of 36): not a GEMM worth a matrix kernel — one HBM-bound pass
+            # (rr_head_dgrad_relubias), no channel padding; under conv16 the bf16 image of dx comes out of the same pass
+            sums = _ZEROS.take(2 * c, dy.device)
+            want16 = _CONV16 and _mode() == MATH_BF16 and c % 256 == 0 and n * h * wd >= _CONV16_MIN_PIXELS
+            out16 = torch.empty_like(out, dtype=torch.bfloat16) if want16 else None
+            _C.check(_C.fn("rr_head_dgrad_relubias")(_C.ptr(dy), _C.ptr(w), _C.ptr(out), _C.ptr(out16), _C.ptr(bnsum_z), _C.ptr(sums),
+                                                     n * h * wd, c, k, int(accumulate), _C.stream()), "rr_head_dgrad_relubias")
+            if want16:
+                b16_attach(out, out16)
+            bnsum.sums, bnsum.dz = sums, out
+            return out
         # producer = conv + bias + ReLU: masked gradient + bias column sums in this launch's epilogue.  A 10- or
         # 2-channel dy (hm / offset heads) is zero-padded to a multiple of 4 for the vector kernel (25 MB at 8x256x256)
         kp = (k + 3) // 4 * 4
@@ -487,6 +574,23 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False,
         bnsum.sums, bnsum.dz = sums, out
         return out
     flops = 2.0 * dy.shape[0] * dy.shape[2] * dy.shape[3] * k * c * r * s
+    if (stride == 1 and pad[0] < r and pad[1] < s and conv16_ok(k, c, r, s, 1, n * h * wd, dy, out)
+            and not (bnsum is not None and bnsum.relu_bias)):
+        # csrc/conv16.hip: the forward kernel on dY's bf16 image and the flipped filter's bf16 copy.  (The producer's
+        # BatchNorm-backward sums are not carried by this kernel yet: `bnsum` stays untouched and the producer runs
+        # rr_bn_bwd_reduce — a pass of 0.2 ms at 8 x 256 x 256 x 256 against the 0.35 ms the launch saves.)
+        dy16 = bf16_of(dy)
+        if wt16 is None:
+            if wt is None:
+                wt = torch.empty(k * c * r * s, dtype=torch.float32, device=dy.device)
+                _C.check(_C.fn("rr_weight_flip_transpose")(_C.ptr(w), _C.ptr(wt), k, c, r, s, _C.stream()), "rr_weight_flip_transpose")
+            wt16 = torch.empty(wt.numel(), dtype=torch.bfloat16, device=dy.device)
+            _C.check(_C.fn("rr_to_bf16")(_C.ptr(wt), _C.ptr(wt16), wt.numel(), _C.stream()), "rr_to_bf16")
+        _C.check(_timed("conv16_dgrad_s1", flops,
+                        lambda: _C.fn("rr_conv16_dgrad_s1")(_C.ptr(dy16), _C.ptr(wt16), _C.ptr(out), None, n, h, wd, c, k, r, s, pad[0], pad[1],
+                                                            int(accumulate), _C.stream()), (n, h, wd, c, k, r, s, stride),
+                        2.0 * (dy.numel() + w.numel()) + 4.0 * out.numel() * (2 if accumulate else 1)), "rr_conv16_dgrad_s1")
+        return out
     # (bf16 operands: the forward kernel at every size — its split-K covers the small maps, and the dgrad kernel is fp32-only)
     if (stride == 1 and k % 4 == 0 and c % 4 == 0 and r * s <= 64 and pad[0] < r and pad[1] < s and _DGRAD_VIA_FPROP
             and (dy.shape[2] * dy.shape[3] >= _DGRAD_VIA_FPROP_MIN_PIXELS or _bf16_ok(k, c, r, s, dy, out, pixels=n * h * wd))):
@@ -551,9 +655,17 @@ def conv_wgrad(x, dy, dw, stride=1, pad=(0, 0), explicit_out=False, algo_c=None)
     n, c, h, wd = x.shape
     k, c2, r, s = dw.shape
     assert c == c2 and dy.shape[1] == k
-    bf = _bf16_ok(c, k, r, s, x, dy, pixels=dy.shape[0] * dy.shape[2] * dy.shape[3]) if (c > 32 and k > 32) else 0
-    f = _C.fn(("rr_conv_wgrad", "rr_conv_wgrad_bf16", "rr_conv_wgrad_f16x3")[bf])
     flops = 2.0 * dy.shape[0] * dy.shape[2] * dy.shape[3] * k * (c * r * s if algo_c is None else algo_c)
+    npix = dy.shape[0] * dy.shape[2] * dy.shape[3]
+    if (_CONV16 and _mode() == MATH_BF16 and not explicit_out and npix >= _CONV16_MIN_PIXELS and x.is_cuda
+            and _C.fn("rr_conv16_wgrad_supported")(c, k, r, s, stride) and max(x.numel(), dy.numel()) * 2 < (1 << 31)):
+        x16, dy16 = bf16_of(x), bf16_of(dy)
+        _C.check(_timed("conv16_wgrad", flops,
+                        lambda: _C.fn("rr_conv16_wgrad")(_C.ptr(x16), _C.ptr(dy16), _C.ptr(dw), n, h, wd, c, k, r, s, stride, pad[0], pad[1],
+                                                         _C.stream()), (n, h, wd, c, k, r, s, stride)), "rr_conv16_wgrad")
+        return dw
+    bf = _bf16_ok(c, k, r, s, x, dy, pixels=npix) if (c > 32 and k > 32) else 0
+    f = _C.fn(("rr_conv_wgrad", "rr_conv_wgrad_bf16", "rr_conv_wgrad_f16x3")[bf])
     wtail = (_C.ptr(amax_of(x)), _C.ptr(amax_of(dy)), _C.stream()) if bf == MATH_F16X3 else (_C.stream(),)
     _C.check(_timed("conv_wgrad<BN=%d>%s" % (128 if c > 32 else 32, ("", "+bf16", "+f16x3")[bf]), flops,
                     lambda: f(_C.ptr(x), _C.ptr(dy), _C.ptr(dw), n, h, wd, c, k, r, s, stride, pad[0], pad[1],
@@ -655,6 +767,14 @@ def bn_apply(y, scale, shift, residual=None, relu=False, res_scale=None, res_shi
                  "rr_bn_apply_amax")
         out._rr_amax = (out._version, torch.cuda.current_stream(y.device).cuda_stream, word)
         return out
+    if _CONV16 and _mode() == MATH_BF16 and y.is_cuda and (c % 256 == 0 or c == 128) and n * h * w >= _CONV16_MIN_PIXELS:
+        # the bf16 image the consuming convolution (csrc/conv16.hip) reads, written in the same pass
+        out16 = torch.empty_like(out, dtype=torch.bfloat16)
+        _C.check(_C.fn("rr_bn_apply_b16")(_C.ptr(y), _C.ptr(scale), _C.ptr(shift), _C.ptr(residual), _C.ptr(res_scale),
+                                          _C.ptr(res_shift), _C.ptr(out), _C.ptr(out16), y.numel(), c, int(relu), _C.stream()),
+                 "rr_bn_apply_b16")
+        b16_attach(out, out16)
+        return out
     _C.check(_C.fn("rr_bn_apply")(_C.ptr(y), _C.ptr(scale), _C.ptr(shift), _C.ptr(residual), _C.ptr(res_scale),
                                   _C.ptr(res_shift), _C.ptr(out), y.numel(), c, int(relu), _C.stream()), "rr_bn_apply")
     return out
@@ -689,6 +809,14 @@ def bn_bwd_apply(dz, z, y, mean, invstd, gamma, sums, count, want_g=False, dgamm
                                                _C.ptr(dx), _C.ptr(g), int(g_into is not None), _C.ptr(dgamma), _C.ptr(dbeta),
                                                y.numel(), c, _C.ptr(word), _C.stream()), "rr_bn_bwd_apply_amax")
         dx._rr_amax = (dx._version, torch.cuda.current_stream(y.device).cuda_stream, word)
+        return dx, g
+    if _CONV16 and _mode() == MATH_BF16 and y.is_cuda and c % 256 == 0 and n * h * w >= _CONV16_MIN_PIXELS:
+        dx16 = torch.empty_like(dx, dtype=torch.bfloat16)
+        _C.check(_C.fn("rr_bn_bwd_apply_b16")(_C.ptr(dz), _C.ptr(z), _C.ptr(y), _C.ptr(mean), _C.ptr(invstd), _C.ptr(gamma),
+                                              _C.ptr(mask_scale), _C.ptr(mask_shift), _C.ptr(sums), float(count), _C.ptr(count_dev),
+                                              _C.ptr(dx), _C.ptr(dx16), _C.ptr(g), int(g_into is not None), _C.ptr(dgamma), _C.ptr(dbeta),
+                                              y.numel(), c, _C.stream()), "rr_bn_bwd_apply_b16")
+        b16_attach(dx, dx16)
         return dx, g
     _C.check(_C.fn("rr_bn_bwd_apply_gacc" if g_into is not None else "rr_bn_bwd_apply")(_C.ptr(dz), _C.ptr(z), _C.ptr(y), _C.ptr(mean), _C.ptr(invstd), _C.ptr(gamma),
                                       _C.ptr(mask_scale), _C.ptr(mask_shift), _C.ptr(sums), float(count), _C.ptr(count_dev), _C.ptr(dx), _C.ptr(g), _C.ptr(dgamma), _C.ptr(dbeta),

@@ -155,17 +155,27 @@ def test_bf16_dgrad_carries_the_bn_backward_sums(relu, residual, bf16_switch):
 
 
 def test_bf16_dgrad_relu_bias_epilogue(bf16_switch):
-    """rr_conv_dgrad_s1_relubias_bf16 (heads: conv + bias + ReLU producer): masked store + bias column sums."""
+    """Heads (conv + bias + ReLU producer): masked store + bias column sums under cfg.Model.bf16.  The narrow 1x1 layers
+    (K = 10 / 2 / 34) run rr_head_dgrad_relubias in every arithmetic — an element-wise fp32 pass, operands NOT rounded (closer to
+    the reference than the bf16 contract asks); the implicit-GEMM form rr_conv_dgrad_s1_relubias_bf16 (ops._HEAD_DGRAD = False,
+    and every wider layer) multiplies bf16-rounded operands."""
     from rrnet_amd import ops
     n, c, h, w, k = 2, 256, 64, 64, 10
     z = ops.to_nhwc(torch.relu(_mk((n, c, h, w), 21)).cuda())
     gy = ops.to_nhwc(_mk((n, k, h, w), 22).cuda())
     wt = ops.to_nhwc((_mk((k, c, 1, 1), 23) * 0.05).cuda())
-    link = ops.BnLink()
-    link.relu_bias = link.use_z = True
-    bf16_switch(True)
-    dx = ops.conv_dgrad(gy, wt, (n, c, h, w), 1, (0, 0), bnsum=link, bnsum_z=z)
-    bf16_switch(False)
-    ref = ops.conv_dgrad(ops.to_nhwc(_r(gy)), ops.to_nhwc(_r(wt)), (n, c, h, w), 1, (0, 0)) * (z > 0)
-    _close(dx, ref, "masked dgrad")
-    _close(link.sums[:c], ref.double().sum((0, 2, 3)), "bias gradient", 1e-5)
+    saved = ops._HEAD_DGRAD
+    try:
+        for head_kernel in (True, False):
+            ops._HEAD_DGRAD = head_kernel
+            link = ops.BnLink()
+            link.relu_bias = link.use_z = True
+            bf16_switch(True)
+            dx = ops.conv_dgrad(gy, wt, (n, c, h, w), 1, (0, 0), bnsum=link, bnsum_z=z)
+            bf16_switch(False)
+            q = (lambda t: t) if head_kernel else _r
+            ref = ops.conv_dgrad(ops.to_nhwc(q(gy)), ops.to_nhwc(q(wt)), (n, c, h, w), 1, (0, 0)) * (z > 0)
+            _close(dx, ref, "masked dgrad (head kernel %s)" % head_kernel)
+            _close(link.sums[:c], ref.double().sum((0, 2, 3)), "bias gradient", 1e-5)
+    finally:
+        ops._HEAD_DGRAD = saved

@@ -369,3 +369,39 @@ def test_dgrad_relu_mask_on_the_sum_of_a_fan_in():
     assert link.sums is not None and link.dz is buf
     ref = (ops.conv_dgrad(dy, wt, (n, c, h, w), 1, (1, 1)) + others) * (z > 0)
     assert (buf - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("k", [10, 2, 34])
+def test_head_1x1_dgrad_kernel_accumulate_and_legacy_path(k):
+    """rr_head_dgrad_relubias (round 5: the heads' narrow 1x1 data gradients as ONE element-wise pass instead of a 12 / 4 / 36-deep
+    implicit GEMM): the accumulate form stores (others + dy w) masked, and the result equals the round-3 path
+    (rr_conv_dgrad_s1_relubias on zero-padded channels, ops._HEAD_DGRAD = False) — values, column sums, exact zeros under the mask."""
+    from rrnet_amd import ops
+    n, c, h, w = 2, 256, 96, 128
+    g = torch.Generator().manual_seed(40 + k)
+    dy = ops.to_nhwc(torch.randn(n, k, h, w, generator=g).cuda())
+    wt = ops.to_nhwc((torch.randn(k, c, 1, 1, generator=g) / np.sqrt(k)).cuda())
+    z = ops.to_nhwc(torch.relu(torch.randn(n, c, h, w, generator=g)).cuda())
+    others = ops.to_nhwc(torch.randn(n, c, h, w, generator=g).cuda())
+    outs = {}
+    saved = (ops._HEAD_DGRAD, ops._HEAD_DGRAD_MAX_K)
+    ops._HEAD_DGRAD_MAX_K = 36            # (the product keeps K = 34 on the implicit-GEMM kernel: slower there; checked here all the same)
+    try:
+        for mode in (True, False):
+            ops._HEAD_DGRAD = mode
+            link = ops.BnLink()
+            link.relu_bias = link.use_z = True
+            buf = others.clone()
+            ops.conv_dgrad(dy, wt, (n, c, h, w), 1, (0, 0), out=buf, accumulate=True, bnsum=link, bnsum_z=z)
+            assert link.sums is not None and link.dz is buf
+            outs[mode] = (buf, link.sums[:c].clone())
+    finally:
+        ops._HEAD_DGRAD, ops._HEAD_DGRAD_MAX_K = saved
+    ref = (torch.einsum("nkhw,kc->nchw", dy.double(), wt.double()[:, :, 0, 0]) + others.double()) * (z > 0)
+    scale = float(ref.abs().max())
+    for mode, (buf, sums) in outs.items():
+        assert float((buf.double() - ref).abs().max()) <= 2e-6 * scale, mode
+        assert float((buf * (z <= 0)).abs().max()) == 0.0
+        exp = ref.sum((0, 2, 3))
+        assert float((sums - exp).abs().max()) <= 2e-6 * float(ref.abs().sum((0, 2, 3)).max()), mode
+    assert float((outs[True][0] - outs[False][0]).abs().max()) <= 2e-6 * scale
