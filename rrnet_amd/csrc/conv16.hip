@@ -125,24 +125,35 @@ __global__ __launch_bounds__(512, 1) void conv16_igemm_kernel(const Args a)
     const __amdgpu_buffer_rsrc_t rs_src = make_srd(a.src, (long)a.N * a.SH * a.SW * a.SC * 2);
     const __amdgpu_buffer_rsrc_t rs_flt = make_srd(a.flt, (long)a.DC * RS * a.SC * 2);
 
-    // wave-uniform walk over the K-tiles: tap inner, channel chunk outer
+    // wave-uniform walk over the K-tiles: tap inner, channel chunk outer.  The eight DMA pieces of a K-tile are issued ONE AT A TIME
+    // between the MFMAs of the previous tile (piece(j)): issued back to back behind the barrier they cost every wave of the workgroup
+    // ~800 issue cycles at the same moment, with nothing on the matrix pipe meanwhile.
     int p_cch = 0, p_tap = 0, p_ri = 0, p_si = 0;
-    auto issue = [&](int buf) {
-        const int xdelta = ((p_ri * a.SW + p_si) * a.SC + p_cch * BK) * 2;
-        const int wdelta = (p_tap * a.SC + p_cch * BK) * 2;
-        unsigned char *X = lds + buf * 2 * IMG, *W = X + IMG;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const unsigned ok = (unsigned)(x_mask >> (16 * i + p_tap)) & 1u;
-            const unsigned off = ok ? (unsigned)(x_off[i] + xdelta) : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lds_void *)(X + (i * 8 + wave) * 1024), 16, off, 0, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_flt, (lds_void *)(W + (i * 8 + wave) * 1024), 16, (unsigned)(w_off[i] + wdelta), 0, 0, 0);
+    int xdelta = 0, wdelta = 0, tapbit = 0;
+    auto prep = [&]() {
+        xdelta = ((p_ri * a.SW + p_si) * a.SC + p_cch * BK) * 2;
+        wdelta = (p_tap * a.SC + p_cch * BK) * 2;
+        tapbit = p_tap;
         ++p_tap;
         if (++p_si == a.S) { p_si = 0; ++p_ri; }
         if (p_tap == RS) { p_tap = 0; p_ri = 0; p_si = 0; ++p_cch; }
+    };
+    unsigned p_live = 1u;                        // 0 behind the last K-tile: the pieces still issue (no branch in the MFMA stream) and fetch zeros
+    auto piece = [&](int j, int buf) {           // j = 0..3: pixel rows, 4..7: filter rows
+        unsigned char *X = lds + buf * 2 * IMG, *W = X + IMG;
+        if (j < 4) {
+            const unsigned ok = (unsigned)(x_mask >> (16 * j + tapbit)) & p_live;
+            const unsigned off = ok ? (unsigned)(x_off[j] + xdelta) : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lds_void *)(X + (j * 8 + wave) * 1024), 16, off, 0, 0, 0);
+        } else {
+            const unsigned off = p_live ? (unsigned)(w_off[j - 4] + wdelta) : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_flt, (lds_void *)(W + ((j - 4) * 8 + wave) * 1024), 16, off, 0, 0, 0);
+        }
+    };
+    auto issue = [&](int buf) {
+        prep();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) piece(j, buf);
     };
 
     f32x4 acc[4][8];
@@ -162,7 +173,8 @@ __global__ __launch_bounds__(512, 1) void conv16_igemm_kernel(const Args a)
     __builtin_amdgcn_s_barrier();
     for (int kt = 0; kt < nkt; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nkt) issue(buf ^ 1);             // every read of that buffer finished before the barrier that ended K-tile kt-1
+        p_live = kt + 1 < nkt ? 1u : 0u;           // (every read of the other buffer finished before the barrier that ended K-tile kt-1)
+        prep();
         const unsigned char *B = lds + buf * 2 * IMG;
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh) {
@@ -175,6 +187,7 @@ __global__ __launch_bounds__(512, 1) void conv16_igemm_kernel(const Args a)
                 const bf16x8 xf = *reinterpret_cast<const bf16x8 *>(B + x_base + pi * 16 * ROWB + sw);
 #pragma unroll
                 for (int ci = 0; ci < 4; ++ci) acc[ci][pi] = mfma(wf[ci], xf, acc[ci][pi]);
+                if (kh == 0) piece(pi, buf ^ 1);     // one DMA piece per 4 MFMAs of the tile's first half: the second half covers their latency
             }
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");

@@ -244,9 +244,17 @@ class _ConvBnAct(torch.autograd.Function):
                                  and _G_INTO) else None
         if g_into is not None:
             res_acc.begin(dz.device)
+        # conv16: when the data gradient (if one is wanted) and the weight gradient of this convolution both read dy's bf16
+        # image, the fp32 dy is never written
+        w_t0 = _grad_target(w)
+        rb_link = (in_link is not None and in_link.relu_bias) or (ctx.accs[0] is not None and ctx.accs[0].link is not None
+                                                                    and ctx.accs[0].link.relu_bias)
+        only16 = (not ctx.packed and ctx.xshape is not None and w_t0 is not None and not rb_link
+                  and ops.wgrad16_takes(ctx.xshape, tuple(y.shape), tuple(w.shape), stride)
+                  and (not ctx.needs_input_grad[0] or ops.dgrad16_takes(tuple(y.shape), tuple(w.shape), ctx.xshape, stride, pad)))
         dy, g = ops.bn_bwd_apply(dz, z, y, mean, invstd, gamma, sums, count, want_g,
                                  dg_t if fused_affine else None, db_t if fused_affine else None, cnt_dev, msc, msh,
-                                 g_into=g_into)
+                                 g_into=g_into, bf16_only=only16)
         if g_into is not None:
             res_acc.end(dz.device)
         dx = None

@@ -304,6 +304,7 @@ def bf16_of(t):
     hit = getattr(t, "_rr_b16", None)
     if hit is not None and hit[0] == t._version and (hit[1] is None or hit[1] == sid):
         return hit[2]
+    assert not getattr(t, "_rr_phantom", False), "a bf16-only tensor lost its image"
     assert t.dtype == torch.float32 and t.numel() % 4 == 0
     img = torch.empty_like(t, dtype=torch.bfloat16)
     assert img.stride() == t.stride()
@@ -313,6 +314,34 @@ def bf16_of(t):
     except AttributeError:
         pass
     return img
+
+
+def phantom_f32(shape, device, image):
+    """An fp32 tensor OBJECT of the given logical shape that owns no memory (one element, stride 0) and carries `image` as its
+    bf16 image: the handle of a gradient that exists only in bf16 — every consumer is a conv16 kernel.  A kernel wrapper that
+    would read its fp32 data trips over `is_nhwc` (stride 0) instead of reading garbage."""
+    t = torch.empty(1, dtype=torch.float32, device=device).expand(shape)
+    t._rr_b16 = (t._version, None, image)
+    t._rr_phantom = True
+    return t
+
+
+def dgrad16_takes(dy_shape, w_shape, x_shape, stride, pad, relu_bias_link=False):
+    """True when conv_dgrad(dy, w, x_shape, ...) will go to rr_conv16_dgrad_s1 (mirrors the dispatch there)."""
+    n, c, h, wd = x_shape
+    k, _, r, s = w_shape
+    return bool(stride == 1 and pad[0] < r and pad[1] < s and not relu_bias_link and _CONV16 and _mode() == MATH_BF16
+                and n * h * wd >= _CONV16_MIN_PIXELS and _C.fn("rr_conv16_supported")(k, c, r, s, 1)
+                and max(n * h * wd * c, dy_shape[0] * dy_shape[1] * dy_shape[2] * dy_shape[3]) * 2 < (1 << 31))
+
+
+def wgrad16_takes(x_shape, dy_shape, w_shape, stride):
+    """True when conv_wgrad(x, dy, dw, stride, ...) will go to rr_conv16_wgrad."""
+    k, c, r, s = w_shape
+    npix = dy_shape[0] * dy_shape[2] * dy_shape[3]
+    xn = x_shape[0] * x_shape[1] * x_shape[2] * x_shape[3]
+    return bool(_CONV16 and _mode() == MATH_BF16 and npix >= _CONV16_MIN_PIXELS and _C.fn("rr_conv16_wgrad_supported")(c, k, r, s, stride)
+                and max(xn, npix * k) * 2 < (1 << 31))
 
 
 def conv16_ok(c, k, r, s, stride, pixels, *tensors):
@@ -522,7 +551,7 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False,
     BatchNorm-backward sums are computed in the epilogue and left in bnsum.sums / bnsum.dz.  bnsum_z: the
     convolution's input itself (= the producer's output), needed when bnsum.use_z."""
     _C.require_cuda(dy, w)
-    assert is_nhwc(dy) and is_nhwc(w)
+    assert (is_nhwc(dy) or getattr(dy, "_rr_phantom", False)) and is_nhwc(w)     # (phantom: a bf16-only gradient, see phantom_f32)
     n, c, h, wd = x_shape
     k, c2, r, s = w.shape
     assert c == c2 and dy.shape[1] == k
@@ -651,7 +680,7 @@ def conv_wgrad(x, dy, dw, stride=1, pad=(0, 0), explicit_out=False, algo_c=None)
     """dw [K,C,R,S] (OHWI memory) += x (*) dy.  dw must be pre-zeroed / hold the running gradient.
     explicit_out: take the output size from dy (asymmetric padding, `pad` = leading pads)."""
     _C.require_cuda(x, dy, dw)
-    assert is_nhwc(x) and is_nhwc(dy) and is_nhwc(dw)
+    assert is_nhwc(x) and (is_nhwc(dy) or getattr(dy, "_rr_phantom", False)) and is_nhwc(dw)
     n, c, h, wd = x.shape
     k, c2, r, s = dw.shape
     assert c == c2 and dy.shape[1] == k
@@ -790,9 +819,24 @@ def bn_bwd_reduce(dz, z, y, mean, invstd, extra=0, mask_scale=None, mask_shift=N
 
 
 def bn_bwd_apply(dz, z, y, mean, invstd, gamma, sums, count, want_g=False, dgamma=None, dbeta=None, count_dev=None,
-                 mask_scale=None, mask_shift=None, g_into=None):
-    """-> (dx, g).  g_into: an existing gradient buffer of y's shape that the masked gradient is ADDED to (returned as g)."""
+                 mask_scale=None, mask_shift=None, g_into=None, bf16_only=False):
+    """-> (dx, g).  g_into: an existing gradient buffer of y's shape that the masked gradient is ADDED to (returned as g).
+    bf16_only (conv16): dx is written as a bf16 image only — the caller knows that its data and weight gradient both read
+    that image; the returned dx is a memory-less fp32 handle (phantom_f32)."""
     n, c, h, w = y.shape
+    if bf16_only and _CONV16 and _mode() == MATH_BF16 and y.is_cuda and c % 4 == 0:
+        if g_into is not None:
+            assert is_nhwc(g_into) and g_into.shape == y.shape
+            amax_drop(g_into)
+            g = g_into
+        else:
+            g = empty_nhwc(n, c, h, w, y.device) if want_g else None
+        dx16 = torch.empty((n, h, w, c), dtype=torch.bfloat16, device=y.device).permute(0, 3, 1, 2)
+        _C.check(_C.fn("rr_bn_bwd_apply_b16")(_C.ptr(dz), _C.ptr(z), _C.ptr(y), _C.ptr(mean), _C.ptr(invstd), _C.ptr(gamma),
+                                              _C.ptr(mask_scale), _C.ptr(mask_shift), _C.ptr(sums), float(count), _C.ptr(count_dev),
+                                              None, _C.ptr(dx16), _C.ptr(g), int(g_into is not None), _C.ptr(dgamma), _C.ptr(dbeta),
+                                              y.numel(), c, _C.stream()), "rr_bn_bwd_apply_b16")
+        return phantom_f32((n, c, h, w), y.device, dx16), g
     dx = empty_nhwc(n, c, h, w, y.device)
     if g_into is not None:
         assert is_nhwc(g_into) and g_into.shape == y.shape

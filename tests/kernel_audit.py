@@ -234,10 +234,15 @@ def audit(tol=2e-5, tol_wgrad=2e-4, sample=False, ref_device="cpu"):
                 rec.note("fprop_stats", sig, max(e1, _rel(sums[k:2 * k], s2)), tol)
         return out
 
+    def _data(t):
+        """A bf16-only gradient (ops.phantom_f32: an fp32 handle without memory) -> its bf16 image, the data the kernel read."""
+        return t._rr_b16[2] if getattr(t, "_rr_phantom", False) else t
+
     def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False, bnsum=None, bnsum_z=None, wt=None, wt16=None,
                    wt_split=None):
         base = out.clone() if (out is not None and accumulate) else None
         res = orig["conv_dgrad"](dy, w, x_shape, stride, pad, out, accumulate, bnsum, bnsum_z, wt, wt16, wt_split)   # the cached flipped filters
+        dy = _data(dy)
         relu_mask = None          # conv + bias + ReLU producer: this launch stored the masked gradient
         if bnsum is not None and bnsum.relu_bias and bnsum.sums is not None and bnsum.dz is res:
             relu_mask = bnsum_z
@@ -275,6 +280,8 @@ def audit(tol=2e-5, tol_wgrad=2e-4, sample=False, ref_device="cpu"):
         # bf16 operands: stride-1 layers (the forward kernel on the flipped filter); a 10- / 2-channel dy was zero-padded to 12 / 4
         qq = (stride == 1 or (stride == 2 and ops._BF16_S2_DGRAD)) and pad[0] < w.shape[2] and pad[1] < w.shape[3] and \
             ops._bf16_ok(w.shape[0] if relu_mask is None else (w.shape[0] + 3) // 4 * 4, w.shape[1], w.shape[2], w.shape[3], dy, res)
+        if relu_mask is not None and w.shape[2] == 1 and w.shape[3] == 1 and w.shape[0] <= ops._HEAD_DGRAD_MAX_K and ops._HEAD_DGRAD:
+            qq = 0            # rr_head_dgrad_relubias: an fp32 element-wise pass in every arithmetic, operands not rounded
         if qq:
             sig = sig + ("bf16",)
         if ("dgrad",) + sig not in rec.seen and big(flops):
@@ -307,6 +314,7 @@ def audit(tol=2e-5, tol_wgrad=2e-4, sample=False, ref_device="cpu"):
         check = ("wgrad",) + sig not in rec.seen and not explicit_out
         base = dw.clone() if check else None
         res = orig["conv_wgrad"](x, dy, dw, stride, pad, explicit_out, algo_c)
+        dy = _data(dy)
         flops = 2.0 * dy.numel() * dw.shape[1] * dw.shape[2] * dw.shape[3]
         if check and big(flops):
             rec.sampled.add(("wgrad",) + sig)
@@ -372,6 +380,9 @@ def audit(tol=2e-5, tol_wgrad=2e-4, sample=False, ref_device="cpu"):
             if relu:
                 ref = ref.relu()
             rec.note("bn_apply", sig, _rel(out[ns], ref), tol)
+            img = ops.b16_carry(out)
+            if img is not None:           # the bf16 image written next to the fp32 output (conv16 reads it)
+                rec.note("bn_apply_image", sig, float((_c64(img[ns]) - ref).abs().max() / max(float(ref.abs().max()), 1e-30)), 2.0 ** -8)
         return out
 
     def bn_bwd_reduce(dz, z, y, mean, invstd, extra=0, mask_scale=None, mask_shift=None):
@@ -394,12 +405,12 @@ def audit(tol=2e-5, tol_wgrad=2e-4, sample=False, ref_device="cpu"):
         return out
 
     def bn_bwd_apply(dz, z, y, mean, invstd, gamma, sums, count, want_g=False, dgamma=None, dbeta=None, count_dev=None,
-                     mask_scale=None, mask_shift=None, g_into=None):
-        sig = (tuple(y.shape), z is not None, mask_scale is not None, want_g, g_into is not None)
+                     mask_scale=None, mask_shift=None, g_into=None, bf16_only=False):
+        sig = (tuple(y.shape), z is not None, mask_scale is not None, want_g, g_into is not None, bool(bf16_only))
         todo = ("bn_bwd_apply",) + sig not in rec.seen and count_dev is None
         gbase = g_into.clone() if (g_into is not None and todo) else None
         out = orig["bn_bwd_apply"](dz, z, y, mean, invstd, gamma, sums, count, want_g, dgamma, dbeta, count_dev,
-                                   mask_scale, mask_shift, g_into)
+                                   mask_scale, mask_shift, g_into, bf16_only)
         if todo:
             ns = _img_sample(y.shape[0]) if big_elems(y) else list(range(y.shape[0]))
             if big_elems(y):
@@ -408,7 +419,17 @@ def audit(tol=2e-5, tol_wgrad=2e-4, sample=False, ref_device="cpu"):
             c = y.shape[1]
             xh = (_c64(y[ns]) - _V(mean)) * _V(invstd)
             ref = _V(gamma) * _V(invstd) * (d - _V(sums[:c]) / count - xh * _V(sums[c:2 * c]) / count)
-            e = float((_c64(out[0][ns]) - ref).abs().max() / max(float((_V(gamma) * _V(invstd) * d).abs().max()), 1e-30))
+            scale = max(float((_V(gamma) * _V(invstd) * d).abs().max()), 1e-30)
+            phantom = getattr(out[0], "_rr_phantom", False)
+            if phantom:       # dx exists only as its bf16 image (conv16): equal to the fp64 value up to one bf16 rounding
+                eb = float((_c64(_data(out[0])[ns]) - ref).abs().max() / scale)
+                rec.note("bn_bwd_apply_bf16_only", sig, eb, 2.0 ** -8)
+                e = 0.0
+            else:
+                e = float((_c64(out[0][ns]) - ref).abs().max() / scale)
+                img = ops.b16_carry(out[0])
+                if img is not None:       # the bf16 image written next to dx
+                    rec.note("bn_bwd_apply_image", sig, float((_c64(img[ns]) - ref).abs().max() / scale), 2.0 ** -8)
             if want_g:
                 e = max(e, _rel(out[1][ns], d if gbase is None else d + _c64(gbase[ns])))
             rec.note("bn_bwd_apply", sig, e, tol)

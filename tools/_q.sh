@@ -1,5 +1,2 @@
-python -m pytest tests/test_conv_gpu.py tests/test_conv_bf16_gpu.py tests/test_model_gpu.py -m gpu -q -x -k "relu or head or stage1" 2>&1 | grep -v Warn | tail -6
-for i in 1; do python tools/bench_config4.py --plain --bf16 --steps 8 2>/dev/null | python -c "import json,sys;d=json.loads(sys.stdin.readline());print('c4 plain',d['value'],d['ms_per_step'])"; done
-python tools/bench_config4.py --steps 8 2>/dev/null | python -c "import json,sys;d=json.loads(sys.stdin.readline());print('c4 dcn',d['value'],d['ms_per_step'])"
-python bench.py --steps 10 --warmup 3 --no-extras --no-cpu-baseline --no-host-fed 2>/dev/null | python -c "import json,sys;d=json.loads(sys.stdin.readline());print('headline',d['value'],d['ms_per_step'],d['step_mfma_frac'],d['roofline']['frac'])"
-RR_HEAD_DGRAD=0 python bench.py --steps 10 --warmup 3 --no-extras --no-cpu-baseline --no-host-fed 2>/dev/null | python -c "import json,sys;d=json.loads(sys.stdin.readline());print('headline head_dgrad=0',d['value'],d['ms_per_step'],d['step_mfma_frac'],d['roofline']['frac'])"
+python -m pytest tests/test_bf16_model_gpu.py -m gpu -q -x -k "every_kernel" 2>&1 | grep -E "Error|error|assert|bad|^E " | head -20
+for i in 1 2; do python tools/bench_config4.py --plain --bf16 --steps 8 2>/dev/null | python -c "import json,sys;d=json.loads(sys.stdin.readline());print('c4 plain',d['value'],d['ms_per_step'],d['allocator']['allocated_peak_GiB'])"; done
