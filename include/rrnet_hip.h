@@ -543,6 +543,12 @@ size_t rr_dcn_dyb_bytes(int n, int p, int q, int k);
 int rr_dcn_dgrad_bf16_ws(const float *x, const float *offset, const float *mask, const float *w, const float *dy, float *dx,
                          float *doffset, float *dmask, int n, int h, int wd, int c, int k, int r, int s, int stride, int pad_h,
                          int pad_w, int dilation, int deformable_groups, void *dyb, hipStream_t stream);
+/* ... with dY's bf16 image already in HBM (written by dY's producer: rr_head_dgrad_relubias / rr_to_bf16): no conversion
+ * inside the call.  dy (fp32) is still read by the d offset / d mask side where the column path is taken. */
+int rr_dcn_dgrad_bf16_img(const float *x, const float *offset, const float *mask, const float *w, const float *dy,
+                          const unsigned short *dy_bf16, float *dx, float *doffset, float *dmask, int n, int h, int wd,
+                          int c, int k, int r, int s, int stride, int pad_h, int pad_w, int dilation,
+                          int deformable_groups, hipStream_t stream);
 /* rr_dcn_dgrad with bf16 matrix operands (dY, W rounded to bf16; fp32 accumulation and scatter): the backward of
  * rr_dcn_fwd_bf16.  Layers the window kernel does not take run rr_dcn_dgrad's fp32 kernel. */
 int rr_dcn_dgrad_bf16(const float *x, const float *offset, const float *mask, const float *w, const float *dy, float *dx,

@@ -43,7 +43,6 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void;
 
 constexpr int TP = 256;            // pixels per tile
-constexpr int TCH = 256;           // output channels per tile
 constexpr int BK = 64;             // reduction indices per K-tile
 constexpr int ROWB = BK * 2;       // bytes per LDS row
 constexpr int IMG = 256 * ROWB;    // bytes per operand image (32 KiB)
@@ -76,12 +75,19 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_srd(const void *p, long b
 
 __device__ __forceinline__ f32x4 mfma(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 
+// TCH: output channels per workgroup — 256 (8 waves as 2 pixel halves x 4 channel quarters, wave tile 64 ch x 128 px) or 128 (for
+// K = 384: 4 pixel quarters x 2 channel halves, wave tile 64 ch x 64 px; 96 KiB of LDS)
+template <int TCH>
 __global__ __launch_bounds__(512, 1) void conv16_igemm_kernel(const Args a)
 {
+    constexpr int WCH = TCH / 64, WPX = 8 / WCH;          // waves along the channels / the pixels
+    constexpr int PI = (TP / WPX) / 16;                   // 16-pixel tiles per wave (8 or 4)
+    constexpr int NWP = TCH / 64;                         // filter-image DMA pieces per wave and K-tile (4 or 2)
+    constexpr int IMGW = TCH * ROWB, STG = IMG + IMGW;    // bytes of the filter image / of one buffer
     extern __shared__ __align__(16) unsigned char lds[];          // [2][pixel image | filter image]
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wp = wave >> 2, wc = wave & 3;                       // pixel half, channel quarter of the wave's tile
+    const int wp = wave / WCH, wc = wave % WCH;                    // pixel part, channel part of the wave's tile
     const int nct = a.DC / TCH;
     const int logical = xcd_remap(blockIdx.x, gridDim.x);
     const int c_tile = logical % nct, m_tile = logical / nct;
@@ -120,7 +126,7 @@ __global__ __launch_bounds__(512, 1) void conv16_igemm_kernel(const Args a)
             }
         x_mask |= (unsigned long long)mk << (16 * i);
         x_off[i] = (int)(((((long)n * a.SH + ih0) * a.SW + iw0) * a.SC) * 2 + chunk * 16);
-        w_off[i] = (int)(((long)(k0 + row) * RS * a.SC) * 2 + chunk * 16);
+        w_off[i] = (int)(((long)(k0 + (row < TCH ? row : 0)) * RS * a.SC) * 2 + chunk * 16);      // (rows >= TCH: unused when NWP < 4)
     }
     const __amdgpu_buffer_rsrc_t rs_src = make_srd(a.src, (long)a.N * a.SH * a.SW * a.SC * 2);
     const __amdgpu_buffer_rsrc_t rs_flt = make_srd(a.flt, (long)a.DC * RS * a.SC * 2);
@@ -140,7 +146,7 @@ __global__ __launch_bounds__(512, 1) void conv16_igemm_kernel(const Args a)
     };
     unsigned p_live = 1u;                        // 0 behind the last K-tile: the pieces still issue (no branch in the MFMA stream) and fetch zeros
     auto piece = [&](int j, int buf) {           // j = 0..3: pixel rows, 4..7: filter rows
-        unsigned char *X = lds + buf * 2 * IMG, *W = X + IMG;
+        unsigned char *X = lds + buf * STG, *W = X + IMG;
         if (j < 4) {
             const unsigned ok = (unsigned)(x_mask >> (16 * j + tapbit)) & p_live;
             const unsigned off = ok ? (unsigned)(x_off[j] + xdelta) : OOB;
@@ -153,20 +159,20 @@ __global__ __launch_bounds__(512, 1) void conv16_igemm_kernel(const Args a)
     auto issue = [&](int buf) {
         prep();
 #pragma unroll
-        for (int j = 0; j < 8; ++j) piece(j, buf);
+        for (int j = 0; j < 4 + NWP; ++j) piece(j, buf);
     };
 
-    f32x4 acc[4][8];
+    f32x4 acc[4][PI];
 #pragma unroll
     for (int ci = 0; ci < 4; ++ci)
 #pragma unroll
-        for (int pi = 0; pi < 8; ++pi) acc[ci][pi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int pi = 0; pi < PI; ++pi) acc[ci][pi] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // fragment addresses: row (lane % 16) of a 16-row block, chunk (kh * 4 + lane / 16) ^ ((lane % 16) >> 1)
     const int fr = lane & 15, fq = lane >> 4;
     const int f_row = fr * ROWB;
     const int f_sw0 = ((fq) ^ (fr >> 1)) * 16, f_sw1 = ((4 + fq) ^ (fr >> 1)) * 16;
-    const int x_base = wp * 128 * ROWB + f_row, w_base = IMG + wc * 64 * ROWB + f_row;
+    const int x_base = wp * (TP / WPX) * ROWB + f_row, w_base = IMG + wc * 64 * ROWB + f_row;
 
     issue(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -175,7 +181,7 @@ __global__ __launch_bounds__(512, 1) void conv16_igemm_kernel(const Args a)
         const int buf = kt & 1;
         p_live = kt + 1 < nkt ? 1u : 0u;           // (every read of the other buffer finished before the barrier that ended K-tile kt-1)
         prep();
-        const unsigned char *B = lds + buf * 2 * IMG;
+        const unsigned char *B = lds + buf * STG;
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh) {
             const int sw = kh ? f_sw1 : f_sw0;
@@ -183,18 +189,19 @@ __global__ __launch_bounds__(512, 1) void conv16_igemm_kernel(const Args a)
 #pragma unroll
             for (int ci = 0; ci < 4; ++ci) wf[ci] = *reinterpret_cast<const bf16x8 *>(B + w_base + ci * 16 * ROWB + sw);
 #pragma unroll
-            for (int pi = 0; pi < 8; ++pi) {
+            for (int pi = 0; pi < PI; ++pi) {
                 const bf16x8 xf = *reinterpret_cast<const bf16x8 *>(B + x_base + pi * 16 * ROWB + sw);
 #pragma unroll
                 for (int ci = 0; ci < 4; ++ci) acc[ci][pi] = mfma(wf[ci], xf, acc[ci][pi]);
-                if (kh == 0) piece(pi, buf ^ 1);     // one DMA piece per 4 MFMAs of the tile's first half: the second half covers their latency
+                // one DMA piece per 4 MFMAs, from the start of the tile: the rest of the tile covers their latency
+                if (kh * PI + pi < 4 + NWP) piece(kh * PI + pi, buf ^ 1);
             }
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
 
-    // ---- epilogue.  acc[ci][pi][j] = channel k0 + wc*64 + ci*16 + fq*4 + j of pixel m0 + wp*128 + pi*16 + fr
+    // ---- epilogue.  acc[ci][pi][j] = channel k0 + wc*64 + ci*16 + fq*4 + j of pixel m0 + wp*(256/WPX) + pi*16 + fr
     const int ch0 = k0 + wc * 64 + fq * 4;
     double s1[4][4], s2[4][4];
     if (a.slab != nullptr) {
@@ -209,8 +216,8 @@ __global__ __launch_bounds__(512, 1) void conv16_igemm_kernel(const Args a)
         f32x4 bv = {0.f, 0.f, 0.f, 0.f};
         if (a.bias != nullptr) bv = *reinterpret_cast<const f32x4 *>(a.bias + ch);
 #pragma unroll
-        for (int pi = 0; pi < 8; ++pi) {
-            const int m = m0 + wp * 128 + pi * 16 + fr;
+        for (int pi = 0; pi < PI; ++pi) {
+            const int m = m0 + wp * (TP / WPX) + pi * 16 + fr;
             f32x4 v = acc[ci][pi] + bv;
             if (a.relu) {
 #pragma unroll
@@ -236,7 +243,7 @@ __global__ __launch_bounds__(512, 1) void conv16_igemm_kernel(const Args a)
     }
     if (a.slab != nullptr) {
         // per-block column statistics: sum over this lane's 8 pixel tiles (above), over the 16 pixel lanes, over the two pixel halves
-        double *red = reinterpret_cast<double *>(lds);              // [2 halves][256 channels][2]
+        double *red = reinterpret_cast<double *>(lds);              // [WPX pixel parts][TCH channels][2]
 #pragma unroll
         for (int ci = 0; ci < 4; ++ci)
 #pragma unroll
@@ -249,14 +256,17 @@ __global__ __launch_bounds__(512, 1) void conv16_igemm_kernel(const Args a)
                 }
                 if (fr == 0) {
                     const int cl = wc * 64 + ci * 16 + fq * 4 + j;
-                    red[(wp * 256 + cl) * 2] = u;
-                    red[(wp * 256 + cl) * 2 + 1] = q;
+                    red[(wp * TCH + cl) * 2] = u;
+                    red[(wp * TCH + cl) * 2 + 1] = q;
                 }
             }
         __syncthreads();
-        if (t < 512) {
+        if (t < 2 * TCH) {
             const int cl = t >> 1, which = t & 1;
-            a.slab[((size_t)m_tile * 2 + which) * a.DC + k0 + cl] = red[cl * 2 + which] + red[(256 + cl) * 2 + which];
+            double v = 0.0;
+#pragma unroll
+            for (int p = 0; p < WPX; ++p) v += red[(p * TCH + cl) * 2 + which];
+            a.slab[((size_t)m_tile * 2 + which) * a.DC + k0 + cl] = v;
         }
     }
 }
@@ -271,14 +281,24 @@ int check_shape(const char *name, int n, int h, int wd, int c, int k, int r, int
 
 int launch_igemm(const Args &a, hipStream_t stream, const char *name)
 {
-    const int mt = rr_cdiv(a.M, TP), nct = a.DC / TCH;
-    const size_t ldsb = 4 * (size_t)IMG;
-    static bool attr = false;
-    if (!attr) {
-        RR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv16_igemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb), name);
-        attr = true;
+    const int mt = rr_cdiv(a.M, TP);
+    if (a.DC % 256 == 0) {
+        const size_t ldsb = 2 * (size_t)(IMG + 256 * ROWB);
+        static bool attr = false;
+        if (!attr) {
+            RR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv16_igemm_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb), name);
+            attr = true;
+        }
+        hipLaunchKernelGGL(conv16_igemm_kernel<256>, dim3(mt * (a.DC / 256)), dim3(512), ldsb, stream, a);
+    } else {
+        const size_t ldsb = 2 * (size_t)(IMG + 128 * ROWB);
+        static bool attr = false;
+        if (!attr) {
+            RR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv16_igemm_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb), name);
+            attr = true;
+        }
+        hipLaunchKernelGGL(conv16_igemm_kernel<128>, dim3(mt * (a.DC / 128)), dim3(512), ldsb, stream, a);
     }
-    hipLaunchKernelGGL(conv16_igemm_kernel, dim3(mt * nct), dim3(512), ldsb, stream, a);
     RR_CHECK_LAUNCH(name);
     return RR_OK;
 }
@@ -438,7 +458,7 @@ extern "C" {
 
 int rr_conv16_supported(int c, int k, int r, int s, int stride)
 {
-    return c % BK == 0 && k % TCH == 0 && r * s <= 16 && (stride == 1 || stride == 2);
+    return c % BK == 0 && k % 128 == 0 && r * s <= 16 && (stride == 1 || stride == 2);
 }
 
 size_t rr_conv16_stat_slab_bytes(int n, int p, int q, int k) { return sizeof(double) * 2 * (size_t)rr_cdiv((long)n * p * q, TP) * k; }

@@ -2210,7 +2210,7 @@ __global__ __launch_bounds__(256) void dcn_to_bf16_kernel(const f32x4 *src, u16x
 static int dcn_dgrad_impl(const float *x, const float *offset, const float *mask, const float *w, const float *dy,
                           float *dx, float *doffset, float *dmask, int n, int h, int wd, int c, int k, int r, int s,
                           int stride, int pad_h, int pad_w, int dilation, int deformable_groups, int bf16, hipStream_t stream,
-                          unsigned short *dyb = nullptr)
+                          unsigned short *dyb = nullptr, bool dyb_ready = false)
 {
     DcnBwdArgs b{};
     const int rc = fill_args(b.a, x, offset, mask, w, n, h, wd, c, k, r, s, stride, pad_h, pad_w, dilation, deformable_groups);
@@ -2241,7 +2241,9 @@ static int dcn_dgrad_impl(const float *x, const float *offset, const float *mask
         if (r * s == 9 && ldsw <= 160 * 1024 - 512) {
             const dim3 grid(n * wb.w.tiles_y * wb.w.tiles_x);
             if (bf16) {
-                if (dyb != nullptr && k % 4 == 0) {
+                if (dyb != nullptr && dyb_ready) {
+                    wb.dyb = dyb;                 // the caller's bf16 image of dY (written by dY's producer): nothing to convert
+                } else if (dyb != nullptr && k % 4 == 0) {
                     const long n4 = (long)b.a.M * k / 4;
                     long cb = (n4 + 255) / 256;
                     if (cb > 256 * 32) cb = 256 * 32;
@@ -2298,6 +2300,17 @@ extern "C" int rr_dcn_dgrad_bf16_ws(const float *x, const float *offset, const f
 {
     return dcn_dgrad_impl(x, offset, mask, w, dy, dx, doffset, dmask, n, h, wd, c, k, r, s, stride, pad_h, pad_w, dilation,
                           deformable_groups, 1, stream, static_cast<unsigned short *>(dyb));
+}
+
+// dy_bf16: dY's bf16 image as its producer left it (same element order as dy; csrc/conv16.hip's contract) — no conversion pass
+extern "C" int rr_dcn_dgrad_bf16_img(const float *x, const float *offset, const float *mask, const float *w, const float *dy,
+                                     const unsigned short *dy_bf16, float *dx, float *doffset, float *dmask, int n, int h, int wd,
+                                     int c, int k, int r, int s, int stride, int pad_h, int pad_w, int dilation,
+                                     int deformable_groups, hipStream_t stream)
+{
+    RR_CHECK_ARG(dy_bf16 != nullptr, "rr_dcn_dgrad_bf16_img: the bf16 image of dy is required");
+    return dcn_dgrad_impl(x, offset, mask, w, dy, dx, doffset, dmask, n, h, wd, c, k, r, s, stride, pad_h, pad_w, dilation,
+                          deformable_groups, 1, stream, const_cast<unsigned short *>(dy_bf16), true);
 }
 
 extern "C" int rr_dcn_split_fwd(const float *om, long m, int third, float *offset, float *mask, hipStream_t stream)

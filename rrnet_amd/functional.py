@@ -678,7 +678,7 @@ def _share_b16(x, views):
         return
     hit = getattr(x, "_rr_b16", None)
     if hit is None or hit[0] != x._version:
-        if not (ops._CONV16 and (x.shape[1] % 256 == 0 or x.shape[1] == 128)
+        if not (ops._CONV16 and x.shape[1] % 128 == 0
                 and x.shape[0] * x.shape[2] * x.shape[3] >= ops._CONV16_MIN_PIXELS and ops.is_nhwc(x)):
             return
         ops.bf16_of(x)
@@ -788,7 +788,8 @@ def fanout_shared(x, n):
     if acc is None:
         acc = GradAcc()
         acc.link = getattr(x, "_rr_bnlink", None)
-    outs[0].grad_fn.acc = acc               # (the node object is the ctx its backward receives)
+    if outs[0].grad_fn is not None:         # (None under torch.no_grad(): nothing will run a backward)
+        outs[0].grad_fn.acc = acc           # (the node object is the ctx its backward receives)
     amax = getattr(x, "_rr_amax", None)     # (split-operand kernels: the views ARE x — its remembered maximum travels with them)
     for o in outs:
         o._rr_acc = acc

@@ -273,7 +273,7 @@ def amax_drop(t):
 # remembered the same way.  Like the remembered maxima it must be dropped when a kernel rewrites the tensor through its
 # raw pointer (amax_drop does both), is valid on the stream that made it, and on every stream once published.
 _CONV16 = os.environ.get("RR_CONV16", "1") != "0"               # 0: the round-4 kernels (fp32 tensors, converted inside every launch)
-_CONV16_MIN_PIXELS = int(os.environ.get("RR_CONV16_MIN_PIXELS", "16384"))    # output pixels below which 256-pixel tiles cannot fill the chip
+_CONV16_MIN_PIXELS = int(os.environ.get("RR_CONV16_MIN_PIXELS", "8192"))     # output pixels below which the 256-pixel tiles lose to the round-4 kernels (8 x 32 x 32 x 384: 351 vs 229 TFLOP/s; 16 x 16: 24 workgroups)
 
 
 def b16_attach(t, image):
@@ -796,7 +796,7 @@ def bn_apply(y, scale, shift, residual=None, relu=False, res_scale=None, res_shi
                  "rr_bn_apply_amax")
         out._rr_amax = (out._version, torch.cuda.current_stream(y.device).cuda_stream, word)
         return out
-    if _CONV16 and _mode() == MATH_BF16 and y.is_cuda and (c % 256 == 0 or c == 128) and n * h * w >= _CONV16_MIN_PIXELS:
+    if _CONV16 and _mode() == MATH_BF16 and y.is_cuda and c % 128 == 0 and n * h * w >= _CONV16_MIN_PIXELS:
         # the bf16 image the consuming convolution (csrc/conv16.hip) reads, written in the same pass
         out16 = torch.empty_like(out, dtype=torch.bfloat16)
         _C.check(_C.fn("rr_bn_apply_b16")(_C.ptr(y), _C.ptr(scale), _C.ptr(shift), _C.ptr(residual), _C.ptr(res_scale),
@@ -854,7 +854,7 @@ def bn_bwd_apply(dz, z, y, mean, invstd, gamma, sums, count, want_g=False, dgamm
                                                y.numel(), c, _C.ptr(word), _C.stream()), "rr_bn_bwd_apply_amax")
         dx._rr_amax = (dx._version, torch.cuda.current_stream(y.device).cuda_stream, word)
         return dx, g
-    if _CONV16 and _mode() == MATH_BF16 and y.is_cuda and c % 256 == 0 and n * h * w >= _CONV16_MIN_PIXELS:
+    if _CONV16 and _mode() == MATH_BF16 and y.is_cuda and c % 128 == 0 and n * h * w >= _CONV16_MIN_PIXELS:
         dx16 = torch.empty_like(dx, dtype=torch.bfloat16)
         _C.check(_C.fn("rr_bn_bwd_apply_b16")(_C.ptr(dz), _C.ptr(z), _C.ptr(y), _C.ptr(mean), _C.ptr(invstd), _C.ptr(gamma),
                                               _C.ptr(mask_scale), _C.ptr(mask_shift), _C.ptr(sums), float(count), _C.ptr(count_dev),
@@ -1296,6 +1296,13 @@ def dcn_dgrad(x, offset, mask, w, dy, stride, pad, dilation, dg, bf16=False):
     doff = torch.empty_like(offset)
     dmask = torch.empty_like(mask)
     assert doff.stride() == offset.stride() and dmask.stride() == mask.stride()
+    img = b16_carry(dy) if (bf16 and _DCN_DYB) else None
+    if img is not None and getattr(dy, "_rr_b16")[1] in (None, torch.cuda.current_stream(dy.device).cuda_stream):
+        # dY's producer already left its bf16 image (the heads' 1x1 data gradient): no conversion pass
+        _C.check(_C.fn("rr_dcn_dgrad_bf16_img")(_C.ptr(x), _C.ptr(offset), _C.ptr(mask), _C.ptr(w), _C.ptr(dy), _C.ptr(img), _C.ptr(dx),
+                                                _C.ptr(doff), _C.ptr(dmask), n, h, wd, c, k, r, s, stride, pad[0], pad[1],
+                                                dilation, dg, _C.stream()), "rr_dcn_dgrad_bf16_img")
+        return dx, doff, dmask
     if bf16 and _DCN_DYB:
         # dY rounded to bf16 once per call (caller scratch): the sweep's eight re-reads of a block's dY tile stay in L2
         dyb = torch.empty(_C.fn("rr_dcn_dyb_bytes")(dy.shape[0], dy.shape[2], dy.shape[3], k), dtype=torch.uint8, device=x.device)

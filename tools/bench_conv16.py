@@ -111,7 +111,8 @@ def main():
     a = ap.parse_args()
     shapes = [tuple(int(v) for v in a.shape.split(","))] if a.shape else [
         (2, 64, 24, 40, 256, 3, 1), (1, 128, 33, 47, 256, 3, 2), (2, 256, 32, 32, 256, 1, 1),
-        (8, 256, 256, 256, 256, 3, 1), (8, 256, 128, 128, 256, 3, 1), (8, 128, 512, 512, 256, 3, 2), (8, 512, 8, 8, 512, 3, 1)]
+        (2, 128, 20, 36, 384, 3, 1), (8, 256, 256, 256, 256, 3, 1), (8, 256, 128, 128, 256, 3, 1), (8, 128, 512, 512, 256, 3, 2), (8, 384, 64, 64, 384, 3, 1),
+        (8, 256, 128, 128, 384, 3, 2), (8, 384, 32, 32, 384, 3, 1)]
     for s in shapes:
         print(json.dumps(run_shape(*s, reps=a.reps)), flush=True)
 
