@@ -22,8 +22,11 @@
 //               sixteen different 16-byte bank slots: conflict-free without padding.  An LDS-DMA wave-instruction writes 1 KiB
 //               = 8 rows x 128 B linearly (lane l -> slot l); the swizzle is applied on the SOURCE side (lane l fetches the
 //               chunk that belongs in slot l), every lane reads a whole 128-byte line's share of its row
-//   pipeline    K-tile kt+1's eight DMA pieces per wave are issued before the MFMAs of K-tile kt and have the whole tile's matrix
-//               time to land; one `s_waitcnt vmcnt(0)` + raw s_barrier per K-tile
+//   pipeline    K-tile kt+1's DMA pieces are dealt one per 4 MFMAs over the first half of K-tile kt and have the rest of the tile's
+//               matrix time to land; one `s_waitcnt vmcnt(0)` + raw s_barrier per K-tile.  Built and measured against it (round 5):
+//               a ring of FOUR 32-deep stages filled three steps ahead with a counted vmcnt (never draining the memory pipe):
+//               1.06 PFLOP/s at the dominant layer against 1.09-1.10 for this form — twice the barriers per MFMA cost what the
+//               deeper prefetch gained; not kept
 //   borders     taps that fall outside the image (and rows beyond M) read through an out-of-range buffer offset: the hardware
 //               returns zeros into LDS, nothing is selected or branched on
 // Algorithmic bytes per launch: the bf16 input once + the bf16 filter + the output once (256 -> 256 3x3 on 8 x 256 x 256: 268 MB + 1.2 MB

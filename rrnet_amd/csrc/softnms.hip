@@ -284,7 +284,13 @@ __device__ __forceinline__ RegCand wave_best(RegCand c)
 
 constexpr int SMALL_SEG_REG = 256;          // one box per lane of four waves
 constexpr int REG_DEAD = 0x7fffffff;         // position of a box that is out of the game (dead, or a padding slot)
-constexpr int REG_MASK_WORDS = 96;           // 32-bit words of one dead-position mask: positions < 3072
+constexpr int REG_MASK_WORDS = 288;          // 32-bit words of one dead-position mask: positions < 9216
+// Round 5: a death step usually kills a handful of boxes.  Their positions go to a short LDS LIST (REG_LIST entries, two buffers)
+// and the renumbering works on that list — O(deaths^2) broadcast reads — instead of popcount scans over the position mask, which
+// for a 9000-box segment walked up to 288 words per moved box (and per lane for the pre-selected next box): ~6 of the 8.4 us per
+// outer step.  Steps with more deaths than the list holds keep the mask path.
+constexpr int REG_LIST = 64;
+constexpr int REG_LDS_WORDS = 2 * 16 * 8 + 2 * REG_MASK_WORDS + 2 * REG_LIST + 4;
 
 // lds: [2][16] exchange slots of 8 words + [2][REG_MASK_WORDS] dead-position masks (zero on entry)
 template <int T, int NB>
@@ -293,7 +299,10 @@ __device__ __forceinline__ void soft_nms_registers(float *b, const int stride, c
 {
     constexpr int W = T / 64;
     unsigned *slots = lds;                       // [2][16][8]
-    unsigned *masks = lds + 2 * 16 * 8;          // [2][REG_MASK_WORDS] dead positions of the current / the previous death step
+    unsigned *masks = lds + 2 * 16 * 8;          // [2][REG_MASK_WORDS] dead positions of the current / the previous death step (mask path)
+    int *dlist = reinterpret_cast<int *>(masks + 2 * REG_MASK_WORDS);      // [2][REG_LIST] dead positions of a death step (list path)
+    int *dcount = dlist + 2 * REG_LIST;          // [2] entries of each list (zero on entry)
+    bool mask_dirty = false;                     // the other mask buffer holds bits of an earlier mask-path step
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float x1[NB], y1[NB], x2[NB], y2[NB], sc[NB], ar[NB];
     unsigned key[NB];                            // sortable_key(sc[j]), refreshed when the score changes
@@ -453,13 +462,57 @@ __device__ __forceinline__ void soft_nms_registers(float *b, const int stride, c
         sel = block_best(c, ndead, D);
         if (D == 0) continue;
         // ---- renumbering = the reference's swap-with-last compaction: the k-th dead position from the left below the new
-        // N receives the k-th surviving box from the right end.  Dead positions of this step -> bits of an LDS mask.
+        // N receives the k-th surviving box from the right end.
+        const int newN = N - D;
+        if (D <= REG_LIST) {
+            // list path: the step's dead positions, unordered, in LDS
+            int *dl = dlist + mbuf * REG_LIST;
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+                if (deadbits & (1u << j)) dl[atomicAdd(&dcount[mbuf], 1)] = pos[j];
+            __syncthreads();
+            auto new_pos = [&](int p) -> int {
+                int above = 0;                                    // dead positions in (p, N)
+                for (int e = 0; e < D; ++e) above += dl[e] > p ? 1 : 0;
+                const int r = (N - 1 - p) - above;                // rank from the right among the survivors of [newN, N)
+                for (int e = 0; e < D; ++e) {                     // the hole with exactly r holes to its left
+                    const int h = dl[e];
+                    if (h >= newN) continue;
+                    int below = 0;
+                    for (int f = 0; f < D; ++f) below += dl[f] < h ? 1 : 0;
+                    if (below == r) return h;
+                }
+                return p;
+            };
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int p = pos[j];
+                if (deadbits & (1u << j)) pos[j] = REG_DEAD;
+                else if (p >= newN && p < N) pos[j] = new_pos(p);
+            }
+            if (sel.tied || sel.ks == 0u) {
+                N = newN;
+                sel = block_best(lane_best(i), 0, dummy);
+            } else {
+                const int q = (int)~sel.kp;
+                if (q >= newN && q < N) sel.kp = ~(unsigned)new_pos(q);
+                N = newN;
+            }
+            // the OTHER list's counter (the previous death step's) is reset now: every wave left that list at least one barrier ago
+            mbuf ^= 1;
+            if (tid == 0) dcount[mbuf] = 0;
+            if (mask_dirty) {                                       // (block-uniform) bits of an earlier mask-path step in that buffer
+                for (int w = tid; w < REG_MASK_WORDS; w += T) masks[mbuf * REG_MASK_WORDS + w] = 0u;
+                mask_dirty = false;
+            }
+            continue;
+        }
+        // mask path (more deaths than the list holds): dead positions of this step -> bits of an LDS mask
         unsigned *mk = masks + mbuf * REG_MASK_WORDS;
 #pragma unroll
         for (int j = 0; j < NB; ++j)
             if (deadbits & (1u << j)) atomicOr(&mk[pos[j] >> 5], 1u << (pos[j] & 31));
         __syncthreads();
-        const int newN = N - D;
         // new position of a survivor that sits at p in [newN, N): its rank r from the right among the survivors of that
         // range is the index, from the left, of the dead position in (i, newN) it moves to
         auto new_pos = [&](int p) -> int {
@@ -506,10 +559,12 @@ __device__ __forceinline__ void soft_nms_registers(float *b, const int stride, c
             if (q >= newN && q < N) sel.kp = ~(unsigned)new_pos(q);
             N = newN;
         }
-        // the OTHER mask (the previous death step's) is cleared now: every wave left it at least one barrier ago; this
-        // one is read until the next barrier and will be cleared by the next death step
+        // the OTHER buffers (the previous death step's) are cleared now: every wave left them at least one barrier ago; this
+        // mask is read until the next barrier and will be cleared by the next death step
         mbuf ^= 1;
+        if (tid == 0) dcount[mbuf] = 0;
         for (int w = tid; w < REG_MASK_WORDS; w += T) masks[mbuf * REG_MASK_WORDS + w] = 0u;
+        mask_dirty = true;                                          // (the mask just used, cleared by the next death step whichever path it takes)
     }
     if (my_err) *err = 1;
     // rows [0, N) in selection order = position order
@@ -593,11 +648,11 @@ template <int T, int NB>
 __global__ __launch_bounds__(T) void soft_nms_reg_kernel(float *boxes, const int *seg_off, const int *seg_len, int stride,
                                                          float sigma, float Nt, float thr, int method, int *n_out, int *err)
 {
-    __shared__ __align__(16) unsigned lds[2 * 16 * 8 + 2 * REG_MASK_WORDS];
+    __shared__ __align__(16) unsigned lds[REG_LDS_WORDS];
     const int seg = blockIdx.x;
     const int off = seg_off[seg];
     const int n = seg_len ? seg_len[seg] : seg_off[seg + 1] - off;
-    for (int w = threadIdx.x; w < 2 * 16 * 8 + 2 * REG_MASK_WORDS; w += T) lds[w] = 0u;
+    for (int w = threadIdx.x; w < REG_LDS_WORDS; w += T) lds[w] = 0u;
     __syncthreads();
     float *b = boxes + (size_t)off * stride;
     if (T > 256 && n <= SMALL_SEG_REG) {         // a short segment in a launch sized for long ones: the first four waves, one box each
@@ -656,7 +711,11 @@ static int soft_nms_launch(float *boxes, const int *seg_off, const int *seg_len,
     // (measured, one segment: 2500 boxes 4.97 against 5.57 ms for the LDS loop; at 5000 / 9000 boxes — six / nine boxes per
     // lane of a 1024-thread workgroup, 128 registers per lane — the register kernel spills and loses, 15.7 against 14.2 and
     // 52 against 38 ms: it takes segments of up to 3072 boxes)
-    if (max_seg_boxes <= 3072 && softnms_reg_enabled() && !throughput_regime) {
+    // (round 5, with the list renumbering: one 9000-box segment 29 ms in registers — 18 boxes per lane of 512 threads, 256 registers,
+    // no scratch — against 38 ms for the LDS loop on its global workspace; a batch of such segments likewise: the LDS loop has no
+    // LDS for them and runs out of L2)
+    static const int reg_max = getenv("RR_SOFTNMS_REG_MAX") ? atoi(getenv("RR_SOFTNMS_REG_MAX")) : 9216;
+    if (max_seg_boxes <= reg_max && max_seg_boxes <= 9216 && softnms_reg_enabled() && (!throughput_regime || !in_lds)) {
         // register-resident kernels: T x NB boxes per segment
 #define LAUNCH_REG(T, NB)                                                                                              \
         hipLaunchKernelGGL((soft_nms_reg_kernel<T, NB>), dim3(nseg), dim3(T), 0, stream, boxes, seg_off, seg_len, stride, sigma, \
@@ -666,7 +725,9 @@ static int soft_nms_launch(float *boxes, const int *seg_off, const int *seg_len,
         // (measured: 1024 x 2 for 1500 boxes, four waves per SIMD, is 30 % slower than 512 x 3: a 16-wave barrier and exchange)
         if (max_seg_boxes <= 256) LAUNCH_REG(256, 1);
         else if (max_seg_boxes <= 1536) LAUNCH_REG(512, 3);
-        else LAUNCH_REG(1024, 3);
+        else if (max_seg_boxes <= 3072) LAUNCH_REG(1024, 3);
+        else if (max_seg_boxes <= 6144) LAUNCH_REG(512, 12);
+        else LAUNCH_REG(512, 18);
 #undef LAUNCH_REG
         RR_CHECK_LAUNCH("rr_soft_nms_segments");
         return RR_OK;

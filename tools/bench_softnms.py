@@ -145,12 +145,12 @@ def run(sizes=(150, 1500, 9000), many=1280, cpu=True, reps=5):
                 assert kept == kept_cpu, (n, kept, kept_cpu)      # same algorithm, same boxes (bit-exactness: tests/)
             # outer steps executed by the longest segment = boxes it keeps (the loop ends when i reaches the shrunk N)
             steps = int(n_out.max().item())
-            threads = 64 if n <= 192 else (256 if n <= 2560 else 1024)
+            threads = 64 if n <= 192 else (256 if n <= 256 else (512 if (n <= 1536 or n > 3072) else 1024))       # register kernels: 256 x 1, 512 x 3, 1024 x 3, 512 x 12 / 18
             fl = floor.get("T%d_x%d" % (threads, 1 if nseg == 1 else many)) if isinstance(floor, dict) else None
             rows.append({"N": n, "segments": nseg, "ms": round(ms, 4), "boxes_per_sec": round(nseg * n / (ms * 1e-3), 1),
                          "kept": kept, "outer_steps": steps, "us_per_outer_step": round(ms * 1e3 / max(steps, 1), 4),
                          "floor_us_per_step": fl, "threads_per_segment": threads,
-                         "path": "LDS" if n <= 6000 else "global workspace",
+                         "path": ("registers" if (n <= 9216 and (n > 6000 or nseg <= 512 or n <= 256)) else "LDS loop"),
                          "cpu_oracle_ms_per_segment": None if cpu_ms is None else round(cpu_ms, 3),
                          "cpu_oracle_boxes_per_sec": None if cpu_ms is None else round(n / (cpu_ms * 1e-3), 1)})
             del base, work
