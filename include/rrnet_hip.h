@@ -184,13 +184,23 @@ int rr_conv16_wgrad(const unsigned short *x, const unsigned short *dy, float *dw
  * rounded to nearest even — written in the same pass, so the convolution that consumes the tensor never reads the fp32
  * one.  out / dx (fp32) may be NULL when nothing else reads them.  rr_to_bf16: the plain conversion, for operands that
  * come from elsewhere (fan-in sums, the up-sample add, head gradients). */
-int rr_bn_apply_b16(const float *y, const float *scale, const float *shift, const float *res, const float *res_scale,
-                    const float *res_shift, float *out, unsigned short *out16, long total, int c, int relu,
-                    hipStream_t stream);
-int rr_bn_bwd_apply_b16(const float *dz, const float *z, const float *y, const float *mean, const float *invstd,
-                        const float *gamma, const float *mask_scale, const float *mask_shift, const double *sums,
-                        double count, const double *count_dev, float *dx, unsigned short *dx16, float *g_out,
-                        int g_accumulate, float *dgamma, float *dbeta, long total, int c, hipStream_t stream);
+int rr_bn_apply_b16(const float *y, const float *scale, const float *shift, const float *res, const unsigned short *res16,
+                    const float *res_scale, const float *res_shift, float *out, unsigned short *out16, long total, int c,
+                    int relu, hipStream_t stream);
+int rr_bn_bwd_apply_b16(const float *dz, const float *z, const unsigned short *z16, const float *y, const float *mean,
+                        const float *invstd, const float *gamma, const float *mask_scale, const float *mask_shift,
+                        const double *sums, double count, const double *count_dev, float *dx, unsigned short *dx16,
+                        float *g_out, int g_accumulate, float *dgamma, float *dbeta, long total, int c, hipStream_t stream);
+/* res16 / z16: the residual / the layer's own output (the ReLU mask's source) when it exists ONLY as its bf16 image (an
+ * activation every consumer of which reads bf16: rrnet_amd.ops.phantom_f32); give res or res16, z or z16, never both.
+ * rr_bn_bwd_reduce_b16: rr_bn_bwd_reduce with the mask from z16 (sums pre-zeroed).  rr_upsample2x_add_b16: the hourglass
+ * up-path add (backbones/hourglass.py:121-124, even sizes) with either operand as fp32 or bf16 and the result as fp32
+ * and / or bf16.  rr_from_bf16: the widening copy (a consumer without a bf16 form materialises the fp32 tensor). */
+int rr_bn_bwd_reduce_b16(const float *dz, const unsigned short *z16, const float *y, const float *mean, const float *invstd,
+                         double *sums, long npix, int c, hipStream_t stream);
+int rr_upsample2x_add_b16(const float *up1, const unsigned short *up1_16, const float *low, const unsigned short *low_16,
+                          float *out, unsigned short *out16, int n, int h, int w, int c, hipStream_t stream);
+int rr_from_bf16(const unsigned short *x, float *out, long total, hipStream_t stream);
 int rr_to_bf16(const float *x, unsigned short *out, long total, hipStream_t stream);
 
 /* Data gradient of a head's narrow 1x1 convolution (K = 10 / 2 / 34 output channels behind a 3x3 conv + bias + ReLU:

@@ -18,6 +18,7 @@ import torch
 import torch.nn as nn
 
 from rrnet_amd import functional as RF
+from rrnet_amd import ops
 
 __all__ = ['HourglassNet', 'Hourglass', 'ResidualBlock', 'ConvBNRelu', 'hourglass_net', 'hourglass_tiny']
 
@@ -152,6 +153,8 @@ class Hourglass(nn.Module):
         cur = torch.cuda.current_stream(x.device)
         side.wait_stream(cur)
         xa.record_stream(side)
+        if ops.b16_carry(xa) is not None:
+            ops.b16_carry(xa).record_stream(side)
         with torch.cuda.stream(side):
             RF.branch_stress(x.device)
             up1 = self.up1(xa)
@@ -186,19 +189,24 @@ class HourglassNet(nn.Module):
 
     def forward(self, x):
         """-> list of num_stacks pre-ReLU feature maps [B, num_feats, H/4, W/4] (NHWC memory)."""
-        pre = RF.conv_bn_act(x, self.pre_layer[0], self.pre_layer[1], relu=True)
-        pre = self.pre_layer[3](pre)
-        outs = []
-        for i in range(self.num_stacks):
-            last = i == self.num_stacks - 1
-            pa, pb = (pre, None) if last else RF.fanout_shared(pre, 2)[:2]
-            feat = self.convs[i](self.hgs[i](pa))
-            outs.append(feat)
-            if not last:
-                act = RF.relu(feat)
-                a = RF.conv_bn_act(pb, self.inter_[i][0], self.inter_[i][1], relu=False)
-                pre = RF.conv_bn_act(act, self.conv_[i][0], self.conv_[i][1], relu=True, residual=a)
-                pre = self.residual[i](pre)
+        # Under cfg.Model.bf16 the activations that stay inside the backbone may exist as bf16 images only (ops.phantom_scope:
+        # every layer that reads them here reads the image); what leaves it — the feature maps — is produced outside the scope.
+        with ops.phantom_scope(True):
+            pre = RF.conv_bn_act(x, self.pre_layer[0], self.pre_layer[1], relu=True)
+            pre = self.pre_layer[3](pre)
+            outs = []
+            for i in range(self.num_stacks):
+                last = i == self.num_stacks - 1
+                pa, pb = (pre, None) if last else RF.fanout_shared(pre, 2)[:2]
+                hg = self.hgs[i](pa)
+                with ops.phantom_scope(False):
+                    feat = self.convs[i](hg)
+                outs.append(feat)
+                if not last:
+                    act = RF.relu(feat)
+                    a = RF.conv_bn_act(pb, self.inter_[i][0], self.inter_[i][1], relu=False)
+                    pre = RF.conv_bn_act(act, self.conv_[i][0], self.conv_[i][1], relu=True, residual=a)
+                    pre = self.residual[i](pre)
         return outs
 
 

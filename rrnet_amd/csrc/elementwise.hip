@@ -19,6 +19,14 @@ typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 // four fp32 -> four bf16 (round to nearest even, v_cvt_pk_bf16_f32; NaN stays NaN)
 __device__ __forceinline__ u16x4 to_bf16x4(f32x4 v) { return __builtin_bit_cast(u16x4, __builtin_convertvector(v, bf16x4)); }
+// four bf16 -> four fp32 (exact)
+__device__ __forceinline__ f32x4 from_bf16x4(u16x4 v)
+{
+    f32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = __builtin_bit_cast(float, (unsigned)v[e] << 16);
+    return r;
+}
 
 constexpr int EW_THREADS = 256;
 inline int ew_blocks(long n4) { long b = (n4 + EW_THREADS - 1) / EW_THREADS; return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b)); }
@@ -136,7 +144,8 @@ template <bool AMAX>
 __global__ __launch_bounds__(EW_THREADS) void bn_apply_kernel(const f32x4 *y, const float *scale, const float *shift,
                                                               const f32x4 *res, const float *res_scale,
                                                               const float *res_shift, f32x4 *out, long n4, int C4,
-                                                              int relu, unsigned *amax, u16x4 *out16 = nullptr)
+                                                              int relu, unsigned *amax, u16x4 *out16 = nullptr,
+                                                              const u16x4 *res16 = nullptr)
 {
     float vmax = 0.f;
     for (long i = (long)blockIdx.x * EW_THREADS + threadIdx.x; i < n4; i += (long)gridDim.x * EW_THREADS) {
@@ -144,8 +153,8 @@ __global__ __launch_bounds__(EW_THREADS) void bn_apply_kernel(const f32x4 *y, co
         f32x4 v = y[i];
         const f32x4 sc = *reinterpret_cast<const f32x4 *>(scale + c), sh = *reinterpret_cast<const f32x4 *>(shift + c);
         v = rr_bn_affine4(v, sc, sh);
-        if (res) {
-            f32x4 r = res[i];
+        if (res || res16) {
+            f32x4 r = res16 ? from_bf16x4(res16[i]) : res[i];     // (res16: the residual exists only as its bf16 image)
             if (res_scale) {
                 const f32x4 rs = *reinterpret_cast<const f32x4 *>(res_scale + c);
                 const f32x4 rh = *reinterpret_cast<const f32x4 *>(res_shift + c);
@@ -176,7 +185,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_apply_kernel(const f32x4 *y, co
 __global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_kernel(const float *dz, const float *z, const float *y,
                                                                    const float *mean, const float *invstd,
                                                                    const float *mscale, const float *mshift,
-                                                                   double *sums, long npix, int C)
+                                                                   double *sums, long npix, int C, const unsigned short *z16 = nullptr)
 {
     __shared__ double red[2][EW_THREADS * 4];
     const int C4 = C / 4;                      // <= EW_THREADS (checked by the launcher)
@@ -201,8 +210,8 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_kernel(const float *
                     const long off = p * C + cq * 4;
                     f32x4 g = *reinterpret_cast<const f32x4 *>(dz + off);
                     const f32x4 yy = *reinterpret_cast<const f32x4 *>(y + off);
-                    if (z) {
-                        const f32x4 zz = *reinterpret_cast<const f32x4 *>(z + off);
+                    if (z || z16) {
+                        const f32x4 zz = z16 ? from_bf16x4(*reinterpret_cast<const u16x4 *>(z16 + off)) : *reinterpret_cast<const f32x4 *>(z + off);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) g[e] = zz[e] > 0.f ? g[e] : 0.f;
                     } else if (mscale) {      // ReLU mask recomputed from y: z = relu(y*scale+shift), no residual
@@ -244,7 +253,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(const f32x4 *d
                                                                   const double *sums, double count_h,
                                                                   const double *count_d, f32x4 *dx, f32x4 *g_out,
                                                                   float *dgamma, float *dbeta, long n4, int C, int g_acc,
-                                                                  unsigned *amax, u16x4 *dx16 = nullptr)
+                                                                  unsigned *amax, u16x4 *dx16 = nullptr, const u16x4 *z16 = nullptr)
 {
     float vmax = 0.f;
     const int C4 = C / 4;
@@ -260,8 +269,8 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(const f32x4 *d
         const int c = (int)(i % C4) * 4;
         f32x4 g = dz[i];
         const f32x4 yy = y[i];
-        if (z) {
-            const f32x4 zz = z[i];
+        if (z || z16) {
+            const f32x4 zz = z16 ? from_bf16x4(z16[i]) : z[i];
 #pragma unroll
             for (int e = 0; e < 4; ++e) g[e] = zz[e] > 0.f ? g[e] : 0.f;
         } else if (mscale) {
@@ -410,18 +419,25 @@ __global__ __launch_bounds__(EW_THREADS) void colsum4_kernel(const f32x4 *dy, co
 // ---- hourglass up path ---------------------------------------------------------------------
 // out[n,h,w,:] = up1[n,h,w,:] + low[n,h/2,w/2,:]     (nn.Upsample(scale_factor=2), nearest; the
 // bilinear align_corners resize that follows in the reference is the identity at equal sizes)
-__global__ __launch_bounds__(EW_THREADS) void upsample2x_add_kernel(const f32x4 *up1, const f32x4 *low, f32x4 *out,
-                                                                    int N, int H, int W, int C4)
+__global__ __launch_bounds__(EW_THREADS) void upsample2x_add_kernel(const f32x4 *up1, const f32x4 *low, f32x4 *out, int N, int H, int W,
+                                                                    int C4, const u16x4 *up1_16 = nullptr, const u16x4 *low_16 = nullptr,
+                                                                    u16x4 *out16 = nullptr)
 {
-    const long n4 = (long)N * H * W * C4;
+    // up1_16 / low_16: the operand exists only as its bf16 image (conv16 activations); out may be null when out16 is given
     const int LH = H / 2, LW = W / 2;
+    const long n4 = (long)N * H * W * C4;
     for (long i = (long)blockIdx.x * EW_THREADS + threadIdx.x; i < n4; i += (long)gridDim.x * EW_THREADS) {
         const int c = (int)(i % C4);
         long p = i / C4;
         const int w = (int)(p % W); p /= W;
         const int h = (int)(p % H);
         const int n = (int)(p / H);
-        out[i] = up1[i] + low[(((long)n * LH + h / 2) * LW + w / 2) * C4 + c];
+        const long li = (((long)n * LH + h / 2) * LW + w / 2) * C4 + c;
+        const f32x4 a = up1_16 ? from_bf16x4(up1_16[i]) : up1[i];
+        const f32x4 b = low_16 ? from_bf16x4(low_16[li]) : low[li];
+        const f32x4 v = a + b;
+        if (out) out[i] = v;
+        if (out16) out16[i] = to_bf16x4(v);
     }
 }
 
@@ -791,15 +807,58 @@ extern "C" int rr_head_dgrad_relubias(const float *dy, const float *w, float *dx
     return RR_OK;
 }
 
-extern "C" int rr_bn_apply_b16(const float *y, const float *scale, const float *shift, const float *res,
+extern "C" int rr_bn_apply_b16(const float *y, const float *scale, const float *shift, const float *res, const unsigned short *res16,
                                const float *res_scale, const float *res_shift, float *out, unsigned short *out16, long total,
                                int c, int relu, hipStream_t stream)
 {
-    RR_CHECK_ARG(c % 4 == 0 && total % c == 0 && (out != nullptr || out16 != nullptr), "rr_bn_apply_b16: C=%d must be a multiple of 4, one output required", c);
+    RR_CHECK_ARG(c % 4 == 0 && total % c == 0 && (out != nullptr || out16 != nullptr) && !(res != nullptr && res16 != nullptr),
+                 "rr_bn_apply_b16: C=%d must be a multiple of 4, one output required, the residual in ONE precision", c);
     const long n4 = total / 4;
     EW_LAUNCH(bn_apply_kernel<false>, n4, stream, (const f32x4 *)y, scale, shift, (const f32x4 *)res, res_scale, res_shift,
-              (f32x4 *)out, n4, c / 4, relu, (unsigned *)nullptr, (u16x4 *)out16);
+              (f32x4 *)out, n4, c / 4, relu, (unsigned *)nullptr, (u16x4 *)out16, (const u16x4 *)res16);
     RR_CHECK_LAUNCH("rr_bn_apply_b16");
+    return RR_OK;
+}
+
+__global__ __launch_bounds__(EW_THREADS) void from_bf16_kernel(const u16x4 *x, f32x4 *out, long n4)
+{
+    for (long i = (long)blockIdx.x * EW_THREADS + threadIdx.x; i < n4; i += (long)gridDim.x * EW_THREADS) out[i] = from_bf16x4(x[i]);
+}
+
+extern "C" int rr_from_bf16(const unsigned short *x, float *out, long total, hipStream_t stream)
+{
+    RR_CHECK_ARG(total % 4 == 0 && x != nullptr && out != nullptr, "rr_from_bf16: element count must be a multiple of 4");
+    EW_LAUNCH(from_bf16_kernel, total / 4, stream, (const u16x4 *)x, (f32x4 *)out, total / 4);
+    RR_CHECK_LAUNCH("rr_from_bf16");
+    return RR_OK;
+}
+
+extern "C" int rr_upsample2x_add_b16(const float *up1, const unsigned short *up1_16, const float *low, const unsigned short *low_16,
+                                     float *out, unsigned short *out16, int n, int h, int w, int c, hipStream_t stream)
+{
+    RR_CHECK_ARG(c % 4 == 0 && h % 2 == 0 && w % 2 == 0 && (up1 != nullptr) != (up1_16 != nullptr) && (low != nullptr) != (low_16 != nullptr)
+                 && (out != nullptr || out16 != nullptr), "rr_upsample2x_add_b16: even H, W, C %% 4 == 0, each operand in ONE precision, one output");
+    const long n4 = (long)n * h * w * (c / 4);
+    EW_LAUNCH(upsample2x_add_kernel, n4, stream, (const f32x4 *)up1, (const f32x4 *)low, (f32x4 *)out, n, h, w, c / 4, (const u16x4 *)up1_16,
+              (const u16x4 *)low_16, (u16x4 *)out16);
+    RR_CHECK_LAUNCH("rr_upsample2x_add_b16");
+    return RR_OK;
+}
+
+extern "C" int rr_bn_bwd_reduce_b16(const float *dz, const unsigned short *z16, const float *y, const float *mean,
+                                    const float *invstd, double *sums, long npix, int c, hipStream_t stream)
+{
+    // rr_bn_bwd_reduce with the ReLU mask read from the bf16 image of the layer's output (sums pre-zeroed)
+    RR_CHECK_ARG(c % 4 == 0 && c <= 1024 && z16 != nullptr, "rr_bn_bwd_reduce_b16: C=%d must be a multiple of 4 and <= 1024", c);
+    const int c4 = c / 4;
+    const int lanes = EW_THREADS / c4 > 0 ? EW_THREADS / c4 : 1;
+    long blocks = (npix + lanes * 8 - 1) / (lanes * 8);
+    const long cap = npix >= 400000 ? 1024 : (npix >= 16384 ? 512 : 256);
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((int)blocks), dim3(EW_THREADS), 0, stream, dz, (const float *)nullptr, y, mean, invstd,
+                       (const float *)nullptr, (const float *)nullptr, sums, npix, c, z16);
+    RR_CHECK_LAUNCH("rr_bn_bwd_reduce_b16");
     return RR_OK;
 }
 
@@ -852,14 +911,15 @@ static int bn_bwd_apply_impl(const float *dz, const float *z, const float *y, co
                              const float *invstd, const float *gamma, const float *mask_scale,
                              const float *mask_shift, const double *sums, double count,
                              const double *count_dev, float *dx, float *g_out, float *dgamma, float *dbeta,
-                             long total, int c, int g_acc, hipStream_t stream, unsigned *amax = nullptr, unsigned short *dx16 = nullptr)
+                             long total, int c, int g_acc, hipStream_t stream, unsigned *amax = nullptr, unsigned short *dx16 = nullptr,
+                             const unsigned short *z16 = nullptr)
 {
     RR_CHECK_ARG(c % 4 == 0 && total % c == 0, "rr_bn_bwd_apply: C=%d must be a multiple of 4", c);
     const long n4 = total / 4;
-    if (dx16 != nullptr)
+    if (dx16 != nullptr || z16 != nullptr)
         EW_LAUNCH(bn_bwd_apply_kernel<false>, n4, stream, (const f32x4 *)dz, (const f32x4 *)z, (const f32x4 *)y, mean, invstd, gamma,
                   mask_scale, mask_shift, sums, count, count_dev, (f32x4 *)dx, (f32x4 *)g_out, dgamma, dbeta, n4, c, g_acc,
-                  (unsigned *)nullptr, (u16x4 *)dx16);
+                  (unsigned *)nullptr, (u16x4 *)dx16, (const u16x4 *)z16);
     else if (amax != nullptr)
         EW_LAUNCH(bn_bwd_apply_kernel<true>, n4, stream, (const f32x4 *)dz, (const f32x4 *)z, (const f32x4 *)y, mean, invstd, gamma,
                   mask_scale, mask_shift, sums, count, count_dev, (f32x4 *)dx, (f32x4 *)g_out, dgamma, dbeta, n4, c, g_acc, amax);
@@ -871,15 +931,16 @@ static int bn_bwd_apply_impl(const float *dz, const float *z, const float *y, co
     return RR_OK;
 }
 
-extern "C" int rr_bn_bwd_apply_b16(const float *dz, const float *z, const float *y, const float *mean,
+extern "C" int rr_bn_bwd_apply_b16(const float *dz, const float *z, const unsigned short *z16, const float *y, const float *mean,
                                    const float *invstd, const float *gamma, const float *mask_scale,
                                    const float *mask_shift, const double *sums, double count,
                                    const double *count_dev, float *dx, unsigned short *dx16, float *g_out, int g_accumulate,
                                    float *dgamma, float *dbeta, long total, int c, hipStream_t stream)
 {
-    RR_CHECK_ARG(dx16 != nullptr && (!g_accumulate || g_out != nullptr), "rr_bn_bwd_apply_b16: dx16 (and the fan-in buffer when accumulating) required");
+    RR_CHECK_ARG((dx != nullptr || dx16 != nullptr) && (!g_accumulate || g_out != nullptr) && !(z != nullptr && z16 != nullptr),
+                 "rr_bn_bwd_apply_b16: one of dx / dx16 (and the fan-in buffer when accumulating) required, the mask source in ONE precision");
     return bn_bwd_apply_impl(dz, z, y, mean, invstd, gamma, mask_scale, mask_shift, sums, count, count_dev, dx, g_out, dgamma,
-                             dbeta, total, c, g_accumulate ? 1 : 0, stream, nullptr, dx16);
+                             dbeta, total, c, g_accumulate ? 1 : 0, stream, nullptr, dx16, z16);
 }
 
 extern "C" int rr_bn_bwd_apply_amax(const float *dz, const float *z, const float *y, const float *mean,

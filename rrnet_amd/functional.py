@@ -127,7 +127,7 @@ class _ConvBnAct(torch.autograd.Function):
         ctx.accs = (x_acc, res_acc)
         ctx.links = (in_link, out_link)
         ctx.bf16 = ops.BF16
-        x = ops.to_nhwc(x)
+        x = ops.to_nhwc(x, keep_phantom=True)          # (a bf16-only input: the conv16 kernels read its image)
         wc = ops.to_nhwc(w)
         _wamax_attach(w, wc)
         n, _, h, wd = x.shape
@@ -175,8 +175,11 @@ class _ConvBnAct(torch.autograd.Function):
                 ctx.cfg = (stride, pad, relu, count, sync, False)
                 return ops.conv_fprop(x, ops.to_nhwc(wc * scale.view(-1, 1, 1, 1)), shift, stride, pad, relu)
             y = ops.conv_fprop(x, wc, None, stride, pad, False, w16=_w16_of(w)[0])
-        res = ops.to_nhwc(residual) if residual is not None else None
-        z = ops.bn_apply(y, scale, shift, res, relu)
+        res = ops.to_nhwc(residual, keep_phantom=True) if residual is not None else None
+        # inside the backbone (ops.phantom_scope) the activation is written as a bf16 image only where the shape qualifies: every
+        # consumer there reads the image (conv16 operands, the next block's residual, the ReLU mask of this layer's backward)
+        z = ops.bn_apply(y, scale, shift, res, relu,
+                         bf16_only=bn.training and ops.phantom_out_ok(k, y.shape[0] * y.shape[2] * y.shape[3], y.device))
         if bn.training:
             # ReLU mask: layers with a residual need their output z; the others recompute it from y (one tensor
             # read less in each of the two backward passes)
@@ -185,6 +188,7 @@ class _ConvBnAct(torch.autograd.Function):
                                   scale if remask else None, shift if remask else None)
             ctx.x_amax = ops.amax_carry(x)      # (split-operand kernels: the weight gradient reuses the forward's reduction)
             ctx.x_b16 = ops.b16_carry(x)        # (conv16 kernels: the weight gradient reads the forward's bf16 image of x)
+            ctx.z_b16 = ops.b16_carry(z) if (relu and not remask) else None      # (a bf16-only z: its image is the mask's source)
             if out_link is not None:
                 # what a consumer's data gradient needs to produce this layer's BatchNorm-backward sums in its epilogue
                 out_link.y, out_link.mean, out_link.invstd = y, mean, invstd
@@ -206,6 +210,7 @@ class _ConvBnAct(torch.autograd.Function):
         branch_stress(dz.device)
         ops.amax_restore(x, getattr(ctx, "x_amax", None))
         ops.b16_restore(x, getattr(ctx, "x_b16", None))
+        ops.b16_restore(z, getattr(ctx, "z_b16", None))
         stride, pad, relu, count, sync, has_res = ctx.cfg
         w, gamma_p, beta_p = ctx.params
         dz = ops.to_nhwc(dz)
@@ -674,6 +679,11 @@ class _FanOut(torch.autograd.Function):
 def _share_b16(x, views):
     """conv16 kernels: the fan-out views ARE x — its bf16 image (written by x's producer, or converted once here so that the
     n consumers do not convert n times) travels with them."""
+    if ops.is_phantom(x):                  # a bf16-only tensor: its views must keep the image, whatever the mode
+        img = ops.image_of(x)
+        for o in views:
+            o._rr_b16 = (o._version, x._rr_b16[1], img)
+        return
     if ops.BF16 != ops.MATH_BF16 or not x.is_cuda or x.dim() != 4 or x.dtype != torch.float32:
         return
     hit = getattr(x, "_rr_b16", None)
@@ -839,9 +849,10 @@ class _UpsampleAdd(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, up1, low):
-        up1, low = ops.to_nhwc(up1), ops.to_nhwc(low)
+        up1, low = ops.to_nhwc(up1, keep_phantom=True), ops.to_nhwc(low, keep_phantom=True)
         ctx.low_shape = tuple(low.shape)
-        return ops.upsample_add_fwd(up1, low)
+        return ops.upsample_add_fwd(up1, low, bf16_only=ops.phantom_out_ok(up1.shape[1], up1.shape[0] * up1.shape[2] * up1.shape[3],
+                                                                           up1.device))
 
     @staticmethod
     def backward(ctx, dout):

@@ -111,8 +111,47 @@ def is_nhwc(t):
     return t.dim() == 4 and t.permute(0, 2, 3, 1).is_contiguous()
 
 
-def to_nhwc(t):
-    """Returns a tensor with the same logical NCHW shape whose memory is NHWC."""
+def is_phantom(t):
+    """A bf16-only activation / gradient (phantom_f32): an fp32 tensor OBJECT without memory — every stride 0 — whose values live in
+    its bf16 image.  Recognised by its strides, so views and tensors unpacked from an autograd node stay recognisable; such a new
+    object has lost the image link, and using it fails loudly (image_of) instead of reading one repeated value."""
+    # (strides all zero alone would also match an expanded scalar — autograd's gradient of `.sum()`; a phantom is the SECOND element
+    # of a two-element storage, which views and saved tensors preserve)
+    return (t is not None and t.dim() == 4 and t.stride() == (0, 0, 0, 0) and t.numel() > 1 and t.storage_offset() == 1
+            and t.untyped_storage().nbytes() == 8)
+
+
+def image_of(t):
+    hit = getattr(t, "_rr_b16", None)
+    if hit is None:
+        raise RuntimeError("a bf16-only tensor of shape %s reached a consumer without its bf16 image (a view / saved tensor whose "
+                           "producer did not hand the image on: ops.b16_carry / b16_restore)" % (tuple(t.shape),))
+    return hit[2]
+
+
+def f32_of(t):
+    """The fp32 tensor a consumer without a bf16 form needs: t itself, or — for a bf16-only tensor — its image widened into a FRESH
+    tensor of the caller's (allocated on the current stream, never remembered on t: a copy cached on the tensor object in the forward
+    outlived it until the backward, where the weight-gradient side stream read it while the main stream's allocator had already
+    reused the block — found by the stress arm of tests/test_streams_gpu.py)."""
+    if not is_phantom(t):
+        return t
+    img = image_of(t)
+    if _PHANTOM_TRACE:
+        import traceback
+        key = (tuple(t.shape), traceback.format_stack(limit=4)[0].strip().split("\n")[0])
+        PHANTOM_WIDENED[key] = PHANTOM_WIDENED.get(key, 0) + 1
+    out = torch.empty_like(img, dtype=torch.float32)
+    assert out.stride() == img.stride()
+    _C.check(_C.fn("rr_from_bf16")(_C.ptr(img), _C.ptr(out), img.numel(), _C.stream()), "rr_from_bf16")
+    return out
+
+
+def to_nhwc(t, keep_phantom=False):
+    """Returns a tensor with the same logical NCHW shape whose memory is NHWC.  A bf16-only tensor is handed through only to
+    callers that say they can read its image (keep_phantom); everybody else receives the widened fp32 copy."""
+    if is_phantom(t):
+        return t if keep_phantom else f32_of(t)
     if is_nhwc(t):
         return t
     return t.contiguous(memory_format=CL)
@@ -276,6 +315,38 @@ _CONV16 = os.environ.get("RR_CONV16", "1") != "0"               # 0: the round-4
 _CONV16_MIN_PIXELS = int(os.environ.get("RR_CONV16_MIN_PIXELS", "8192"))     # output pixels below which the 256-pixel tiles lose to the round-4 kernels (8 x 32 x 32 x 384: 351 vs 229 TFLOP/s; 16 x 16: 24 workgroups)
 
 
+class _PhantomScope(threading.local):
+    def __init__(self):
+        self.on = False
+
+
+_PHANTOM = _PhantomScope()
+_PHANTOM_TRACE = os.environ.get("RR_PHANTOM_TRACE", "0") == "1"       # count, by shape and caller, the bf16-only tensors that had to be widened
+PHANTOM_WIDENED = {}
+_PHANTOM_ENABLED = os.environ.get("RR_BF16_ONLY_ACT", "1") != "0"      # 0: every activation keeps its fp32 tensor next to the image
+
+
+class phantom_scope:
+    """Inside (HourglassNet.forward under cfg.Model.bf16): conv -> bn [-> +res] -> relu layers and the up-path add may return
+    bf16-ONLY activations (phantom_f32) where the shape qualifies — everything that consumes them there reads the image.  Tensors
+    that leave the backbone are produced outside the scope and are ordinary fp32 tensors."""
+
+    def __init__(self, on=True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        self.prev, _PHANTOM.on = _PHANTOM.on, self.on
+
+    def __exit__(self, *exc):
+        _PHANTOM.on = self.prev
+
+
+def phantom_out_ok(c, pixels, device):
+    # (no grad-mode test: inside an autograd Function's forward grad mode is always off)
+    return bool(_PHANTOM.on and _PHANTOM_ENABLED and _CONV16 and _mode() == MATH_BF16 and device.type == "cuda"
+                and c % 256 == 0 and pixels >= _CONV16_MIN_PIXELS)
+
+
 def b16_attach(t, image):
     t._rr_b16 = (t._version, torch.cuda.current_stream(t.device).cuda_stream, image)
 
@@ -300,11 +371,12 @@ def b16_publish(t):
 
 def bf16_of(t):
     """bf16 image of the fp32 NHWC tensor t (same logical shape, same memory order)."""
+    if is_phantom(t):
+        return image_of(t)
     sid = torch.cuda.current_stream(t.device).cuda_stream
     hit = getattr(t, "_rr_b16", None)
     if hit is not None and hit[0] == t._version and (hit[1] is None or hit[1] == sid):
         return hit[2]
-    assert not getattr(t, "_rr_phantom", False), "a bf16-only tensor lost its image"
     assert t.dtype == torch.float32 and t.numel() % 4 == 0
     img = torch.empty_like(t, dtype=torch.bfloat16)
     assert img.stride() == t.stride()
@@ -320,9 +392,8 @@ def phantom_f32(shape, device, image):
     """An fp32 tensor OBJECT of the given logical shape that owns no memory (one element, stride 0) and carries `image` as its
     bf16 image: the handle of a gradient that exists only in bf16 — every consumer is a conv16 kernel.  A kernel wrapper that
     would read its fp32 data trips over `is_nhwc` (stride 0) instead of reading garbage."""
-    t = torch.empty(1, dtype=torch.float32, device=device).expand(shape)
-    t._rr_b16 = (t._version, None, image)
-    t._rr_phantom = True
+    t = torch.empty(2, dtype=torch.float32, device=device)[1:].expand(shape)       # (element 1 of 2: is_phantom's signature)
+    t._rr_b16 = (t._version, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else None, image)
     return t
 
 
@@ -402,14 +473,17 @@ def conv_fprop(x, w, bias=None, stride=1, pad=(0, 0), relu=False, want_stats=Fal
     algo_kg: the useful reduction length when the operands carry zero padding (timer FLOPs stay algorithmic)."""
     _C.require_cuda(x, w, bias)
     assert x.dtype == torch.float32 and w.dtype == torch.float32
-    assert is_nhwc(x) and is_nhwc(w), "conv_fprop wants NHWC activations / OHWI weights"
     n, c, h, wd = x.shape
     k, c2, r, s = w.shape
     assert c == c2
     p, q = out_hw(h, wd, r, s, stride, pad[0], pad[1])
     y = empty_nhwc(n, k, p, q, x.device)
     slab = None
-    if conv16_ok(c, k, r, s, stride, n * p * q, x, y):
+    use16 = conv16_ok(c, k, r, s, stride, n * p * q, x, y)
+    if is_phantom(x) and not use16:
+        x = f32_of(x)                       # a bf16-only input in front of a layer the conv16 kernels do not take
+    assert (is_nhwc(x) or is_phantom(x)) and is_nhwc(w), "conv_fprop wants NHWC activations / OHWI weights"
+    if use16:
         # both operands as bf16 tensors (csrc/conv16.hip): x's image from its producer (or converted once), the filter's from
         # the flat cache
         x16 = bf16_of(x)
@@ -551,7 +625,7 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False,
     BatchNorm-backward sums are computed in the epilogue and left in bnsum.sums / bnsum.dz.  bnsum_z: the
     convolution's input itself (= the producer's output), needed when bnsum.use_z."""
     _C.require_cuda(dy, w)
-    assert (is_nhwc(dy) or getattr(dy, "_rr_phantom", False)) and is_nhwc(w)     # (phantom: a bf16-only gradient, see phantom_f32)
+    assert (is_nhwc(dy) or is_phantom(dy)) and is_nhwc(w)     # (phantom: a bf16-only gradient, see phantom_f32)
     n, c, h, wd = x_shape
     k, c2, r, s = w.shape
     assert c == c2 and dy.shape[1] == k
@@ -561,6 +635,16 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False,
     else:
         amax_drop(out)                # an existing tensor rewritten / added into through its pointer
     assert is_nhwc(out)
+    if bnsum is not None and bnsum_z is not None and is_phantom(bnsum_z):
+        # the producer's output exists only as a bf16 image: the fp32-reading epilogues cannot take their mask from it — a ReLU /
+        # bias producer gets the widened copy, a BatchNorm producer runs its own reduce pass (rr_bn_bwd_reduce_b16)
+        if bnsum.relu_bias:
+            bnsum_z = f32_of(bnsum_z)
+        else:
+            bnsum = None
+    if is_phantom(dy) and not (stride == 1 and pad[0] < r and pad[1] < s and conv16_ok(k, c, r, s, 1, n * h * wd, dy, out)
+                               and not (bnsum is not None and bnsum.relu_bias)):
+        dy = f32_of(dy)
     if (bnsum is not None and bnsum.relu_bias and _DGRAD_BNSUM and stride == 1 and c % 4 == 0
             and bnsum_z is not None and is_nhwc(bnsum_z) and bnsum_z.shape == out.shape and out.numel() * 4 < (1 << 31)
             and r * s <= 64 and pad[0] < r and pad[1] < s and dy.shape[2] * dy.shape[3] >= _DGRAD_VIA_FPROP_MIN_PIXELS
@@ -680,7 +764,7 @@ def conv_wgrad(x, dy, dw, stride=1, pad=(0, 0), explicit_out=False, algo_c=None)
     """dw [K,C,R,S] (OHWI memory) += x (*) dy.  dw must be pre-zeroed / hold the running gradient.
     explicit_out: take the output size from dy (asymmetric padding, `pad` = leading pads)."""
     _C.require_cuda(x, dy, dw)
-    assert is_nhwc(x) and (is_nhwc(dy) or getattr(dy, "_rr_phantom", False)) and is_nhwc(dw)
+    assert (is_nhwc(x) or is_phantom(x)) and (is_nhwc(dy) or is_phantom(dy)) and is_nhwc(dw)
     n, c, h, wd = x.shape
     k, c2, r, s = dw.shape
     assert c == c2 and dy.shape[1] == k
@@ -693,6 +777,7 @@ def conv_wgrad(x, dy, dw, stride=1, pad=(0, 0), explicit_out=False, algo_c=None)
                         lambda: _C.fn("rr_conv16_wgrad")(_C.ptr(x16), _C.ptr(dy16), _C.ptr(dw), n, h, wd, c, k, r, s, stride, pad[0], pad[1],
                                                          _C.stream()), (n, h, wd, c, k, r, s, stride)), "rr_conv16_wgrad")
         return dw
+    x, dy = f32_of(x), f32_of(dy)            # (bf16-only operands in front of a layer the conv16 weight gradient does not take)
     bf = _bf16_ok(c, k, r, s, x, dy, pixels=npix) if (c > 32 and k > 32) else 0
     f = _C.fn(("rr_conv_wgrad", "rr_conv_wgrad_bf16", "rr_conv_wgrad_f16x3")[bf])
     wtail = (_C.ptr(amax_of(x)), _C.ptr(amax_of(dy)), _C.stream()) if bf == MATH_F16X3 else (_C.stream(),)
@@ -784,9 +869,24 @@ def bn_eval_coeffs(gamma, beta, running_mean, running_var, eps):
     return scale, shift
 
 
-def bn_apply(y, scale, shift, residual=None, relu=False, res_scale=None, res_shift=None):
-    assert is_nhwc(y) and (residual is None or (is_nhwc(residual) and residual.shape == y.shape))
+def bn_apply(y, scale, shift, residual=None, relu=False, res_scale=None, res_shift=None, bf16_only=False):
+    """bf16_only (conv16, ops.phantom_scope): the output is written as a bf16 image only and returned as a memory-less fp32
+    handle (phantom_f32).  A bf16-only residual is read from its image."""
+    res_ph = is_phantom(residual)
+    assert is_nhwc(y) and (residual is None or ((is_nhwc(residual) or res_ph) and residual.shape == y.shape))
     n, c, h, w = y.shape
+    want16 = _CONV16 and _mode() == MATH_BF16 and y.is_cuda and c % 128 == 0 and n * h * w >= _CONV16_MIN_PIXELS
+    if (bf16_only or res_ph) and y.is_cuda and c % 4 == 0:
+        out = None if bf16_only else empty_nhwc(n, c, h, w, y.device)
+        out16 = torch.empty((n, h, w, c), dtype=torch.bfloat16, device=y.device).permute(0, 3, 1, 2) if (bf16_only or want16) else None
+        _C.check(_C.fn("rr_bn_apply_b16")(_C.ptr(y), _C.ptr(scale), _C.ptr(shift), _C.ptr(None if res_ph else residual),
+                                          _C.ptr(image_of(residual) if res_ph else None), _C.ptr(res_scale), _C.ptr(res_shift),
+                                          _C.ptr(out), _C.ptr(out16), y.numel(), c, int(relu), _C.stream()), "rr_bn_apply_b16")
+        if bf16_only:
+            return phantom_f32((n, c, h, w), y.device, out16)
+        if out16 is not None:
+            b16_attach(out, out16)
+        return out
     out = empty_nhwc(n, c, h, w, y.device)
     if _mode() == MATH_F16X3 and y.is_cuda and n * h * w >= _SPLIT_MIN_PIXELS and _FUSED_AMAX_FWD:
         # split-operand convolutions: the consumer's operand scale comes out of this pass (see amax_of)
@@ -796,10 +896,10 @@ def bn_apply(y, scale, shift, residual=None, relu=False, res_scale=None, res_shi
                  "rr_bn_apply_amax")
         out._rr_amax = (out._version, torch.cuda.current_stream(y.device).cuda_stream, word)
         return out
-    if _CONV16 and _mode() == MATH_BF16 and y.is_cuda and c % 128 == 0 and n * h * w >= _CONV16_MIN_PIXELS:
+    if want16:
         # the bf16 image the consuming convolution (csrc/conv16.hip) reads, written in the same pass
         out16 = torch.empty_like(out, dtype=torch.bfloat16)
-        _C.check(_C.fn("rr_bn_apply_b16")(_C.ptr(y), _C.ptr(scale), _C.ptr(shift), _C.ptr(residual), _C.ptr(res_scale),
+        _C.check(_C.fn("rr_bn_apply_b16")(_C.ptr(y), _C.ptr(scale), _C.ptr(shift), _C.ptr(residual), None, _C.ptr(res_scale),
                                           _C.ptr(res_shift), _C.ptr(out), _C.ptr(out16), y.numel(), c, int(relu), _C.stream()),
                  "rr_bn_apply_b16")
         b16_attach(out, out16)
@@ -812,6 +912,10 @@ def bn_apply(y, scale, shift, residual=None, relu=False, res_scale=None, res_shi
 def bn_bwd_reduce(dz, z, y, mean, invstd, extra=0, mask_scale=None, mask_shift=None):
     n, c, h, w = y.shape
     sums = _ZEROS.take(2 * c + extra, y.device)            # pre-zeroed pool slice: no memset launch per layer
+    if is_phantom(z):                                       # the layer's output exists only as its bf16 image: the mask comes from there
+        _C.check(_C.fn("rr_bn_bwd_reduce_b16")(_C.ptr(dz), _C.ptr(image_of(z)), _C.ptr(y), _C.ptr(mean), _C.ptr(invstd), _C.ptr(sums),
+                                               n * h * w, c, _C.stream()), "rr_bn_bwd_reduce_b16")
+        return sums
     _C.check(_C.fn("rr_bn_bwd_reduce")(_C.ptr(dz), _C.ptr(z), _C.ptr(y), _C.ptr(mean), _C.ptr(invstd),
                                        _C.ptr(mask_scale), _C.ptr(mask_shift), _C.ptr(sums),
                                        n * h * w, c, 1, _C.stream()), "rr_bn_bwd_reduce")
@@ -824,19 +928,28 @@ def bn_bwd_apply(dz, z, y, mean, invstd, gamma, sums, count, want_g=False, dgamm
     bf16_only (conv16): dx is written as a bf16 image only — the caller knows that its data and weight gradient both read
     that image; the returned dx is a memory-less fp32 handle (phantom_f32)."""
     n, c, h, w = y.shape
-    if bf16_only and _CONV16 and _mode() == MATH_BF16 and y.is_cuda and c % 4 == 0:
+    z_ph = is_phantom(z)
+    only16 = bool(bf16_only and _CONV16 and _mode() == MATH_BF16 and y.is_cuda and c % 4 == 0)
+    if only16 or z_ph:
         if g_into is not None:
             assert is_nhwc(g_into) and g_into.shape == y.shape
             amax_drop(g_into)
             g = g_into
         else:
             g = empty_nhwc(n, c, h, w, y.device) if want_g else None
-        dx16 = torch.empty((n, h, w, c), dtype=torch.bfloat16, device=y.device).permute(0, 3, 1, 2)
-        _C.check(_C.fn("rr_bn_bwd_apply_b16")(_C.ptr(dz), _C.ptr(z), _C.ptr(y), _C.ptr(mean), _C.ptr(invstd), _C.ptr(gamma),
-                                              _C.ptr(mask_scale), _C.ptr(mask_shift), _C.ptr(sums), float(count), _C.ptr(count_dev),
-                                              None, _C.ptr(dx16), _C.ptr(g), int(g_into is not None), _C.ptr(dgamma), _C.ptr(dbeta),
-                                              y.numel(), c, _C.stream()), "rr_bn_bwd_apply_b16")
-        return phantom_f32((n, c, h, w), y.device, dx16), g
+        want16 = only16 or (_CONV16 and _mode() == MATH_BF16 and c % 128 == 0 and n * h * w >= _CONV16_MIN_PIXELS)
+        dx = None if only16 else empty_nhwc(n, c, h, w, y.device)
+        dx16 = torch.empty((n, h, w, c), dtype=torch.bfloat16, device=y.device).permute(0, 3, 1, 2) if want16 else None
+        _C.check(_C.fn("rr_bn_bwd_apply_b16")(_C.ptr(dz), _C.ptr(None if z_ph else z), _C.ptr(image_of(z) if z_ph else None), _C.ptr(y),
+                                              _C.ptr(mean), _C.ptr(invstd), _C.ptr(gamma), _C.ptr(mask_scale), _C.ptr(mask_shift),
+                                              _C.ptr(sums), float(count), _C.ptr(count_dev), _C.ptr(dx), _C.ptr(dx16), _C.ptr(g),
+                                              int(g_into is not None), _C.ptr(dgamma), _C.ptr(dbeta), y.numel(), c, _C.stream()),
+                 "rr_bn_bwd_apply_b16")
+        if only16:
+            return phantom_f32((n, c, h, w), y.device, dx16), g
+        if dx16 is not None:
+            b16_attach(dx, dx16)
+        return dx, g
     dx = empty_nhwc(n, c, h, w, y.device)
     if g_into is not None:
         assert is_nhwc(g_into) and g_into.shape == y.shape
@@ -856,7 +969,7 @@ def bn_bwd_apply(dz, z, y, mean, invstd, gamma, sums, count, want_g=False, dgamm
         return dx, g
     if _CONV16 and _mode() == MATH_BF16 and y.is_cuda and c % 128 == 0 and n * h * w >= _CONV16_MIN_PIXELS:
         dx16 = torch.empty_like(dx, dtype=torch.bfloat16)
-        _C.check(_C.fn("rr_bn_bwd_apply_b16")(_C.ptr(dz), _C.ptr(z), _C.ptr(y), _C.ptr(mean), _C.ptr(invstd), _C.ptr(gamma),
+        _C.check(_C.fn("rr_bn_bwd_apply_b16")(_C.ptr(dz), _C.ptr(z), None, _C.ptr(y), _C.ptr(mean), _C.ptr(invstd), _C.ptr(gamma),
                                               _C.ptr(mask_scale), _C.ptr(mask_shift), _C.ptr(sums), float(count), _C.ptr(count_dev),
                                               _C.ptr(dx), _C.ptr(dx16), _C.ptr(g), int(g_into is not None), _C.ptr(dgamma), _C.ptr(dbeta),
                                               y.numel(), c, _C.stream()), "rr_bn_bwd_apply_b16")
@@ -899,8 +1012,25 @@ def bias_relu_bwd(dy, z, dbias):
     return masked if z is not None else dy
 
 
-def upsample_add_fwd(up1, low):
+def upsample_add_fwd(up1, low, bf16_only=False):
+    """up1 + nearest-2x(low) (bilinear-align-corners resize for odd sizes).  Either operand may be a bf16-only activation;
+    bf16_only: the sum is written as a bf16 image only (phantom_f32)."""
     n, c, h, w = up1.shape
+    fast = (2 * low.shape[2] == h and 2 * low.shape[3] == w and c % 4 == 0 and up1.is_cuda)
+    if fast and (bf16_only or is_phantom(up1) or is_phantom(low)):
+        u_ph, l_ph = is_phantom(up1), is_phantom(low)
+        want16 = bf16_only or (_CONV16 and _mode() == MATH_BF16 and c % 128 == 0 and n * h * w >= _CONV16_MIN_PIXELS)
+        out = None if bf16_only else empty_nhwc(n, c, h, w, up1.device)
+        out16 = torch.empty((n, h, w, c), dtype=torch.bfloat16, device=up1.device).permute(0, 3, 1, 2) if want16 else None
+        _C.check(_C.fn("rr_upsample2x_add_b16")(_C.ptr(None if u_ph else up1), _C.ptr(image_of(up1) if u_ph else None),
+                                                _C.ptr(None if l_ph else low), _C.ptr(image_of(low) if l_ph else None),
+                                                _C.ptr(out), _C.ptr(out16), n, h, w, c, _C.stream()), "rr_upsample2x_add_b16")
+        if bf16_only:
+            return phantom_f32((n, c, h, w), up1.device, out16)
+        if out16 is not None:
+            b16_attach(out, out16)
+        return out
+    up1, low = f32_of(up1), f32_of(low)
     out = empty_nhwc(n, c, h, w, up1.device)
     _C.check(_C.fn("rr_upsample_add_fwd")(_C.ptr(up1), _C.ptr(low), _C.ptr(out), n, h, w, low.shape[2], low.shape[3],
                                           c, _C.stream()), "rr_upsample_add_fwd")

@@ -146,6 +146,10 @@ def audit(tol=2e-5, tol_wgrad=2e-4, sample=False, ref_device="cpu"):
     def big(flops):
         return sample and flops > SAMPLE_FLOPS
 
+    def _dat(t):
+        """A bf16-only tensor (ops.phantom_f32: an fp32 handle without memory) -> its bf16 image, the data the kernel read / wrote."""
+        return ops.image_of(t) if (t is not None and ops.is_phantom(t)) else t
+
     def big_elems(t):
         return sample and t.numel() > (1 << 24)
 
@@ -191,6 +195,7 @@ def audit(tol=2e-5, tol_wgrad=2e-4, sample=False, ref_device="cpu"):
 
     def conv_fprop(x, w, bias=None, stride=1, pad=(0, 0), relu=False, want_stats=False, algo_kg=None, w16=None, w_split=None):
         out = orig["conv_fprop"](x, w, bias, stride, pad, relu, want_stats, algo_kg, w16, w_split)   # w16 / w_split: cached copies of w
+        x = _dat(x)
         y = out[0] if want_stats else out
         sig = (tuple(x.shape), tuple(w.shape), stride, tuple(pad), bias is not None, relu, want_stats)
         flops = 2.0 * y.numel() * w.shape[1] * w.shape[2] * w.shape[3]
@@ -235,14 +240,14 @@ def audit(tol=2e-5, tol_wgrad=2e-4, sample=False, ref_device="cpu"):
         return out
 
     def _data(t):
-        """A bf16-only gradient (ops.phantom_f32: an fp32 handle without memory) -> its bf16 image, the data the kernel read."""
-        return t._rr_b16[2] if getattr(t, "_rr_phantom", False) else t
+        """A bf16-only tensor (ops.phantom_f32: an fp32 handle without memory) -> its bf16 image, the data the kernel read / wrote."""
+        return ops.image_of(t) if ops.is_phantom(t) else t
 
     def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False, bnsum=None, bnsum_z=None, wt=None, wt16=None,
                    wt_split=None):
         base = out.clone() if (out is not None and accumulate) else None
         res = orig["conv_dgrad"](dy, w, x_shape, stride, pad, out, accumulate, bnsum, bnsum_z, wt, wt16, wt_split)   # the cached flipped filters
-        dy = _data(dy)
+        dy, bnsum_z = _dat(dy), _dat(bnsum_z)
         relu_mask = None          # conv + bias + ReLU producer: this launch stored the masked gradient
         if bnsum is not None and bnsum.relu_bias and bnsum.sums is not None and bnsum.dz is res:
             relu_mask = bnsum_z
@@ -314,7 +319,7 @@ def audit(tol=2e-5, tol_wgrad=2e-4, sample=False, ref_device="cpu"):
         check = ("wgrad",) + sig not in rec.seen and not explicit_out
         base = dw.clone() if check else None
         res = orig["conv_wgrad"](x, dy, dw, stride, pad, explicit_out, algo_c)
-        dy = _data(dy)
+        dy, x = _dat(dy), _dat(x)
         flops = 2.0 * dy.numel() * dw.shape[1] * dw.shape[2] * dw.shape[3]
         if check and big(flops):
             rec.sampled.add(("wgrad",) + sig)
@@ -367,27 +372,33 @@ def audit(tol=2e-5, tol_wgrad=2e-4, sample=False, ref_device="cpu"):
             d = d * ((y.detach().to(REF["dev"]).double() * _V(mask_scale) + _V(mask_shift)) > 0)
         return d
 
-    def bn_apply(y, scale, shift, residual=None, relu=False, res_scale=None, res_shift=None):
-        out = orig["bn_apply"](y, scale, shift, residual, relu, res_scale, res_shift)
-        sig = (tuple(y.shape), residual is not None, relu)
+    def bn_apply(y, scale, shift, residual=None, relu=False, res_scale=None, res_shift=None, bf16_only=False):
+        out = orig["bn_apply"](y, scale, shift, residual, relu, res_scale, res_shift, bf16_only)
+        sig = (tuple(y.shape), residual is not None, relu, ops.is_phantom(residual), ops.is_phantom(out))
         if ("bn_apply",) + sig not in rec.seen:
             ns = _img_sample(y.shape[0]) if big_elems(y) else list(range(y.shape[0]))
             if big_elems(y):
                 rec.sampled.add(("bn_apply",) + sig)
             ref = _c64(y[ns]) * _V(scale) + _V(shift)
             if residual is not None:
-                ref = ref + _c64(residual[ns])
+                ref = ref + _c64(_dat(residual)[ns])          # (a bf16-only residual: the image is the data)
             if relu:
                 ref = ref.relu()
-            rec.note("bn_apply", sig, _rel(out[ns], ref), tol)
-            img = ops.b16_carry(out)
-            if img is not None:           # the bf16 image written next to the fp32 output (conv16 reads it)
-                rec.note("bn_apply_image", sig, float((_c64(img[ns]) - ref).abs().max() / max(float(ref.abs().max()), 1e-30)), 2.0 ** -8)
+            scale_ = max(float(ref.abs().max()), 1e-30)
+            if ops.is_phantom(out):       # the output exists only as its bf16 image: the fp64 value up to one bf16 rounding
+                rec.note("bn_apply_bf16_only", sig, float((_c64(_dat(out)[ns]) - ref).abs().max() / scale_), 2.0 ** -8)
+                rec.note("bn_apply", sig, 0.0, tol)
+            else:
+                rec.note("bn_apply", sig, _rel(out[ns], ref), tol)
+                img = ops.b16_carry(out)
+                if img is not None:           # the bf16 image written next to the fp32 output (conv16 reads it)
+                    rec.note("bn_apply_image", sig, float((_c64(img[ns]) - ref).abs().max() / scale_), 2.0 ** -8)
         return out
 
     def bn_bwd_reduce(dz, z, y, mean, invstd, extra=0, mask_scale=None, mask_shift=None):
         out = orig["bn_bwd_reduce"](dz, z, y, mean, invstd, extra, mask_scale, mask_shift)
-        sig = (tuple(y.shape), z is not None, mask_scale is not None)
+        sig = (tuple(y.shape), z is not None, mask_scale is not None, ops.is_phantom(z))
+        z = _dat(z)
         if ("bn_bwd_reduce",) + sig not in rec.seen:
             c = y.shape[1]
             s1, s2, a1, a2 = (_zeros64(c) for _ in range(4))
@@ -406,11 +417,12 @@ def audit(tol=2e-5, tol_wgrad=2e-4, sample=False, ref_device="cpu"):
 
     def bn_bwd_apply(dz, z, y, mean, invstd, gamma, sums, count, want_g=False, dgamma=None, dbeta=None, count_dev=None,
                      mask_scale=None, mask_shift=None, g_into=None, bf16_only=False):
-        sig = (tuple(y.shape), z is not None, mask_scale is not None, want_g, g_into is not None, bool(bf16_only))
+        sig = (tuple(y.shape), z is not None, mask_scale is not None, want_g, g_into is not None, bool(bf16_only), ops.is_phantom(z))
         todo = ("bn_bwd_apply",) + sig not in rec.seen and count_dev is None
         gbase = g_into.clone() if (g_into is not None and todo) else None
         out = orig["bn_bwd_apply"](dz, z, y, mean, invstd, gamma, sums, count, want_g, dgamma, dbeta, count_dev,
                                    mask_scale, mask_shift, g_into, bf16_only)
+        z = _dat(z)
         if todo:
             ns = _img_sample(y.shape[0]) if big_elems(y) else list(range(y.shape[0]))
             if big_elems(y):
@@ -420,7 +432,7 @@ def audit(tol=2e-5, tol_wgrad=2e-4, sample=False, ref_device="cpu"):
             xh = (_c64(y[ns]) - _V(mean)) * _V(invstd)
             ref = _V(gamma) * _V(invstd) * (d - _V(sums[:c]) / count - xh * _V(sums[c:2 * c]) / count)
             scale = max(float((_V(gamma) * _V(invstd) * d).abs().max()), 1e-30)
-            phantom = getattr(out[0], "_rr_phantom", False)
+            phantom = ops.is_phantom(out[0])
             if phantom:       # dx exists only as its bf16 image (conv16): equal to the fp64 value up to one bf16 rounding
                 eb = float((_c64(_data(out[0])[ns]) - ref).abs().max() / scale)
                 rec.note("bn_bwd_apply_bf16_only", sig, eb, 2.0 ** -8)
@@ -450,14 +462,19 @@ def audit(tol=2e-5, tol_wgrad=2e-4, sample=False, ref_device="cpu"):
             rec.note("sum_n", sig, _rel(out[ns], ref), tol)
         return out
 
-    def upsample_add_fwd(up1, low):
-        out = orig["upsample_add_fwd"](up1, low)
-        sig = (tuple(up1.shape), tuple(low.shape))
+    def upsample_add_fwd(up1, low, bf16_only=False):
+        out = orig["upsample_add_fwd"](up1, low, bf16_only)
+        sig = (tuple(up1.shape), tuple(low.shape), ops.is_phantom(up1), ops.is_phantom(low), ops.is_phantom(out))
         if ("upsample_add_fwd",) + sig not in rec.seen:
             ns = _img_sample(up1.shape[0]) if big_elems(up1) else list(range(up1.shape[0]))
-            u = F.interpolate(_c64(low[ns]), scale_factor=2)
+            u = F.interpolate(_c64(_dat(low)[ns]), scale_factor=2)
             u = F.interpolate(u, size=tuple(up1.shape[2:]), mode="bilinear", align_corners=True)
-            rec.note("upsample_add_fwd", sig, _rel(out[ns], _c64(up1[ns]) + u), tol)
+            ref = _c64(_dat(up1)[ns]) + u
+            if ops.is_phantom(out):
+                rec.note("upsample_add_bf16_only", sig, float((_c64(_dat(out)[ns]) - ref).abs().max() / max(float(ref.abs().max()), 1e-30)), 2.0 ** -8)
+                rec.note("upsample_add_fwd", sig, 0.0, tol)
+            else:
+                rec.note("upsample_add_fwd", sig, _rel(out[ns], ref), tol)
         return out
 
     def upsample_add_bwd(dout, low_shape):

@@ -144,14 +144,28 @@ def test_bf16_dgrad_carries_the_bn_backward_sums(relu, residual, bf16_switch):
     link.msc, link.msh = (scale, shift) if (relu and not residual) else (None, None)
     gy = ops.to_nhwc(_mk((n, k, h, w), 13).cuda())
     wt = ops.to_nhwc((_mk((k, c, 3, 3), 14) * 0.02).cuda())
-    bf16_switch(True)
-    dx = ops.conv_dgrad(gy, wt, (n, c, h, w), 1, (1, 1), bnsum=link, bnsum_z=z)
-    bf16_switch(False)
-    assert link.sums is not None and link.dz is dx
-    ref = ops.bn_bwd_reduce(dx, z if link.use_z else None, y, mean, invstd, mask_scale=link.msc, mask_shift=link.msh)
-    _close(link.sums[:2 * c], ref[:2 * c], "bn-backward sums", 1e-5)
-    dx_ref = ops.conv_dgrad(ops.to_nhwc(_r(gy)), ops.to_nhwc(_r(wt)), (n, c, h, w), 1, (1, 1))
-    _close(dx, dx_ref, "dgrad with sums")
+    saved = ops._CONV16
+    try:
+        ops._CONV16 = False                 # the round-4 kernel: its epilogue carries the sums
+        bf16_switch(True)
+        dx = ops.conv_dgrad(gy, wt, (n, c, h, w), 1, (1, 1), bnsum=link, bnsum_z=z)
+        bf16_switch(False)
+        assert link.sums is not None and link.dz is dx
+        ref = ops.bn_bwd_reduce(dx, z if link.use_z else None, y, mean, invstd, mask_scale=link.msc, mask_shift=link.msh)
+        _close(link.sums[:2 * c], ref[:2 * c], "bn-backward sums", 1e-5)
+        dx_ref = ops.conv_dgrad(ops.to_nhwc(_r(gy)), ops.to_nhwc(_r(wt)), (n, c, h, w), 1, (1, 1))
+        _close(dx, dx_ref, "dgrad with sums")
+        # csrc/conv16.hip takes the same launch by default and does NOT carry the sums: the link stays empty, so the producer
+        # runs its own reduce pass (functional._ConvBnAct._backward) — same gradient
+        ops._CONV16 = True
+        link.sums = link.dz = None
+        bf16_switch(True)
+        dx16 = ops.conv_dgrad(gy, wt, (n, c, h, w), 1, (1, 1), bnsum=link, bnsum_z=z)
+        bf16_switch(False)
+        assert link.sums is None and link.dz is None
+        _close(dx16, dx_ref, "conv16 dgrad")
+    finally:
+        ops._CONV16 = saved
 
 
 def test_bf16_dgrad_relu_bias_epilogue(bf16_switch):
