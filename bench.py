@@ -185,9 +185,26 @@ def config2_split(a, steps=5):
 
 def config4_train_step(a, steps=5):
     """BASELINE configs[3] at model level (tools/bench_config4.py): the headline train step with the three heads' 3x3
-    convolutions replaced by DCN layers (bf16 matrix operands, non-degenerate offsets), same batch, same loop."""
+    convolutions replaced by DCN layers (bf16 matrix operands, non-degenerate offsets), same batch, same loop; `plain` = the
+    same bf16 model without the DCN heads; `conv16_dominant_layer` = the 16-bit-activation convolutions (csrc/conv16.hip) at the
+    dominant layer, against the 2.5 PFLOP/s dense bf16 peak."""
     import bench_config4
-    return bench_config4.run(a.batch, a.size, steps, True, a.backbone)
+    out = bench_config4.run(a.batch, a.size, steps, True, a.backbone)
+    try:
+        pl = bench_config4.run(a.batch, a.size, steps, False, a.backbone, True)
+        out["plain"] = {kk: pl[kk] for kk in ("value", "unit", "ms_per_step", "steps", "workload", "allocator", "step_mfma_frac", "finite_after_timed_steps")
+                        if kk in pl}
+    except Exception as e:
+        out["plain"] = {"value": None, "error": repr(e)}
+    try:
+        import bench_conv16
+        r = bench_conv16.run_shape(8, 256, 256, 256, 256, 3, 1, reps=10, check=True)
+        out["conv16_dominant_layer"] = {"shape": "N8 C256 256x256 K256 3x3", "gflop": 618.5, "mfma_peak_tflops": 2500.0,
+                                        **{kk: r[kk] for kk in r if kk.endswith("_tflops") or kk.endswith("_ms") or kk.endswith("_err")},
+                                        "fprop_frac_of_peak": round(r["fprop_nostats_tflops"] / 2500.0, 4)}
+    except Exception as e:
+        out["conv16_dominant_layer"] = {"error": repr(e)}
+    return out
 
 
 def host_fed_steps(op, cfg, a, step_no):
@@ -335,7 +352,7 @@ def main():
                 # (tools/prof_bench.sh -> tools/pmc_traffic.py -> profiles/rNN_traffic_pmc.json); PMC counters
                 # cannot be read from inside the process, so the field names its source
                 traffic, traffic_source = None, None
-                for tag in ("r04", "r03", "r02", "r01"):
+                for tag in ("r05", "r04", "r03", "r02", "r01"):
                     tpath = os.path.join(ROOT, "profiles", "%s_traffic_pmc.json" % tag)
                     if os.path.exists(tpath) and a.backbone == "hourglass" and a.size == 1024 and a.batch == 8:
                         with open(tpath) as f:

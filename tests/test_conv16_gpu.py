@@ -1,0 +1,124 @@
+"""GPU: the 16-bit-ACTIVATION convolutions (csrc/conv16.hip, round 5) against the fp32 kernels of csrc/conv.hip run on the same
+bf16-rounded operands.  Contract (include/rrnet_hip.h): products of two bf16 values are exact in fp32, so what may differ is the
+summation order: 2e-5 of the output scale (weight gradient 5e-5: up to 524 288 terms per element).  Reference of the convolution
+itself: nn.Conv2d of /root/reference/backbones/hourglass.py:12-61 (fp32; the precision is builder-defined, BASELINE configs[3])."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+# n, c, h, w, k, r, stride
+SHAPES = [
+    (2, 64, 24, 40, 256, 3, 1),        # one channel chunk, M = 1920: a partial last pixel tile
+    (1, 128, 33, 47, 256, 3, 2),       # stride 2, odd sizes
+    (2, 256, 32, 32, 256, 1, 1),       # 1x1
+    (2, 128, 20, 36, 384, 3, 1),       # K = 384: the 128-channel tile variant
+    (1, 384, 17, 29, 384, 3, 1),
+    (2, 256, 64, 64, 256, 3, 1),       # several pixel tiles, image borders inside tiles
+    (1, 256, 40, 24, 512, 3, 2),
+]
+
+
+def _mk(shape, seed):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    return torch.randn(shape, device="cuda", generator=g)
+
+
+def _close(a, b, what, bound):
+    scale = float(b.abs().max())
+    err = float((a.float() - b.float()).abs().max())
+    assert err <= bound * max(scale, 1e-30), "%s: %.3e of scale %.3e (%.2e)" % (what, err, scale, err / max(scale, 1e-30))
+
+
+@pytest.mark.parametrize("cfg", SHAPES, ids=lambda c: "n%dc%dh%dw%dk%dr%d_s%d" % c)
+def test_conv16_kernels_equal_fp32_kernels_on_rounded_operands(cfg):
+    from rrnet_amd import _C, ops
+    n, c, h, w, k, r, stride = cfg
+    pad = (r // 2, r // 2)
+    x = ops.to_nhwc(_mk((n, c, h, w), 1).relu_())
+    wt = ops.to_nhwc(_mk((k, c, r, r), 2) / float(np.sqrt(c * r * r)))
+    bias = _mk((k,), 3)
+    x16, w16 = x.to(torch.bfloat16), wt.to(torch.bfloat16)
+    xr, wr = x16.float(), w16.float()
+    p, q = ops.out_hw(h, w, r, r, stride, pad[0], pad[1])
+    assert _C.fn("rr_conv16_supported")(c, k, r, r, stride)
+    # ---- forward + BatchNorm partial sums
+    y = ops.empty_nhwc(n, k, p, q, x.device)
+    slab = torch.empty(_C.fn("rr_conv16_stat_slab_bytes")(n, p, q, k) // 8, dtype=torch.float64, device=x.device)
+    f = _C.fn("rr_conv16_fprop")
+    _C.check(f(_C.ptr(x16), _C.ptr(w16), None, _C.ptr(y), None, _C.ptr(slab), n, h, w, c, k, r, r, stride, pad[0], pad[1], 0, _C.stream()), "fprop")
+    ref, rslab = ops.conv_fprop(xr, wr, None, stride, pad, False, want_stats=True)
+    _close(y, ref, "fprop", 2e-5)
+    s16, s32 = ops.bn_reduce_slab(slab, k), ops.bn_reduce_slab(rslab, k)
+    yd = ref.double()
+    assert float((s16[:k] - s32[:k]).abs().max()) <= 2e-5 * float(yd.abs().sum((0, 2, 3)).max())
+    assert float((s16[k:] - s32[k:]).abs().max()) <= 2e-5 * float((yd * yd).sum((0, 2, 3)).max())
+    # ---- bias + ReLU epilogue, fp32 and bf16 outputs
+    y16 = torch.empty((n, p, q, k), dtype=torch.bfloat16, device=x.device).permute(0, 3, 1, 2)
+    _C.check(f(_C.ptr(x16), _C.ptr(w16), _C.ptr(bias), _C.ptr(y), _C.ptr(y16), None, n, h, w, c, k, r, r, stride, pad[0], pad[1], 1, _C.stream()), "fprop")
+    ref2 = ops.conv_fprop(xr, wr, bias, stride, pad, True)
+    _close(y, ref2, "bias + relu", 2e-5)
+    assert torch.equal(y16, y.to(torch.bfloat16))                     # the bf16 output IS the fp32 one rounded to nearest even
+    # ---- stride-1 data gradient (plain and accumulate) through the flipped filter
+    dy = ops.to_nhwc(_mk((n, k, p, q), 4))
+    dy16 = dy.to(torch.bfloat16)
+    if stride == 1 and _C.fn("rr_conv16_supported")(k, c, r, r, 1):
+        wflip = torch.empty(k * c * r * r, dtype=torch.float32, device=x.device)
+        _C.check(_C.fn("rr_weight_flip_transpose")(_C.ptr(wr), _C.ptr(wflip), k, c, r, r, _C.stream()), "flip")
+        wflip16 = wflip.to(torch.bfloat16)
+        base = ops.to_nhwc(_mk((n, c, h, w), 5))
+        dx = base.clone()
+        fd = _C.fn("rr_conv16_dgrad_s1")
+        _C.check(fd(_C.ptr(dy16), _C.ptr(wflip16), _C.ptr(dx), None, n, h, w, c, k, r, r, pad[0], pad[1], 1, _C.stream()), "dgrad")
+        refd = ops.conv_dgrad(dy16.float(), wr, (n, c, h, w), 1, pad)
+        _close(dx, refd + base, "dgrad (accumulate)", 2e-5)
+        _C.check(fd(_C.ptr(dy16), _C.ptr(wflip16), _C.ptr(dx), None, n, h, w, c, k, r, r, pad[0], pad[1], 0, _C.stream()), "dgrad")
+        _close(dx, refd, "dgrad", 2e-5)
+    # ---- weight gradient
+    if _C.fn("rr_conv16_wgrad_supported")(c, k, r, r, stride):
+        dw = ops.zeros_nhwc(k, c, r, r, x.device)
+        _C.check(_C.fn("rr_conv16_wgrad")(_C.ptr(x16), _C.ptr(dy16), _C.ptr(dw), n, h, w, c, k, r, r, stride, pad[0], pad[1], _C.stream()), "wgrad")
+        refw = ops.conv_wgrad(xr, dy16.float(), ops.zeros_nhwc(k, c, r, r, x.device), stride, pad)
+        _close(dw, refw, "wgrad", 5e-5)
+        _C.check(_C.fn("rr_conv16_wgrad")(_C.ptr(x16), _C.ptr(dy16), _C.ptr(dw), n, h, w, c, k, r, r, stride, pad[0], pad[1], _C.stream()), "wgrad")
+        _close(dw, 2 * refw, "wgrad accumulates into dw", 5e-5)
+
+
+def test_conv16_dispatch_images_and_bf16_only_tensors():
+    """The host side of the conv16 path (rrnet_amd/ops.py): bn_apply / bn_bwd_apply leave bf16 images on their outputs under
+    cfg.Model.bf16, conv_fprop / conv_dgrad / conv_wgrad read them (same result as the explicit entry points), a bf16-only tensor
+    (phantom_f32) is recognised structurally — an expanded scalar is NOT — and widens to exactly its image."""
+    from rrnet_amd import ops
+    n, c, h, w, k = 2, 256, 64, 64, 256
+    y = ops.to_nhwc(_mk((n, c, h, w), 11))
+    scale, shift = _mk((c,), 12).abs() + 0.5, _mk((c,), 13)
+    wt = ops.to_nhwc(_mk((k, c, 3, 3), 14) * 0.02)
+    with ops.bf16_scope(ops.MATH_BF16):
+        z = ops.bn_apply(y, scale, shift, None, True)
+        img = ops.b16_carry(z)
+        assert img is not None and torch.equal(img, z.to(torch.bfloat16))
+        with ops.phantom_scope(True):
+            assert ops.phantom_out_ok(c, n * h * w, y.device)
+            zp = ops.bn_apply(y, scale, shift, None, True, bf16_only=True)
+        assert ops.is_phantom(zp) and not ops.is_phantom(z) and tuple(zp.shape) == tuple(z.shape)
+        assert torch.equal(ops.image_of(zp), img)
+        assert torch.equal(ops.f32_of(zp), img.float()) and torch.equal(ops.to_nhwc(zp), img.float())
+        assert ops.to_nhwc(zp, keep_phantom=True) is zp
+        view = zp.view_as(zp)
+        assert ops.is_phantom(view)                                  # views stay recognisable ...
+        with pytest.raises(RuntimeError):
+            ops.image_of(view)                                       # ... and fail loudly without their image
+        out_a = ops.conv_fprop(z, wt, None, 1, (1, 1))               # reads z's image
+        out_p = ops.conv_fprop(zp, wt, None, 1, (1, 1))              # reads the bf16-only tensor's image
+        assert torch.equal(out_a, out_p)
+        # a bf16-only residual and a bf16-only mask source give the values of their fp32 twins rounded the same way
+        r_real = ops.bn_apply(y, scale, shift, z, True)
+        r_ph = ops.bn_apply(y, scale, shift, zp, True)
+        _close(r_ph, ops.bn_apply(y, scale, shift, ops.to_nhwc(img.float()), True), "bf16-only residual", 1e-6)
+        assert float((r_real - r_ph).abs().max()) <= 2.0 ** -8 * float(r_real.abs().max())
+    expanded = torch.ones(1, device="cuda").expand(n, c, h, w)       # autograd's gradient of .sum(): strides all zero, NOT a phantom
+    assert not ops.is_phantom(expanded)
+    assert torch.equal(ops.to_nhwc(expanded), torch.ones((n, c, h, w), device="cuda"))
+    ref = ops.conv_fprop(ops.to_nhwc(img.float()), ops.to_nhwc(wt.to(torch.bfloat16).float()), None, 1, (1, 1))
+    _close(out_p, ref, "conv16 through the dispatch", 2e-5)
