@@ -33,6 +33,7 @@ def run(batch=8, size=1024, steps=5, dcn=True, backbone="hourglass", bf16=None, 
     if cfg.Distributed.gpu_id < 0:
         cfg.Distributed.gpu_id, cfg.Distributed.rank, cfg.Distributed.world_size = 0, 0, 1
     try:
+        torch.cuda.reset_peak_memory_stats()             # (the allocator peak reported below is THIS run's, not the process's)
         torch.manual_seed(cfg.seed)
         op = RRNetOperator(cfg)                          # the synthetic pool is cached: no host-side regeneration
         op.model.train()
