@@ -212,7 +212,7 @@ def host_fed_steps(op, cfg, a, step_no):
     copy stream, one batch ahead) -> {"value", "ms_per_step", ...}.  Reported next to the device-resident headline."""
     from rrnet_amd.datasets.synthetic import HostFedDronesDET
     ld = HostFedDronesDET(cfg, a.batch, a.size, a.size, rank=0, pool=2)
-    for _ in range(2):
+    for _ in range(3):
         op.train_step(step_no, ld.get_batch()); step_no += 1
     torch.cuda.synchronize()
     t0 = time.perf_counter()

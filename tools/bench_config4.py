@@ -33,6 +33,9 @@ def run(batch=8, size=1024, steps=5, dcn=True, backbone="hourglass", bf16=None, 
     if cfg.Distributed.gpu_id < 0:
         cfg.Distributed.gpu_id, cfg.Distributed.rank, cfg.Distributed.world_size = 0, 0, 1
     try:
+        import gc
+        gc.collect()                                     # an operator of an earlier run in this process (reference cycles): its
+        torch.cuda.empty_cache()                         # tensors would count into this run's peak and fragment its pool
         torch.cuda.reset_peak_memory_stats()             # (the allocator peak reported below is THIS run's, not the process's)
         torch.manual_seed(cfg.seed)
         op = RRNetOperator(cfg)                          # the synthetic pool is cached: no host-side regeneration
