@@ -173,6 +173,11 @@ int rr_conv16_fprop(const unsigned short *x, const unsigned short *w, const floa
                     int relu, hipStream_t stream);
 int rr_conv16_dgrad_s1(const unsigned short *dy, const unsigned short *wt, float *dx, unsigned short *dx16, int n, int h,
                        int wd, int c, int k, int r, int s, int pad_h, int pad_w, int accumulate, hipStream_t stream);
+/* Stride-2 data gradient (rr_conv_dgrad_s2_bf16's contract: dx [n,h,w,c] = / += the gradient of a stride-2 convolution with filter
+ * w [k][r][s][c] (fp32, rounded to bf16 while its parity-class sub-filters are packed into wsub: k*r*s*c bf16 of caller scratch);
+ * dy bf16 [n,p,q,k]).  K % 64 == 0, C % 128 == 0, R*S <= 16, non-negative leading pads in every class (3x3 pad 1, 1x1 pad 0). */
+int rr_conv16_dgrad_s2(const unsigned short *dy, const float *w, float *dx, int n, int h, int wd, int c, int k, int r, int s,
+                       int pad_h, int pad_w, int accumulate, unsigned short *wsub, hipStream_t stream);
 /* dw [k][r][s][c] fp32 += x (*) dy, both bf16 (rr_conv_wgrad's contract on bf16-rounded operands; fp32 atomics).
  * Shapes: rr_conv16_wgrad_supported (K % 256 == 0, C % 128 == 0, stride 1 or 2; tensors < 2 GiB). */
 int rr_conv16_wgrad_supported(int c, int k, int r, int s, int stride);
@@ -184,19 +189,22 @@ int rr_conv16_wgrad(const unsigned short *x, const unsigned short *dy, float *dw
  * rounded to nearest even — written in the same pass, so the convolution that consumes the tensor never reads the fp32
  * one.  out / dx (fp32) may be NULL when nothing else reads them.  rr_to_bf16: the plain conversion, for operands that
  * come from elsewhere (fan-in sums, the up-sample add, head gradients). */
-int rr_bn_apply_b16(const float *y, const float *scale, const float *shift, const float *res, const unsigned short *res16,
-                    const float *res_scale, const float *res_shift, float *out, unsigned short *out16, long total, int c,
-                    int relu, hipStream_t stream);
-int rr_bn_bwd_apply_b16(const float *dz, const float *z, const unsigned short *z16, const float *y, const float *mean,
-                        const float *invstd, const float *gamma, const float *mask_scale, const float *mask_shift,
-                        const double *sums, double count, const double *count_dev, float *dx, unsigned short *dx16,
-                        float *g_out, int g_accumulate, float *dgamma, float *dbeta, long total, int c, hipStream_t stream);
-/* res16 / z16: the residual / the layer's own output (the ReLU mask's source) when it exists ONLY as its bf16 image (an
- * activation every consumer of which reads bf16: rrnet_amd.ops.phantom_f32); give res or res16, z or z16, never both.
- * rr_bn_bwd_reduce_b16: rr_bn_bwd_reduce with the mask from z16 (sums pre-zeroed).  rr_upsample2x_add_b16: the hourglass
+int rr_bn_apply_b16(const float *y, const unsigned short *y16, const float *scale, const float *shift, const float *res,
+                    const unsigned short *res16, const float *res_scale, const float *res_shift, float *out,
+                    unsigned short *out16, long total, int c, int relu, hipStream_t stream);
+int rr_bn_bwd_apply_b16(const float *dz, const float *z, const unsigned short *z16, const float *y, const unsigned short *y16,
+                        const float *mean, const float *invstd, const float *gamma, const float *mask_scale,
+                        const float *mask_shift, const double *sums, double count, const double *count_dev, float *dx,
+                        unsigned short *dx16, float *g_out, int g_accumulate, float *dgamma, float *dbeta, long total,
+                        int c, hipStream_t stream);
+/* y16 / res16 / z16: the convolution's pre-BN output / the residual / the layer's own output (the ReLU mask's source) when
+ * it exists ONLY as its bf16 image (a tensor every consumer of which reads bf16: rrnet_amd.ops.phantom_f32); give y or
+ * y16 (exactly one), res or res16, z or z16 (at most one each).
+ * rr_bn_bwd_reduce_b16: rr_bn_bwd_reduce with z and / or y from their images (sums pre-zeroed).  rr_upsample2x_add_b16: the hourglass
  * up-path add (backbones/hourglass.py:121-124, even sizes) with either operand as fp32 or bf16 and the result as fp32
  * and / or bf16.  rr_from_bf16: the widening copy (a consumer without a bf16 form materialises the fp32 tensor). */
-int rr_bn_bwd_reduce_b16(const float *dz, const unsigned short *z16, const float *y, const float *mean, const float *invstd,
+int rr_bn_bwd_reduce_b16(const float *dz, const float *z, const unsigned short *z16, const float *y, const unsigned short *y16,
+                         const float *mean, const float *invstd, const float *mask_scale, const float *mask_shift,
                          double *sums, long npix, int c, hipStream_t stream);
 int rr_upsample2x_add_b16(const float *up1, const unsigned short *up1_16, const float *low, const unsigned short *low_16,
                           float *out, unsigned short *out16, int n, int h, int w, int c, hipStream_t stream);

@@ -59,6 +59,9 @@ struct Args {
     const float *bias;
     double *slab;                  // [mtiles][2][DC] per-block column sums / sums of squares of the fp32 result, or null
     int N, SH, SW, SC, DH, DW, DC, R, S, stride, pad_h, pad_w, relu, accumulate, M;
+    // strided destination (stride-2 data gradient, one output parity class per launch): logical output pixel (n, h, w) of the DH x DW
+    // grid lands at pixel (n, h * osh + oh0, w * osw + ow0) of an OH x OW map; osh == 0: dense
+    int OH, OW, osh, osw, oh0, ow0;
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nb)
@@ -234,7 +237,11 @@ __global__ __launch_bounds__(512, 1) void conv16_igemm_kernel(const Args a)
                 }
             }
             if (m < a.M) {
-                const size_t o = (size_t)m * a.DC + ch;
+                size_t o = (size_t)m * a.DC + ch;
+                if (a.osh != 0) {
+                    const int n_ = m / hw, rem_ = m - n_ * hw, h_ = rem_ / a.DW, w_ = rem_ - h_ * a.DW;
+                    o = (((size_t)n_ * a.OH + h_ * a.osh + a.oh0) * a.OW + w_ * a.osw + a.ow0) * a.DC + ch;
+                }
                 if (a.dst != nullptr) {
                     if (a.accumulate) v += *reinterpret_cast<const f32x4 *>(a.dst + o);
                     *reinterpret_cast<f32x4 *>(a.dst + o) = v;
@@ -245,32 +252,56 @@ __global__ __launch_bounds__(512, 1) void conv16_igemm_kernel(const Args a)
         }
     }
     if (a.slab != nullptr) {
-        // per-block column statistics: sum over this lane's 8 pixel tiles (above), over the 16 pixel lanes, over the two pixel halves
-        double *red = reinterpret_cast<double *>(lds);              // [WPX pixel parts][TCH channels][2]
+        // per-block column statistics: this lane's sums over its pixel tiles (above) go to LDS as they are — [channel][pixel part x 16
+        // pixel lanes] pairs of doubles, 128 KiB — and one thread per (channel, sum) adds the 32 / 64 partials (rotated start:
+        // conflict-free reads).  64 LDS writes + 32 reads per lane instead of 512 ds_bpermute (the shuffle tree this replaced cost
+        // 0.04 of the 0.63 ms launch at the dominant layer).
+        double *red = reinterpret_cast<double *>(lds);
+        constexpr int PARTS = WPX * 16;
 #pragma unroll
         for (int ci = 0; ci < 4; ++ci)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                double u = s1[ci][j], q = s2[ci][j];
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {
-                    u += __shfl_xor(u, o, 64);
-                    q += __shfl_xor(q, o, 64);
-                }
-                if (fr == 0) {
-                    const int cl = wc * 64 + ci * 16 + fq * 4 + j;
-                    red[(wp * TCH + cl) * 2] = u;
-                    red[(wp * TCH + cl) * 2 + 1] = q;
-                }
+                const int cl = wc * 64 + ci * 16 + fq * 4 + j;
+                double *d = red + ((size_t)cl * PARTS + wp * 16 + fr) * 2;
+                d[0] = s1[ci][j];
+                d[1] = s2[ci][j];
             }
         __syncthreads();
         if (t < 2 * TCH) {
             const int cl = t >> 1, which = t & 1;
             double v = 0.0;
-#pragma unroll
-            for (int p = 0; p < WPX; ++p) v += red[(p * TCH + cl) * 2 + which];
+#pragma unroll 8
+            for (int e = 0; e < PARTS; ++e) v += red[((size_t)cl * PARTS + ((e + cl) & (PARTS - 1))) * 2 + which];
             a.slab[((size_t)m_tile * 2 + which) * a.DC + k0 + cl] = v;
         }
+    }
+}
+
+// Stride-2 data gradient as four stride-1 correlations, one per output parity class (ph, pw) = (h % 2, w % 2), each with the
+// sub-filter of the taps that reach the class (a 3x3 visits 1 / 2 / 2 / 4 taps instead of masking three quarters of a dilated
+// filter) — csrc/conv_bf16.hip's decomposition; here the sub-filters are packed, flipped and transposed straight to bf16
+// ([c][i'][j'][k], i' = Rc-1-i), class blocks in the order (0,0), (0,1), (1,0), (1,1).
+__global__ __launch_bounds__(256) void parity_pack_bf16_kernel(const float *w, unsigned short *wsub, int K, int C, int R, int S, int pad_h,
+                                                               int pad_w, long total)
+{
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int k = (int)(idx % K);
+        long rest = idx / K;
+        const int tap = (int)(rest % (R * S));
+        const int c = (int)(rest / (R * S));
+        const int r = tap / S, s = tap - r * S;
+        const int ph = (r - pad_h) & 1, pw = (s - pad_w) & 1;
+        const int r0 = (ph + pad_h) & 1, s0 = (pw + pad_w) & 1;
+        const int Rc = (R - r0 + 1) / 2, Sc = (S - s0 + 1) / 2;
+        long base = 0;
+        for (int cl = 0; cl < ph * 2 + pw; ++cl) {
+            const int q0 = ((cl >> 1) + pad_h) & 1, t0 = ((cl & 1) + pad_w) & 1;
+            base += (long)C * (q0 < R ? (R - q0 + 1) / 2 : 0) * (t0 < S ? (S - t0 + 1) / 2 : 0) * K;
+        }
+        const int ii = Rc - 1 - (r - r0) / 2, jj = Sc - 1 - (s - s0) / 2;
+        const __bf16 v = (__bf16)w[((long)k * R * S + tap) * C + c];
+        wsub[base + (((long)c * Rc + ii) * Sc + jj) * K + k] = __builtin_bit_cast(unsigned short, v);
     }
 }
 
@@ -294,7 +325,7 @@ int launch_igemm(const Args &a, hipStream_t stream, const char *name)
         }
         hipLaunchKernelGGL(conv16_igemm_kernel<256>, dim3(mt * (a.DC / 256)), dim3(512), ldsb, stream, a);
     } else {
-        const size_t ldsb = 2 * (size_t)(IMG + 128 * ROWB);
+        const size_t ldsb = 128 * 1024;        // (two buffers need 96 KiB; the statistics epilogue's table 128)
         static bool attr = false;
         if (!attr) {
             RR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv16_igemm_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb), name);
@@ -498,6 +529,51 @@ int rr_conv16_dgrad_s1(const unsigned short *dy, const unsigned short *wt, float
     a.M = n * h * wd;
     a.accumulate = accumulate;
     return launch_igemm(a, stream, "rr_conv16_dgrad_s1");
+}
+
+int rr_conv16_dgrad_s2(const unsigned short *dy, const float *w, float *dx, int n, int h, int wd, int c, int k, int r, int s,
+                       int pad_h, int pad_w, int accumulate, unsigned short *wsub, hipStream_t stream)
+{
+    RR_CHECK_ARG(n > 0 && h > 0 && wd > 0 && dy && w && dx && wsub && pad_h >= 0 && pad_w >= 0, "rr_conv16_dgrad_s2: bad arguments");
+    RR_CHECK_ARG(k % BK == 0 && c % 128 == 0 && r * s <= 16, "rr_conv16_dgrad_s2: unsupported shape c=%d k=%d %dx%d", c, k, r, s);
+    const int p = (h + 2 * pad_h - r) / 2 + 1, q = (wd + 2 * pad_w - s) / 2 + 1;
+    RR_CHECK_ARG(p > 0 && q > 0 && (long)n * p * q * k * 2 < (1l << 31), "rr_conv16_dgrad_s2: empty or oversized dy");
+    const long total = (long)k * c * r * s;
+    hipLaunchKernelGGL(parity_pack_bf16_kernel, dim3((int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256)), dim3(256), 0, stream,
+                       w, wsub, k, c, r, s, pad_h, pad_w, total);
+    RR_CHECK_LAUNCH("rr_conv16_dgrad_s2(pack)");
+    int Rc[4], Sc[4], lead_h[4], lead_w[4];
+    bool any_empty = false;
+    for (int cl = 0; cl < 4; ++cl) {
+        const int ph = cl >> 1, pw = cl & 1;
+        const int r0 = (ph + pad_h) & 1, s0 = (pw + pad_w) & 1;
+        Rc[cl] = r0 < r ? (r - r0 + 1) / 2 : 0;
+        Sc[cl] = s0 < s ? (s - s0 + 1) / 2 : 0;
+        lead_h[cl] = (Rc[cl] - 1) - (ph + pad_h - r0) / 2;
+        lead_w[cl] = (Sc[cl] - 1) - (pw + pad_w - s0) / 2;
+        const int Hc = (h - ph + 1) / 2, Wc = (wd - pw + 1) / 2;
+        if (Hc > 0 && Wc > 0 && Rc[cl] * Sc[cl] == 0) any_empty = true;
+        RR_CHECK_ARG(Rc[cl] * Sc[cl] == 0 || (lead_h[cl] >= 0 && lead_w[cl] >= 0), "rr_conv16_dgrad_s2: unsupported padding %d,%d", pad_h, pad_w);
+    }
+    if (any_empty && !accumulate) RR_CHECK_HIP(hipMemsetAsync(dx, 0, sizeof(float) * (size_t)n * h * wd * c, stream), "rr_conv16_dgrad_s2");
+    long base = 0;
+    for (int cl = 0; cl < 4; ++cl) {
+        const int ph = cl >> 1, pw = cl & 1;
+        const int Hc = (h - ph + 1) / 2, Wc = (wd - pw + 1) / 2;
+        const long blk = (long)c * Rc[cl] * Sc[cl] * k;
+        if (blk > 0 && Hc > 0 && Wc > 0) {
+            Args a{};
+            a.src = dy; a.flt = wsub + base; a.dst = dx;
+            a.N = n; a.SH = p; a.SW = q; a.SC = k; a.DC = c; a.R = Rc[cl]; a.S = Sc[cl]; a.stride = 1;
+            a.pad_h = lead_h[cl]; a.pad_w = lead_w[cl];
+            a.DH = Hc; a.DW = Wc; a.M = n * Hc * Wc;
+            a.accumulate = accumulate;
+            a.OH = h; a.OW = wd; a.osh = 2; a.osw = 2; a.oh0 = ph; a.ow0 = pw;
+            if (int rc = launch_igemm(a, stream, "rr_conv16_dgrad_s2")) return rc;
+        }
+        base += blk;
+    }
+    return RR_OK;
 }
 
 int rr_conv16_wgrad_supported(int c, int k, int r, int s, int stride)

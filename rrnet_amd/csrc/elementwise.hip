@@ -145,12 +145,12 @@ __global__ __launch_bounds__(EW_THREADS) void bn_apply_kernel(const f32x4 *y, co
                                                               const f32x4 *res, const float *res_scale,
                                                               const float *res_shift, f32x4 *out, long n4, int C4,
                                                               int relu, unsigned *amax, u16x4 *out16 = nullptr,
-                                                              const u16x4 *res16 = nullptr)
+                                                              const u16x4 *res16 = nullptr, const u16x4 *y16 = nullptr)
 {
     float vmax = 0.f;
     for (long i = (long)blockIdx.x * EW_THREADS + threadIdx.x; i < n4; i += (long)gridDim.x * EW_THREADS) {
         const int c = (int)(i % C4) * 4;
-        f32x4 v = y[i];
+        f32x4 v = y16 ? from_bf16x4(y16[i]) : y[i];          // (y16: the convolution's output exists only as its bf16 image)
         const f32x4 sc = *reinterpret_cast<const f32x4 *>(scale + c), sh = *reinterpret_cast<const f32x4 *>(shift + c);
         v = rr_bn_affine4(v, sc, sh);
         if (res || res16) {
@@ -185,7 +185,8 @@ __global__ __launch_bounds__(EW_THREADS) void bn_apply_kernel(const f32x4 *y, co
 __global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_kernel(const float *dz, const float *z, const float *y,
                                                                    const float *mean, const float *invstd,
                                                                    const float *mscale, const float *mshift,
-                                                                   double *sums, long npix, int C, const unsigned short *z16 = nullptr)
+                                                                   double *sums, long npix, int C, const unsigned short *z16 = nullptr,
+                                                                   const unsigned short *y16 = nullptr)
 {
     __shared__ double red[2][EW_THREADS * 4];
     const int C4 = C / 4;                      // <= EW_THREADS (checked by the launcher)
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_kernel(const float *
                 if (p < npix) {
                     const long off = p * C + cq * 4;
                     f32x4 g = *reinterpret_cast<const f32x4 *>(dz + off);
-                    const f32x4 yy = *reinterpret_cast<const f32x4 *>(y + off);
+                    const f32x4 yy = y16 ? from_bf16x4(*reinterpret_cast<const u16x4 *>(y16 + off)) : *reinterpret_cast<const f32x4 *>(y + off);
                     if (z || z16) {
                         const f32x4 zz = z16 ? from_bf16x4(*reinterpret_cast<const u16x4 *>(z16 + off)) : *reinterpret_cast<const f32x4 *>(z + off);
 #pragma unroll
@@ -253,7 +254,8 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(const f32x4 *d
                                                                   const double *sums, double count_h,
                                                                   const double *count_d, f32x4 *dx, f32x4 *g_out,
                                                                   float *dgamma, float *dbeta, long n4, int C, int g_acc,
-                                                                  unsigned *amax, u16x4 *dx16 = nullptr, const u16x4 *z16 = nullptr)
+                                                                  unsigned *amax, u16x4 *dx16 = nullptr, const u16x4 *z16 = nullptr,
+                                                                  const u16x4 *y16 = nullptr)
 {
     float vmax = 0.f;
     const int C4 = C / 4;
@@ -268,7 +270,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(const f32x4 *d
     for (long i = (long)blockIdx.x * EW_THREADS + threadIdx.x; i < n4; i += (long)gridDim.x * EW_THREADS) {
         const int c = (int)(i % C4) * 4;
         f32x4 g = dz[i];
-        const f32x4 yy = y[i];
+        const f32x4 yy = y16 ? from_bf16x4(y16[i]) : y[i];
         if (z || z16) {
             const f32x4 zz = z16 ? from_bf16x4(z16[i]) : z[i];
 #pragma unroll
@@ -807,15 +809,16 @@ extern "C" int rr_head_dgrad_relubias(const float *dy, const float *w, float *dx
     return RR_OK;
 }
 
-extern "C" int rr_bn_apply_b16(const float *y, const float *scale, const float *shift, const float *res, const unsigned short *res16,
+extern "C" int rr_bn_apply_b16(const float *y, const unsigned short *y16, const float *scale, const float *shift, const float *res, const unsigned short *res16,
                                const float *res_scale, const float *res_shift, float *out, unsigned short *out16, long total,
                                int c, int relu, hipStream_t stream)
 {
-    RR_CHECK_ARG(c % 4 == 0 && total % c == 0 && (out != nullptr || out16 != nullptr) && !(res != nullptr && res16 != nullptr),
-                 "rr_bn_apply_b16: C=%d must be a multiple of 4, one output required, the residual in ONE precision", c);
+    RR_CHECK_ARG(c % 4 == 0 && total % c == 0 && (out != nullptr || out16 != nullptr) && !(res != nullptr && res16 != nullptr)
+                 && (y != nullptr) != (y16 != nullptr),
+                 "rr_bn_apply_b16: C=%d must be a multiple of 4, one output required, y and the residual each in ONE precision", c);
     const long n4 = total / 4;
     EW_LAUNCH(bn_apply_kernel<false>, n4, stream, (const f32x4 *)y, scale, shift, (const f32x4 *)res, res_scale, res_shift,
-              (f32x4 *)out, n4, c / 4, relu, (unsigned *)nullptr, (u16x4 *)out16, (const u16x4 *)res16);
+              (f32x4 *)out, n4, c / 4, relu, (unsigned *)nullptr, (u16x4 *)out16, (const u16x4 *)res16, (const u16x4 *)y16);
     RR_CHECK_LAUNCH("rr_bn_apply_b16");
     return RR_OK;
 }
@@ -845,19 +848,21 @@ extern "C" int rr_upsample2x_add_b16(const float *up1, const unsigned short *up1
     return RR_OK;
 }
 
-extern "C" int rr_bn_bwd_reduce_b16(const float *dz, const unsigned short *z16, const float *y, const float *mean,
-                                    const float *invstd, double *sums, long npix, int c, hipStream_t stream)
+extern "C" int rr_bn_bwd_reduce_b16(const float *dz, const float *z, const unsigned short *z16, const float *y, const unsigned short *y16,
+                                    const float *mean, const float *invstd, const float *mask_scale, const float *mask_shift,
+                                    double *sums, long npix, int c, hipStream_t stream)
 {
-    // rr_bn_bwd_reduce with the ReLU mask read from the bf16 image of the layer's output (sums pre-zeroed)
-    RR_CHECK_ARG(c % 4 == 0 && c <= 1024 && z16 != nullptr, "rr_bn_bwd_reduce_b16: C=%d must be a multiple of 4 and <= 1024", c);
+    // rr_bn_bwd_reduce with the ReLU mask's source and / or the pre-BN output read from their bf16 images (sums pre-zeroed)
+    RR_CHECK_ARG(c % 4 == 0 && c <= 1024 && !(z != nullptr && z16 != nullptr) && (y != nullptr) != (y16 != nullptr),
+                 "rr_bn_bwd_reduce_b16: C=%d must be a multiple of 4 and <= 1024; z and y each in ONE precision", c);
     const int c4 = c / 4;
     const int lanes = EW_THREADS / c4 > 0 ? EW_THREADS / c4 : 1;
     long blocks = (npix + lanes * 8 - 1) / (lanes * 8);
     const long cap = npix >= 400000 ? 1024 : (npix >= 16384 ? 512 : 256);
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((int)blocks), dim3(EW_THREADS), 0, stream, dz, (const float *)nullptr, y, mean, invstd,
-                       (const float *)nullptr, (const float *)nullptr, sums, npix, c, z16);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((int)blocks), dim3(EW_THREADS), 0, stream, dz, z, y, mean, invstd, mask_scale, mask_shift,
+                       sums, npix, c, z16, y16);
     RR_CHECK_LAUNCH("rr_bn_bwd_reduce_b16");
     return RR_OK;
 }
@@ -912,14 +917,14 @@ static int bn_bwd_apply_impl(const float *dz, const float *z, const float *y, co
                              const float *mask_shift, const double *sums, double count,
                              const double *count_dev, float *dx, float *g_out, float *dgamma, float *dbeta,
                              long total, int c, int g_acc, hipStream_t stream, unsigned *amax = nullptr, unsigned short *dx16 = nullptr,
-                             const unsigned short *z16 = nullptr)
+                             const unsigned short *z16 = nullptr, const unsigned short *y16 = nullptr)
 {
     RR_CHECK_ARG(c % 4 == 0 && total % c == 0, "rr_bn_bwd_apply: C=%d must be a multiple of 4", c);
     const long n4 = total / 4;
-    if (dx16 != nullptr || z16 != nullptr)
+    if (dx16 != nullptr || z16 != nullptr || y16 != nullptr)
         EW_LAUNCH(bn_bwd_apply_kernel<false>, n4, stream, (const f32x4 *)dz, (const f32x4 *)z, (const f32x4 *)y, mean, invstd, gamma,
                   mask_scale, mask_shift, sums, count, count_dev, (f32x4 *)dx, (f32x4 *)g_out, dgamma, dbeta, n4, c, g_acc,
-                  (unsigned *)nullptr, (u16x4 *)dx16, (const u16x4 *)z16);
+                  (unsigned *)nullptr, (u16x4 *)dx16, (const u16x4 *)z16, (const u16x4 *)y16);
     else if (amax != nullptr)
         EW_LAUNCH(bn_bwd_apply_kernel<true>, n4, stream, (const f32x4 *)dz, (const f32x4 *)z, (const f32x4 *)y, mean, invstd, gamma,
                   mask_scale, mask_shift, sums, count, count_dev, (f32x4 *)dx, (f32x4 *)g_out, dgamma, dbeta, n4, c, g_acc, amax);
@@ -931,16 +936,17 @@ static int bn_bwd_apply_impl(const float *dz, const float *z, const float *y, co
     return RR_OK;
 }
 
-extern "C" int rr_bn_bwd_apply_b16(const float *dz, const float *z, const unsigned short *z16, const float *y, const float *mean,
+extern "C" int rr_bn_bwd_apply_b16(const float *dz, const float *z, const unsigned short *z16, const float *y, const unsigned short *y16, const float *mean,
                                    const float *invstd, const float *gamma, const float *mask_scale,
                                    const float *mask_shift, const double *sums, double count,
                                    const double *count_dev, float *dx, unsigned short *dx16, float *g_out, int g_accumulate,
                                    float *dgamma, float *dbeta, long total, int c, hipStream_t stream)
 {
-    RR_CHECK_ARG((dx != nullptr || dx16 != nullptr) && (!g_accumulate || g_out != nullptr) && !(z != nullptr && z16 != nullptr),
-                 "rr_bn_bwd_apply_b16: one of dx / dx16 (and the fan-in buffer when accumulating) required, the mask source in ONE precision");
+    RR_CHECK_ARG((dx != nullptr || dx16 != nullptr) && (!g_accumulate || g_out != nullptr) && !(z != nullptr && z16 != nullptr)
+                 && (y != nullptr) != (y16 != nullptr),
+                 "rr_bn_bwd_apply_b16: one of dx / dx16 (and the fan-in buffer when accumulating) required; z and y each in ONE precision");
     return bn_bwd_apply_impl(dz, z, y, mean, invstd, gamma, mask_scale, mask_shift, sums, count, count_dev, dx, g_out, dgamma,
-                             dbeta, total, c, g_accumulate ? 1 : 0, stream, nullptr, dx16, z16);
+                             dbeta, total, c, g_accumulate ? 1 : 0, stream, nullptr, dx16, z16, y16);
 }
 
 extern "C" int rr_bn_bwd_apply_amax(const float *dz, const float *z, const float *y, const float *mean,

@@ -143,7 +143,10 @@ class _ConvBnAct(torch.autograd.Function):
                 y, slab, x = ops.conv_fprop_packed(x, wc, stride, pad, want_stats=True)
                 ctx.packed = True
             else:
-                y, slab = ops.conv_fprop(x, wc, None, stride, pad, False, want_stats=True, w16=_w16_of(w)[0])
+                # (inside the backbone, where the shape qualifies, the pre-BN output too is written as a bf16 image only: the
+                # statistics come out of the fp32 accumulators, BatchNorm apply / backward read the image)
+                y, slab = ops.conv_fprop(x, wc, None, stride, pad, False, want_stats=True, w16=_w16_of(w)[0],
+                                         y_bf16_only=ops.phantom_y_ok(k, x, wc, stride, pad))
             count = float(y.numel() // k)
             cnt_dev = None
             mom = bn.momentum if bn.momentum is not None else 0.1
@@ -189,6 +192,7 @@ class _ConvBnAct(torch.autograd.Function):
             ctx.x_amax = ops.amax_carry(x)      # (split-operand kernels: the weight gradient reuses the forward's reduction)
             ctx.x_b16 = ops.b16_carry(x)        # (conv16 kernels: the weight gradient reads the forward's bf16 image of x)
             ctx.z_b16 = ops.b16_carry(z) if (relu and not remask) else None      # (a bf16-only z: its image is the mask's source)
+            ctx.y_b16 = ops.b16_carry(y) if ops.is_phantom(y) else None
             if out_link is not None:
                 # what a consumer's data gradient needs to produce this layer's BatchNorm-backward sums in its epilogue
                 out_link.y, out_link.mean, out_link.invstd = y, mean, invstd
@@ -211,6 +215,7 @@ class _ConvBnAct(torch.autograd.Function):
         ops.amax_restore(x, getattr(ctx, "x_amax", None))
         ops.b16_restore(x, getattr(ctx, "x_b16", None))
         ops.b16_restore(z, getattr(ctx, "z_b16", None))
+        ops.b16_restore(y, getattr(ctx, "y_b16", None))
         stride, pad, relu, count, sync, has_res = ctx.cfg
         w, gamma_p, beta_p = ctx.params
         dz = ops.to_nhwc(dz)

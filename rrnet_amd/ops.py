@@ -347,6 +347,19 @@ def phantom_out_ok(c, pixels, device):
                 and c % 256 == 0 and pixels >= _CONV16_MIN_PIXELS)
 
 
+_PHANTOM_Y = os.environ.get("RR_BF16_ONLY_Y", "1") != "0"      # 0: pre-BN convolution outputs keep their fp32 tensor
+
+
+def phantom_y_ok(k, x, w, stride, pad):
+    """conv -> bn layers inside the backbone (phantom_scope): may the convolution's pre-BN output exist as a bf16 image only?"""
+    if not (_PHANTOM_Y and x.is_cuda):
+        return False
+    n, c, h, wd = x.shape
+    r, s = w.shape[2], w.shape[3]
+    p, q = out_hw(h, wd, r, s, stride, pad[0], pad[1])
+    return phantom_out_ok(k, n * p * q, x.device) and conv16_ok(c, k, r, s, stride, n * p * q, x)
+
+
 def b16_attach(t, image):
     t._rr_b16 = (t._version, torch.cuda.current_stream(t.device).cuda_stream, image)
 
@@ -401,6 +414,10 @@ def dgrad16_takes(dy_shape, w_shape, x_shape, stride, pad, relu_bias_link=False)
     """True when conv_dgrad(dy, w, x_shape, ...) will go to rr_conv16_dgrad_s1 (mirrors the dispatch there)."""
     n, c, h, wd = x_shape
     k, _, r, s = w_shape
+    if stride == 2:
+        return bool(_s2_parity_pads_ok(r, s, pad) and _CONV16 and _mode() == MATH_BF16 and _BF16_S2_DGRAD and k % 64 == 0 and c % 128 == 0
+                    and r * s <= 16 and n * h * wd // 4 >= _CONV16_MIN_PIXELS
+                    and max(n * h * wd * c, dy_shape[0] * dy_shape[1] * dy_shape[2] * dy_shape[3]) * 2 < (1 << 31))
     return bool(stride == 1 and pad[0] < r and pad[1] < s and not relu_bias_link and _CONV16 and _mode() == MATH_BF16
                 and n * h * wd >= _CONV16_MIN_PIXELS and _C.fn("rr_conv16_supported")(k, c, r, s, 1)
                 and max(n * h * wd * c, dy_shape[0] * dy_shape[1] * dy_shape[2] * dy_shape[3]) * 2 < (1 << 31))
@@ -467,7 +484,8 @@ def _math_tail(mode, filter16, src, flt, filter_split):
     return (_C.stream(),)
 
 
-def conv_fprop(x, w, bias=None, stride=1, pad=(0, 0), relu=False, want_stats=False, algo_kg=None, w16=None, w_split=None):
+def conv_fprop(x, w, bias=None, stride=1, pad=(0, 0), relu=False, want_stats=False, algo_kg=None, w16=None, w_split=None,
+               y_bf16_only=False):
     """x [N,C,H,W] (NHWC memory), w [K,C,R,S] (OHWI memory) -> y [N,K,P,Q] (NHWC memory)
     and, if want_stats, the per-block BatchNorm partial-sum slab (see rr_conv_fprop).
     algo_kg: the useful reduction length when the operands carry zero padding (timer FLOPs stay algorithmic)."""
@@ -477,9 +495,15 @@ def conv_fprop(x, w, bias=None, stride=1, pad=(0, 0), relu=False, want_stats=Fal
     k, c2, r, s = w.shape
     assert c == c2
     p, q = out_hw(h, wd, r, s, stride, pad[0], pad[1])
-    y = empty_nhwc(n, k, p, q, x.device)
+    use16 = conv16_ok(c, k, r, s, stride, n * p * q, x) and n * p * q * k * 4 < (1 << 31)
+    y16 = None
+    if use16 and y_bf16_only:
+        # the output as a bf16 image only (the caller's BatchNorm reads it; the statistics below come from the fp32 accumulators)
+        y16 = torch.empty((n, p, q, k), dtype=torch.bfloat16, device=x.device).permute(0, 3, 1, 2)
+        y = phantom_f32((n, k, p, q), x.device, y16)
+    else:
+        y = empty_nhwc(n, k, p, q, x.device)
     slab = None
-    use16 = conv16_ok(c, k, r, s, stride, n * p * q, x, y)
     if is_phantom(x) and not use16:
         x = f32_of(x)                       # a bf16-only input in front of a layer the conv16 kernels do not take
     assert (is_nhwc(x) or is_phantom(x)) and is_nhwc(w), "conv_fprop wants NHWC activations / OHWI weights"
@@ -493,9 +517,11 @@ def conv_fprop(x, w, bias=None, stride=1, pad=(0, 0), relu=False, want_stats=Fal
             slab = torch.empty(_C.fn("rr_conv16_stat_slab_bytes")(n, p, q, k) // 8, dtype=torch.float64, device=x.device)
         flops = 2.0 * n * p * q * k * (c * r * s if algo_kg is None else algo_kg)
         _C.check(_timed("conv16_fprop", flops,
-                        lambda: _C.fn("rr_conv16_fprop")(_C.ptr(x16), _C.ptr(w16), _C.ptr(bias), _C.ptr(y), None, _C.ptr(slab), n, h, wd, c, k,
-                                                         r, s, stride, pad[0], pad[1], int(relu), _C.stream()),
-                        (n, h, wd, c, k, r, s, stride), 2.0 * (x.numel() + w.numel()) + 4.0 * y.numel()), "rr_conv16_fprop")
+                        lambda: _C.fn("rr_conv16_fprop")(_C.ptr(x16), _C.ptr(w16), _C.ptr(bias), _C.ptr(None if y16 is not None else y),
+                                                         _C.ptr(y16), _C.ptr(slab), n, h, wd, c, k, r, s, stride, pad[0], pad[1],
+                                                         int(relu), _C.stream()),
+                        (n, h, wd, c, k, r, s, stride), 2.0 * (x.numel() + w.numel()) + (2.0 if y16 is not None else 4.0) * y.numel()),
+                 "rr_conv16_fprop")
         return (y, slab) if want_stats else y
     if want_stats:
         nbytes = _C.fn("rr_conv_stat_slab_bytes")(n, p, q, k)
@@ -635,6 +661,8 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False,
     else:
         amax_drop(out)                # an existing tensor rewritten / added into through its pointer
     assert is_nhwc(out)
+    if bnsum is not None and not bnsum.relu_bias and bnsum.y is not None and is_phantom(bnsum.y):
+        bnsum = None                  # the producer's pre-BN output exists only as a bf16 image: it runs its own reduce pass
     if bnsum is not None and bnsum_z is not None and is_phantom(bnsum_z):
         # the producer's output exists only as a bf16 image: the fp32-reading epilogues cannot take their mask from it — a ReLU /
         # bias producer gets the widened copy, a BatchNorm producer runs its own reduce pass (rr_bn_bwd_reduce_b16)
@@ -642,8 +670,10 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False,
             bnsum_z = f32_of(bnsum_z)
         else:
             bnsum = None
-    if is_phantom(dy) and not (stride == 1 and pad[0] < r and pad[1] < s and conv16_ok(k, c, r, s, 1, n * h * wd, dy, out)
-                               and not (bnsum is not None and bnsum.relu_bias)):
+    s2_16 = (stride == 2 and _s2_parity_pads_ok(r, s, pad) and _CONV16 and _mode() == MATH_BF16 and _BF16_S2_DGRAD and dy.is_cuda
+             and k % 64 == 0 and c % 128 == 0 and r * s <= 16 and n * h * wd // 4 >= _CONV16_MIN_PIXELS)
+    if is_phantom(dy) and not s2_16 and not (stride == 1 and pad[0] < r and pad[1] < s and conv16_ok(k, c, r, s, 1, n * h * wd, dy, out)
+                                             and not (bnsum is not None and bnsum.relu_bias)):
         dy = f32_of(dy)
     if (bnsum is not None and bnsum.relu_bias and _DGRAD_BNSUM and stride == 1 and c % 4 == 0
             and bnsum_z is not None and is_nhwc(bnsum_z) and bnsum_z.shape == out.shape and out.numel() * 4 < (1 << 31)
@@ -741,6 +771,17 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False,
                         lambda: f1(_C.ptr(dy), _C.ptr(wt), _C.ptr(out), n, h, wd, c, k, r, s, pad[0], pad[1],
                                    int(accumulate), *tail), (n, h, wd, c, k, r, s, stride),
                         4.0 * (dy.numel() + out.numel() * (2 if accumulate else 1) + w.numel())), "rr_conv_dgrad_s1")
+        return out
+    if (stride == 2 and _s2_parity_pads_ok(r, s, pad) and _CONV16 and _mode() == MATH_BF16 and _BF16_S2_DGRAD and dy.is_cuda
+            and k % 64 == 0 and c % 128 == 0 and r * s <= 16 and n * h * wd // 4 >= _CONV16_MIN_PIXELS
+            and max(dy.numel(), out.numel()) * 2 < (1 << 31)):
+        # csrc/conv16.hip: the four parity-class launches on dY's bf16 image and bf16 sub-filters packed inside the call
+        dy16 = bf16_of(dy)
+        wsub16 = torch.empty(k * c * r * s, dtype=torch.bfloat16, device=dy.device)
+        _C.check(_timed("conv16_dgrad_s2", flops,
+                        lambda: _C.fn("rr_conv16_dgrad_s2")(_C.ptr(dy16), _C.ptr(w), _C.ptr(out), n, h, wd, c, k, r, s, pad[0], pad[1],
+                                                            int(accumulate), _C.ptr(wsub16), _C.stream()), (n, h, wd, c, k, r, s, stride)),
+                 "rr_conv16_dgrad_s2")
         return out
     if (stride == 2 and _s2_parity_pads_ok(r, s, pad) and _bf16_ok(k, c, r, s, dy, out, pixels=n * h * wd // 4)
             and _BF16_S2_DGRAD):
@@ -872,16 +913,17 @@ def bn_eval_coeffs(gamma, beta, running_mean, running_var, eps):
 def bn_apply(y, scale, shift, residual=None, relu=False, res_scale=None, res_shift=None, bf16_only=False):
     """bf16_only (conv16, ops.phantom_scope): the output is written as a bf16 image only and returned as a memory-less fp32
     handle (phantom_f32).  A bf16-only residual is read from its image."""
-    res_ph = is_phantom(residual)
-    assert is_nhwc(y) and (residual is None or ((is_nhwc(residual) or res_ph) and residual.shape == y.shape))
+    res_ph, y_ph = is_phantom(residual), is_phantom(y)
+    assert (is_nhwc(y) or y_ph) and (residual is None or ((is_nhwc(residual) or res_ph) and residual.shape == y.shape))
     n, c, h, w = y.shape
     want16 = _CONV16 and _mode() == MATH_BF16 and y.is_cuda and c % 128 == 0 and n * h * w >= _CONV16_MIN_PIXELS
-    if (bf16_only or res_ph) and y.is_cuda and c % 4 == 0:
+    if (bf16_only or res_ph or y_ph) and y.is_cuda and c % 4 == 0:
         out = None if bf16_only else empty_nhwc(n, c, h, w, y.device)
         out16 = torch.empty((n, h, w, c), dtype=torch.bfloat16, device=y.device).permute(0, 3, 1, 2) if (bf16_only or want16) else None
-        _C.check(_C.fn("rr_bn_apply_b16")(_C.ptr(y), _C.ptr(scale), _C.ptr(shift), _C.ptr(None if res_ph else residual),
-                                          _C.ptr(image_of(residual) if res_ph else None), _C.ptr(res_scale), _C.ptr(res_shift),
-                                          _C.ptr(out), _C.ptr(out16), y.numel(), c, int(relu), _C.stream()), "rr_bn_apply_b16")
+        _C.check(_C.fn("rr_bn_apply_b16")(_C.ptr(None if y_ph else y), _C.ptr(image_of(y) if y_ph else None), _C.ptr(scale), _C.ptr(shift),
+                                          _C.ptr(None if res_ph else residual), _C.ptr(image_of(residual) if res_ph else None),
+                                          _C.ptr(res_scale), _C.ptr(res_shift), _C.ptr(out), _C.ptr(out16), y.numel(), c, int(relu),
+                                          _C.stream()), "rr_bn_apply_b16")
         if bf16_only:
             return phantom_f32((n, c, h, w), y.device, out16)
         if out16 is not None:
@@ -899,7 +941,7 @@ def bn_apply(y, scale, shift, residual=None, relu=False, res_scale=None, res_shi
     if want16:
         # the bf16 image the consuming convolution (csrc/conv16.hip) reads, written in the same pass
         out16 = torch.empty_like(out, dtype=torch.bfloat16)
-        _C.check(_C.fn("rr_bn_apply_b16")(_C.ptr(y), _C.ptr(scale), _C.ptr(shift), _C.ptr(residual), None, _C.ptr(res_scale),
+        _C.check(_C.fn("rr_bn_apply_b16")(_C.ptr(y), None, _C.ptr(scale), _C.ptr(shift), _C.ptr(residual), None, _C.ptr(res_scale),
                                           _C.ptr(res_shift), _C.ptr(out), _C.ptr(out16), y.numel(), c, int(relu), _C.stream()),
                  "rr_bn_apply_b16")
         b16_attach(out, out16)
@@ -912,9 +954,12 @@ def bn_apply(y, scale, shift, residual=None, relu=False, res_scale=None, res_shi
 def bn_bwd_reduce(dz, z, y, mean, invstd, extra=0, mask_scale=None, mask_shift=None):
     n, c, h, w = y.shape
     sums = _ZEROS.take(2 * c + extra, y.device)            # pre-zeroed pool slice: no memset launch per layer
-    if is_phantom(z):                                       # the layer's output exists only as its bf16 image: the mask comes from there
-        _C.check(_C.fn("rr_bn_bwd_reduce_b16")(_C.ptr(dz), _C.ptr(image_of(z)), _C.ptr(y), _C.ptr(mean), _C.ptr(invstd), _C.ptr(sums),
-                                               n * h * w, c, _C.stream()), "rr_bn_bwd_reduce_b16")
+    z_ph, y_ph = is_phantom(z), is_phantom(y)
+    if z_ph or y_ph:                                        # the layer's output / pre-BN output exist only as bf16 images
+        _C.check(_C.fn("rr_bn_bwd_reduce_b16")(_C.ptr(dz), _C.ptr(None if z_ph else z), _C.ptr(image_of(z) if z_ph else None),
+                                               _C.ptr(None if y_ph else y), _C.ptr(image_of(y) if y_ph else None), _C.ptr(mean),
+                                               _C.ptr(invstd), _C.ptr(mask_scale), _C.ptr(mask_shift), _C.ptr(sums), n * h * w, c,
+                                               _C.stream()), "rr_bn_bwd_reduce_b16")
         return sums
     _C.check(_C.fn("rr_bn_bwd_reduce")(_C.ptr(dz), _C.ptr(z), _C.ptr(y), _C.ptr(mean), _C.ptr(invstd),
                                        _C.ptr(mask_scale), _C.ptr(mask_shift), _C.ptr(sums),
@@ -928,9 +973,9 @@ def bn_bwd_apply(dz, z, y, mean, invstd, gamma, sums, count, want_g=False, dgamm
     bf16_only (conv16): dx is written as a bf16 image only — the caller knows that its data and weight gradient both read
     that image; the returned dx is a memory-less fp32 handle (phantom_f32)."""
     n, c, h, w = y.shape
-    z_ph = is_phantom(z)
+    z_ph, y_ph = is_phantom(z), is_phantom(y)
     only16 = bool(bf16_only and _CONV16 and _mode() == MATH_BF16 and y.is_cuda and c % 4 == 0)
-    if only16 or z_ph:
+    if only16 or z_ph or y_ph:
         if g_into is not None:
             assert is_nhwc(g_into) and g_into.shape == y.shape
             amax_drop(g_into)
@@ -940,7 +985,8 @@ def bn_bwd_apply(dz, z, y, mean, invstd, gamma, sums, count, want_g=False, dgamm
         want16 = only16 or (_CONV16 and _mode() == MATH_BF16 and c % 128 == 0 and n * h * w >= _CONV16_MIN_PIXELS)
         dx = None if only16 else empty_nhwc(n, c, h, w, y.device)
         dx16 = torch.empty((n, h, w, c), dtype=torch.bfloat16, device=y.device).permute(0, 3, 1, 2) if want16 else None
-        _C.check(_C.fn("rr_bn_bwd_apply_b16")(_C.ptr(dz), _C.ptr(None if z_ph else z), _C.ptr(image_of(z) if z_ph else None), _C.ptr(y),
+        _C.check(_C.fn("rr_bn_bwd_apply_b16")(_C.ptr(dz), _C.ptr(None if z_ph else z), _C.ptr(image_of(z) if z_ph else None),
+                                              _C.ptr(None if y_ph else y), _C.ptr(image_of(y) if y_ph else None),
                                               _C.ptr(mean), _C.ptr(invstd), _C.ptr(gamma), _C.ptr(mask_scale), _C.ptr(mask_shift),
                                               _C.ptr(sums), float(count), _C.ptr(count_dev), _C.ptr(dx), _C.ptr(dx16), _C.ptr(g),
                                               int(g_into is not None), _C.ptr(dgamma), _C.ptr(dbeta), y.numel(), c, _C.stream()),
@@ -969,7 +1015,7 @@ def bn_bwd_apply(dz, z, y, mean, invstd, gamma, sums, count, want_g=False, dgamm
         return dx, g
     if _CONV16 and _mode() == MATH_BF16 and y.is_cuda and c % 128 == 0 and n * h * w >= _CONV16_MIN_PIXELS:
         dx16 = torch.empty_like(dx, dtype=torch.bfloat16)
-        _C.check(_C.fn("rr_bn_bwd_apply_b16")(_C.ptr(dz), _C.ptr(z), None, _C.ptr(y), _C.ptr(mean), _C.ptr(invstd), _C.ptr(gamma),
+        _C.check(_C.fn("rr_bn_bwd_apply_b16")(_C.ptr(dz), _C.ptr(z), None, _C.ptr(y), None, _C.ptr(mean), _C.ptr(invstd), _C.ptr(gamma),
                                               _C.ptr(mask_scale), _C.ptr(mask_shift), _C.ptr(sums), float(count), _C.ptr(count_dev),
                                               _C.ptr(dx), _C.ptr(dx16), _C.ptr(g), int(g_into is not None), _C.ptr(dgamma), _C.ptr(dbeta),
                                               y.numel(), c, _C.stream()), "rr_bn_bwd_apply_b16")

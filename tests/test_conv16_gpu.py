@@ -17,6 +17,7 @@ SHAPES = [
     (1, 384, 17, 29, 384, 3, 1),
     (2, 256, 64, 64, 256, 3, 1),       # several pixel tiles, image borders inside tiles
     (1, 256, 40, 24, 512, 3, 2),
+    (2, 128, 32, 48, 256, 1, 2),       # 1x1 stride 2 (a projection block's skip): three of the four parity classes are empty
 ]
 
 
@@ -75,6 +76,17 @@ def test_conv16_kernels_equal_fp32_kernels_on_rounded_operands(cfg):
         _close(dx, refd + base, "dgrad (accumulate)", 2e-5)
         _C.check(fd(_C.ptr(dy16), _C.ptr(wflip16), _C.ptr(dx), None, n, h, w, c, k, r, r, pad[0], pad[1], 0, _C.stream()), "dgrad")
         _close(dx, refd, "dgrad", 2e-5)
+    # ---- stride-2 data gradient: four parity-class launches with a strided destination (plain and accumulate)
+    if stride == 2 and k % 64 == 0 and c % 128 == 0:
+        base = ops.to_nhwc(_mk((n, c, h, w), 6))
+        dx = base.clone()
+        wsub = torch.empty(k * c * r * r, dtype=torch.bfloat16, device=x.device)
+        f2 = _C.fn("rr_conv16_dgrad_s2")
+        _C.check(f2(_C.ptr(dy16), _C.ptr(wt), _C.ptr(dx), n, h, w, c, k, r, r, pad[0], pad[1], 1, _C.ptr(wsub), _C.stream()), "dgrad_s2")
+        ref2d = ops.conv_dgrad(dy16.float(), wr, (n, c, h, w), 2, pad)
+        _close(dx, ref2d + base, "stride-2 dgrad (accumulate)", 2e-5)
+        _C.check(f2(_C.ptr(dy16), _C.ptr(wt), _C.ptr(dx), n, h, w, c, k, r, r, pad[0], pad[1], 0, _C.ptr(wsub), _C.stream()), "dgrad_s2")
+        _close(dx, ref2d, "stride-2 dgrad", 2e-5)
     # ---- weight gradient
     if _C.fn("rr_conv16_wgrad_supported")(c, k, r, r, stride):
         dw = ops.zeros_nhwc(k, c, r, r, x.device)
