@@ -173,6 +173,10 @@ int rr_conv16_fprop(const unsigned short *x, const unsigned short *w, const floa
                     int relu, hipStream_t stream);
 int rr_conv16_dgrad_s1(const unsigned short *dy, const unsigned short *wt, float *dx, unsigned short *dx16, int n, int h,
                        int wd, int c, int k, int r, int s, int pad_h, int pad_w, int accumulate, hipStream_t stream);
+/* ... and the backward of the ReLU in front of the convolution applied in the epilogue (rr_conv_dgrad_s1_relubias without the
+ * column sums: the producer is a bare ReLU, functional._ReLU): dx = (dx_conv [+ dx]) * (relu_out > 0). */
+int rr_conv16_dgrad_s1_relumask(const unsigned short *dy, const unsigned short *wt, float *dx, int n, int h, int wd, int c, int k,
+                                int r, int s, int pad_h, int pad_w, int accumulate, const float *relu_out, hipStream_t stream);
 /* Stride-2 data gradient (rr_conv_dgrad_s2_bf16's contract: dx [n,h,w,c] = / += the gradient of a stride-2 convolution with filter
  * w [k][r][s][c] (fp32, rounded to bf16 while its parity-class sub-filters are packed into wsub: k*r*s*c bf16 of caller scratch);
  * dy bf16 [n,p,q,k]).  K % 64 == 0, C % 128 == 0, R*S <= 16, non-negative leading pads in every class (3x3 pad 1, 1x1 pad 0). */

@@ -57,6 +57,7 @@ struct Args {
     float *dst;                    // [N,DH,DW,DC] fp32 or null
     unsigned short *dst16;         // the same rounded to bf16, or null
     const float *bias;
+    const float *mask_z;           // data gradient into a ReLU's input: [N,DH,DW,DC] fp32, the ReLU's OUTPUT; the (summed) gradient is stored where it is > 0, else 0
     double *slab;                  // [mtiles][2][DC] per-block column sums / sums of squares of the fp32 result, or null
     int N, SH, SW, SC, DH, DW, DC, R, S, stride, pad_h, pad_w, relu, accumulate, M;
     // strided destination (stride-2 data gradient, one output parity class per launch): logical output pixel (n, h, w) of the DH x DW
@@ -244,6 +245,11 @@ __global__ __launch_bounds__(512, 1) void conv16_igemm_kernel(const Args a)
                 }
                 if (a.dst != nullptr) {
                     if (a.accumulate) v += *reinterpret_cast<const f32x4 *>(a.dst + o);
+                    if (a.mask_z != nullptr) {
+                        const f32x4 zz = *reinterpret_cast<const f32x4 *>(a.mask_z + (size_t)m * a.DC + ch);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = zz[j] > 0.f ? v[j] : 0.f;
+                    }
                     *reinterpret_cast<f32x4 *>(a.dst + o) = v;
                 }
                 if (a.dst16 != nullptr)
@@ -529,6 +535,24 @@ int rr_conv16_dgrad_s1(const unsigned short *dy, const unsigned short *wt, float
     a.M = n * h * wd;
     a.accumulate = accumulate;
     return launch_igemm(a, stream, "rr_conv16_dgrad_s1");
+}
+
+int rr_conv16_dgrad_s1_relumask(const unsigned short *dy, const unsigned short *wt, float *dx, int n, int h, int wd, int c, int k,
+                                int r, int s, int pad_h, int pad_w, int accumulate, const float *relu_out, hipStream_t stream)
+{
+    // rr_conv16_dgrad_s1 whose epilogue applies the backward of the ReLU that produced the convolution's input: what is stored is
+    // (dx [+ what dx held]) * (relu_out > 0) — the LAST contributor of a fan-in does this on the complete sum (functional._ReLU)
+    if (int rc = check_shape("rr_conv16_dgrad_s1_relumask", n, h, wd, k, c, r, s, 1, pad_h, pad_w)) return rc;
+    RR_CHECK_ARG(pad_h < r && pad_w < s && dy && wt && dx && relu_out, "rr_conv16_dgrad_s1_relumask: bad arguments");
+    Args a{};
+    a.src = dy; a.flt = wt; a.dst = dx; a.mask_z = relu_out;
+    a.N = n; a.SH = h + 2 * pad_h - r + 1; a.SW = wd + 2 * pad_w - s + 1; a.SC = k; a.DC = c; a.R = r; a.S = s; a.stride = 1;
+    a.pad_h = r - 1 - pad_h; a.pad_w = s - 1 - pad_w;
+    a.DH = h; a.DW = wd;
+    RR_CHECK_ARG(a.SH > 0 && a.SW > 0, "rr_conv16_dgrad_s1_relumask: empty dy");
+    a.M = n * h * wd;
+    a.accumulate = accumulate;
+    return launch_igemm(a, stream, "rr_conv16_dgrad_s1_relumask");
 }
 
 int rr_conv16_dgrad_s2(const unsigned short *dy, const float *w, float *dx, int n, int h, int wd, int c, int k, int r, int s,

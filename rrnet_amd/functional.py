@@ -842,7 +842,7 @@ def relu(x):
     link = None
     if torch.is_grad_enabled() and x.requires_grad and x.dim() == 4 and x.shape[1] % 4 == 0:
         link = ops.BnLink()
-        link.relu_bias = link.use_z = True
+        link.relu_bias = link.use_z = link.mask_only = True
     out = _ReLU.apply(x, link)
     if link is not None:
         out._rr_bnlink = link

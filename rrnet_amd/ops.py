@@ -608,13 +608,14 @@ class BnLink:
     statistics, and the source of its ReLU mask (z for layers with a residual, scale / shift otherwise).  The consumer's
     backward leaves `sums` (and the gradient tensor they were taken of) here; the producer's backward picks them up
     instead of running rr_bn_bwd_reduce when the gradient it receives is that very tensor."""
-    __slots__ = ("y", "use_z", "mean", "invstd", "msc", "msh", "sums", "dz", "consumers", "relu_bias")
+    __slots__ = ("y", "use_z", "mean", "invstd", "msc", "msh", "sums", "dz", "consumers", "relu_bias", "mask_only")
 
     def __init__(self):
         self.y = self.mean = self.invstd = self.msc = self.msh = self.sums = self.dz = None
         # relu_bias: the producer is conv + bias + ReLU (a head's 3x3 layer): the consumer's data gradient stores the
         # ReLU-masked gradient and sums[:c] is the producer's bias gradient (rr_conv_dgrad_s1_relubias)
         self.relu_bias = False
+        self.mask_only = False      # relu_bias, and the producer is a bare ReLU (functional._ReLU): only the mask is wanted, no column sums
         # the mask comes from the producer's OUTPUT z (layers with a residual).  The link must not hold z itself — z
         # carries the link as an attribute, and such a cycle keeps a step's activations alive until the cyclic GC runs
         # (the caching allocator then thrashes); the consumer passes its own saved input, which IS z.
@@ -679,6 +680,22 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False,
             and bnsum_z is not None and is_nhwc(bnsum_z) and bnsum_z.shape == out.shape and out.numel() * 4 < (1 << 31)
             and r * s <= 64 and pad[0] < r and pad[1] < s and dy.shape[2] * dy.shape[3] >= _DGRAD_VIA_FPROP_MIN_PIXELS
             and (n * h * wd) % 128 == 0):      # whole 128-row tiles only (see fprop_impl in csrc/conv.hip)
+        if bnsum.mask_only and pad[0] < r and pad[1] < s and conv16_ok(k, c, r, s, 1, n * h * wd, dy, out) and not is_phantom(bnsum_z):
+            # the producer is a bare ReLU (its mask is all that is wanted): conv16's data gradient with the mask in its epilogue
+            dy16 = bf16_of(dy)
+            if wt16 is None:
+                if wt is None:
+                    wt = torch.empty(k * c * r * s, dtype=torch.float32, device=dy.device)
+                    _C.check(_C.fn("rr_weight_flip_transpose")(_C.ptr(w), _C.ptr(wt), k, c, r, s, _C.stream()), "rr_weight_flip_transpose")
+                wt16 = torch.empty(wt.numel(), dtype=torch.bfloat16, device=dy.device)
+                _C.check(_C.fn("rr_to_bf16")(_C.ptr(wt), _C.ptr(wt16), wt.numel(), _C.stream()), "rr_to_bf16")
+            flops_m = 2.0 * dy.shape[0] * dy.shape[2] * dy.shape[3] * k * c * r * s
+            _C.check(_timed("conv16_dgrad_s1+relumask", flops_m,
+                            lambda: _C.fn("rr_conv16_dgrad_s1_relumask")(_C.ptr(dy16), _C.ptr(wt16), _C.ptr(out), n, h, wd, c, k, r, s, pad[0],
+                                                                         pad[1], int(accumulate), _C.ptr(bnsum_z), _C.stream()),
+                            (n, h, wd, c, k, r, s, stride)), "rr_conv16_dgrad_s1_relumask")
+            bnsum.sums, bnsum.dz = _ZEROS.take(2, dy.device), out          # (sums: the "done" marker _ReLU.backward looks for)
+            return out
         if r == 1 and s == 1 and k <= _HEAD_DGRAD_MAX_K and 1024 % c == 0 and _HEAD_DGRAD and dy.is_cuda:
             # a head's narrow 1x1 layer (K = 10 / 2 / 34 of 36): not a GEMM worth a matrix kernel — one HBM-bound pass
             # (rr_head_dgrad_relubias), no channel padding; under conv16 the bf16 image of dx comes out of the same pass

@@ -134,3 +134,24 @@ def test_conv16_dispatch_images_and_bf16_only_tensors():
     assert torch.equal(ops.to_nhwc(expanded), torch.ones((n, c, h, w), device="cuda"))
     ref = ops.conv_fprop(ops.to_nhwc(img.float()), ops.to_nhwc(wt.to(torch.bfloat16).float()), None, 1, (1, 1))
     _close(out_p, ref, "conv16 through the dispatch", 2e-5)
+
+
+def test_conv16_dgrad_with_relu_mask_epilogue():
+    """rr_conv16_dgrad_s1_relumask (a bare ReLU in front of the convolution, functional._ReLU): the last contributor of a fan-in stores
+    (others + dx) * (relu_out > 0); through the dispatch (ops.conv_dgrad with a mask_only link) and against the fp32 kernels."""
+    from rrnet_amd import ops
+    n, c, h, w, k = 2, 256, 64, 64, 256
+    dy = ops.to_nhwc(_mk((n, k, h, w), 31))
+    wt = ops.to_nhwc(_mk((k, c, 3, 3), 32) / 48.0)
+    z = ops.to_nhwc(_mk((n, c, h, w), 33).relu_())
+    others = ops.to_nhwc(_mk((n, c, h, w), 34))
+    link = ops.BnLink()
+    link.relu_bias = link.use_z = link.mask_only = True
+    buf = others.clone()
+    with ops.bf16_scope(ops.MATH_BF16):
+        ops.conv_dgrad(dy, wt, (n, c, h, w), 1, (1, 1), out=buf, accumulate=True, bnsum=link, bnsum_z=z)
+    assert link.sums is not None and link.dz is buf
+    r = lambda t: t.to(torch.bfloat16).float()
+    ref = (ops.conv_dgrad(ops.to_nhwc(r(dy)), ops.to_nhwc(r(wt)), (n, c, h, w), 1, (1, 1)) + others) * (z > 0)
+    _close(buf, ref, "masked fan-in sum", 2e-5)
+    assert float((buf * (z <= 0)).abs().max()) == 0.0
