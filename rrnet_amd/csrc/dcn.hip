@@ -1239,6 +1239,16 @@ __device__ __forceinline__ float dpp_sum8(float v)
     return v;
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// float -> int, round to nearest with ties toward +inf (floor(x + 0.5)): ONE instruction where __float2int_rn takes two
+// (v_rndne_f32 + v_cvt_i32_f32); the fixed-point window's rounding bound (half a unit per add) is the same.
+__device__ __forceinline__ int cvt_rpi(float x)
+{
+    int r;
+    asm("v_cvt_rpi_i32_f32_e32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
 struct DcnWinBwdArgs {
     DcnWinArgs w;
     const float *dy;
@@ -1248,13 +1258,23 @@ struct DcnWinBwdArgs {
     // 4 MB L2 (32 workgroups x 128 KB) and come from HBM eight times (4.3 of the 5.9 GB the kernel fetched in round 2);
     // as 64 KB of bf16 they stay in L2, and the staging needs no convert.
     const unsigned short *dyb;
+    // DMA sweep: the weights packed to bf16 [tap][32-channel chunk][filter][32] (dcn_pack_weights_kernel, the forward's layout)
+    const unsigned short *wpk;
 };
 
 // F32: the matrix operands stay fp32 (v_mfma_f32_32x32x2_f32, K-steps of 16 filters: the same LDS bytes as 32 in bf16);
 // everything after the GEMM sweep is shared.
-template <int RS, bool F32>      // RS taps (9 for 3x3): one accumulator tile per tap lives in registers through a chunk
+// DMA (round 5; bf16 only, K % 32 == 0, dY given as a bf16 image, weights pre-packed): both operands of the K sweep go
+// global -> LDS by buffer_load ... lds into TWO operand images (no staging registers, no converts, no ds_write, one
+// barrier per K-step).  The second image lies over the d-input window, which holds nothing during the sweep (it is
+// flushed and zero at every chunk boundary) and is zeroed again after it.  dY image: [128 px][32 ko] bf16, 64-byte rows
+// without padding, 16-byte chunks XOR-swizzled with (row >> 2) & 3 on the SOURCE side (as the forward's weight image);
+// weight image [tap][32 ko][32 ch] exactly as packed: the transpose read needs no swizzle.  Before: 1.8 of the kernel's
+// 5.3 ms were this sweep's staging (fp32 weight loads, converts, ds_writes, two barriers per step around 0.25 ms of MFMA).
+template <int RS, bool F32, bool DMA = false>      // RS taps (9 for 3x3): one accumulator tile per tap lives in registers through a chunk
 __global__ __launch_bounds__(512) void dcn_dgrad_win_kernel(const DcnWinBwdArgs wb)
 {
+    static_assert(!(DMA && F32), "the DMA sweep is bf16 only");
     // 512 threads = 8 waves, two per SIMD: the window leaves room for ONE workgroup per CU, and the epilogue is a chain
     // of dependent LDS / L2 round trips that a single wave per SIMD cannot hide.  Wave w computes pixel rows
     // 32 (w & 3) .. +31 of the block for taps 5 (w >> 2) .. +4 (five accumulator tiles; the ninth..tenth slot idles).
@@ -1268,9 +1288,9 @@ __global__ __launch_bounds__(512) void dcn_dgrad_win_kernel(const DcnWinBwdArgs 
     extern __shared__ __align__(16) unsigned char smem[];
     const int npx = wa.WH * wa.WW;
     int *dxw = reinterpret_cast<int *>(smem);                                       // [npx][33] fixed point (see below)
-    int *geo_i = dxw + (size_t)((npx * WSTR + 3) & ~3);                             // [BM][RS]: window pixel of corner 0 | corner-valid bits << 16 | SLOW
-    float *geo_f = reinterpret_cast<float *>(geo_i + BM * RS);                      // [BM][RS][3]: lh, lw, mask
-    float *red = geo_f + BM * RS * 3;                                               // [BM][RS][3]: d mask, d off h, d off w
+    // [BM][RS] x {lh, lw, mask, window pixel of corner 0 | corner-valid bits << 16 | SLOW}: one ds_read_b128 per sample
+    f32x4 *geo4 = reinterpret_cast<f32x4 *>(dxw + (size_t)((npx * WSTR + 3) & ~3));
+    float *red = reinterpret_cast<float *>(geo4 + BM * RS);                         // [BM][RS][3]: d mask, d off h, d off w
     float *xw = red + BM * RS * 3;                                                  // [npx][32]: the input window of this chunk
     unsigned short *As = reinterpret_cast<unsigned short *>(xw + (size_t)npx * CW); // [BM][LDKH]   (single image: operands
     unsigned short *Bs = As + A_ELEMS;                                              // bf16: [RS][32 ko][32 ch]; fp32: [RS][32 ch][LDF] (prefetched in registers)
@@ -1341,8 +1361,7 @@ __global__ __launch_bounds__(512) void dcn_dgrad_win_kernel(const DcnWinBwdArgs 
                     }
                 }
             }
-            geo_i[it] = packed;
-            geo_f[it * 3] = flh; geo_f[it * 3 + 1] = flw; geo_f[it * 3 + 2] = mk;
+            geo4[it] = f32x4{flh, flw, mk, __int_as_float(packed)};
             atomicMax(&mkmax_bits, (int)(__float_as_uint(mk) & 0x7fffffffu));      // |mask| bound of the block (non-negative floats order as ints)
         }
         __syncthreads();
@@ -1373,6 +1392,24 @@ __global__ __launch_bounds__(512) void dcn_dgrad_win_kernel(const DcnWinBwdArgs 
 
     f32x4 ra[2], rb[TG];
     u16x4 rah[2];
+    __amdgpu_buffer_rsrc_t rs_dy, rs_w;
+    unsigned dma_offa = 0;
+    if constexpr (DMA) {
+        auto rsrc = [](const void *ptr, long bytes) {
+            const unsigned long long u = reinterpret_cast<unsigned long long>(ptr);
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u);
+            const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+            void *q = reinterpret_cast<void *>(((unsigned long long)hi << 32) | lo);
+            return __builtin_amdgcn_make_buffer_rsrc(q, 0, __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
+        };
+        rs_dy = rsrc(wb.dyb, (long)a.M * a.K * 2);
+        rs_w = rsrc(wb.wpk, (long)RS * a.C * a.K * 2);
+        // this lane's 16 bytes of the wave's dY piece: pixel row 16 wave + lane / 4, slot lane % 4 <- chunk slot ^ swizzle(row)
+        const int row = wave * 16 + (lane >> 2);
+        const int p = y0 + row / WIN_TW, q = x0 + row % WIN_TW;
+        const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+        dma_offa = (p < a.P && q < a.Q) ? (unsigned)(((((long)n * a.P + p) * a.Q + q) * a.K + chunk * 8) * 2) : 0x80000000u;   // beyond the buffer: zeros
+    }
     for (int cch = 0; cch < cpt; ++cch) {
         const int c0 = cch * CW;
         const int g = c0 / cpg;
@@ -1459,6 +1496,49 @@ __global__ __launch_bounds__(512) void dcn_dgrad_win_kernel(const DcnWinBwdArgs 
         for (int i = 0; i < TG; ++i)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+        if constexpr (DMA) {
+            typedef __attribute__((address_space(3))) void lds_void;
+            unsigned short *buf1 = reinterpret_cast<unsigned short *>(dxw);     // second operand image: over the (empty) d-input window
+            // piece j of a K-step: 0..7 = 16 pixel rows of dY each, 8..25 = half a tap's weight tile each; wave w issues j = w, w + 8, ...
+            auto prefetch = [&](int kc, int buf) {
+                unsigned short *A = buf ? buf1 : As;
+                unsigned short *B = A + BM * 32;
+                const int wv = __builtin_amdgcn_readfirstlane(wave);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_dy, (lds_void *)(A + wv * 512), 16, dma_offa, kc * 64, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const int b = wv + 8 * i;
+                    if (b < 2 * RS) {
+                        const int tap = b >> 1;
+                        const unsigned so = (unsigned)(((((long)tap * cpt + cch) * a.K + kc * 32 + (b & 1) * 16) * 32) * 2);
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void *)(B + b * 512), 16, (unsigned)lane * 16u,
+                                                                 __builtin_amdgcn_readfirstlane(so), 0, 0);
+                    }
+                }
+            };
+            prefetch(0, 0);
+            for (int kc = 0; kc < nkc; ++kc) {
+                const int buf = kc & 1;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();                         // image `buf` landed for every wave; everyone is done reading the other one
+                if (kc + 1 < nkc) prefetch(kc + 1, buf ^ 1);
+                const unsigned short *A = buf ? buf1 : As;
+                const unsigned short *B = A + BM * 32;
+                const int row = wpx * 32 + lr;
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const bf16x8 fa = *reinterpret_cast<const bf16x8 *>(A + row * 32 + (((kk * 2 + lh_) ^ ((row >> 2) & 3)) * 8));
+#pragma unroll
+                    for (int i = 0; i < TG; ++i) {
+                        const int tap = wtg * TG + i;
+                        if (tap < RS) {                   // wave-uniform
+                            const bf16x8 fb = lds_tr_frag(B + tap * 32 * CW, kk * 16, lane);
+                            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[i], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        } else {
         issue(0);
         for (int kc = 0; kc < nkc; ++kc) {
             commit();
@@ -1497,6 +1577,7 @@ __global__ __launch_bounds__(512) void dcn_dgrad_win_kernel(const DcnWinBwdArgs 
             }
             __syncthreads();
         }
+        }
         // ---- the window accumulates in FIXED POINT: ds_add_f32 costs ~190 cycles per wave-instruction on this part
         //      (3 cycles per lane, serialised across the waves of a CU; measured), ds_add_u32 ~7.  Scale (per channel) =
         //      the power of two that keeps `maxhits` contributions (the most any window pixel receives, counted in
@@ -1513,6 +1594,10 @@ __global__ __launch_bounds__(512) void dcn_dgrad_win_kernel(const DcnWinBwdArgs 
         amax = max(amax, __shfl_xor(amax, 32, 64));          // the two lane halves hold the same channel
         if (lh_ == 0) wmaxc[wave][lr] = amax;
         __syncthreads();
+        if constexpr (DMA) {                // every wave is past the sweep: the window under the second operand image back to zero
+            constexpr int WORDS4 = (BM * 32 + RS * 32 * CW) * 2 / 16;
+            for (int i = t; i < WORDS4; i += NT) reinterpret_cast<f32x4 *>(dxw)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
         if (t < CW) {
             int bbits = wmaxc[0][t];
 #pragma unroll
@@ -1532,63 +1617,82 @@ __global__ __launch_bounds__(512) void dcn_dgrad_win_kernel(const DcnWinBwdArgs 
         }
         __syncthreads();
         const f32x4 fx4 = *reinterpret_cast<const f32x4 *>(fxs + a_col);      // this thread's four channels
-        // ---- epilogue per tap: accumulators -> LDS -> (pixel row, 4 channels) threads
-        for (int tap = 0; tap < RS; ++tap) {            // a real loop: only the accumulator -> LDS copy is per-tap code
-            if (tap / TG == wtg) {                      // the four waves that hold this tap's tiles
-                float *sp = stage + (wpx * 32 + 4 * lh_) * SST + lr;
-#define RR_PUT(T)                                                                                   \
-    case T:                                                                                         \
-        _Pragma("unroll") for (int e = 0; e < 16; ++e) sp[((e & 3) + 8 * (e >> 2)) * SST] = acc[T][e]; \
+        // ---- epilogue: accumulators -> LDS -> (pixel row, 4 channels) threads, TWO taps per barrier pair (round 5): at
+        //      step i the waves of tap group 0 stage tap i and those of group 1 tap TG + i — every wave writes, five
+        //      barrier pairs per chunk instead of nine.  Stage rows are 32 floats without padding (a wave's b128 reads
+        //      cover 1 KB contiguously; the two lane halves of a write hit the same banks, which a 64-lane b32 write
+        //      pays anyway): two images fit the idle operand area.
+        constexpr int SST2 = 32;
+        for (int step = 0; step < TG; ++step) {        // a real loop: only the accumulator -> LDS copy is per-step code
+            if (wtg * TG + step < RS) {
+                float *sp = stage + wtg * (BM * SST2) + (wpx * 32 + 4 * lh_) * SST2 + lr;
+#define RR_PUT(T)                                                                                    \
+    case T:                                                                                          \
+        _Pragma("unroll") for (int e = 0; e < 16; ++e) sp[((e & 3) + 8 * (e >> 2)) * SST2] = acc[T][e]; \
         break;
-                switch (tap - wtg * TG) {
+                switch (step) {
                     RR_PUT(0) RR_PUT(1) RR_PUT(2) RR_PUT(3) RR_PUT(4)
                     default: break;
                 }
 #undef RR_PUT
             }
             __syncthreads();
+            const int ntap = (TG + step < RS) ? 2 : 1;
+            for (int u = 0; u < ntap; ++u) {
+                const int tap = u * TG + step;
+                const float *stg = stage + u * (BM * SST2);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int r = a_row + 64 * j;
-                const int gi = geo_i[r * RS + tap];
-                const int valid = (gi >> 16) & 15;
-                float s_m = 0.f, s_h = 0.f, s_w = 0.f;
-                if (!(gi & GEO_SLOW)) {
-                    // Fast samples (the whole 2x2 footprint inside the window; also samples without any valid corner:
-                    // gi == 0, mask 0): BRANCH-FREE.  A corner outside the image has its weight zeroed (it adds 0 to a
-                    // window pixel the flush skips) and reads a window pixel that was filled with zeros; the per-corner
-                    // `if valid` / `if weight != 0` tests of round 2 were four divergent-branch sequences per sample —
-                    // a third of the ~510 VALU + ~150 SALU instructions this loop issued per tap and wave.
-                    const float flh = geo_f[(r * RS + tap) * 3], flw = geo_f[(r * RS + tap) * 3 + 1], mk = geo_f[(r * RS + tap) * 3 + 2];
-                    const float hh = 1.f - flh, hw = 1.f - flw;
-                    const float wt[4] = {(valid & 1) ? hh * hw : 0.f, (valid & 2) ? hh * flw : 0.f, (valid & 4) ? flh * hw : 0.f,
-                                         (valid & 8) ? flh * flw : 0.f};
-                    const float dhw[4] = {-hw, -flw, hw, flw};
-                    const float dww[4] = {-hh, hh, -flh, flh};
-                    const f32x4 gcol = *reinterpret_cast<const f32x4 *>(stage + r * SST + a_col);
-                    const f32x4 gs = gcol * (fx4 * mk);                    // column gradient x mask in each channel's fixed-point unit
-                    const float *xb = xw + (size_t)(gi & 0xffff) * CW + a_col;
-                    int *db = dxw + (gi & 0xffff) * WSTR + a_col;
-                    // d mask = sum_e wt_e <gcol, x_e>, d offset = mask * sum_e dwt_e <gcol, x_e>: one dot product per corner
+                for (int j = 0; j < 2; ++j) {
+                    const int r = a_row + 64 * j;
+                    const f32x4 gq = geo4[r * RS + tap];                     // flh, flw, mask, packed corner word
+                    const int gi = __float_as_int(gq[3]);
+                    const float flh = gq[0], flw = gq[1], mk = gq[2];
+                    float s_m = 0.f, s_h = 0.f, s_w = 0.f;
+                    if (!(gi & GEO_SLOW)) {
+                        // Fast samples (the whole 2x2 footprint inside the window; also samples without any valid corner:
+                        // gi == 0, mask 0): BRANCH-FREE and, since round 5, MASK-FREE.  A corner outside the image reads a
+                        // window pixel that was filled with zeros (its dot product is 0) and adds into a window pixel the
+                        // flush discards — no per-corner validity selects.  Two channels per packed-fp32 instruction.
+                        const float hh = 1.f - flh, hw = 1.f - flw;
+                        const f32x2 wcol = {hw, flw};
+                        const f32x2 w01 = wcol * hh, w23 = wcol * flh;       // corner weights (top row, bottom row)
+                        const f32x4 gcol = *reinterpret_cast<const f32x4 *>(stg + r * SST2 + a_col);
+                        const f32x2 g01 = {gcol[0], gcol[1]}, g23 = {gcol[2], gcol[3]};
+                        const f32x2 q01 = g01 * (f32x2{fx4[0], fx4[1]} * mk);   // column gradient x mask in each channel's fixed-point unit
+                        const f32x2 q23 = g23 * (f32x2{fx4[2], fx4[3]} * mk);
+                        const int base = gi & 0xffff;
+                        const float *xb = xw + (size_t)base * CW + a_col;
+                        int *db = dxw + base * WSTR + a_col;
+                        float d[4];
+                        f32x4 xc[4];                 // the four corner reads first: a later read would wait behind the adds in flight
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int po = (e >> 1) * wa.WW + (e & 1);
-                        const f32x4 xv = *reinterpret_cast<const f32x4 *>(xb + po * CW);
-                        const float d = gcol[0] * xv[0] + gcol[1] * xv[1] + gcol[2] * xv[2] + gcol[3] * xv[3];
-                        s_m += wt[e] * d; s_h += dhw[e] * d; s_w += dww[e] * d;
+                        for (int e = 0; e < 4; ++e) xc[e] = *reinterpret_cast<const f32x4 *>(xb + ((e >> 1) * wa.WW + (e & 1)) * CW);
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) atomicAdd(db + po * WSTR + c, __float2int_rn(gs[c] * wt[e]));   // ds_add_u32
-                    }
-                    s_h *= mk; s_w *= mk;
-                } else if (valid) {
-                    const float flh = geo_f[(r * RS + tap) * 3], flw = geo_f[(r * RS + tap) * 3 + 1], mk = geo_f[(r * RS + tap) * 3 + 2];
-                    const float hh = 1.f - flh, hw = 1.f - flw;
-                    const float wt[4] = {hh * hw, hh * flw, flh * hw, flh * flw};
-                    const float dhw[4] = {-hw, -flw, hw, flw};
-                    const float dww[4] = {-hh, hh, -flh, flh};
-                    const f32x4 gcol = *reinterpret_cast<const f32x4 *>(stage + r * SST + a_col);
-                    const f32x4 gs = gcol * fx4;                           // column gradient in each channel's fixed-point unit
-                    {
+                        for (int e = 0; e < 4; ++e) {
+                            const int po = (e >> 1) * wa.WW + (e & 1);
+                            const f32x4 xv = xc[e];
+                            const f32x2 dd = g01 * f32x2{xv[0], xv[1]} + g23 * f32x2{xv[2], xv[3]};
+                            d[e] = dd[0] + dd[1];
+                            const float we = e == 0 ? w01[0] : e == 1 ? w01[1] : e == 2 ? w23[0] : w23[1];
+                            const f32x2 c01 = q01 * we, c23 = q23 * we;
+                            atomicAdd(db + po * WSTR + 0, cvt_rpi(c01[0]));      // ds_add_u32
+                            atomicAdd(db + po * WSTR + 1, cvt_rpi(c01[1]));
+                            atomicAdd(db + po * WSTR + 2, cvt_rpi(c23[0]));
+                            atomicAdd(db + po * WSTR + 3, cvt_rpi(c23[1]));
+                        }
+                        // d mask = sum_e wt_e <gcol, x_e>, d offset = mask * sum_e dwt_e <gcol, x_e>: one dot product per corner
+                        s_m = w01[0] * d[0] + w01[1] * d[1] + w23[0] * d[2] + w23[1] * d[3];
+                        s_m = gi ? s_m : 0.f;            // a sample wholly outside the image (gi == 0, mask 0) sits on window pixel 0, which holds data
+                        s_h = mk * (hw * (d[2] - d[0]) + flw * (d[3] - d[1]));
+                        s_w = mk * (hh * (d[1] - d[0]) + flh * (d[3] - d[2]));
+                    } else if ((gi >> 16) & 15) {
+                        const int valid = (gi >> 16) & 15;
+                        const float hh = 1.f - flh, hw = 1.f - flw;
+                        const float wt[4] = {hh * hw, hh * flw, flh * hw, flh * flw};
+                        const float dhw[4] = {-hw, -flw, hw, flw};
+                        const float dww[4] = {-hh, hh, -flh, flh};
+                        const f32x4 gcol = *reinterpret_cast<const f32x4 *>(stg + r * SST2 + a_col);
+                        const f32x4 gs = gcol * fx4;                           // column gradient in each channel's fixed-point unit
                         // footprint not inside the window (offset beyond the margin): position again from the offsets
                         const int p = y0 + r / WIN_TW, q = x0 + r % WIN_TW;
                         const float *po = a.offset + (((long)n * a.P + p) * a.Q + q) * (2 * a.dg * RS) + g_cur * 2 * RS + 2 * tap;
@@ -1604,13 +1708,13 @@ __global__ __launch_bounds__(512) void dcn_dgrad_win_kernel(const DcnWinBwdArgs 
                             f32x4 xv;
                             if (inwin) xv = *reinterpret_cast<const f32x4 *>(xw + (size_t)(ly * wa.WW + lx) * CW + a_col);
                             else xv = *reinterpret_cast<const f32x4 *>(a.x + (img + (long)hy * a.W + wx) * a.C + c0 + a_col);
-                            const float d = gcol[0] * xv[0] + gcol[1] * xv[1] + gcol[2] * xv[2] + gcol[3] * xv[3];
-                            s_m += wt[e] * d; s_h += dhw[e] * d; s_w += dww[e] * d;
+                            const float dd = gcol[0] * xv[0] + gcol[1] * xv[1] + gcol[2] * xv[2] + gcol[3] * xv[3];
+                            s_m += wt[e] * dd; s_h += dhw[e] * dd; s_w += dww[e] * dd;
                             if (wt[e] != 0.f) {
                                 if (inwin) {
                                     int *d4 = dxw + (ly * wa.WW + lx) * WSTR + a_col;
 #pragma unroll
-                                    for (int c = 0; c < 4; ++c) atomicAdd(d4 + c, __float2int_rn(gs[c] * (mk * wt[e])));
+                                    for (int c = 0; c < 4; ++c) atomicAdd(d4 + c, cvt_rpi(gs[c] * (mk * wt[e])));
                                 } else {
                                     float *d4 = wb.dx + (img + (long)hy * a.W + wx) * a.C + c0 + a_col;
 #pragma unroll
@@ -1618,16 +1722,16 @@ __global__ __launch_bounds__(512) void dcn_dgrad_win_kernel(const DcnWinBwdArgs 
                                 }
                             }
                         }
+                        s_h *= mk; s_w *= mk;
                     }
-                    s_h *= mk; s_w *= mk;
-                }
-                s_m = dpp_sum8(s_m); s_h = dpp_sum8(s_h); s_w = dpp_sum8(s_w);      // the 8 threads of a pixel row
-                if ((t & 7) == 0) {
-                    float *rd = red + (r * RS + tap) * 3;
-                    rd[0] += s_m; rd[1] += s_h; rd[2] += s_w;
+                    s_m = dpp_sum8(s_m); s_h = dpp_sum8(s_h); s_w = dpp_sum8(s_w);      // the 8 threads of a pixel row
+                    if ((t & 7) < 3) {                  // lanes 0 / 1 / 2 of the row add d mask / d offset h / d offset w
+                        const float v = (t & 7) == 0 ? s_m : (t & 7) == 1 ? s_h : s_w;
+                        red[(r * RS + tap) * 3 + (t & 7)] += v;
+                    }
                 }
             }
-            __syncthreads();        // stage is rewritten by the next tap
+            __syncthreads();        // the stage images are rewritten by the next step
         }
         // ---- flush this chunk's window: lane <-> channel, 128-byte row segments, one global atomic per touched element
         {
@@ -1638,10 +1742,11 @@ __global__ __launch_bounds__(512) void dcn_dgrad_win_kernel(const DcnWinBwdArgs 
                 const int iv = dxw[px * WSTR + c];
                 const int ly = px / wa.WW, lx = px - ly * wa.WW;
                 const int gy = wy0 + ly, gx = wx0 + lx;
-                if (iv != 0) {                                   // inside the image by construction (only valid corners add)
-                    unsafeAtomicAdd(wb.dx + (img + (long)gy * a.W + gx) * a.C + c0 + c, (float)iv * fx_inv);
+                const bool inside = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+                if (iv != 0) {                                   // window pixels outside the image collect sums nobody wants (mask-free fast path)
+                    if (inside) unsafeAtomicAdd(wb.dx + (img + (long)gy * a.W + gx) * a.C + c0 + c, (float)iv * fx_inv);
                     dxw[px * WSTR + c] = 0;
-                } else if (nonfinite && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+                } else if (nonfinite && inside) {
                     unsafeAtomicAdd(wb.dx + (img + (long)gy * a.W + gx) * a.C + c0 + c, __int_as_float(0x7fc00000));
                 }
             }
@@ -2210,7 +2315,7 @@ __global__ __launch_bounds__(256) void dcn_to_bf16_kernel(const f32x4 *src, u16x
 static int dcn_dgrad_impl(const float *x, const float *offset, const float *mask, const float *w, const float *dy,
                           float *dx, float *doffset, float *dmask, int n, int h, int wd, int c, int k, int r, int s,
                           int stride, int pad_h, int pad_w, int dilation, int deformable_groups, int bf16, hipStream_t stream,
-                          unsigned short *dyb = nullptr, bool dyb_ready = false)
+                          unsigned short *dyb = nullptr, bool dyb_ready = false, unsigned short *wpk = nullptr)
 {
     DcnBwdArgs b{};
     const int rc = fill_args(b.a, x, offset, mask, w, n, h, wd, c, k, r, s, stride, pad_h, pad_w, dilation, deformable_groups);
@@ -2250,6 +2355,18 @@ static int dcn_dgrad_impl(const float *x, const float *offset, const float *mask
                     hipLaunchKernelGGL(dcn_to_bf16_kernel, dim3((int)cb), dim3(256), 0, stream, reinterpret_cast<const f32x4 *>(dy),
                                        reinterpret_cast<u16x4 *>(dyb), n4);
                     wb.dyb = dyb;
+                }
+                static const bool dma_on = [] { const char *e = getenv("RR_DCN_DGRAD_DMA"); return !(e && e[0] == '0'); }();
+                if (dma_on && wb.dyb != nullptr && wpk != nullptr && k % 32 == 0 && (long)b.a.M * k * 2 < (1l << 31)) {
+                    // both sweep operands by LDS-DMA: the weights packed to bf16 (the forward's layout) once per call
+                    hipLaunchKernelGGL(dcn_pack_weights_kernel, dim3(rr_cdiv((long)k * r * s * c / 4, 256)), dim3(256), 0, stream, w, wpk, k, c,
+                                       r * s);
+                    wb.wpk = wpk;
+                    RR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(dcn_dgrad_win_kernel<9, false, true>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw), "rr_dcn_dgrad");
+                    hipLaunchKernelGGL((dcn_dgrad_win_kernel<9, false, true>), grid, dim3(512), ldsw, stream, wb);
+                    RR_CHECK_LAUNCH("rr_dcn_dgrad");
+                    return RR_OK;
                 }
                 hipFuncSetAttribute(reinterpret_cast<const void *>(dcn_dgrad_win_kernel<9, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw);
                 hipLaunchKernelGGL((dcn_dgrad_win_kernel<9, false>), grid, dim3(512), ldsw, stream, wb);
@@ -2311,6 +2428,27 @@ extern "C" int rr_dcn_dgrad_bf16_img(const float *x, const float *offset, const 
     RR_CHECK_ARG(dy_bf16 != nullptr, "rr_dcn_dgrad_bf16_img: the bf16 image of dy is required");
     return dcn_dgrad_impl(x, offset, mask, w, dy, dx, doffset, dmask, n, h, wd, c, k, r, s, stride, pad_h, pad_w, dilation,
                           deformable_groups, 1, stream, const_cast<unsigned short *>(dy_bf16), true);
+}
+
+// Workspace of rr_dcn_dgrad_bf16_packed: the weights packed to bf16, then (when the caller has no bf16 image of dY) dY in bf16
+extern "C" size_t rr_dcn_dgrad_ws_bytes(int n, int p, int q, int c, int k, int r, int s, int have_dy_bf16)
+{
+    const size_t wb = ((size_t)c * k * r * s * sizeof(unsigned short) + 255) & ~(size_t)255;
+    return wb + (have_dy_bf16 ? 0 : (size_t)n * p * q * k * sizeof(unsigned short));
+}
+
+extern "C" int rr_dcn_dgrad_bf16_packed(const float *x, const float *offset, const float *mask, const float *w, const float *dy,
+                                        const unsigned short *dy_bf16, float *dx, float *doffset, float *dmask, int n, int h,
+                                        int wd, int c, int k, int r, int s, int stride, int pad_h, int pad_w, int dilation,
+                                        int deformable_groups, void *ws, hipStream_t stream)
+{
+    RR_CHECK_ARG(ws != nullptr, "rr_dcn_dgrad_bf16_packed: workspace required (rr_dcn_dgrad_ws_bytes)");
+    unsigned short *wpk = static_cast<unsigned short *>(ws);
+    const size_t wbytes = ((size_t)c * k * r * s * sizeof(unsigned short) + 255) & ~(size_t)255;
+    unsigned short *dyb = dy_bf16 ? const_cast<unsigned short *>(dy_bf16)
+                                  : reinterpret_cast<unsigned short *>(static_cast<unsigned char *>(ws) + wbytes);
+    return dcn_dgrad_impl(x, offset, mask, w, dy, dx, doffset, dmask, n, h, wd, c, k, r, s, stride, pad_h, pad_w, dilation,
+                          deformable_groups, 1, stream, dyb, dy_bf16 != nullptr, wpk);
 }
 
 extern "C" int rr_dcn_split_fwd(const float *om, long m, int third, float *offset, float *mask, hipStream_t stream)

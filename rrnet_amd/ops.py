@@ -1490,7 +1490,19 @@ def dcn_dgrad(x, offset, mask, w, dy, stride, pad, dilation, dg, bf16=False):
     dmask = torch.empty_like(mask)
     assert doff.stride() == offset.stride() and dmask.stride() == mask.stride()
     img = b16_carry(dy) if (bf16 and _DCN_DYB) else None
-    if img is not None and getattr(dy, "_rr_b16")[1] in (None, torch.cuda.current_stream(dy.device).cuda_stream):
+    if img is not None and getattr(dy, "_rr_b16")[1] not in (None, torch.cuda.current_stream(dy.device).cuda_stream):
+        img = None
+    if bf16 and _DCN_DYB and _DCN_WPACK:
+        # both sweep operands by LDS-DMA: weights packed to bf16 inside the call; dY = its producer's bf16 image when there is
+        # one (the heads' 1x1 data gradient), else rounded once into the workspace
+        ws = torch.empty(_C.fn("rr_dcn_dgrad_ws_bytes")(dy.shape[0], dy.shape[2], dy.shape[3], c, k, r, s, int(img is not None)),
+                         dtype=torch.uint8, device=x.device)
+        _C.check(_C.fn("rr_dcn_dgrad_bf16_packed")(_C.ptr(x), _C.ptr(offset), _C.ptr(mask), _C.ptr(w), _C.ptr(dy),
+                                                   _C.ptr(img) if img is not None else None, _C.ptr(dx), _C.ptr(doff), _C.ptr(dmask),
+                                                   n, h, wd, c, k, r, s, stride, pad[0], pad[1], dilation, dg, _C.ptr(ws),
+                                                   _C.stream()), "rr_dcn_dgrad_bf16_packed")
+        return dx, doff, dmask
+    if img is not None:
         # dY's producer already left its bf16 image (the heads' 1x1 data gradient): no conversion pass
         _C.check(_C.fn("rr_dcn_dgrad_bf16_img")(_C.ptr(x), _C.ptr(offset), _C.ptr(mask), _C.ptr(w), _C.ptr(dy), _C.ptr(img), _C.ptr(dx),
                                                 _C.ptr(doff), _C.ptr(dmask), n, h, wd, c, k, r, s, stride, pad[0], pad[1],
