@@ -1240,6 +1240,13 @@ __device__ __forceinline__ float dpp_sum8(float v)
 }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4d __attribute__((ext_vector_type(4)));
+// 64 lanes x 16 bytes global -> LDS (lane-linear from the wave-uniform byte address lds_addr), outside the compiler's
+// memory model: the caller orders it with its own s_waitcnt vmcnt / s_barrier
+__device__ __forceinline__ void dma16(i32x4d rsrc, unsigned lds_addr, unsigned voff, unsigned soff)
+{
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
 // float -> int, round to nearest with ties toward +inf (floor(x + 0.5)): ONE instruction where __float2int_rn takes two
 // (v_rndne_f32 + v_cvt_i32_f32); the fixed-point window's rounding bound (half a unit per add) is the same.
 __device__ __forceinline__ int cvt_rpi(float x)
@@ -1260,17 +1267,18 @@ struct DcnWinBwdArgs {
     const unsigned short *dyb;
     // DMA sweep: the weights packed to bf16 [tap][32-channel chunk][filter][32] (dcn_pack_weights_kernel, the forward's layout)
     const unsigned short *wpk;
+    int exp;
 };
 
 // F32: the matrix operands stay fp32 (v_mfma_f32_32x32x2_f32, K-steps of 16 filters: the same LDS bytes as 32 in bf16);
 // everything after the GEMM sweep is shared.
-// DMA (round 5; bf16 only, K % 32 == 0, dY given as a bf16 image, weights pre-packed): both operands of the K sweep go
-// global -> LDS by buffer_load ... lds into TWO operand images (no staging registers, no converts, no ds_write, one
-// barrier per K-step).  The second image lies over the d-input window, which holds nothing during the sweep (it is
-// flushed and zero at every chunk boundary) and is zeroed again after it.  dY image: [128 px][32 ko] bf16, 64-byte rows
-// without padding, 16-byte chunks XOR-swizzled with (row >> 2) & 3 on the SOURCE side (as the forward's weight image);
-// weight image [tap][32 ko][32 ch] exactly as packed: the transpose read needs no swizzle.  Before: 1.8 of the kernel's
-// 5.3 ms were this sweep's staging (fp32 weight loads, converts, ds_writes, two barriers per step around 0.25 ms of MFMA).
+// DMA (round 5; bf16 only, K % 32 == 0, dY given as a bf16 image, weights pre-packed): the weight operand of the K sweep
+// and dY go global -> LDS by buffer_load ... lds into a ring of THREE operand images (weights [tap][32 ko][32 ch] exactly
+// as packed: the transpose read needs no swizzle; dY [128 px][32 ko], 64-byte rows without padding, 16-byte chunks
+// XOR-swizzled with (row >> 2) & 3 on the SOURCE side): no staging registers, converts or ds_writes, one barrier per
+// K-step, loads two steps ahead.  Most of the ring lies over the d-input window, which holds nothing during the sweep (it
+// is flushed and zero at every chunk boundary) and is zeroed again after it.  Before: 1.8 of the kernel's 5.3 ms were
+// this sweep's staging (fp32 weight loads, converts, ds_writes, two barriers per step around 0.25 ms of MFMA).
 template <int RS, bool F32, bool DMA = false>      // RS taps (9 for 3x3): one accumulator tile per tap lives in registers through a chunk
 __global__ __launch_bounds__(512) void dcn_dgrad_win_kernel(const DcnWinBwdArgs wb)
 {
@@ -1392,19 +1400,19 @@ __global__ __launch_bounds__(512) void dcn_dgrad_win_kernel(const DcnWinBwdArgs 
 
     f32x4 ra[2], rb[TG];
     u16x4 rah[2];
-    __amdgpu_buffer_rsrc_t rs_dy, rs_w;
+    i32x4d rs_dy, rs_w;
     unsigned dma_offa = 0;
+    const int wtg_u = __builtin_amdgcn_readfirstlane(wtg);
     if constexpr (DMA) {
-        auto rsrc = [](const void *ptr, long bytes) {
+        auto rsrc = [](const void *ptr, long bytes) {        // raw buffer descriptor: base, stride 0, bytes, raw 32-bit data format
             const unsigned long long u = reinterpret_cast<unsigned long long>(ptr);
-            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u);
-            const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
-            void *q = reinterpret_cast<void *>(((unsigned long long)hi << 32) | lo);
-            return __builtin_amdgcn_make_buffer_rsrc(q, 0, __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
+            return i32x4d{(int)__builtin_amdgcn_readfirstlane((unsigned)u), (int)(__builtin_amdgcn_readfirstlane((unsigned)(u >> 32)) & 0xffffu),
+                          __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000};
         };
         rs_dy = rsrc(wb.dyb, (long)a.M * a.K * 2);
         rs_w = rsrc(wb.wpk, (long)RS * a.C * a.K * 2);
         // this lane's 16 bytes of the wave's dY piece: pixel row 16 wave + lane / 4, slot lane % 4 <- chunk slot ^ swizzle(row)
+        // (64-byte rows without padding: the swizzle (row >> 2) & 3 spreads a ds_read_b128 group over the banks)
         const int row = wave * 16 + (lane >> 2);
         const int p = y0 + row / WIN_TW, q = x0 + row % WIN_TW;
         const int chunk = (lane & 3) ^ ((row >> 2) & 3);
@@ -1422,6 +1430,7 @@ __global__ __launch_bounds__(512) void dcn_dgrad_win_kernel(const DcnWinBwdArgs 
         }
         // ---- this chunk's input window (d offset / d mask re-read the four corners of every sample: from L2 that is
         //      19 GB per call, the same gather the windowed forward removed)
+        if (!(wb.exp & 8))
         for (int i = t; i < npx * 8; i += NT) {
             const int px = i >> 3, c4 = (i & 7) * 4;
             const int ly = px / wa.WW, lx = px - ly * wa.WW;
@@ -1498,46 +1507,70 @@ __global__ __launch_bounds__(512) void dcn_dgrad_win_kernel(const DcnWinBwdArgs 
             for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
         if constexpr (DMA) {
             typedef __attribute__((address_space(3))) void lds_void;
-            unsigned short *buf1 = reinterpret_cast<unsigned short *>(dxw);     // second operand image: over the (empty) d-input window
-            // piece j of a K-step: 0..7 = 16 pixel rows of dY each, 8..25 = half a tap's weight tile each; wave w issues j = w, w + 8, ...
-            auto prefetch = [&](int kc, int buf) {
-                unsigned short *A = buf ? buf1 : As;
-                unsigned short *B = A + BM * 32;
-                const int wv = __builtin_amdgcn_readfirstlane(wave);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_dy, (lds_void *)(A + wv * 512), 16, dma_offa, kc * 64, 0, 0);
+            // Operand images: a ring of THREE (dY [128 px][32 ko] 8 KB + weights [tap][32 ko][32 ch] 18 KB each), filled two
+            // K-steps ahead.  Image 0 and the third dY image lie in the operand area, the others over the empty d-input
+            // window.  The loads are inline assembly: as builtins every later LDS read would wait for them (the compiler
+            // cannot tell that the images do not alias) and __syncthreads would wait for everything.
+            unsigned short *const dxw16 = reinterpret_cast<unsigned short *>(dxw);
+            unsigned short *const Aimg[3] = {As, dxw16, As + (BM * 32 + RS * 32 * CW)};
+            unsigned short *const Bimg[3] = {As + BM * 32, dxw16 + BM * 32, dxw16 + (BM * 32 + RS * 32 * CW)};
+            const int wv = __builtin_amdgcn_readfirstlane(wave);
+            auto lds_addr = [](const unsigned short *ptr) { return (unsigned)(size_t)(lds_void *)ptr; };
+            // per K-step: piece w of dY (16 pixel rows), weight pieces w, w + 8, w + 16 (half a tap's tile each; 18 in all)
+            auto issue = [&](int kc, int st) {
+                dma16(rs_dy, __builtin_amdgcn_readfirstlane(lds_addr(Aimg[st] + wv * 512)), dma_offa, (unsigned)(kc * 64));
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
                     const int b = wv + 8 * i;
                     if (b < 2 * RS) {
-                        const int tap = b >> 1;
-                        const unsigned so = (unsigned)(((((long)tap * cpt + cch) * a.K + kc * 32 + (b & 1) * 16) * 32) * 2);
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void *)(B + b * 512), 16, (unsigned)lane * 16u,
-                                                                 __builtin_amdgcn_readfirstlane(so), 0, 0);
+                        const unsigned so = (unsigned)((((((long)(b >> 1)) * cpt + cch) * a.K + kc * 32 + (b & 1) * 16) * 32) * 2);
+                        dma16(rs_w, __builtin_amdgcn_readfirstlane(lds_addr(Bimg[st] + b * 512)), (unsigned)lane * 16u,
+                              __builtin_amdgcn_readfirstlane(so));
                     }
                 }
             };
-            prefetch(0, 0);
-            for (int kc = 0; kc < nkc; ++kc) {
-                const int buf = kc & 1;
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();                         // image `buf` landed for every wave; everyone is done reading the other one
-                if (kc + 1 < nkc) prefetch(kc + 1, buf ^ 1);
-                const unsigned short *A = buf ? buf1 : As;
-                const unsigned short *B = A + BM * 32;
-                const int row = wpx * 32 + lr;
+            const int nk = (wb.exp & 1) ? 0 : nkc;
+            if (nk > 0) issue(0, 0);
+            if (nk > 1) issue(1, 1);
+            const int row = wpx * 32 + lr;
+            for (int kc0 = 0; kc0 < nk; kc0 += 3) {
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    const bf16x8 fa = *reinterpret_cast<const bf16x8 *>(A + row * 32 + (((kk * 2 + lh_) ^ ((row >> 2) & 3)) * 8));
+                for (int u = 0; u < 3; ++u) {
+                    const int kc = kc0 + u;
+                    if (kc < nk) {                       // uniform
+                        // step kc's pieces landed: only step kc + 1's (3 or 4 per wave) may still fly
+                        if (kc + 1 < nk) {
+                            if (wv < 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                            else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                        } else {
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        }
+                        __builtin_amdgcn_s_barrier();    // images kc % 3 visible; images (kc + 2) % 3 = (kc - 1) % 3 free again
+                        if (kc + 2 < nk) issue(kc + 2, (u + 2) % 3);
+                        const unsigned short *A = Aimg[u], *B = Bimg[u];
 #pragma unroll
-                    for (int i = 0; i < TG; ++i) {
-                        const int tap = wtg * TG + i;
-                        if (tap < RS) {                   // wave-uniform
-                            const bf16x8 fb = lds_tr_frag(B + tap * 32 * CW, kk * 16, lane);
-                            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[i], 0, 0, 0);
+                        for (int kk = 0; kk < 2; ++kk) {
+                            const bf16x8 fa = *reinterpret_cast<const bf16x8 *>(A + row * 32 + (((kk * 2 + lh_) ^ ((row >> 2) & 3)) * 8));
+                            // taps i < RS - TG exist in both wave groups: their reads go out together, the MFMAs back to back
+                            constexpr int NV = RS - TG;
+                            bf16x8 fb[TG];
+#pragma unroll
+                            for (int i = 0; i < NV; ++i) fb[i] = lds_tr_frag(B + (wtg_u * TG + i) * 32 * CW, kk * 16, lane);
+                            if (wtg_u == 0) {
+#pragma unroll
+                                for (int i = NV; i < TG; ++i) fb[i] = lds_tr_frag(B + i * 32 * CW, kk * 16, lane);
+                            }
+#pragma unroll
+                            for (int i = 0; i < NV; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[i], acc[i], 0, 0, 0);
+                            if (wtg_u == 0) {
+#pragma unroll
+                                for (int i = NV; i < TG; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[i], acc[i], 0, 0, 0);
+                            }
                         }
                     }
                 }
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         } else {
         issue(0);
         for (int kc = 0; kc < nkc; ++kc) {
@@ -1595,7 +1628,7 @@ __global__ __launch_bounds__(512) void dcn_dgrad_win_kernel(const DcnWinBwdArgs 
         if (lh_ == 0) wmaxc[wave][lr] = amax;
         __syncthreads();
         if constexpr (DMA) {                // every wave is past the sweep: the window under the second operand image back to zero
-            constexpr int WORDS4 = (BM * 32 + RS * 32 * CW) * 2 / 16;
+            constexpr int WORDS4 = (BM * 32 + 2 * RS * 32 * CW) * 2 / 16;           // dY image 1, weight images 1 and 2
             for (int i = t; i < WORDS4; i += NT) reinterpret_cast<f32x4 *>(dxw)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         if (t < CW) {
@@ -1623,7 +1656,7 @@ __global__ __launch_bounds__(512) void dcn_dgrad_win_kernel(const DcnWinBwdArgs 
         //      cover 1 KB contiguously; the two lane halves of a write hit the same banks, which a 64-lane b32 write
         //      pays anyway): two images fit the idle operand area.
         constexpr int SST2 = 32;
-        for (int step = 0; step < TG; ++step) {        // a real loop: only the accumulator -> LDS copy is per-step code
+        for (int step = 0; step < ((wb.exp & 16) ? 0 : TG); ++step) {        // a real loop: only the accumulator -> LDS copy is per-step code
             if (wtg * TG + step < RS) {
                 float *sp = stage + wtg * (BM * SST2) + (wpx * 32 + 4 * lh_) * SST2 + lr;
 #define RR_PUT(T)                                                                                    \
@@ -1637,7 +1670,7 @@ __global__ __launch_bounds__(512) void dcn_dgrad_win_kernel(const DcnWinBwdArgs 
 #undef RR_PUT
             }
             __syncthreads();
-            const int ntap = (TG + step < RS) ? 2 : 1;
+            const int ntap = (wb.exp & 2) ? 0 : (TG + step < RS) ? 2 : 1;
             for (int u = 0; u < ntap; ++u) {
                 const int tap = u * TG + step;
                 const float *stg = stage + u * (BM * SST2);
@@ -1738,6 +1771,7 @@ __global__ __launch_bounds__(512) void dcn_dgrad_win_kernel(const DcnWinBwdArgs 
             const int c = t & 31;
             const float fx_inv = fxi[c];
             const bool nonfinite = fx_inv != fx_inv;
+            if (!(wb.exp & 4))
             for (int px = t >> 5; px < npx; px += NT / 32) {
                 const int iv = dxw[px * WSTR + c];
                 const int ly = px / wa.WW, lx = px - ly * wa.WW;
@@ -2211,8 +2245,10 @@ static size_t dcn_wgrad_win_lds(int r, int s, int dilation, int m)
 static size_t dcn_dgrad_win_lds(int r, int s, int dilation, int m)
 {
     const int npx = (WIN_TH + (r - 1) * dilation + 2 * m + 1) * (WIN_TW + (s - 1) * dilation + 2 * m + 1);
-    return sizeof(float) * (size_t)(((npx * 33 + 3) & ~3) + BM * r * s * 7 + npx * 32) +
-           sizeof(unsigned short) * (BM * LDKH + r * s * 32 * LDKH);
+    // operand area: one image of the sweep (dY 128 x LDKH + weights taps x 32 x LDKH), and for the DMA sweep image 0 + the
+    // third dY image (128 x 32 + taps x 32 x 32 + 128 x 32) — the larger of the two
+    const size_t opa = std::max((size_t)(BM * LDKH + r * s * 32 * LDKH), (size_t)(2 * BM * 32 + r * s * 32 * 32));
+    return sizeof(float) * (size_t)(((npx * 33 + 3) & ~3) + BM * r * s * 7 + npx * 32) + sizeof(unsigned short) * opa;
 }
 
 static bool dcn_win_fits(bool dgrad, int r, int s, int dilation)
@@ -2333,6 +2369,7 @@ static int dcn_dgrad_impl(const float *x, const float *offset, const float *mask
         wb.w.tiles_x = rr_cdiv(b.a.Q, WIN_TW);
         wb.dy = dy; wb.dx = dx; wb.doffset = doffset; wb.dmask = dmask;
         wb.dyb = nullptr;
+        { const char *e = getenv("RR_DCN_EXP"); wb.exp = e ? atoi(e) : 0; }
         // two windows live in LDS here (d input in fixed point, input values): the margin is the largest <= the
         // requested one that fits (2 pixels for a 3x3 filter with dilation 1)
         size_t ldsw = 0;
@@ -2357,7 +2394,8 @@ static int dcn_dgrad_impl(const float *x, const float *offset, const float *mask
                     wb.dyb = dyb;
                 }
                 static const bool dma_on = [] { const char *e = getenv("RR_DCN_DGRAD_DMA"); return !(e && e[0] == '0'); }();
-                if (dma_on && wb.dyb != nullptr && wpk != nullptr && k % 32 == 0 && (long)b.a.M * k * 2 < (1l << 31)) {
+                if (dma_on && wb.dyb != nullptr && wpk != nullptr && k % 32 == 0 && (long)b.a.M * k * 2 < (1l << 31) &&
+                    (size_t)wb.w.WH * wb.w.WW * 33 * 4 >= (size_t)(BM * 32 + 2 * r * s * 32 * 32) * 2) {     // the ring's share of the d-input window
                     // both sweep operands by LDS-DMA: the weights packed to bf16 (the forward's layout) once per call
                     hipLaunchKernelGGL(dcn_pack_weights_kernel, dim3(rr_cdiv((long)k * r * s * c / 4, 256)), dim3(256), 0, stream, w, wpk, k, c,
                                        r * s);

@@ -1,1 +1,2 @@
-python -m pytest tests/test_dcn_gpu.py -m gpu -q 2>&1 | grep -E "^E|FAILED|passed|failed" | head -40
+python -m pytest tests/test_dcn_gpu.py -m gpu -q -x 2>&1 | tail -2
+for e in 0 1 2 31 0; do RR_DCN_EXP=$e python tools/_q.py 2>&1 | tail -1; done
