@@ -1267,6 +1267,7 @@ struct DcnWinBwdArgs {
     const unsigned short *dyb;
     // DMA sweep: the weights packed to bf16 [tap][32-channel chunk][filter][32] (dcn_pack_weights_kernel, the forward's layout)
     const unsigned short *wpk;
+    int goff_at;        // byte offset of the window-pixel offset table in dynamic LDS (behind everything else)
     int exp;
 };
 
@@ -1303,6 +1304,7 @@ __global__ __launch_bounds__(512) void dcn_dgrad_win_kernel(const DcnWinBwdArgs 
     unsigned short *As = reinterpret_cast<unsigned short *>(xw + (size_t)npx * CW); // [BM][LDKH]   (single image: operands
     unsigned short *Bs = As + A_ELEMS;                                              // bf16: [RS][32 ko][32 ch]; fp32: [RS][32 ch][LDF] (prefetched in registers)
     float *stage = reinterpret_cast<float *>(As);                                   // [BM][SST]: epilogue only, over the idle operand images
+    int *gofft = reinterpret_cast<int *>(smem + wb.goff_at);                        // [npx] (DMA sweep only): d-input element offset of a window pixel
     float *Af = reinterpret_cast<float *>(As), *Bf = reinterpret_cast<float *>(Bs);  // F32: [BM][LDF], [RS][32][LDF]
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -1400,8 +1402,10 @@ __global__ __launch_bounds__(512) void dcn_dgrad_win_kernel(const DcnWinBwdArgs 
 
     f32x4 ra[2], rb[TG];
     u16x4 rah[2];
-    i32x4d rs_dy, rs_w;
+    i32x4d rs_dy, rs_w, rs_x;
     unsigned dma_offa = 0;
+    constexpr int XP = 6;                  // window pieces per wave: up to 6 x 8 x 8 = 384 window pixels
+    constexpr int FP = 23;                 // flush pixels per thread: 16 x 23 = 368 (two fp32 windows of more pixels do not fit LDS anyway)
     const int wtg_u = __builtin_amdgcn_readfirstlane(wtg);
     if constexpr (DMA) {
         auto rsrc = [](const void *ptr, long bytes) {        // raw buffer descriptor: base, stride 0, bytes, raw 32-bit data format
@@ -1409,6 +1413,13 @@ __global__ __launch_bounds__(512) void dcn_dgrad_win_kernel(const DcnWinBwdArgs 
             return i32x4d{(int)__builtin_amdgcn_readfirstlane((unsigned)u), (int)(__builtin_amdgcn_readfirstlane((unsigned)(u >> 32)) & 0xffffu),
                           __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000};
         };
+        rs_x = rsrc(a.x, (long)a.N * a.H * a.W * a.C * 4);
+        // window pixel -> element offset of its first channel in d input (-1 outside the image): the flush's table
+        for (int px = t; px < npx; px += NT) {
+            const int ly = px / wa.WW, lx = px - ly * wa.WW;
+            const int gy = wy0 + ly, gx = wx0 + lx;
+            gofft[px] = (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? (int)((img + (long)gy * a.W + gx) * a.C) : -1;
+        }
         rs_dy = rsrc(wb.dyb, (long)a.M * a.K * 2);
         rs_w = rsrc(wb.wpk, (long)RS * a.C * a.K * 2);
         // this lane's 16 bytes of the wave's dY piece: pixel row 16 wave + lane / 4, slot lane % 4 <- chunk slot ^ swizzle(row)
@@ -1430,7 +1441,23 @@ __global__ __launch_bounds__(512) void dcn_dgrad_win_kernel(const DcnWinBwdArgs 
         }
         // ---- this chunk's input window (d offset / d mask re-read the four corners of every sample: from L2 that is
         //      19 GB per call, the same gather the windowed forward removed)
-        if (!(wb.exp & 8))
+        if constexpr (DMA) {
+            // asynchronously, 8 pixels x 128 bytes per wave-instruction; lands under the sweep (whose last step waits for everything)
+            typedef __attribute__((address_space(3))) void lds_void;
+            const int wv = __builtin_amdgcn_readfirstlane(wave);
+            if (!(wb.exp & 8)) {
+#pragma unroll
+            for (int i = 0; i < XP; ++i) {
+                const int piece = wv + 8 * i;
+                const int px = piece * 8 + (lane >> 3);
+                if (piece * 8 < npx && px < npx) {          // lanes past the window's last pixel stay out (exec mask)
+                    const int go = gofft[px];                // (written before the first chunk's barriers)
+                    dma16(rs_x, __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void *)(xw + piece * 256)),
+                          go >= 0 ? (unsigned)go * 4u + (unsigned)(lane & 7) * 16u : 0x80000000u, (unsigned)(c0 * 4));      // outside the image: zeros
+                }
+            }
+            }
+        } else
         for (int i = t; i < npx * 8; i += NT) {
             const int px = i >> 3, c4 = (i & 7) * 4;
             const int ly = px / wa.WW, lx = px - ly * wa.WW;
@@ -1670,16 +1697,28 @@ __global__ __launch_bounds__(512) void dcn_dgrad_win_kernel(const DcnWinBwdArgs 
 #undef RR_PUT
             }
             __syncthreads();
-            const int ntap = (wb.exp & 2) ? 0 : (TG + step < RS) ? 2 : 1;
-            for (int u = 0; u < ntap; ++u) {
-                const int tap = u * TG + step;
-                const float *stg = stage + u * (BM * SST2);
+            // Items of this step: (tap u TG + step, pixel row a_row + 64 j), k = 2 u + j.  Software-pipelined: the sample
+            // geometry of all items first, then item k + 1's LDS reads (column gradient, four corner rows of x) go out
+            // BEFORE item k's sixteen ds_adds — a read issued behind them waits until the LDS queue has drained them.
+            const int nit = (wb.exp & 2) ? 0 : (TG + step < RS) ? 4 : 2;
+            struct ItemLd { f32x4 gcol; f32x4 xc[4]; };
+            f32x4 gq4[4];                                          // flh, flw, mask, packed corner word
+            auto load_geo = [&](int k) { gq4[k] = geo4[(a_row + 64 * (k & 1)) * RS + (k >> 1) * TG + step]; };
+            auto load_item = [&](int k, ItemLd &L) {
+                const int r = a_row + 64 * (k & 1);
+                const int base = __float_as_int(gq4[k][3]) & 0xffff;          // slow samples: 0 (their reads are not used)
+                L.gcol = *reinterpret_cast<const f32x4 *>(stage + (k >> 1) * (BM * SST2) + r * SST2 + a_col);
+                const float *xb = xw + (size_t)base * CW + a_col;
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int r = a_row + 64 * j;
-                    const f32x4 gq = geo4[r * RS + tap];                     // flh, flw, mask, packed corner word
+                for (int e = 0; e < 4; ++e) L.xc[e] = *reinterpret_cast<const f32x4 *>(xb + ((e >> 1) * wa.WW + (e & 1)) * CW);
+            };
+            auto process = [&](int k, const ItemLd &L) {
+                    const int tap = (k >> 1) * TG + step;
+                    const int r = a_row + 64 * (k & 1);
+                    const f32x4 gq = gq4[k];
                     const int gi = __float_as_int(gq[3]);
                     const float flh = gq[0], flw = gq[1], mk = gq[2];
+                    const f32x4 gcol = L.gcol;
                     float s_m = 0.f, s_h = 0.f, s_w = 0.f;
                     if (!(gi & GEO_SLOW)) {
                         // Fast samples (the whole 2x2 footprint inside the window; also samples without any valid corner:
@@ -1689,21 +1728,15 @@ __global__ __launch_bounds__(512) void dcn_dgrad_win_kernel(const DcnWinBwdArgs 
                         const float hh = 1.f - flh, hw = 1.f - flw;
                         const f32x2 wcol = {hw, flw};
                         const f32x2 w01 = wcol * hh, w23 = wcol * flh;       // corner weights (top row, bottom row)
-                        const f32x4 gcol = *reinterpret_cast<const f32x4 *>(stg + r * SST2 + a_col);
                         const f32x2 g01 = {gcol[0], gcol[1]}, g23 = {gcol[2], gcol[3]};
                         const f32x2 q01 = g01 * (f32x2{fx4[0], fx4[1]} * mk);   // column gradient x mask in each channel's fixed-point unit
                         const f32x2 q23 = g23 * (f32x2{fx4[2], fx4[3]} * mk);
-                        const int base = gi & 0xffff;
-                        const float *xb = xw + (size_t)base * CW + a_col;
-                        int *db = dxw + base * WSTR + a_col;
+                        int *db = dxw + (gi & 0xffff) * WSTR + a_col;
                         float d[4];
-                        f32x4 xc[4];                 // the four corner reads first: a later read would wait behind the adds in flight
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) xc[e] = *reinterpret_cast<const f32x4 *>(xb + ((e >> 1) * wa.WW + (e & 1)) * CW);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const int po = (e >> 1) * wa.WW + (e & 1);
-                            const f32x4 xv = xc[e];
+                            const f32x4 xv = L.xc[e];
                             const f32x2 dd = g01 * f32x2{xv[0], xv[1]} + g23 * f32x2{xv[2], xv[3]};
                             d[e] = dd[0] + dd[1];
                             const float we = e == 0 ? w01[0] : e == 1 ? w01[1] : e == 2 ? w23[0] : w23[1];
@@ -1724,8 +1757,7 @@ __global__ __launch_bounds__(512) void dcn_dgrad_win_kernel(const DcnWinBwdArgs 
                         const float wt[4] = {hh * hw, hh * flw, flh * hw, flh * flw};
                         const float dhw[4] = {-hw, -flw, hw, flw};
                         const float dww[4] = {-hh, hh, -flh, flh};
-                        const f32x4 gcol = *reinterpret_cast<const f32x4 *>(stg + r * SST2 + a_col);
-                        const f32x4 gs = gcol * fx4;                           // column gradient in each channel's fixed-point unit
+                                                const f32x4 gs = gcol * fx4;                           // column gradient in each channel's fixed-point unit
                         // footprint not inside the window (offset beyond the margin): position again from the offsets
                         const int p = y0 + r / WIN_TW, q = x0 + r % WIN_TW;
                         const float *po = a.offset + (((long)n * a.P + p) * a.Q + q) * (2 * a.dg * RS) + g_cur * 2 * RS + 2 * tap;
@@ -1762,6 +1794,33 @@ __global__ __launch_bounds__(512) void dcn_dgrad_win_kernel(const DcnWinBwdArgs 
                         const float v = (t & 7) == 0 ? s_m : (t & 7) == 1 ? s_h : s_w;
                         red[(r * RS + tap) * 3 + (t & 7)] += v;
                     }
+            };
+            if constexpr (DMA) {
+                if (nit > 0) {
+                    ItemLd L0, L1;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (k < nit) load_geo(k);
+                    load_item(0, L0);
+                    load_item(1, L1);
+                    process(0, L0);
+                    if (nit > 2) load_item(2, L0);
+                    process(1, L1);
+                    if (nit > 2) {
+                        load_item(3, L1);
+                        process(2, L0);
+                        process(3, L1);
+                    }
+                }
+            } else {                        // (the staging registers of the plain sweep leave no room for a second item in flight)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (k < nit) {
+                        ItemLd L;
+                        load_geo(k);
+                        load_item(k, L);
+                        process(k, L);
+                    }
                 }
             }
             __syncthreads();        // the stage images are rewritten by the next step
@@ -1771,7 +1830,27 @@ __global__ __launch_bounds__(512) void dcn_dgrad_win_kernel(const DcnWinBwdArgs 
             const int c = t & 31;
             const float fx_inv = fxi[c];
             const bool nonfinite = fx_inv != fx_inv;
-            if (!(wb.exp & 4))
+            if constexpr (DMA) {
+                // the pixel positions do not depend on the chunk: element offsets computed once per workgroup (goff), LDS
+                // addresses with immediate offsets
+                if (!(wb.exp & 4)) {
+                float *const dxc = wb.dx + c0 + c;
+                int *const dw = dxw + (t >> 5) * WSTR + c;
+#pragma unroll
+                for (int i = 0; i < FP; ++i) {
+                    if ((t >> 5) + 16 * i < npx) {
+                        const int iv = dw[i * 16 * WSTR];
+                        const int go = gofft[(t >> 5) + 16 * i];
+                        if (iv != 0) {
+                            if (go >= 0) unsafeAtomicAdd(dxc + go, (float)iv * fx_inv);
+                            dw[i * 16 * WSTR] = 0;
+                        } else if (nonfinite && go >= 0) {
+                            unsafeAtomicAdd(dxc + go, __int_as_float(0x7fc00000));
+                        }
+                    }
+                }
+                }
+            } else
             for (int px = t >> 5; px < npx; px += NT / 32) {
                 const int iv = dxw[px * WSTR + c];
                 const int ly = px / wa.WW, lx = px - ly * wa.WW;
@@ -2395,14 +2474,18 @@ static int dcn_dgrad_impl(const float *x, const float *offset, const float *mask
                 }
                 static const bool dma_on = [] { const char *e = getenv("RR_DCN_DGRAD_DMA"); return !(e && e[0] == '0'); }();
                 if (dma_on && wb.dyb != nullptr && wpk != nullptr && k % 32 == 0 && (long)b.a.M * k * 2 < (1l << 31) &&
+                    (long)n * h * wd * c * 4 < (1l << 31) && wb.w.WH * wb.w.WW <= 368 &&
+                    ldsw + (size_t)wb.w.WH * wb.w.WW * 4 + 16 <= 160 * 1024 - 512 &&
                     (size_t)wb.w.WH * wb.w.WW * 33 * 4 >= (size_t)(BM * 32 + 2 * r * s * 32 * 32) * 2) {     // the ring's share of the d-input window
                     // both sweep operands by LDS-DMA: the weights packed to bf16 (the forward's layout) once per call
                     hipLaunchKernelGGL(dcn_pack_weights_kernel, dim3(rr_cdiv((long)k * r * s * c / 4, 256)), dim3(256), 0, stream, w, wpk, k, c,
                                        r * s);
                     wb.wpk = wpk;
+                    wb.goff_at = (int)ldsw;
+                    const size_t ldsd = ldsw + (((size_t)wb.w.WH * wb.w.WW * 4 + 15) & ~(size_t)15);
                     RR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(dcn_dgrad_win_kernel<9, false, true>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw), "rr_dcn_dgrad");
-                    hipLaunchKernelGGL((dcn_dgrad_win_kernel<9, false, true>), grid, dim3(512), ldsw, stream, wb);
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsd), "rr_dcn_dgrad");
+                    hipLaunchKernelGGL((dcn_dgrad_win_kernel<9, false, true>), grid, dim3(512), ldsd, stream, wb);
                     RR_CHECK_LAUNCH("rr_dcn_dgrad");
                     return RR_OK;
                 }
