@@ -546,6 +546,13 @@ int rr_dcn_col2im(const float *x, const float *offset, const float *mask, const 
  * otherwise float atomics on the bilinear corners), doffset and dmask (plain stores).
  * Replace ext/dcn/src/cuda/dcn_v2_cuda.cu:206-335 + dcn_v2_im2col_cuda.cu:197-327.  Layers they do not take
  * (rr_dcn_fused_bwd_supported == 0) go through the column path above. */
+/* rr_dcn_wgrad_bf16 with dY's bf16 image (same element order as dy; its producer's image or one rr_to_bf16 pass): the dY
+ * operand reaches LDS by buffer_load ... lds, no conversion inside (round 5).  Same results as rr_dcn_wgrad_bf16.
+ * Replaces the dW GEMM of dcn_v2_cuda_backward (ext/dcn/src/cuda/dcn_v2_cuda.cu:283-301). */
+int rr_dcn_wgrad_bf16_img(const float *x, const float *offset, const float *mask, const float *dy, const unsigned short *dy_bf16,
+                          float *dw, int n, int h, int wd, int c, int k, int r, int s, int stride, int pad_h, int pad_w,
+                          int dilation, int deformable_groups, hipStream_t stream);
+
 /* 1 when rr_dcn_wgrad / rr_dcn_dgrad (and their _bf16 forms) take a layer of this shape, 0 when the host layer has to
  * run the column path (rr_dcn_im2col / rr_dcn_col2im + the conv GEMMs). */
 int rr_dcn_fused_bwd_supported(int c, int k, int r, int s, int stride, int deformable_groups);      /* dilation 1 */

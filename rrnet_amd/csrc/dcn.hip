@@ -1883,12 +1883,20 @@ struct DcnWinWgradArgs {
     const float *dy;
     float *dw;
     int splits, ktiles;
+    int dma_window;     // x is addressable with 32-bit byte offsets: the window goes global -> LDS by DMA
+    const unsigned short *dyb;      // DYDMA: dY's bf16 image
+    int exp;
 };
 
 // F32: fp32 operands (v_mfma_f32_32x32x2_f32) in sub-blocks of 32 pixels — the same LDS bytes as 64 pixels of bf16.
-template <int RS, bool F32>
+// DYDMA (round 5; bf16, K % 32 == 0, dY given as a bf16 image): wave w's dY operand (filters 32 w .. +31 of the tile) goes
+// global -> LDS by buffer_load ... lds into a PRIVATE ring of six 16-pixel slices (1 KB each, [pixel][32 filters] as dY lies
+// in memory: the transpose read makes the operand) — no staging registers, converts, ds_writes, and no barrier for this
+// operand: the next sub-block's four slices are issued while this one's are consumed.
+template <int RS, bool F32, bool DYDMA = false>
 __global__ __launch_bounds__(512) void dcn_wgrad_win_kernel(const DcnWinWgradArgs wb)
 {
+    static_assert(!(DYDMA && F32), "the dY ring is bf16 only");
     const DcnWinArgs &wa = wb.w;
     const DcnArgs &a = wa.a;
     constexpr int CW = 32, NT = 512, GEO_SLOW = 1 << 20, KT = 256;
@@ -1898,10 +1906,9 @@ __global__ __launch_bounds__(512) void dcn_wgrad_win_kernel(const DcnWinWgradArg
     extern __shared__ __align__(16) unsigned char smem[];
     const int npx = wa.WH * wa.WW;
     float *xw = reinterpret_cast<float *>(smem);                                    // [npx][32]
-    int *geo_i = reinterpret_cast<int *>(xw + (size_t)npx * CW);                    // [BM][RS]: as in dcn_dgrad_win_bf16_kernel
-    float *geo_f = reinterpret_cast<float *>(geo_i + BM * RS);                      // [BM][RS][3]: lh, lw, mask
-    unsigned short *dyT = reinterpret_cast<unsigned short *>(geo_f + BM * RS * 3);  // [256 filters][LDP pixels]
-    unsigned short *colT = dyT + KT * 72;                                           // [RS][32 channels][LDP pixels]
+    f32x4 *geo4 = reinterpret_cast<f32x4 *>(xw + (size_t)npx * CW);                 // [BM][RS] x {lh, lw, mask, packed corner word}: as in dcn_dgrad_win_kernel
+    unsigned short *dyT = reinterpret_cast<unsigned short *>(geo4 + BM * RS);       // [256 filters][LDP pixels]
+    unsigned short *colT = dyT + (DYDMA ? 8 * 6 * 512 : KT * 72);                   // [RS][32 channels][LDP pixels]; DYDMA: dyT = 8 waves x 6 slices x [16 px][32 filters]
     float *dyF = reinterpret_cast<float *>(dyT), *colF = reinterpret_cast<float *>(colT);   // F32 images, same bytes
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -1925,8 +1932,9 @@ __global__ __launch_bounds__(512) void dcn_wgrad_win_kernel(const DcnWinWgradArg
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[tap][e] = 0.f;
 
-    f32x4 rdy[PG];
+    f32x4 rdy[DYDMA ? 1 : PG];
     auto issue_dy = [&](int tile, int sub) {                 // PG pixels x 4 filters, a 1 KB row segment per wave and pixel
+        if constexpr (DYDMA) return;
         int bid = tile;
         const int txi = bid % wa.tiles_x; bid /= wa.tiles_x;
         const int tyi = bid % wa.tiles_y;
@@ -1935,11 +1943,13 @@ __global__ __launch_bounds__(512) void dcn_wgrad_win_kernel(const DcnWinWgradArg
         const int p = tyi * WIN_TH + r0 / WIN_TW, q0 = txi * WIN_TW + r0 % WIN_TW;
         const int f = k0 + 4 * fq;
 #pragma unroll
-        for (int i = 0; i < PG; ++i)
+        for (int i = 0; i < (DYDMA ? 1 : PG); ++i)
             rdy[i] = *reinterpret_cast<const f32x4 *>((p < a.P && q0 + i < a.Q && f < a.K)
                                                           ? wb.dy + (((long)n * a.P + p) * a.Q + q0 + i) * a.K + f : a.zero);
     };
     auto commit_dy = [&]() {
+        if constexpr (DYDMA) return;
+        if (wb.exp & 8) return;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if constexpr (F32) {
@@ -1951,42 +1961,87 @@ __global__ __launch_bounds__(512) void dcn_wgrad_win_kernel(const DcnWinWgradArg
             // bf16: [filter slab of 32][pixel][32 filters], as dY lies in memory; the MFMA fragment (8 consecutive
             // pixels of one filter) comes out of the transpose read
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
+            for (int i = 0; i < (DYDMA ? 1 : 8); ++i)
                 *reinterpret_cast<u16x4 *>(dyT + ((fq >> 3) * HP + 8 * pg + i) * 32 + 4 * (fq & 7)) = f2bf4(rdy[i]);
         }
     };
 
-    int tile = split;
-    if (tile < ntiles) issue_dy(tile, 0);
-    for (; tile < ntiles; tile += wb.splits) {
-        int bid = tile;
+    // Input window of a block and this workgroup's chunk: global -> LDS by buffer_load ... lds (8 pixels x 128 bytes per
+    // wave-instruction, zeros outside the image), and the sample geometry of deformable group g.  Both are prepared for the
+    // NEXT block as soon as the last samples of the current one are built — under its last MFMA phase (round 5; before,
+    // every block started with a synchronous window copy and the geometry's dependent global reads: ~0.9 of 2.34 ms).
+    typedef __attribute__((address_space(3))) void lds_void;
+    const i32x4d rs_x = [&] {
+        const unsigned long long u = reinterpret_cast<unsigned long long>(a.x);
+        return i32x4d{(int)__builtin_amdgcn_readfirstlane((unsigned)u), (int)(__builtin_amdgcn_readfirstlane((unsigned)(u >> 32)) & 0xffffu),
+                      __builtin_amdgcn_readfirstlane((int)((long)a.N * a.H * a.W * a.C * 4)), 0x00020000};
+    }();
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    constexpr int GI = (BM * RS + NT - 1) / NT;            // geometry items per thread (3)
+    float g_oh[GI], g_ow[GI], g_mk[GI];                    // offsets and mask of the next block's items, loaded under the MFMAs
+    auto prepare_issue = [&](int tl) {
+        if (wb.exp & 4) return;
+        int bid = tl;
         const int txi = bid % wa.tiles_x; bid /= wa.tiles_x;
         const int tyi = bid % wa.tiles_y;
         const int n = bid / wa.tiles_y;
         const int y0 = tyi * WIN_TH, x0 = txi * WIN_TW;
         const int wy0 = y0 - a.pad_h - wa.RW, wx0 = x0 - a.pad_w - wa.RW;
         const long img = (long)n * a.H * a.W;
-        __syncthreads();                                     // the previous block's last samples / MFMA reads are done
-        // ---- input window of this block and chunk, sample geometry of deformable group g
-        for (int i = t; i < npx * 8; i += NT) {
-            const int px = i >> 3, c4 = (i & 7) * 4;
-            const int ly = px / wa.WW, lx = px - ly * wa.WW;
-            const int gy = wy0 + ly, gx = wx0 + lx;
-            const bool ok = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-            *reinterpret_cast<f32x4 *>(xw + (size_t)i * 4) =
-                *reinterpret_cast<const f32x4 *>(ok ? a.x + (img + (long)gy * a.W + gx) * a.C + c0 + c4 : a.zero);
+        if (wb.dma_window) {
+            for (int piece = wv; piece * 8 < npx; piece += 8) {
+                const int px = piece * 8 + (lane >> 3);
+                if (px < npx) {                                  // lanes past the window's last pixel stay out (exec mask)
+                    const int ly = px / wa.WW, lx = px - ly * wa.WW;
+                    const int gy = wy0 + ly, gx = wx0 + lx;
+                    const bool ok = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+                    dma16(rs_x, __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void *)(xw + piece * 256)),
+                          ok ? (unsigned)(((img + (long)gy * a.W + gx) * a.C) * 4) + (unsigned)(lane & 7) * 16u : 0x80000000u, (unsigned)(c0 * 4));
+                }
+            }
+        } else {
+            for (int i = t; i < npx * 8; i += NT) {
+                const int px = i >> 3, c4 = (i & 7) * 4;
+                const int ly = px / wa.WW, lx = px - ly * wa.WW;
+                const int gy = wy0 + ly, gx = wx0 + lx;
+                const bool ok = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+                *reinterpret_cast<f32x4 *>(xw + (size_t)i * 4) =
+                    *reinterpret_cast<const f32x4 *>(ok ? a.x + (img + (long)gy * a.W + gx) * a.C + c0 + c4 : a.zero);
+            }
         }
-        for (int it = t; it < BM * RS; it += NT) {
+#pragma unroll
+        for (int i = 0; i < GI; ++i) {
+            const int it = t + i * NT;
+            const int r = it / RS, tap = it - r * RS;
+            const int p = y0 + r / WIN_TW, q = x0 + r % WIN_TW;
+            g_oh[i] = 0.f; g_ow[i] = 0.f; g_mk[i] = 0.f;
+            if (it < BM * RS && p < a.P && q < a.Q) {
+                const long m = ((long)n * a.P + p) * a.Q + q;
+                const float *po = a.offset + m * (2 * a.dg * RS) + g * 2 * RS + 2 * tap;
+                g_oh[i] = po[0]; g_ow[i] = po[1];
+                g_mk[i] = a.mask[m * (a.dg * RS) + g * RS + tap];
+            }
+        }
+    };
+    auto prepare_finish = [&](int tl) {
+        if (wb.exp & 4) return;
+        int bid = tl;
+        const int txi = bid % wa.tiles_x; bid /= wa.tiles_x;
+        const int tyi = bid % wa.tiles_y;
+        const int y0 = tyi * WIN_TH, x0 = txi * WIN_TW;
+        const int wy0 = y0 - a.pad_h - wa.RW, wx0 = x0 - a.pad_w - wa.RW;
+#pragma unroll
+        for (int i = 0; i < GI; ++i) {
+            const int it = t + i * NT;
+            if (it >= BM * RS) continue;
             const int r = it / RS, tap = it - r * RS;
             const int p = y0 + r / WIN_TW, q = x0 + r % WIN_TW;
             int packed = 0;
             float flh = 0.f, flw = 0.f, mk = 0.f;
             if (p < a.P && q < a.Q) {
-                const long m = ((long)n * a.P + p) * a.Q + q;
-                const float *po = a.offset + m * (2 * a.dg * RS) + g * 2 * RS + 2 * tap;
                 const int ti = tap / a.S, tj = tap - ti * a.S;
-                const float h = (float)(p - a.pad_h + ti * a.dil) + po[0];
-                const float w = (float)(q - a.pad_w + tj * a.dil) + po[1];
+                const float h = (float)(p - a.pad_h + ti * a.dil) + g_oh[i];
+                const float w = (float)(q - a.pad_w + tj * a.dil) + g_ow[i];
                 if (h > -1.f && w > -1.f && h < (float)a.H && w < (float)a.W) {
                     const float hf = floorf(h), wf = floorf(w);
                     const int h0 = (int)hf, w0 = (int)wf;
@@ -2000,33 +2055,70 @@ __global__ __launch_bounds__(512) void dcn_wgrad_win_kernel(const DcnWinWgradArg
                     const bool fast = ly >= 0 && ly + 1 < wa.WH && lx >= 0 && lx + 1 < wa.WW;
                     packed = (valid << 16) | (fast ? (ly * wa.WW + lx) : GEO_SLOW);
                     flh = h - hf; flw = w - wf;
-                    mk = a.mask[m * (a.dg * RS) + g * RS + tap];
+                    mk = g_mk[i];
                 }
             }
-            geo_i[it] = packed;
-            geo_f[it * 3] = flh; geo_f[it * 3 + 1] = flw; geo_f[it * 3 + 2] = mk;
+            geo4[it] = f32x4{flh, flw, mk, __int_as_float(packed)};
         }
+    };
+
+    // DYDMA: slice kk (16 pixels = one row of the 8 x 16 block) of sub-block `sub` of block tl -> ring slot `slot` of this wave
+    const i32x4d rs_dy = [&] {
+        const unsigned long long u = reinterpret_cast<unsigned long long>(wb.dyb);
+        return i32x4d{(int)__builtin_amdgcn_readfirstlane((unsigned)u), (int)(__builtin_amdgcn_readfirstlane((unsigned)(u >> 32)) & 0xffffu),
+                      __builtin_amdgcn_readfirstlane((int)((long)a.M * a.K * 2)), 0x00020000};
+    }();
+    unsigned short *const ring = dyT + wv * (6 * 512);
+    auto issue_slice = [&](int tl, int sub, int kk, int slot) {
+        int bid = tl;
+        const int txi = bid % wa.tiles_x; bid /= wa.tiles_x;
+        const int tyi = bid % wa.tiles_y;
+        const int n = bid / wa.tiles_y;
+        const int p = tyi * WIN_TH + sub * (HP / WIN_TW) + kk, q = txi * WIN_TW + (lane >> 2);
+        const unsigned off = (p < a.P && q < a.Q) ? (unsigned)(((((long)n * a.P + p) * a.Q + q) * a.K + (lane & 3) * 8) * 2) : 0x80000000u;
+        dma16(rs_dy, __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void *)(ring + slot * 512)), off, (unsigned)((k0 + wv * 32) * 2));
+    };
+    int slot = 0;                                            // ring slot of the current sub-block's first slice
+
+    int tile = split;
+    if (tile < ntiles) {
+        prepare_issue(tile); prepare_finish(tile); issue_dy(tile, 0);
+        if constexpr (DYDMA) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) issue_slice(tile, 0, kk, kk);
+        }
+    }
+    for (; tile < ntiles; tile += wb.splits) {
+        int bid = tile;
+        const int txi = bid % wa.tiles_x; bid /= wa.tiles_x;
+        const int tyi = bid % wa.tiles_y;
+        const int n = bid / wa.tiles_y;
+        const int y0 = tyi * WIN_TH, x0 = txi * WIN_TW;
+        const long img = (long)n * a.H * a.W;
         for (int half = 0; half < NSUB; ++half) {
+            if (half == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's window pieces landed
             __syncthreads();                                 // window + geometry visible; dyT / colT free again
             commit_dy();
             // ---- masked bilinear samples of 64 pixels x 9 taps x 32 channels, bf16, pixel-minor
             const int r = half * HP + a_row;
-#pragma unroll 3
-            for (int ti_ = 0; ti_ < NTAP; ++ti_) {
+#pragma unroll(DYDMA ? 3 : 1)
+            for (int ti_ = 0; ti_ < ((wb.exp & 1) ? 0 : NTAP); ++ti_) {
                 const int tap = tap0 + ti_;
                 if (tap >= RS) break;
-                const int gi = geo_i[r * RS + tap];
+                const f32x4 gq = geo4[r * RS + tap];
+                const int gi = __float_as_int(gq[3]);
                 const int valid = (gi >> 16) & 15;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (valid) {
-                    const float flh = geo_f[(r * RS + tap) * 3], flw = geo_f[(r * RS + tap) * 3 + 1], mk = geo_f[(r * RS + tap) * 3 + 2];
+                    const float flh = gq[0], flw = gq[1], mk = gq[2];
                     const float hh = 1.f - flh, hw = 1.f - flw;
                     const float wt[4] = {hh * hw * mk, hh * flw * mk, flh * hw * mk, flh * flw * mk};     // as make_tap: the forward's samples exactly
                     if (!(gi & GEO_SLOW)) {
+                        // a corner outside the image reads a window pixel filled with zeros: no validity selects (adding
+                        // weight x 0 leaves the forward's sum bit for bit)
                         const float *xb = xw + (size_t)(gi & 0xffff) * CW + a_col;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if ((valid >> e) & 1) v += *reinterpret_cast<const f32x4 *>(xb + ((e >> 1) * wa.WW + (e & 1)) * CW) * wt[e];
+                        for (int e = 0; e < 4; ++e) v += *reinterpret_cast<const f32x4 *>(xb + ((e >> 1) * wa.WW + (e & 1)) * CW) * wt[e];
                     } else {
                         const int p = y0 + r / WIN_TW, q = x0 + r % WIN_TW;
                         const float *po = a.offset + (((long)n * a.P + p) * a.Q + q) * (2 * a.dg * RS) + g * 2 * RS + 2 * tap;
@@ -2048,10 +2140,24 @@ __global__ __launch_bounds__(512) void dcn_wgrad_win_kernel(const DcnWinWgradArg
             }
             __syncthreads();
             // next half block's dY lands under the MFMAs
+            if constexpr (DYDMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this sub-block's dY slices (issued a phase ago)
             if (half + 1 < NSUB) issue_dy(tile, half + 1);
-            else if (tile + wb.splits < ntiles) issue_dy(tile + wb.splits, 0);
+            else if (tile + wb.splits < ntiles) {            // the window is free: every sample of this block is built
+                prepare_issue(tile + wb.splits);
+                if constexpr (!DYDMA) prepare_finish(tile + wb.splits);       // (no registers to hold the offsets through the MFMA phase next to the dY staging)
+                issue_dy(tile + wb.splits, 0);
+            }
+            // DYDMA: the sub-block after this one, whose slices go out while this one's are consumed
+            const bool nx_ok = half + 1 < NSUB || tile + wb.splits < ntiles;
+            const int nx_tile = half + 1 < NSUB ? tile : tile + wb.splits, nx_sub = half + 1 < NSUB ? half + 1 : 0;
+            if constexpr (DYDMA) {
+                if (nx_ok) {
+                    issue_slice(nx_tile, nx_sub, 0, (slot + 4) % 6);
+                    issue_slice(nx_tile, nx_sub, 1, (slot + 5) % 6);
+                }
+            }
 #pragma unroll
-            for (int kk = 0; kk < HP / 16; ++kk) {
+            for (int kk = 0; kk < ((wb.exp & 2) ? 0 : HP / 16); ++kk) {
                 if constexpr (F32) {
                     // lane half lh_ takes pixels 8 lh_ .. +7 of the 16-pixel step (A and B agree on the pairing)
                     const f32x4 fa0 = *reinterpret_cast<const f32x4 *>(dyF + (wave * 32 + lr) * LDP + kk * 16 + 8 * lh_);
@@ -2066,7 +2172,17 @@ __global__ __launch_bounds__(512) void dcn_wgrad_win_kernel(const DcnWinWgradArg
                         for (int e = 0; e < 4; ++e) acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[e], fb1[e], acc[tap], 0, 0, 0);
                     }
                 } else {
-                    const bf16x8 fa = lds_tr_frag(dyT + wave * HP * 32, kk * 16, lane);
+                    bf16x8 fa;
+                    if constexpr (DYDMA) {
+                        const int sl = (slot + kk) % 6;
+                        fa = lds_tr_frag(ring + sl * 512, 0, lane);
+                        if (kk < 2 && nx_ok) {               // its slot takes slice kk + 2 of the next sub-block once the read is through
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                            issue_slice(nx_tile, nx_sub, kk + 2, sl);
+                        }
+                    } else {
+                        fa = lds_tr_frag(dyT + wave * HP * 32, kk * 16, lane);
+                    }
 #pragma unroll
                     for (int tap = 0; tap < RS; ++tap) {
                         const bf16x8 fb = lds_tr_frag(colT + tap * HP * CW, kk * 16, lane);
@@ -2074,6 +2190,10 @@ __global__ __launch_bounds__(512) void dcn_wgrad_win_kernel(const DcnWinWgradArg
                     }
                 }
             }
+            if constexpr (DYDMA) slot = (slot + 4) % 6;
+            // the next block's geometry from the offsets / masks that arrived under the MFMAs (the table is free since the last samples)
+            if constexpr (DYDMA)
+                if (half + 1 == NSUB && tile + wb.splits < ntiles) prepare_finish(tile + wb.splits);
         }
     }
     // ---- dW += this workgroup's partial sums: lane <-> channel, 128-byte row segments
@@ -2337,7 +2457,7 @@ static bool dcn_win_fits(bool dgrad, int r, int s, int dilation)
 
 static int dcn_wgrad_win(const float *x, const float *offset, const float *mask, const float *dy, float *dw, int n, int h,
                          int wd, int c, int k, int r, int s, int stride, int pad_h, int pad_w, int dilation,
-                         int deformable_groups, int bf16, hipStream_t stream)
+                         int deformable_groups, int bf16, hipStream_t stream, const unsigned short *dyb = nullptr)
 {
     const int rw = dcn_win_margin();
     if (rw > 0 && stride == 1 && r * s == 9 && c % 32 == 0 && k % 4 == 0 && h < 32768 && wd < 32768 &&
@@ -2349,11 +2469,16 @@ static int dcn_wgrad_win(const float *x, const float *offset, const float *mask,
         wb.w.tiles_x = rr_cdiv(wb.w.a.Q, WIN_TW);
         wb.dy = dy; wb.dw = dw;
         size_t ldsw = 0;
+        static const bool dydma_on = [] { const char *e = getenv("RR_DCN_WGRAD_DMA"); return !(e && e[0] == '0'); }();
+        const bool dydma = dydma_on && bf16 && dyb != nullptr && k % 32 == 0 && (long)wb.w.a.M * k * 2 < (1l << 31) &&
+                           (long)n * h * wd * c * 4 < (1l << 31);
         for (int m = rw; m >= 1; --m) {
             wb.w.RW = m;
             wb.w.WH = WIN_TH + (r - 1) * dilation + 2 * m + 1;
             wb.w.WW = WIN_TW + (s - 1) * dilation + 2 * m + 1;
             ldsw = dcn_wgrad_win_lds(r, s, dilation, m);
+            // the dY ring: 8 waves x 6 KB instead of the 256 x 72 image; the samples unpadded
+            if (dydma) ldsw = ldsw - sizeof(unsigned short) * (size_t)((256 + r * s * 32) * 72) + sizeof(unsigned short) * (size_t)(8 * 6 * 512 + r * s * 64 * 32);
             if (ldsw <= 160 * 1024 - 512) break;
         }
         if (ldsw <= 160 * 1024 - 512) {
@@ -2364,7 +2489,14 @@ static int dcn_wgrad_win(const float *x, const float *offset, const float *mask,
             if (splits > 8) splits = splits / 8 * 8;
             if (splits > ntiles) splits = ntiles;
             wb.splits = splits;
-            if (bf16) {
+            wb.dma_window = (long)n * h * wd * c * 4 < (1l << 31);
+            { const char *e = getenv("RR_DCN_EXPW"); wb.exp = e ? atoi(e) : 0; }
+            wb.dyb = dyb;
+            if (dydma) {
+                RR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(dcn_wgrad_win_kernel<9, false, true>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw), "rr_dcn_wgrad");
+                hipLaunchKernelGGL((dcn_wgrad_win_kernel<9, false, true>), dim3(splits * per_split), dim3(512), ldsw, stream, wb);
+            } else if (bf16) {
                 hipFuncSetAttribute(reinterpret_cast<const void *>(dcn_wgrad_win_kernel<9, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw);
                 hipLaunchKernelGGL((dcn_wgrad_win_kernel<9, false>), dim3(splits * per_split), dim3(512), ldsw, stream, wb);
             } else {
@@ -2407,6 +2539,18 @@ extern "C" int rr_dcn_wgrad_bf16(const float *x, const float *offset, const floa
                                  int deformable_groups, hipStream_t stream)
 {
     const int rc = dcn_wgrad_win(x, offset, mask, dy, dw, n, h, wd, c, k, r, s, stride, pad_h, pad_w, dilation, deformable_groups, 1, stream);
+    if (rc != -1) return rc;
+    return dcn_wgrad_plain(x, offset, mask, dy, dw, n, h, wd, c, k, r, s, stride, pad_h, pad_w, dilation, deformable_groups, stream);
+}
+
+// rr_dcn_wgrad_bf16 with dY's bf16 image (its producer's, or one rr_to_bf16 pass shared with the data gradient): the dY
+// operand goes global -> LDS by DMA
+extern "C" int rr_dcn_wgrad_bf16_img(const float *x, const float *offset, const float *mask, const float *dy,
+                                     const unsigned short *dy_bf16, float *dw, int n, int h, int wd, int c, int k, int r, int s,
+                                     int stride, int pad_h, int pad_w, int dilation, int deformable_groups, hipStream_t stream)
+{
+    RR_CHECK_ARG(dy_bf16 != nullptr, "rr_dcn_wgrad_bf16_img: the bf16 image of dy is required");
+    const int rc = dcn_wgrad_win(x, offset, mask, dy, dw, n, h, wd, c, k, r, s, stride, pad_h, pad_w, dilation, deformable_groups, 1, stream, dy_bf16);
     if (rc != -1) return rc;
     return dcn_wgrad_plain(x, offset, mask, dy, dw, n, h, wd, c, k, r, s, stride, pad_h, pad_w, dilation, deformable_groups, stream);
 }

@@ -1041,13 +1041,16 @@ class _DCNv2(torch.autograd.Function):
             side = _side_stream(x.device) if DCN_BWD_STREAMS else None
             # a bf16 forward takes the bf16-operand gradients (input window in LDS, d input pre-summed on chip)
             bf = bool(ctx.bf16 and DCN_BF16_BWD)
+            # both kernels take dY's bf16 image by LDS-DMA: its producer's, or ONE conversion pass made here, before the fork
+            # (behind the weight-gradient kernel, which holds every CU, the pass took 2.4 ms instead of 0.2)
+            img = ops.bf16_of(dy) if (bf and ops._DCN_DYB and not ops.is_phantom(dy)) else None
             if side is not None:
                 side.wait_stream(cur)
                 with torch.cuda.stream(side):
                     _stress_delay()
-                    ops.dcn_wgrad(x, off, m, dy, dw, stride, pad, dil, dg, bf16=bf)
+                    ops.dcn_wgrad(x, off, m, dy, dw, stride, pad, dil, dg, bf16=bf, dy_img=img)
             else:
-                ops.dcn_wgrad(x, off, m, dy, dw, stride, pad, dil, dg, bf16=bf)
+                ops.dcn_wgrad(x, off, m, dy, dw, stride, pad, dil, dg, bf16=bf, dy_img=img)
             dx, doff, dmask = ops.dcn_dgrad(x, off, m, w, dy, stride, pad, dil, dg, bf16=bf)
             if side is not None:
                 cur.wait_stream(side)

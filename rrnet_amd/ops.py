@@ -1467,12 +1467,18 @@ def dcn_fused_bwd_supported(c, k, r, s, stride, dg, dilation=1):
     return bool(_C.fn("rr_dcn_fused_bwd_supported_dil")(c, k, r, s, stride, dilation, dg))
 
 
-def dcn_wgrad(x, offset, mask, dy, dw, stride, pad, dilation, dg, bf16=False):
+def dcn_wgrad(x, offset, mask, dy, dw, stride, pad, dilation, dg, bf16=False, dy_img=None):
     """dw [K,C,R,S] (OHWI memory, pre-zeroed or the running gradient) += dY^T x deformed columns; no column buffer.
-    bf16: bf16 matrix operands (dY, samples), input window in LDS (rr_dcn_wgrad_bf16)."""
+    bf16: bf16 matrix operands (dY, samples), input window in LDS (rr_dcn_wgrad_bf16); dy_img: dY's bf16 image, complete on
+    the current stream — the dY operand then reaches LDS by DMA (rr_dcn_wgrad_bf16_img)."""
     assert is_nhwc(x) and is_nhwc(offset) and is_nhwc(mask) and is_nhwc(dy) and is_nhwc(dw)
     n, c, h, wd = x.shape
     k, _, r, s = dw.shape
+    if bf16 and dy_img is not None and _DCN_DYB:
+        _C.check(_C.fn("rr_dcn_wgrad_bf16_img")(_C.ptr(x), _C.ptr(offset), _C.ptr(mask), _C.ptr(dy), _C.ptr(dy_img), _C.ptr(dw), n, h,
+                                                wd, c, k, r, s, stride, pad[0], pad[1], dilation, dg, _C.stream()),
+                 "rr_dcn_wgrad_bf16_img")
+        return dw
     name = "rr_dcn_wgrad_bf16" if bf16 else "rr_dcn_wgrad"
     _C.check(_C.fn(name)(_C.ptr(x), _C.ptr(offset), _C.ptr(mask), _C.ptr(dy), _C.ptr(dw), n, h, wd, c, k, r, s,
                          stride, pad[0], pad[1], dilation, dg, _C.stream()), name)
