@@ -504,13 +504,23 @@ __global__ __launch_bounds__(512) void dcn_fprop_win_kernel(const DcnWinArgs wa)
     };
     auto blend_a = [&](int j) {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        // Two versions behind a WAVE-UNIFORM branch: the common one has no global load in it.  With the per-lane fetch of
+        // far corners inline, the wait for those (rare) loads sat behind the join — an unconditional s_waitcnt vmcnt(0) in
+        // the middle of every K-step, which also waited for the weight tile's DMA issued just before (in-order counter):
+        // 1.62 -> 1.44 ms at the bench layer (round 5).  (Tried and dropped: a ring of three weight images filled two steps
+        // ahead by inline-assembly DMA — 1.54 ms; the step is bound by the gather's LDS traffic, not by the tile's latency.)
+        if (__builtin_amdgcn_ballot_w64(((gof[0] | gof[1] | gof[2] | gof[3]) & 0x80000000u) != 0) == 0) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            f32x4 xv = gxl[e];
-            const unsigned int o = gof[e];
-            if (o & 0x80000000u)       // a corner beyond the window margin (rare): straight from global memory
-                xv = *reinterpret_cast<const f32x4 *>(a.x + (img + (long)(o & 0x7fffffffu)) * a.C + g_c0 + g_col);
-            v += xv * gwt[e];
+            for (int e = 0; e < 4; ++e) v += gxl[e] * gwt[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                f32x4 xv = gxl[e];
+                const unsigned int o = gof[e];
+                if (o & 0x80000000u)       // a corner beyond the window margin (rare): straight from global memory
+                    xv = *reinterpret_cast<const f32x4 *>(a.x + (img + (long)(o & 0x7fffffffu)) * a.C + g_c0 + g_col);
+                v += xv * gwt[e];
+            }
         }
         rv[j] = v;
     };
