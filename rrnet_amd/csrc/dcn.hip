@@ -1278,7 +1278,6 @@ struct DcnWinBwdArgs {
     // DMA sweep: the weights packed to bf16 [tap][32-channel chunk][filter][32] (dcn_pack_weights_kernel, the forward's layout)
     const unsigned short *wpk;
     int goff_at;        // byte offset of the window-pixel offset table in dynamic LDS (behind everything else)
-    int exp;
 };
 
 // F32: the matrix operands stay fp32 (v_mfma_f32_32x32x2_f32, K-steps of 16 filters: the same LDS bytes as 32 in bf16);
@@ -1455,7 +1454,7 @@ __global__ __launch_bounds__(512) void dcn_dgrad_win_kernel(const DcnWinBwdArgs 
             // asynchronously, 8 pixels x 128 bytes per wave-instruction; lands under the sweep (whose last step waits for everything)
             typedef __attribute__((address_space(3))) void lds_void;
             const int wv = __builtin_amdgcn_readfirstlane(wave);
-            if (!(wb.exp & 8)) {
+            {
 #pragma unroll
             for (int i = 0; i < XP; ++i) {
                 const int piece = wv + 8 * i;
@@ -1566,7 +1565,7 @@ __global__ __launch_bounds__(512) void dcn_dgrad_win_kernel(const DcnWinBwdArgs 
                     }
                 }
             };
-            const int nk = (wb.exp & 1) ? 0 : nkc;
+            const int nk = nkc;
             if (nk > 0) issue(0, 0);
             if (nk > 1) issue(1, 1);
             const int row = wpx * 32 + lr;
@@ -1693,7 +1692,7 @@ __global__ __launch_bounds__(512) void dcn_dgrad_win_kernel(const DcnWinBwdArgs 
         //      cover 1 KB contiguously; the two lane halves of a write hit the same banks, which a 64-lane b32 write
         //      pays anyway): two images fit the idle operand area.
         constexpr int SST2 = 32;
-        for (int step = 0; step < ((wb.exp & 16) ? 0 : TG); ++step) {        // a real loop: only the accumulator -> LDS copy is per-step code
+        for (int step = 0; step < TG; ++step) {        // a real loop: only the accumulator -> LDS copy is per-step code
             if (wtg * TG + step < RS) {
                 float *sp = stage + wtg * (BM * SST2) + (wpx * 32 + 4 * lh_) * SST2 + lr;
 #define RR_PUT(T)                                                                                    \
@@ -1710,7 +1709,7 @@ __global__ __launch_bounds__(512) void dcn_dgrad_win_kernel(const DcnWinBwdArgs 
             // Items of this step: (tap u TG + step, pixel row a_row + 64 j), k = 2 u + j.  Software-pipelined: the sample
             // geometry of all items first, then item k + 1's LDS reads (column gradient, four corner rows of x) go out
             // BEFORE item k's sixteen ds_adds — a read issued behind them waits until the LDS queue has drained them.
-            const int nit = (wb.exp & 2) ? 0 : (TG + step < RS) ? 4 : 2;
+            const int nit = (TG + step < RS) ? 4 : 2;
             struct ItemLd { f32x4 gcol; f32x4 xc[4]; };
             f32x4 gq4[4];                                          // flh, flw, mask, packed corner word
             auto load_geo = [&](int k) { gq4[k] = geo4[(a_row + 64 * (k & 1)) * RS + (k >> 1) * TG + step]; };
@@ -1843,7 +1842,7 @@ __global__ __launch_bounds__(512) void dcn_dgrad_win_kernel(const DcnWinBwdArgs 
             if constexpr (DMA) {
                 // the pixel positions do not depend on the chunk: element offsets computed once per workgroup (goff), LDS
                 // addresses with immediate offsets
-                if (!(wb.exp & 4)) {
+                {
                 float *const dxc = wb.dx + c0 + c;
                 int *const dw = dxw + (t >> 5) * WSTR + c;
 #pragma unroll
@@ -1895,7 +1894,6 @@ struct DcnWinWgradArgs {
     int splits, ktiles;
     int dma_window;     // x is addressable with 32-bit byte offsets: the window goes global -> LDS by DMA
     const unsigned short *dyb;      // DYDMA: dY's bf16 image
-    int exp;
 };
 
 // F32: fp32 operands (v_mfma_f32_32x32x2_f32) in sub-blocks of 32 pixels — the same LDS bytes as 64 pixels of bf16.
@@ -1959,7 +1957,6 @@ __global__ __launch_bounds__(512) void dcn_wgrad_win_kernel(const DcnWinWgradArg
     };
     auto commit_dy = [&]() {
         if constexpr (DYDMA) return;
-        if (wb.exp & 8) return;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if constexpr (F32) {
@@ -1990,7 +1987,6 @@ __global__ __launch_bounds__(512) void dcn_wgrad_win_kernel(const DcnWinWgradArg
     constexpr int GI = (BM * RS + NT - 1) / NT;            // geometry items per thread (3)
     float g_oh[GI], g_ow[GI], g_mk[GI];                    // offsets and mask of the next block's items, loaded under the MFMAs
     auto prepare_issue = [&](int tl) {
-        if (wb.exp & 4) return;
         int bid = tl;
         const int txi = bid % wa.tiles_x; bid /= wa.tiles_x;
         const int tyi = bid % wa.tiles_y;
@@ -2034,7 +2030,6 @@ __global__ __launch_bounds__(512) void dcn_wgrad_win_kernel(const DcnWinWgradArg
         }
     };
     auto prepare_finish = [&](int tl) {
-        if (wb.exp & 4) return;
         int bid = tl;
         const int txi = bid % wa.tiles_x; bid /= wa.tiles_x;
         const int tyi = bid % wa.tiles_y;
@@ -2112,7 +2107,7 @@ __global__ __launch_bounds__(512) void dcn_wgrad_win_kernel(const DcnWinWgradArg
             // ---- masked bilinear samples of 64 pixels x 9 taps x 32 channels, bf16, pixel-minor
             const int r = half * HP + a_row;
 #pragma unroll(DYDMA ? 3 : 1)
-            for (int ti_ = 0; ti_ < ((wb.exp & 1) ? 0 : NTAP); ++ti_) {
+            for (int ti_ = 0; ti_ < NTAP; ++ti_) {
                 const int tap = tap0 + ti_;
                 if (tap >= RS) break;
                 const f32x4 gq = geo4[r * RS + tap];
@@ -2167,7 +2162,7 @@ __global__ __launch_bounds__(512) void dcn_wgrad_win_kernel(const DcnWinWgradArg
                 }
             }
 #pragma unroll
-            for (int kk = 0; kk < ((wb.exp & 2) ? 0 : HP / 16); ++kk) {
+            for (int kk = 0; kk < HP / 16; ++kk) {
                 if constexpr (F32) {
                     // lane half lh_ takes pixels 8 lh_ .. +7 of the 16-pixel step (A and B agree on the pairing)
                     const f32x4 fa0 = *reinterpret_cast<const f32x4 *>(dyF + (wave * 32 + lr) * LDP + kk * 16 + 8 * lh_);
@@ -2500,7 +2495,6 @@ static int dcn_wgrad_win(const float *x, const float *offset, const float *mask,
             if (splits > ntiles) splits = ntiles;
             wb.splits = splits;
             wb.dma_window = (long)n * h * wd * c * 4 < (1l << 31);
-            { const char *e = getenv("RR_DCN_EXPW"); wb.exp = e ? atoi(e) : 0; }
             wb.dyb = dyb;
             if (dydma) {
                 RR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(dcn_wgrad_win_kernel<9, false, true>),
@@ -2602,7 +2596,6 @@ static int dcn_dgrad_impl(const float *x, const float *offset, const float *mask
         wb.w.tiles_x = rr_cdiv(b.a.Q, WIN_TW);
         wb.dy = dy; wb.dx = dx; wb.doffset = doffset; wb.dmask = dmask;
         wb.dyb = nullptr;
-        { const char *e = getenv("RR_DCN_EXP"); wb.exp = e ? atoi(e) : 0; }
         // two windows live in LDS here (d input in fixed point, input values): the margin is the largest <= the
         // requested one that fits (2 pixels for a 3x3 filter with dilation 1)
         size_t ldsw = 0;

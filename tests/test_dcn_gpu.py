@@ -100,8 +100,18 @@ def test_dcn_bf16_dgrad_equals_fp32_dgrad_on_rounded_operands(shape):
     dy = torch.randn(n, k, h, w, generator=g).bfloat16().float()
     dev = [ops.to_nhwc(t.cuda()) for t in (x, off, mask, wt, dy)]
     ref = ops.dcn_dgrad(*dev, 1, (1, 1), 1, dg, bf16=False)
-    got = ops.dcn_dgrad(*dev, 1, (1, 1), 1, dg, bf16=True)
+    got = ops.dcn_dgrad(*dev, 1, (1, 1), 1, dg, bf16=True)          # rr_dcn_dgrad_bf16_packed: the LDS-DMA sweep (K % 32 == 0)
     for name, a, b in zip(("dx", "doffset", "dmask"), got, ref):
+        scale = b.abs().max().item()
+        assert (a - b).abs().max().item() <= 5e-5 * scale, (name, (a - b).abs().max().item(), scale)
+    # the register-staged sweep (rr_dcn_dgrad_bf16_ws: what layers with other K take) agrees with it
+    saved = ops._DCN_WPACK
+    ops._DCN_WPACK = False
+    try:
+        old = ops.dcn_dgrad(*dev, 1, (1, 1), 1, dg, bf16=True)
+    finally:
+        ops._DCN_WPACK = saved
+    for name, a, b in zip(("dx", "doffset", "dmask"), got, old):
         scale = b.abs().max().item()
         assert (a - b).abs().max().item() <= 5e-5 * scale, (name, (a - b).abs().max().item(), scale)
 
@@ -134,6 +144,11 @@ def test_dcn_bf16_wgrad_equals_gemm_of_rounded_operands(shape):
     got = dw.double() - base.cuda().double()
     scale = ref.abs().max().item()
     assert (got - ref).abs().max().item() <= 3e-5 * scale, ((got - ref).abs().max().item(), scale)
+    # the same through rr_dcn_wgrad_bf16_img: dY's bf16 image feeds the operand by LDS-DMA (K % 32 == 0; other K fall back inside)
+    dwi = ops.to_nhwc(base.cuda())
+    ops.dcn_wgrad(xd, od, md, dyd, dwi, 1, (1, 1), 1, dg, bf16=True, dy_img=ops.bf16_of(dyd))
+    goti = dwi.double() - base.cuda().double()
+    assert (goti - ref).abs().max().item() <= 3e-5 * scale, ((goti - ref).abs().max().item(), scale)
     # and it is the fp32 kernel's result up to the operand rounding
     dw32 = ops.zeros_nhwc(k, c, 3, 3, device="cuda")
     ops.dcn_wgrad(xd, od, md, dyd, dw32, 1, (1, 1), 1, dg)
