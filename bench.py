@@ -314,6 +314,9 @@ def main():
         and bool(torch.isfinite(op.optimizer.fp.flat).all())
     if not finite:
         raise RuntimeError("bench.py: non-finite losses / gradients / parameters after the timed steps")
+    # the loss tensors hold the last step's autograd graph, whose nodes keep what they attached to their ctx by hand (shared
+    # fan-in buffers, bf16 images, parameter references): 20 GiB that counted into the extras' allocator peaks (round 5)
+    last = None
     # host side of a step: time inside train_step() minus the time blocked in its one device->host read (RoI count)
     host_enqueue_ms = (host_s - ops.SYNC_WAIT_S) / a.steps * 1e3
     ops.TIMER = None

@@ -2015,6 +2015,7 @@ __global__ __launch_bounds__(512) void dcn_wgrad_win_kernel(const DcnWinWgradArg
                     *reinterpret_cast<const f32x4 *>(ok ? a.x + (img + (long)gy * a.W + gx) * a.C + c0 + c4 : a.zero);
             }
         }
+        if constexpr (DYDMA)        // (the other variants read them in prepare_finish, which follows at once: no registers to park them)
 #pragma unroll
         for (int i = 0; i < GI; ++i) {
             const int it = t + i * NT;
@@ -2035,7 +2036,8 @@ __global__ __launch_bounds__(512) void dcn_wgrad_win_kernel(const DcnWinWgradArg
         const int tyi = bid % wa.tiles_y;
         const int y0 = tyi * WIN_TH, x0 = txi * WIN_TW;
         const int wy0 = y0 - a.pad_h - wa.RW, wx0 = x0 - a.pad_w - wa.RW;
-#pragma unroll
+        const int n = bid / wa.tiles_y;
+#pragma unroll(DYDMA ? GI : 1)
         for (int i = 0; i < GI; ++i) {
             const int it = t + i * NT;
             if (it >= BM * RS) continue;
@@ -2045,8 +2047,16 @@ __global__ __launch_bounds__(512) void dcn_wgrad_win_kernel(const DcnWinWgradArg
             float flh = 0.f, flw = 0.f, mk = 0.f;
             if (p < a.P && q < a.Q) {
                 const int ti = tap / a.S, tj = tap - ti * a.S;
-                const float h = (float)(p - a.pad_h + ti * a.dil) + g_oh[i];
-                const float w = (float)(q - a.pad_w + tj * a.dil) + g_ow[i];
+                float oh, ow, omk;
+                if constexpr (DYDMA) { oh = g_oh[i]; ow = g_ow[i]; omk = g_mk[i]; }
+                else {
+                    const long m = ((long)n * a.P + p) * a.Q + q;
+                    const float *po = a.offset + m * (2 * a.dg * RS) + g * 2 * RS + 2 * tap;
+                    oh = po[0]; ow = po[1];
+                    omk = a.mask[m * (a.dg * RS) + g * RS + tap];
+                }
+                const float h = (float)(p - a.pad_h + ti * a.dil) + oh;
+                const float w = (float)(q - a.pad_w + tj * a.dil) + ow;
                 if (h > -1.f && w > -1.f && h < (float)a.H && w < (float)a.W) {
                     const float hf = floorf(h), wf = floorf(w);
                     const int h0 = (int)hf, w0 = (int)wf;
@@ -2060,7 +2070,7 @@ __global__ __launch_bounds__(512) void dcn_wgrad_win_kernel(const DcnWinWgradArg
                     const bool fast = ly >= 0 && ly + 1 < wa.WH && lx >= 0 && lx + 1 < wa.WW;
                     packed = (valid << 16) | (fast ? (ly * wa.WW + lx) : GEO_SLOW);
                     flh = h - hf; flw = w - wf;
-                    mk = g_mk[i];
+                    mk = omk;
                 }
             }
             geo4[it] = f32x4{flh, flw, mk, __int_as_float(packed)};

@@ -22,6 +22,18 @@ from .base_operator import BaseOperator
 from .rrnet_operator import RRNetOperator
 
 
+
+def _released(v):
+    """The same values without the autograd graph (recursively through tuples / lists).  backward() has consumed the graph;
+    handing its roots out would keep every node of the step alive until the caller drops them — and with the nodes what they
+    attach to their ctx by hand (shared fan-in buffers, bf16 images, parameter references): 20 GiB at the bench configuration
+    that a training loop holding `losses` until the next step returns would carry through that step's forward."""
+    if torch.is_tensor(v):
+        return v.detach()
+    if isinstance(v, (tuple, list)):
+        return type(v)(_released(x) for x in v)
+    return v
+
 class CenterNetOperator(BaseOperator):
     def __init__(self, cfg):
         self.cfg = cfg
@@ -58,7 +70,7 @@ class CenterNetOperator(BaseOperator):
         loss = hm_loss + (0.1 * wh_loss) + off_loss
         loss.backward()
         self.optimizer.step()
-        return outs, (loss, hm_loss, wh_loss, off_loss)
+        return _released(outs), _released((loss, hm_loss, wh_loss, off_loss))
 
     def training_process(self):
         self.model.train()

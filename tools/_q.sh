@@ -1,3 +1,4 @@
-python -m pytest tests/test_dcn_gpu.py tests/test_bf16_model_gpu.py -m gpu -q -x 2>&1 | tail -2
-python -m pytest tests/test_streams_gpu.py -m gpu -q -x -k "dcn" 2>&1 | tail -2
-python tools/bench_dcn.py 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print({k:v for k,v in d.items() if 'ms' in k})"
+python -m pytest tests/test_helpers_gpu.py tests/test_train_gpu.py tests/test_configs_gpu.py -m gpu -q -x 2>&1 | tail -2
+python tools/bench_config4.py --steps 3 > /dev/null 2>&1
+python tools/bench_config4.py --steps 8 2>&1 | tail -1 | python -c "import json,sys;d=json.loads(sys.stdin.readline());print('c4 dcn',d['value'],d['ms_per_step'],d['allocator'])"
+python tools/bench_config4.py --plain --bf16 --steps 8 2>&1 | tail -1 | python -c "import json,sys;d=json.loads(sys.stdin.readline());print('c4 plain',d['value'],d['ms_per_step'],d['allocator'])"

@@ -37,6 +37,20 @@ def run(batch=8, size=1024, steps=5, dcn=True, backbone="hourglass", bf16=None, 
         gc.collect()                                     # an operator of an earlier run in this process (reference cycles): its
         torch.cuda.empty_cache()                         # tensors would count into this run's peak and fragment its pool
         torch.cuda.reset_peak_memory_stats()             # (the allocator peak reported below is THIS run's, not the process's)
+        base_gib = torch.cuda.memory_allocated() / 2 ** 30   # what the process still holds from earlier workloads
+        if os.environ.get("RR_BENCH_MEMDEBUG") == "1" and base_gib > 0.5:
+            live = {}
+            for o in gc.get_objects():
+                try:
+                    if torch.is_tensor(o) and o.is_cuda:
+                        st = o.untyped_storage()
+                        live[st.data_ptr()] = (st.nbytes(), tuple(o.shape), str(o.dtype))
+                except Exception:
+                    pass
+            for nb, shp, dt in sorted(live.values(), reverse=True)[:25]:
+                print("  live before config 4: %8.1f MiB %s %s" % (nb / 2 ** 20, shp, dt), file=sys.stderr, flush=True)
+            print("  live before config 4: %.2f GiB allocated, %.2f GiB in python-visible tensors" %
+                  (base_gib, sum(v[0] for v in live.values()) / 2 ** 30), file=sys.stderr, flush=True)
         torch.manual_seed(cfg.seed)
         op = RRNetOperator(cfg)                          # the synthetic pool is cached: no host-side regeneration
         op.model.train()
@@ -79,6 +93,7 @@ def run(batch=8, size=1024, steps=5, dcn=True, backbone="hourglass", bf16=None, 
         ms_ = torch.cuda.memory_stats()
         out["allocator"] = {"reserved_GiB": round(ms_["reserved_bytes.all.current"] / 2 ** 30, 2),
                             "allocated_peak_GiB": round(ms_["allocated_bytes.all.peak"] / 2 ** 30, 2),
+                            "held_by_earlier_workloads_GiB": round(base_gib, 2),
                             "segments": ms_["segment.all.current"], "hipMallocs": ms_["num_device_alloc"],
                             "hipFrees": ms_["num_device_free"], "alloc_retries": ms_["num_alloc_retries"]}
         if backbone == "hourglass" and size == 1024:
