@@ -162,7 +162,7 @@ int rr_conv_wgrad_bf16(const float *x, const float *dy, float *dw, int n, int h,
  * IN HBM: x / dy as written by their producers (rr_bn_apply_b16, rr_bn_bwd_apply_b16, rr_to_bf16), the filter's bf16
  * copy (rr_weight_flip_transpose_batch_bf16: plain for the forward, flipped / transposed for the data gradient).  They
  * reach LDS by LDS-DMA; 256 channels x 256 pixels per workgroup on v_mfma_f32_16x16x32_bf16.
- * Shapes: rr_conv16_supported (C % 64 == 0, K % 256 == 0, R*S <= 16, stride 1 or 2; input < 2 GiB); the host layer keeps
+ * Shapes: rr_conv16_supported (C % 64 == 0, K % 128 == 0, R*S <= 16, stride 1 or 2; input < 2 GiB); the host layer keeps
  * the *_bf16 entry points for the rest.  y / dx (fp32) and y16 / dx16 (the same values rounded to bf16, for a consumer
  * that is again a convolution): either may be NULL, not both.  stat_slab: [ceil(M / 256)][2][K] doubles
  * (rr_conv16_stat_slab_bytes), reduced by rr_bn_reduce_slab / rr_bn_stats_finalize like the fp32 kernel's. */
