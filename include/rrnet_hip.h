@@ -582,12 +582,14 @@ int rr_dcn_dgrad_bf16_img(const float *x, const float *offset, const float *mask
  * bf16 inside the call (the forward's [tap][chunk][filter][32] layout), dY comes as the caller's bf16 image (dy_bf16) or is
  * rounded once into the workspace (dy_bf16 NULL).  ws: rr_dcn_dgrad_ws_bytes(n,p,q,c,k,r,s, dy_bf16 != NULL) bytes.
  * Layers the DMA kernel does not take (K % 32 != 0, other filter sizes ...) run rr_dcn_dgrad_bf16_ws's kernel: same results.
+ * accumulate != 0: dx holds another consumer's gradient of x and is added to (the kernels scatter with float atomics; the
+ * zero fill is skipped) — the host layer's shared fan-in buffer, no separate sum pass.
  * Replaces modulated_deformable_col2im(_coord)_cuda + the dcol GEMM (ext/dcn/src/cuda/dcn_v2_cuda.cu:214-259). */
 size_t rr_dcn_dgrad_ws_bytes(int n, int p, int q, int c, int k, int r, int s, int have_dy_bf16);
 int rr_dcn_dgrad_bf16_packed(const float *x, const float *offset, const float *mask, const float *w, const float *dy,
                              const unsigned short *dy_bf16, float *dx, float *doffset, float *dmask, int n, int h, int wd, int c,
-                             int k, int r, int s, int stride, int pad_h, int pad_w, int dilation, int deformable_groups, void *ws,
-                             hipStream_t stream);
+                             int k, int r, int s, int stride, int pad_h, int pad_w, int dilation, int deformable_groups, int accumulate,
+                             void *ws, hipStream_t stream);
 
 /* rr_dcn_dgrad with bf16 matrix operands (dY, W rounded to bf16; fp32 accumulation and scatter): the backward of
  * rr_dcn_fwd_bf16.  Layers the window kernel does not take run rr_dcn_dgrad's fp32 kernel. */

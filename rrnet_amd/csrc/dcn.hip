@@ -2588,7 +2588,7 @@ __global__ __launch_bounds__(256) void dcn_to_bf16_kernel(const f32x4 *src, u16x
 static int dcn_dgrad_impl(const float *x, const float *offset, const float *mask, const float *w, const float *dy,
                           float *dx, float *doffset, float *dmask, int n, int h, int wd, int c, int k, int r, int s,
                           int stride, int pad_h, int pad_w, int dilation, int deformable_groups, int bf16, hipStream_t stream,
-                          unsigned short *dyb = nullptr, bool dyb_ready = false, unsigned short *wpk = nullptr)
+                          unsigned short *dyb = nullptr, bool dyb_ready = false, unsigned short *wpk = nullptr, bool accumulate = false)
 {
     DcnBwdArgs b{};
     const int rc = fill_args(b.a, x, offset, mask, w, n, h, wd, c, k, r, s, stride, pad_h, pad_w, dilation, deformable_groups);
@@ -2596,7 +2596,7 @@ static int dcn_dgrad_impl(const float *x, const float *offset, const float *mask
     RR_CHECK_ARG(k % 4 == 0, "rr_dcn_dgrad: K=%d must be a multiple of 4", k);
     RR_CHECK_ARG((long)n * h * wd < (1l << 31), "rr_dcn_dgrad: input too large");
     b.dy = dy; b.dx = dx; b.doffset = doffset; b.dmask = dmask;
-    hipMemsetAsync(dx, 0, sizeof(float) * (size_t)n * h * wd * c, stream);
+    if (!accumulate) hipMemsetAsync(dx, 0, sizeof(float) * (size_t)n * h * wd * c, stream);     // (every kernel below ADDS into dx with float atomics)
     const int rw = dcn_win_margin();
     if (rw > 0 && stride == 1 && c % 32 == 0 && h < 32768 && wd < 32768 &&
         (deformable_groups == 1 || (c / deformable_groups) % 32 == 0)) {
@@ -2718,7 +2718,7 @@ extern "C" size_t rr_dcn_dgrad_ws_bytes(int n, int p, int q, int c, int k, int r
 extern "C" int rr_dcn_dgrad_bf16_packed(const float *x, const float *offset, const float *mask, const float *w, const float *dy,
                                         const unsigned short *dy_bf16, float *dx, float *doffset, float *dmask, int n, int h,
                                         int wd, int c, int k, int r, int s, int stride, int pad_h, int pad_w, int dilation,
-                                        int deformable_groups, void *ws, hipStream_t stream)
+                                        int deformable_groups, int accumulate, void *ws, hipStream_t stream)
 {
     RR_CHECK_ARG(ws != nullptr, "rr_dcn_dgrad_bf16_packed: workspace required (rr_dcn_dgrad_ws_bytes)");
     unsigned short *wpk = static_cast<unsigned short *>(ws);
@@ -2726,7 +2726,7 @@ extern "C" int rr_dcn_dgrad_bf16_packed(const float *x, const float *offset, con
     unsigned short *dyb = dy_bf16 ? const_cast<unsigned short *>(dy_bf16)
                                   : reinterpret_cast<unsigned short *>(static_cast<unsigned char *>(ws) + wbytes);
     return dcn_dgrad_impl(x, offset, mask, w, dy, dx, doffset, dmask, n, h, wd, c, k, r, s, stride, pad_h, pad_w, dilation,
-                          deformable_groups, 1, stream, dyb, dy_bf16 != nullptr, wpk);
+                          deformable_groups, 1, stream, dyb, dy_bf16 != nullptr, wpk, accumulate != 0);
 }
 
 extern "C" int rr_dcn_split_fwd(const float *om, long m, int third, float *offset, float *mask, hipStream_t stream)

@@ -63,9 +63,10 @@ class DCN(DCNv2):
         self.conv_offset_mask.bias.data.zero_()
 
     def forward(self, input):
-        # `input` has two consumers here (the offset/mask conv and the deformable conv): plain fan-out views, so that a
-        # shared gradient accumulator tagged on `input` by an outer fan-out is not mistaken for a single-consumer tag
-        xa, xb = RF.fanout(input, 2)
+        # `input` has two consumers here (the offset/mask conv and the deformable conv): views of a shared fan-out — both add
+        # their input gradient into ONE buffer inside their kernels (the convolution in its epilogue, the deformable data
+        # gradient through the atomics it scatters with anyway); an outer fan-out's accumulator on `input` is joined
+        xa, xb, _acc = RF.fanout_shared(input, 2)
         # the offset / mask conv runs on the MFMA conv kernels.  Its 3 * dg * kh * kw output channels (27 for a 3x3) are
         # not a multiple of 4, which would put its two gradients on the scalar-gather kernels (28 ms per config-4 step
         # for the six head layers): the filter bank is zero-padded to the next multiple of 4 and the extra channel

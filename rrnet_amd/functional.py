@@ -1014,14 +1014,30 @@ def differentiable_proposals(wh, offset, rois, roi_pix):
 # ---------------------------------------------------------------------------------------------
 # DCNv2 (ext/dcn/dcn_v2.py:16-52)
 # ---------------------------------------------------------------------------------------------
+def _acc_publish(acc, g):
+    """A non-convolution contributor's gradient g of a fanned-out tensor -> what to hand autograd: g itself when it is the
+    first (it becomes the shared buffer), None after adding it to the buffer otherwise.  (The caller has taken itself off
+    acc.pending.)"""
+    if acc.buf is None:
+        acc.buf = g
+        acc.end(g.device)
+        return g
+    acc.begin(g.device)
+    ops.amax_drop(acc.buf)
+    acc.buf.add_(g)
+    acc.end(g.device)
+    return None
+
+
 class _DCNv2(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, input, offset, mask, weight, bias, stride, padding, dilation, deformable_groups, bf16=False):
+    def forward(ctx, input, offset, mask, weight, bias, stride, padding, dilation, deformable_groups, bf16=False, x_acc=None):
         x, off, m, w = ops.to_nhwc(input), ops.to_nhwc(offset), ops.to_nhwc(mask), ops.to_nhwc(weight)
         ctx.cfg = (int(stride), tuple(padding), int(dilation), int(deformable_groups))
         ctx.save_for_backward(x, off, m, w)
         ctx.params = (weight, bias)
         ctx.bf16 = bool(bf16)
+        ctx.x_acc = x_acc                  # shared fan-in buffer of input's fan-out (dcn_v2_conv registered this node as a contributor)
         return ops.dcn_fwd(x, off, m, w, bias, *ctx.cfg, bf16=bf16)
 
     @staticmethod
@@ -1051,7 +1067,21 @@ class _DCNv2(torch.autograd.Function):
                     ops.dcn_wgrad(x, off, m, dy, dw, stride, pad, dil, dg, bf16=bf, dy_img=img)
             else:
                 ops.dcn_wgrad(x, off, m, dy, dw, stride, pad, dil, dg, bf16=bf, dy_img=img)
-            dx, doff, dmask = ops.dcn_dgrad(x, off, m, w, dy, stride, pad, dil, dg, bf16=bf)
+            x_acc = ctx.x_acc
+            if x_acc is None:
+                dx, doff, dmask = ops.dcn_dgrad(x, off, m, w, dy, stride, pad, dil, dg, bf16=bf)
+            else:
+                # input's fan-out shares one gradient buffer among its consumers (GradAcc): the first to run publishes its
+                # gradient there, the others add into it — here inside the kernel, whose scatter is float atomics anyway
+                x_acc.pending -= 1
+                if x_acc.buf is not None and ops.dcn_dgrad_accumulates(bf):
+                    x_acc.begin(dy.device)
+                    _, doff, dmask = ops.dcn_dgrad(x, off, m, w, dy, stride, pad, dil, dg, bf16=bf, out=x_acc.buf)
+                    x_acc.end(dy.device)
+                    dx = None
+                else:
+                    dx, doff, dmask = ops.dcn_dgrad(x, off, m, w, dy, stride, pad, dil, dg, bf16=bf)
+                    dx = _acc_publish(x_acc, dx)
             if side is not None:
                 cur.wait_stream(side)
         else:
@@ -1065,6 +1095,9 @@ class _DCNv2(torch.autograd.Function):
             del col
             dcol = ops.conv_dgrad(dy1, w1, (1, r * s * c, mtot, 1), 1, (0, 0))
             dx, doff, dmask = ops.dcn_col2im(x, off, m, dcol, r, s, stride, pad, dil, dg)
+            if ctx.x_acc is not None:
+                ctx.x_acc.pending -= 1
+                dx = _acc_publish(ctx.x_acc, dx)
         if w_t is not None:
             _mark(weight)
         db = None
@@ -1075,7 +1108,7 @@ class _DCNv2(torch.autograd.Function):
             db = None if b_t is not None else tgt
             if b_t is not None:
                 _mark(bias)
-        return dx, doff, dmask, (None if w_t is not None else dw), db, None, None, None, None, None
+        return dx, doff, dmask, (None if w_t is not None else dw), db, None, None, None, None, None, None
 
 
 class _DCNSplit(torch.autograd.Function):
@@ -1153,5 +1186,11 @@ def dcn_v2_conv(input, offset, mask, weight, bias, stride, padding, dilation, de
     st = stride if isinstance(stride, int) else stride[0]
     dl = dilation if isinstance(dilation, int) else dilation[0]
     pd = (padding, padding) if isinstance(padding, int) else tuple(padding)
+    x_acc = getattr(input, "_rr_acc", None)      # input is a view of a shared fan-out (fanout_shared): contribute to its buffer
+    if x_acc is not None:
+        if torch.is_grad_enabled() and input.requires_grad:
+            x_acc.pending += 1
+        else:
+            x_acc = None
     return _DCNv2.apply(input, offset, mask, weight, bias, st, pd, dl, deformable_groups,
-                        DCN_BF16 if bf16 is None else bool(bf16))
+                        DCN_BF16 if bf16 is None else bool(bf16), x_acc)

@@ -410,6 +410,12 @@ def phantom_f32(shape, device, image):
     return t
 
 
+def wgrad_16bit_shape(c, k, r, s):
+    """Layer shapes whose weight gradient leaves the fp32 kernel when a 16-bit arithmetic is on (conv_wgrad's dispatch; the
+    kernel audit mirrors it)."""
+    return c > 32 and (k > 32 or (k >= 16 and r * s >= 9))
+
+
 def dgrad16_takes(dy_shape, w_shape, x_shape, stride, pad, relu_bias_link=False):
     """True when conv_dgrad(dy, w, x_shape, ...) will go to rr_conv16_dgrad_s1 (mirrors the dispatch there)."""
     n, c, h, wd = x_shape
@@ -836,7 +842,9 @@ def conv_wgrad(x, dy, dw, stride=1, pad=(0, 0), explicit_out=False, algo_c=None)
                                                          _C.stream()), (n, h, wd, c, k, r, s, stride)), "rr_conv16_wgrad")
         return dw
     x, dy = f32_of(x), f32_of(dy)            # (bf16-only operands in front of a layer the conv16 weight gradient does not take)
-    bf = _bf16_ok(c, k, r, s, x, dy, pixels=npix) if (c > 32 and k > 32) else 0
+    # (narrow filter banks stay on the fp32 kernel's 32-filter tiles — except 3x3 banks of 16..32 filters, the DCN offset / mask
+    #  convolution's 28: measured 1.20 ms fp32 against 0.54 ms on the bf16 kernel's 128-wide tile at the config-4 layer)
+    bf = _bf16_ok(c, k, r, s, x, dy, pixels=npix) if wgrad_16bit_shape(c, k, r, s) else 0
     f = _C.fn(("rr_conv_wgrad", "rr_conv_wgrad_bf16", "rr_conv_wgrad_f16x3")[bf])
     wtail = (_C.ptr(amax_of(x)), _C.ptr(amax_of(dy)), _C.stream()) if bf == MATH_F16X3 else (_C.stream(),)
     _C.check(_timed("conv_wgrad<BN=%d>%s" % (128 if c > 32 else 32, ("", "+bf16", "+f16x3")[bf]), flops,
@@ -1485,13 +1493,22 @@ def dcn_wgrad(x, offset, mask, dy, dw, stride, pad, dilation, dg, bf16=False, dy
     return dw
 
 
-def dcn_dgrad(x, offset, mask, w, dy, stride, pad, dilation, dg, bf16=False):
+def dcn_dgrad_accumulates(bf16):
+    """True when dcn_dgrad(..., out=buf) adds into buf inside the kernel (the LDS-DMA data gradient of the bf16 path)."""
+    return bool(bf16 and _DCN_DYB and _DCN_WPACK)
+
+
+def dcn_dgrad(x, offset, mask, w, dy, stride, pad, dilation, dg, bf16=False, out=None):
     """-> dx, doffset, dmask; the column gradient never leaves the MFMA accumulators / LDS.  bf16: bf16 matrix operands
     (dY, W) and d input pre-summed in an LDS window before the global atomics (rr_dcn_dgrad_bf16)."""
     assert is_nhwc(x) and is_nhwc(offset) and is_nhwc(mask) and is_nhwc(dy) and is_nhwc(w)
     n, c, h, wd = x.shape
     k, _, r, s = w.shape
-    dx = empty_nhwc(n, c, h, wd, x.device)
+    # out: a buffer that already holds another consumer's gradient of x — d input is ADDED to it (dcn_dgrad_accumulates only)
+    assert out is None or (dcn_dgrad_accumulates(bf16) and is_nhwc(out) and tuple(out.shape) == tuple(x.shape))
+    dx = out if out is not None else empty_nhwc(n, c, h, wd, x.device)
+    if out is not None:
+        amax_drop(out)                # an existing tensor added into through its pointer
     doff = torch.empty_like(offset)
     dmask = torch.empty_like(mask)
     assert doff.stride() == offset.stride() and dmask.stride() == mask.stride()
@@ -1505,8 +1522,8 @@ def dcn_dgrad(x, offset, mask, w, dy, stride, pad, dilation, dg, bf16=False):
                          dtype=torch.uint8, device=x.device)
         _C.check(_C.fn("rr_dcn_dgrad_bf16_packed")(_C.ptr(x), _C.ptr(offset), _C.ptr(mask), _C.ptr(w), _C.ptr(dy),
                                                    _C.ptr(img) if img is not None else None, _C.ptr(dx), _C.ptr(doff), _C.ptr(dmask),
-                                                   n, h, wd, c, k, r, s, stride, pad[0], pad[1], dilation, dg, _C.ptr(ws),
-                                                   _C.stream()), "rr_dcn_dgrad_bf16_packed")
+                                                   n, h, wd, c, k, r, s, stride, pad[0], pad[1], dilation, dg, int(out is not None),
+                                                   _C.ptr(ws), _C.stream()), "rr_dcn_dgrad_bf16_packed")
         return dx, doff, dmask
     if img is not None:
         # dY's producer already left its bf16 image (the heads' 1x1 data gradient): no conversion pass

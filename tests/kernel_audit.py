@@ -320,7 +320,8 @@ def audit(tol=2e-5, tol_wgrad=2e-4, sample=False, ref_device="cpu"):
 
     def conv_wgrad(x, dy, dw, stride=1, pad=(0, 0), explicit_out=False, algo_c=None):
         sig = (tuple(x.shape), tuple(dy.shape), tuple(dw.shape), stride, tuple(pad), explicit_out)
-        qq = ops._bf16_ok(x.shape[1], dy.shape[1], dw.shape[2], dw.shape[3], x, dy) and x.shape[1] > 32 and dy.shape[1] > 32
+        qq = ops._bf16_ok(x.shape[1], dy.shape[1], dw.shape[2], dw.shape[3], x, dy) and \
+            ops.wgrad_16bit_shape(x.shape[1], dy.shape[1], dw.shape[2], dw.shape[3])
         if qq:
             sig = sig + ("bf16",)
         check = ("wgrad",) + sig not in rec.seen and not explicit_out
