@@ -182,11 +182,12 @@ __global__ __launch_bounds__(EW_THREADS) void bn_apply_kernel(const f32x4 *y, co
 // per-channel sums of dy and dy*xhat, dy = dz * (z > 0 if z given).  Each workgroup walks a slice of
 // the pixels with a fixed channel quad per thread, reduces over its pixel lanes in LDS and adds one
 // double per channel per workgroup to sums[2][C].
+template <bool IMG>      // IMG: y (and z, when given) come as bf16 images — the batched-load main loop below
 __global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_kernel(const float *dz, const float *z, const float *y,
                                                                    const float *mean, const float *invstd,
                                                                    const float *mscale, const float *mshift,
-                                                                   double *sums, long npix, int C, const unsigned short *z16 = nullptr,
-                                                                   const unsigned short *y16 = nullptr)
+                                                                   double *sums, long npix, int C, const unsigned short *z16,
+                                                                   const unsigned short *y16)
 {
     __shared__ double red[2][EW_THREADS * 4];
     const int C4 = C / 4;                      // <= EW_THREADS (checked by the launcher)
@@ -204,6 +205,37 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_kernel(const float *
         const long step = (long)gridDim.x * lanes;
         for (long p0 = (long)blockIdx.x * lanes + pl; p0 < npix; p0 += step * 8) {
             f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+            if (IMG && p0 + 7 * step < npix) {
+                // all eight pixels exist: every load first, then the arithmetic.  With the bounds test around each pixel the
+                // compiler kept ONE pixel's loads in flight per wave — enough for 16-byte fp32 loads (5.1 TB/s), not for the
+                // 8-byte image loads of the bf16-only tensors (same 0.31 ms for two thirds of the bytes; round 5)
+                f32x4 gv[8];
+                u16x4 yv[8], zv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const long off = (p0 + u * step) * C + cq * 4;
+                    gv[u] = *reinterpret_cast<const f32x4 *>(dz + off);
+                    yv[u] = *reinterpret_cast<const u16x4 *>(y16 + off);
+                    if (z16) zv[u] = *reinterpret_cast<const u16x4 *>(z16 + off);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    f32x4 g = gv[u];
+                    const f32x4 yy = from_bf16x4(yv[u]);
+                    if (z16) {
+                        const f32x4 zz = from_bf16x4(zv[u]);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) g[e] = zz[e] > 0.f ? g[e] : 0.f;
+                    } else if (mscale) {
+                        const f32x4 zz = rr_bn_affine4(yy, msc, msh);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) g[e] = zz[e] > 0.f ? g[e] : 0.f;
+                    }
+                    const f32x4 xh = (yy - mu) * is;
+                    s1 += g;
+                    s2 += g * xh;
+                }
+            } else
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const long p = p0 + u * step;
@@ -861,8 +893,12 @@ extern "C" int rr_bn_bwd_reduce_b16(const float *dz, const float *z, const unsig
     const long cap = npix >= 400000 ? 1024 : (npix >= 16384 ? 512 : 256);
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((int)blocks), dim3(EW_THREADS), 0, stream, dz, z, y, mean, invstd, mask_scale, mask_shift,
-                       sums, npix, c, z16, y16);
+    if (y16 != nullptr && z == nullptr)       // (the ReLU mask from its image, from y, or none)
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3((int)blocks), dim3(EW_THREADS), 0, stream, dz, z, y, mean, invstd, mask_scale,
+                           mask_shift, sums, npix, c, z16, y16);
+    else
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3((int)blocks), dim3(EW_THREADS), 0, stream, dz, z, y, mean, invstd, mask_scale,
+                           mask_shift, sums, npix, c, z16, y16);
     RR_CHECK_LAUNCH("rr_bn_bwd_reduce_b16");
     return RR_OK;
 }
@@ -906,8 +942,8 @@ extern "C" int rr_bn_bwd_reduce(const float *dz, const float *z, const float *y,
     const long cap = npix >= 400000 ? 1024 : (npix >= 16384 ? 512 : 256);
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((int)blocks), dim3(EW_THREADS), 0, stream, dz, z, y, mean, invstd, mask_scale,
-                       mask_shift, sums, npix, c);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3((int)blocks), dim3(EW_THREADS), 0, stream, dz, z, y, mean, invstd, mask_scale,
+                       mask_shift, sums, npix, c, (const unsigned short *)nullptr, (const unsigned short *)nullptr);
     RR_CHECK_LAUNCH("rr_bn_bwd_reduce");
     return RR_OK;
 }

@@ -1,3 +1,4 @@
-python -m pytest tests/test_dcn_gpu.py tests/test_bf16_model_gpu.py tests/test_conv_bf16_gpu.py -m gpu -q -x 2>&1 | tail -2
-python tools/bench_config4.py --steps 3 > /dev/null 2>&1
-for i in 1 2; do python tools/bench_config4.py --steps 8 2>&1 | tail -1 | python -c "import json,sys;d=json.loads(sys.stdin.readline());print('c4 dcn',d['value'],d['ms_per_step'],d['allocator']['allocated_peak_GiB'])"; done
+python -m pytest tests/test_model_gpu.py tests/test_conv16_gpu.py tests/test_bf16_model_gpu.py -m gpu -q -x 2>&1 | tail -2
+python tools/bench_config4.py --plain --bf16 --steps 3 > /dev/null 2>&1
+for i in 1 2; do python tools/bench_config4.py --plain --bf16 --steps 8 2>&1 | tail -1 | python -c "import json,sys;d=json.loads(sys.stdin.readline());print('c4 plain',d['value'],d['ms_per_step'])"; done
+python tools/bench_config4.py --steps 8 2>&1 | tail -1 | python -c "import json,sys;d=json.loads(sys.stdin.readline());print('c4 dcn',d['value'],d['ms_per_step'])"
