@@ -508,7 +508,11 @@ __global__ __launch_bounds__(512) void dcn_fprop_win_kernel(const DcnWinArgs wa)
         // far corners inline, the wait for those (rare) loads sat behind the join — an unconditional s_waitcnt vmcnt(0) in
         // the middle of every K-step, which also waited for the weight tile's DMA issued just before (in-order counter):
         // 1.62 -> 1.44 ms at the bench layer (round 5).  (Tried and dropped: a ring of three weight images filled two steps
-        // ahead by inline-assembly DMA — 1.54 ms; the step is bound by the gather's LDS traffic, not by the tile's latency.)
+        // ahead by inline-assembly DMA — 1.54 ms; and producer / consumer waves (four waves gather + blend + DMA, four waves MFMA on
+        // 64 x 128 tiles) — 1.52 ms: on this part one wave's MFMAs and another wave's VALU work on the same SIMD do not overlap,
+        // the two roles' times add, as the split-operand kernels found in round 4.  Of the 1.44 ms about 0.5 are
+        // not the K-steps: window fetch / store 0.27, output stores 0.17, geometry 0.03 (variant builds); workgroup turnover itself
+        // is nothing — 4096 workgroups of this shape with 88 barriers each take 0.10 ms in all, tools/wg_turnover_probe.hip.)
         if (__builtin_amdgcn_ballot_w64(((gof[0] | gof[1] | gof[2] | gof[3]) & 0x80000000u) != 0) == 0) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v += gxl[e] * gwt[e];
