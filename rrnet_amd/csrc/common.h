@@ -39,7 +39,35 @@ void rr_set_error(const char *fmt, ...);
         }                                                                  \
     } while (0)
 
+typedef float rr_f32x4_fwd __attribute__((ext_vector_type(4)));
 static inline int rr_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// Zero fill of one or two buffers in ONE launch.  hipMemsetAsync turns into three to four tiny runtime kernels per call
+// (fillBufferAligned + copyBuffer: 607 of them for the 165 fills of a train step, rocprofv3); the split-K layers zero their
+// output and their statistics slab in front of every launch.  16-byte multiples take the kernel, anything else the runtime.
+static __global__ __launch_bounds__(256) void rr_zero2_kernel(rr_f32x4_fwd *a, long na, rr_f32x4_fwd *b, long nb)
+{
+    const rr_f32x4_fwd z = {0.f, 0.f, 0.f, 0.f};
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < na; i += stride) a[i] = z;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nb; i += stride) b[i] = z;
+}
+static inline hipError_t rr_zero2(void *a, size_t abytes, void *b, size_t bbytes, hipStream_t stream)
+{
+    if (b == nullptr) bbytes = 0;
+    if ((abytes | bbytes) % 16 != 0 || (reinterpret_cast<size_t>(a) | reinterpret_cast<size_t>(b)) % 16 != 0) {
+        hipError_t e = abytes ? hipMemsetAsync(a, 0, abytes, stream) : hipSuccess;
+        if (e == hipSuccess && bbytes) e = hipMemsetAsync(b, 0, bbytes, stream);
+        return e;
+    }
+    const long na = (long)(abytes / 16), nb = (long)(bbytes / 16);
+    if (na + nb == 0) return hipSuccess;
+    long blocks = (na + nb + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(rr_zero2_kernel, dim3((int)blocks), dim3(256), 0, stream, static_cast<rr_f32x4_fwd *>(a), na,
+                       static_cast<rr_f32x4_fwd *>(b), nb);
+    return hipGetLastError();
+}
 
 // y*scale + shift of a BatchNorm layer as ONE explicit fma.  The forward (bn_apply), the two backward passes that recompute
 // the ReLU mask from y instead of reading z (bn_bwd_reduce / bn_bwd_apply) and the data-gradient epilogue that carries the

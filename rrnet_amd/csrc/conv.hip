@@ -1422,7 +1422,10 @@ static int fprop_impl(const float *x, const float *w, const float *bias, float *
     }
     if (ks > 1) {
         a.ksplit = ks;
-        if (!accumulate) hipMemsetAsync(y, 0, sizeof(float) * (size_t)M * k, stream);
+        // the split-K destination and (filled by colstats_kernel after the launch) the statistics slab: one zero-fill launch
+        const bool zslab = stat_slab != nullptr && bs == nullptr;
+        RR_CHECK_HIP(rr_zero2(accumulate ? nullptr : y, accumulate ? 0 : sizeof(float) * (size_t)M * k, zslab ? stat_slab : nullptr,
+                              zslab ? rr_conv_stat_slab_bytes(n, a.DH, a.DW, k) : 0, stream), "rr_conv_fprop");
     }
     // The epilogue reads the producer's tensors through buffer descriptors with the row inside the tile in the SCALAR offset,
     // which the hardware's range check does not cover: in a partial last tile it would read up to 11 rows past the end of
@@ -1441,7 +1444,6 @@ static int fprop_impl(const float *x, const float *w, const float *bias, float *
         return rr_bn_bwd_reduce(y, bs->z, bs->y, bs->mean, bs->invstd, bs->msc, bs->msh, bs->sums, M, k, 1, stream);
     }
     if (rc == RR_OK && ks > 1 && stat_slab != nullptr) {
-        hipMemsetAsync(stat_slab, 0, rr_conv_stat_slab_bytes(n, a.DH, a.DW, k), stream);
         const int lanes = 256 / (k / 4);
         int sblocks = rr_cdiv(M, (long)lanes * 8);
         if (sblocks > 256) sblocks = 256;
@@ -1668,7 +1670,7 @@ extern "C" int rr_conv_dgrad(const float *dy, const float *w, float *dx, int n, 
         int live = 4;
         while (live > 1 && taps[ord[live - 1]] == 0) --live;
         if (live < 4) {
-            if (!accumulate) hipMemsetAsync(dx, 0, sizeof(float) * (size_t)M * c, stream);
+            if (!accumulate) RR_CHECK_HIP(rr_zero2(dx, sizeof(float) * (size_t)M * c, nullptr, 0, stream), "rr_conv_dgrad");
             gy = live;
         }
         blocks = rr_cdiv((long)n * ((h + 1) / 2) * ((wd + 1) / 2), BM) * rr_cdiv(c, bn);
@@ -1677,7 +1679,7 @@ extern "C" int rr_conv_dgrad(const float *dy, const float *w, float *dx, int n, 
     int ks = a.parity ? 1 : pick_ksplit(blocks * gy, nk);
     if (ks > 1) {
         a.ksplit = ks;
-        if (!accumulate) hipMemsetAsync(dx, 0, sizeof(float) * (size_t)M * c, stream);
+        if (!accumulate) RR_CHECK_HIP(rr_zero2(dx, sizeof(float) * (size_t)M * c, nullptr, 0, stream), "rr_conv_dgrad");
     }
     return launch_igemm<1>(a, bn, scalar, blocks, gy, ks, stream, "rr_conv_dgrad");
 }

@@ -756,7 +756,10 @@ int fprop_impl(const float *x, const float *w, const float *bias, float *y, doub
     if (om != nullptr) ks = 1;       // (the zero fill of a split-K destination would wipe the other parity classes)
     if (ks > 1) {
         a.ksplit = ks;
-        if (!accumulate) RR_CHECK_HIP(hipMemsetAsync(y, 0, sizeof(float) * (size_t)M * k, stream), "rr_conv_fprop_bf16");
+        // the split-K destination and (filled by colstats_bf16_kernel after the launch) the statistics slab: one zero-fill launch
+        const bool zslab = stat_slab != nullptr && bs == nullptr;
+        RR_CHECK_HIP(rr_zero2(accumulate ? nullptr : y, accumulate ? 0 : sizeof(float) * (size_t)M * k, zslab ? stat_slab : nullptr,
+                              zslab ? rr_conv_stat_slab_bytes(n, a.DH, a.DW, k) : 0, stream), "rr_conv_fprop_bf16");
     }
     const bool tiles_full = M % BM == 0;
     RR_CHECK_ARG(bs == nullptr || !bs->relu_bias || tiles_full, "rr_conv_dgrad_s1_relubias_bf16: N*H*W = %ld must be a multiple of 128", M);
@@ -807,7 +810,6 @@ int fprop_impl(const float *x, const float *w, const float *bias, float *y, doub
         return rr_bn_bwd_reduce(y, bs->z, bs->y, bs->mean, bs->invstd, bs->msc, bs->msh, bs->sums, M, k, 1, stream);
     }
     if (rc == RR_OK && ks > 1 && stat_slab != nullptr) {
-        RR_CHECK_HIP(hipMemsetAsync(stat_slab, 0, rr_conv_stat_slab_bytes(n, a.DH, a.DW, k), stream), "rr_conv_fprop_bf16");
         const int lanes = 256 / (k / 4);
         int sblocks = rr_cdiv(M, (long)lanes * 8);
         if (sblocks > 256) sblocks = 256;

@@ -38,3 +38,13 @@ for e in sorted(ev, key=lambda e: -e.device_time_total)[:12]:
     while q is not None and len(chain) < 6:
         chain.append(q.name[:60]); q = q.cpu_parent
     print("%-14s %8.1f us  %s  <- %s" % (e.name, e.device_time_total, e.input_shapes, " <- ".join(chain)))
+# device-side memcpys of the step (hipMemcpyAsync: recorded as their own events) and the op that issued each
+mc = collections.Counter()
+for e in prof.events():
+    if "emcpy" in e.name or "emset" in e.name:
+        chain, q = [], e.cpu_parent
+        while q is not None and len(chain) < 5:
+            chain.append(q.name[:48]); q = q.cpu_parent
+        mc[(e.name[:30], " <- ".join(chain))] += 1
+for k, v in mc.most_common(20):
+    print("memcpy/memset x%4d  %s  <- %s" % (v, k[0], k[1]))
