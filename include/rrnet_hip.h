@@ -183,7 +183,7 @@ int rr_conv16_dgrad_s1_relumask(const unsigned short *dy, const unsigned short *
 int rr_conv16_dgrad_s2(const unsigned short *dy, const float *w, float *dx, int n, int h, int wd, int c, int k, int r, int s,
                        int pad_h, int pad_w, int accumulate, unsigned short *wsub, hipStream_t stream);
 /* dw [k][r][s][c] fp32 += x (*) dy, both bf16 (rr_conv_wgrad's contract on bf16-rounded operands; fp32 atomics).
- * Shapes: rr_conv16_wgrad_supported (K % 256 == 0, C % 128 == 0, stride 1 or 2; tensors < 2 GiB). */
+ * Shapes: rr_conv16_wgrad_supported (K % 128 == 0 — the last 256-filter tile may run half empty —, C % 128 == 0, stride 1 or 2; tensors < 2 GiB). */
 int rr_conv16_wgrad_supported(int c, int k, int r, int s, int stride);
 int rr_conv16_wgrad(const unsigned short *x, const unsigned short *dy, float *dw, int n, int h, int wd, int c, int k,
                     int r, int s, int stride, int pad_h, int pad_w, hipStream_t stream);

@@ -426,7 +426,8 @@ __global__ __launch_bounds__(512, 1) void conv16_wgrad_kernel(const WArgs a)
         for (int j = 0; j < 2; ++j) {
             const long m = (long)st * 32 + j * 16 + (lane >> 2);
             const unsigned okm = (unsigned)live & (unsigned)(m < a.M);
-            const unsigned offa = okm ? (unsigned)((m * a.K + ko0 + wave * 32 + chunk * 8) * 2) : OOB;
+            // (K % 256 == 128: the last filter tile is half empty — its waves' dY blocks read zeros, their MFMAs are skipped below)
+            const unsigned offa = (okm && ko0 + wave * 32 < a.K) ? (unsigned)((m * a.K + ko0 + wave * 32 + chunk * 8) * 2) : OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_dy, (lds_void *)(A + wave * 2048 + j * 1024), 16, offa, 0, 0, 0);
             const int ih = pp[j] * a.stride - a.pad_h + r, iw = pq[j] * a.stride - a.pad_w + s;
             const unsigned okx = okm & (unsigned)((unsigned)ih < (unsigned)a.H) & (unsigned)((unsigned)iw < (unsigned)a.W);
@@ -455,6 +456,7 @@ __global__ __launch_bounds__(512, 1) void conv16_wgrad_kernel(const WArgs a)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+    const bool k_live = ko0 + wk * 64 < a.K;         // this wave's 64 filters exist (K is a multiple of 128)
     issue(st_begin, 0);
     issue(st_begin + 1, 1);
     for (int st = st_begin; st < st_end; ++st) {
@@ -465,6 +467,7 @@ __global__ __launch_bounds__(512, 1) void conv16_wgrad_kernel(const WArgs a)
         else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         const unsigned char *A = lds + stage * STAGE, *B = A + A_BYTES;
+        if (!k_live) continue;                       // (wave-uniform; the wave still issued its pieces and met the barrier)
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             bf16x8 fa[2], fb[TN];
@@ -487,7 +490,7 @@ __global__ __launch_bounds__(512, 1) void conv16_wgrad_kernel(const WArgs a)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int ko = ko0 + (wk * 2 + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                unsafeAtomicAdd(a.dw + ((long)ko * RS + tap) * a.C + c, acc[i][j][e]);
+                if (ko < a.K) unsafeAtomicAdd(a.dw + ((long)ko * RS + tap) * a.C + c, acc[i][j][e]);
             }
     }
 }
@@ -602,7 +605,7 @@ int rr_conv16_dgrad_s2(const unsigned short *dy, const float *w, float *dx, int 
 
 int rr_conv16_wgrad_supported(int c, int k, int r, int s, int stride)
 {
-    return k % 256 == 0 && c % 128 == 0 && r * s <= 64 && (stride == 1 || stride == 2);
+    return k % 128 == 0 && c % 128 == 0 && r * s <= 64 && (stride == 1 || stride == 2);     // (K % 256 == 128: the last 256-filter tile runs half empty)
 }
 
 int rr_conv16_wgrad(const unsigned short *x, const unsigned short *dy, float *dw, int n, int h, int wd, int c, int k,
@@ -619,7 +622,7 @@ int rr_conv16_wgrad(const unsigned short *x, const unsigned short *dy, float *dw
     a.M = n * a.P * a.Q;
     RR_CHECK_ARG((long)a.M * k * 2 < (1l << 31) && (long)n * h * wd * c * 2 < (1l << 31), "rr_conv16_wgrad: tensor beyond 2 GiB");
     const int nt_w = c % 256 == 0 ? 256 : 128;
-    a.kt = k / 256;
+    a.kt = rr_cdiv(k, 256);
     a.nt = c / nt_w;
     const int tiles = a.kt * a.nt * r * s;
     const int total_steps = rr_cdiv(a.M, 32);
