@@ -47,6 +47,16 @@ def main():
         out["reduce_b16"] = {"ms": round(ms, 4), "GBps": round(el * 8 / ms / 1e6, 1), "bytes_per_element": 8}
         ms = _t(lambda: ops.bn_bwd_apply(dz, zp, yp, mean, invstd, gamma, sums, float(n * h * w), bf16_only=True))
         out["apply_b16"] = {"ms": round(ms, 4), "GBps": round(el * 10 / ms / 1e6, 1), "bytes_per_element": 10}
+    scale, shift = torch.ones(c, device="cuda"), torch.zeros(c, device="cuda")
+    ms = _t(lambda: ops.bn_apply(y, scale, shift, relu=True))
+    out["fwd_apply_fp32"] = {"ms": round(ms, 4), "GBps": round(el * 8 / ms / 1e6, 1), "bytes_per_element": 8}
+    with ops.bf16_scope(True):
+        yp = ops.phantom_f32((n, c, h, w), y.device, ops.bf16_of(y))
+        ms = _t(lambda: ops.bn_apply(yp, scale, shift, relu=True, bf16_only=True))
+        out["fwd_apply_b16"] = {"ms": round(ms, 4), "GBps": round(el * 4 / ms / 1e6, 1), "bytes_per_element": 4}
+        rp = ops.phantom_f32((n, c, h, w), y.device, ops.bf16_of(z))
+        ms = _t(lambda: ops.bn_apply(yp, scale, shift, residual=rp, relu=True, bf16_only=True))
+        out["fwd_apply_res_b16"] = {"ms": round(ms, 4), "GBps": round(el * 6 / ms / 1e6, 1), "bytes_per_element": 6}
     print(json.dumps(out))
 
 
