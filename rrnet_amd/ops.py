@@ -630,6 +630,10 @@ class BnLink:
 
 
 _DGRAD_BNSUM = os.environ.get("RR_DGRAD_BNSUM", "1") != "0"
+# the same inside csrc/conv16.hip's data gradient (rr_conv16_dgrad_s1_bnsum, round 5): built, parity-tested, and OFF — with one
+# workgroup per CU the epilogue's image reads are in the open: config-4 step 111.8-113.3 ms with it against 108.9-110.8 ms with the
+# separate rr_bn_bwd_reduce_b16 pass (0.20 ms at the largest layer), back to back on one box
+_CONV16_BNSUM = os.environ.get("RR_CONV16_BNSUM", "0") == "1"
 # measured at 8 x 256 x 256 x 256 (tools/bench_head_dgrad.py): K = 10: 0.23 ms against 0.40, K = 2: 0.22 against 0.39; K = 34 (the WH head: 144 filter
 # registers per lane, two waves per SIMD): 0.58 against 0.48 — that layer stays on the implicit-GEMM kernel
 _HEAD_DGRAD_MAX_K = int(os.environ.get("RR_HEAD_DGRAD_MAX_K", "12"))
@@ -668,9 +672,15 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False,
     else:
         amax_drop(out)                # an existing tensor rewritten / added into through its pointer
     assert is_nhwc(out)
-    if bnsum is not None and not bnsum.relu_bias and bnsum.y is not None and is_phantom(bnsum.y):
+    # conv16's data gradient carries a BatchNorm producer's backward sums itself, reading y / z as fp32 or as their bf16 images
+    sum16 = (_CONV16_BNSUM and bnsum is not None and not bnsum.relu_bias and _DGRAD_BNSUM and bnsum.y is not None and stride == 1
+             and pad[0] < r and pad[1] < s and conv16_ok(k, c, r, s, 1, n * h * wd, dy, out) and (n * h * wd) % 256 == 0
+             and tuple(bnsum.y.shape) == tuple(out.shape) and (is_phantom(bnsum.y) or is_nhwc(bnsum.y))
+             and (not bnsum.use_z or (bnsum_z is not None and tuple(bnsum_z.shape) == tuple(out.shape)
+                                      and (is_phantom(bnsum_z) or is_nhwc(bnsum_z)))))
+    if bnsum is not None and not sum16 and not bnsum.relu_bias and bnsum.y is not None and is_phantom(bnsum.y):
         bnsum = None                  # the producer's pre-BN output exists only as a bf16 image: it runs its own reduce pass
-    if bnsum is not None and bnsum_z is not None and is_phantom(bnsum_z):
+    if bnsum is not None and not sum16 and bnsum_z is not None and is_phantom(bnsum_z):
         # the producer's output exists only as a bf16 image: the fp32-reading epilogues cannot take their mask from it — a ReLU /
         # bias producer gets the widened copy, a BatchNorm producer runs its own reduce pass (rr_bn_bwd_reduce_b16)
         if bnsum.relu_bias:
@@ -752,6 +762,22 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False,
                 _C.check(_C.fn("rr_weight_flip_transpose")(_C.ptr(w), _C.ptr(wt), k, c, r, s, _C.stream()), "rr_weight_flip_transpose")
             wt16 = torch.empty(wt.numel(), dtype=torch.bfloat16, device=dy.device)
             _C.check(_C.fn("rr_to_bf16")(_C.ptr(wt), _C.ptr(wt16), wt.numel(), _C.stream()), "rr_to_bf16")
+        if sum16:
+            yb, zb = bnsum.y, (bnsum_z if bnsum.use_z else None)
+            y_ph, z_ph = is_phantom(yb), (zb is not None and is_phantom(zb))
+            slab = torch.empty(_C.fn("rr_conv16_stat_slab_bytes")(n, h, wd, c) // 8, dtype=torch.float64, device=dy.device)
+            sums = _ZEROS.take(2 * c, dy.device)
+            _C.check(_timed("conv16_dgrad_s1+bnsum", flops,
+                            lambda: _C.fn("rr_conv16_dgrad_s1_bnsum")(
+                                _C.ptr(dy16), _C.ptr(wt16), _C.ptr(out), None, n, h, wd, c, k, r, s, pad[0], pad[1], int(accumulate),
+                                _C.ptr(None if y_ph else yb), _C.ptr(image_of(yb) if y_ph else None),
+                                _C.ptr(None if (zb is None or z_ph) else zb), _C.ptr(image_of(zb) if z_ph else None),
+                                _C.ptr(bnsum.mean), _C.ptr(bnsum.invstd), _C.ptr(None if zb is not None else bnsum.msc),
+                                _C.ptr(None if zb is not None else bnsum.msh), _C.ptr(slab), _C.ptr(sums), _C.stream()),
+                            (n, h, wd, c, k, r, s, stride),
+                            2.0 * (dy.numel() + w.numel()) + 4.0 * out.numel() * (2 if accumulate else 1)), "rr_conv16_dgrad_s1_bnsum")
+            bnsum.sums, bnsum.dz = sums, out
+            return out
         _C.check(_timed("conv16_dgrad_s1", flops,
                         lambda: _C.fn("rr_conv16_dgrad_s1")(_C.ptr(dy16), _C.ptr(wt16), _C.ptr(out), None, n, h, wd, c, k, r, s, pad[0], pad[1],
                                                             int(accumulate), _C.stream()), (n, h, wd, c, k, r, s, stride),

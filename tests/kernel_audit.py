@@ -272,13 +272,15 @@ def audit(tol=2e-5, tol_wgrad=2e-4, sample=False, ref_device="cpu"):
             # the producer's BatchNorm-backward sums from the epilogue: compare with fp64 sums over the whole of the
             # gradient this launch left in memory (the gradient itself is checked below)
             zt = bnsum_z if bnsum.use_z else None
-            bsig = (tuple(res.shape), zt is not None, bnsum.msc is not None, bool(accumulate))
+            yb = _dat(bnsum.y)            # (conv16: the producer's pre-BN output may exist only as its bf16 image)
+            bsig = (tuple(res.shape), zt is not None, bnsum.msc is not None, bool(accumulate)) + \
+                   (("y-image",) if ops.is_phantom(bnsum.y) else ())
             if ("dgrad_bnsum",) + bsig not in rec.seen:
                 c = res.shape[1]
                 s1, s2, a1, a2 = (_zeros64(c) for _ in range(4))
                 for i in range(res.shape[0]):
-                    d = _masked(res[i:i + 1], None if zt is None else zt[i:i + 1], bnsum.y[i:i + 1], bnsum.msc, bnsum.msh)
-                    xh = (_c64(bnsum.y[i:i + 1]) - _V(bnsum.mean)) * _V(bnsum.invstd)
+                    d = _masked(res[i:i + 1], None if zt is None else zt[i:i + 1], yb[i:i + 1], bnsum.msc, bnsum.msh)
+                    xh = (_c64(yb[i:i + 1]) - _V(bnsum.mean)) * _V(bnsum.invstd)
                     s1 += d.sum((0, 2, 3)); a1 += d.abs().sum((0, 2, 3))
                     d = d * xh
                     s2 += d.sum((0, 2, 3)); a2 += d.abs().sum((0, 2, 3))
