@@ -1259,7 +1259,13 @@ typedef int i32x4d __attribute__((ext_vector_type(4)));
 // memory model: the caller orders it with its own s_waitcnt vmcnt / s_barrier
 __device__ __forceinline__ void dma16(i32x4d rsrc, unsigned lds_addr, unsigned voff, unsigned soff)
 {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+    // M0 (the LDS base of the transfer) is a register the compiler reserves for itself and cannot be named as clobbered: it is
+    // saved and restored around the load, so nothing the compiler may keep there is lost
+    unsigned m0_saved;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(m0_saved)
+                 : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
+                 : "memory");
 }
 // float -> int, round to nearest with ties toward +inf (floor(x + 0.5)): ONE instruction where __float2int_rn takes two
 // (v_rndne_f32 + v_cvt_i32_f32); the fixed-point window's rounding bound (half a unit per add) is the same.
