@@ -82,6 +82,26 @@ __device__ __forceinline__ int xcd_remap(int bid, int nb)
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
+// The same descriptor as four SGPR words, and a 64 x 16-byte global -> LDS transfer as inline assembly WITHOUT a compiler-level
+// memory barrier: as a builtin the transfer is an LDS write the scheduler will not move an LDS read across, so the K-tile half
+// that interleaves the next tile's pieces ran read -> wait -> 4 MFMAs with every fragment read's latency in the open (ISA: one
+// `s_waitcnt lgkmcnt(0)` per piece); the pieces write the OTHER buffer, and the tile's vmcnt wait + barrier order them.  M0 (the
+// LDS base) is saved and restored: the compiler reserves it.
+typedef int i32x4w __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ i32x4w make_srd_words(const void *p, long bytes)
+{
+    const unsigned long long u = reinterpret_cast<unsigned long long>(p);
+    return i32x4w{(int)__builtin_amdgcn_readfirstlane((unsigned)u), (int)(__builtin_amdgcn_readfirstlane((unsigned)(u >> 32)) & 0xffffu),
+                  __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000};
+}
+__device__ __forceinline__ void dma16_free(i32x4w rsrc, unsigned lds_addr, unsigned voff)
+{
+    unsigned m0_saved;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(m0_saved)
+                 : "s"(lds_addr), "v"(voff), "s"(rsrc));
+}
+
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_srd(const void *p, long bytes)
 {
     const unsigned long long u = reinterpret_cast<unsigned long long>(p);
@@ -146,8 +166,8 @@ __global__ __launch_bounds__(512, 1) void conv16_igemm_kernel(const Args a)
         x_off[i] = (int)(((((long)n * a.SH + ih0) * a.SW + iw0) * a.SC) * 2 + chunk * 16);
         w_off[i] = (int)(((long)(k0 + (row < TCH ? row : 0)) * RS * a.SC) * 2 + chunk * 16);      // (rows >= TCH: unused when NWP < 4)
     }
-    const __amdgpu_buffer_rsrc_t rs_src = make_srd(a.src, (long)a.N * a.SH * a.SW * a.SC * 2);
-    const __amdgpu_buffer_rsrc_t rs_flt = make_srd(a.flt, (long)a.DC * RS * a.SC * 2);
+    const i32x4w rs_src = make_srd_words(a.src, (long)a.N * a.SH * a.SW * a.SC * 2);
+    const i32x4w rs_flt = make_srd_words(a.flt, (long)a.DC * RS * a.SC * 2);
 
     // wave-uniform walk over the K-tiles: tap inner, channel chunk outer.  The eight DMA pieces of a K-tile are issued ONE AT A TIME
     // between the MFMAs of the previous tile (piece(j)): issued back to back behind the barrier they cost every wave of the workgroup
@@ -168,10 +188,10 @@ __global__ __launch_bounds__(512, 1) void conv16_igemm_kernel(const Args a)
         if (j < 4) {
             const unsigned ok = (unsigned)(x_mask >> (16 * j + tapbit)) & p_live;
             const unsigned off = ok ? (unsigned)(x_off[j] + xdelta) : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lds_void *)(X + (j * 8 + wave) * 1024), 16, off, 0, 0, 0);
+            dma16_free(rs_src, __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void *)(X + (j * 8 + wave) * 1024)), off);
         } else {
             const unsigned off = p_live ? (unsigned)(w_off[j - 4] + wdelta) : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_flt, (lds_void *)(W + ((j - 4) * 8 + wave) * 1024), 16, off, 0, 0, 0);
+            dma16_free(rs_flt, __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void *)(W + ((j - 4) * 8 + wave) * 1024)), off);
         }
     };
     auto issue = [&](int buf) {
@@ -206,11 +226,17 @@ __global__ __launch_bounds__(512, 1) void conv16_igemm_kernel(const Args a)
             bf16x8 wf[4];
 #pragma unroll
             for (int ci = 0; ci < 4; ++ci) wf[ci] = *reinterpret_cast<const bf16x8 *>(B + w_base + ci * 16 * ROWB + sw);
+            // the pixel fragment of group pi + 1 is read BEFORE group pi's four MFMAs: its LDS latency runs under them (the DMA piece
+            // between the groups is a scheduling boundary: the compiler does not move the read across it by itself)
+            bf16x8 xf = *reinterpret_cast<const bf16x8 *>(B + x_base + sw);
 #pragma unroll
             for (int pi = 0; pi < PI; ++pi) {
-                const bf16x8 xf = *reinterpret_cast<const bf16x8 *>(B + x_base + pi * 16 * ROWB + sw);
+                bf16x8 xn = xf;
+                if (pi + 1 < PI) xn = *reinterpret_cast<const bf16x8 *>(B + x_base + (pi + 1) * 16 * ROWB + sw);
+                __builtin_amdgcn_sched_barrier(0);          // (left alone, the scheduler sinks the read back behind the MFMAs)
 #pragma unroll
                 for (int ci = 0; ci < 4; ++ci) acc[ci][pi] = mfma(wf[ci], xf, acc[ci][pi]);
+                xf = xn;
                 // one DMA piece per 4 MFMAs, from the start of the tile: the rest of the tile covers their latency
                 if (kh * PI + pi < 4 + NWP) piece(kh * PI + pi, buf ^ 1);
             }
