@@ -483,8 +483,10 @@ __global__ __launch_bounds__(512, 1) void conv16_wgrad_kernel(const WArgs a)
         pp[j] = rem / a.Q;
         pq[j] = rem - pp[j] * a.Q;
     }
-    const __amdgpu_buffer_rsrc_t rs_dy = make_srd(a.dy, (long)a.M * a.K * 2);
-    const __amdgpu_buffer_rsrc_t rs_x = make_srd(a.x, (long)a.N * a.H * a.W * a.C * 2);
+    // (inline-assembly transfers: as builtins they are LDS writes in the compiler's memory model, and it put an `s_waitcnt vmcnt(0)`
+    //  in front of every step's fragment reads — behind the counted wait below, draining the two steps that were meant to stay in flight)
+    const i32x4w rs_dy = make_srd_words(a.dy, (long)a.M * a.K * 2);
+    const i32x4w rs_x = make_srd_words(a.x, (long)a.N * a.H * a.W * a.C * 2);
     // pieces of a K-step and wave — NT = 256: dY block `wave` and X blocks wave, wave + 8, both pixel halves (6 instructions);
     // NT = 128: dY block `wave` both halves, X block wave % 4 of pixel half wave / 4 (3 instructions).  Every wave issues the same
     // number per step: the counted wait below relies on it.
@@ -499,17 +501,17 @@ __global__ __launch_bounds__(512, 1) void conv16_wgrad_kernel(const WArgs a)
             const unsigned okm = (unsigned)live & (unsigned)(m < a.M);
             // (K % 256 == 128: the last filter tile is half empty — its waves' dY blocks read zeros, their MFMAs are skipped below)
             const unsigned offa = (okm && ko0 + wave * 32 < a.K) ? (unsigned)((m * a.K + ko0 + wave * 32 + chunk * 8) * 2) : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_dy, (lds_void *)(A + wave * 2048 + j * 1024), 16, offa, 0, 0, 0);
+            dma16_free(rs_dy, __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void *)(A + wave * 2048 + j * 1024)), offa);
             const int ih = pp[j] * a.stride - a.pad_h + r, iw = pq[j] * a.stride - a.pad_w + s;
             const unsigned okx = okm & (unsigned)((unsigned)ih < (unsigned)a.H) & (unsigned)((unsigned)iw < (unsigned)a.W);
             const long pix = ((long)pn[j] * a.H + ih) * a.W + iw;
             if constexpr (NB == 8) {
                 const unsigned offx = okx ? (unsigned)((pix * a.C + c0 + wave * 32 + chunk * 8) * 2) : OOB;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void *)(B + wave * 2048 + j * 1024), 16, offx, 0, 0, 0);
+                dma16_free(rs_x, __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void *)(B + wave * 2048 + j * 1024)), offx);
             } else if ((wave >> 2) == j) {              // wave-uniform
                 const int blk = wave & 3;
                 const unsigned offx = okx ? (unsigned)((pix * a.C + c0 + blk * 32 + chunk * 8) * 2) : OOB;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void *)(B + blk * 2048 + j * 1024), 16, offx, 0, 0, 0);
+                dma16_free(rs_x, __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void *)(B + blk * 2048 + j * 1024)), offx);
             }
             pq[j] += 32;
             while (pq[j] >= a.Q) {
