@@ -532,15 +532,21 @@ __global__ __launch_bounds__(512, 1) void conv16_wgrad_kernel(const WArgs a)
     const bool k_live = ko0 + wk * 64 < a.K;         // this wave's 64 filters exist (K is a multiple of 128)
     issue(st_begin, 0);
     issue(st_begin + 1, 1);
-    for (int st = st_begin; st < st_end; ++st) {
-        const int stage = (st - st_begin) & 3;
-        issue(st + 2, (stage + 2) & 3);              // (its buffer was last read in step st-2: two barriers ago)
-        // step st's pieces have landed when at most the 2 x PIECES newer ones are outstanding
-        if constexpr (PIECES == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    // TWO 32-pixel steps per barrier (round 5, late): with one, the two waves of a SIMD were re-aligned every 16 MFMAs — both read
+    // fragments, then both queued on the matrix pipe; over 32 MFMAs the second step's reads run under the first step's MFMAs.  The
+    // four stages hold this pair and the next one (a step beyond the range fetches zeros: at most one dead step per workgroup).
+    for (int st = st_begin; st < st_end; st += 2) {
+        const int stage0 = (st - st_begin) & 3;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this pair's pieces (the only ones in flight) have landed
         __builtin_amdgcn_s_barrier();
-        const unsigned char *A = lds + stage * STAGE, *B = A + A_BYTES;
+        // the other two buffers were read in the previous pair, which every wave has left by now: the next pair goes out BEHIND the
+        // barrier (in front of it a fast wave would overwrite what a slow one still reads) and has this pair's 32 MFMAs to land
+        issue(st + 2, (stage0 + 2) & 3);
+        issue(st + 3, (stage0 + 3) & 3);
         if (!k_live) continue;                       // (wave-uniform; the wave still issued its pieces and met the barrier)
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+        const unsigned char *A = lds + ((stage0 + half) & 3) * STAGE, *B = A + A_BYTES;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             bf16x8 fa[2], fb[TN];
@@ -552,6 +558,7 @@ __global__ __launch_bounds__(512, 1) void conv16_wgrad_kernel(const WArgs a)
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
         }
     }
     const int lr = lane & 31, lh = lane >> 5;

@@ -18,6 +18,8 @@ SHAPES = [
     (2, 256, 64, 64, 256, 3, 1),       # several pixel tiles, image borders inside tiles
     (1, 256, 40, 24, 512, 3, 2),
     (2, 128, 32, 48, 256, 1, 2),       # 1x1 stride 2 (a projection block's skip): three of the four parity classes are empty
+    (8, 256, 128, 128, 384, 3, 2),     # a full-size layer: the weight gradient's stage ring wraps ~18 times per workgroup, odd step count per
+                                       # split, half-empty last filter tile (a stage re-filled one barrier too early showed up here only)
 ]
 
 
