@@ -52,8 +52,8 @@ def parse():
     return ap.parse_args()
 
 
-def _cpu_stepper(seed, size, k):
-    """-> a closure running one oracle train step (forward, criterion, backward, Adam update) on ONE size x size frame and
+def _cpu_stepper(seed, size, k, frames=1):
+    """-> a closure running one oracle train step (forward, criterion, backward, Adam update) on `frames` size x size frames and
     returning its seconds; model, optimizer state and buffers persist between calls (warm steps)."""
     from types import SimpleNamespace
     from oracle import model as om, ops as oo
@@ -71,7 +71,7 @@ def _cpu_stepper(seed, size, k):
         params.append(sd[kk])
     del net
     opt = torch.optim.Adam(params, lr=2.5e-4)
-    imgs, annos, hms, whs, inds, offs, masks, _ = host_batch(*synth_frames(1, size, size, boxes_per_image=100, seed=seed))
+    imgs, annos, hms, whs, inds, offs, masks, _ = host_batch(*synth_frames(frames, size, size, boxes_per_image=100, seed=seed))
     P = om.Params(sd, training=True)
 
     def one():
@@ -85,7 +85,7 @@ def _cpu_stepper(seed, size, k):
     return one
 
 
-def cpu_baseline(seed, k=100, budget_s=240.0):
+def cpu_baseline(seed, k=100, budget_s=300.0):
     """The oracle ("port": torch-CPU restatement of the reference graph, oracle/model.py + ops.py) running the
     hourglass-104 RRNet train step INCLUDING the Adam update on this box's host cores, on the bench's own frame size.
     `value` = 1 / mean of two WARM real 1024x1024 steps (one frame each; a first, cold step of the same stepper is run and
@@ -101,6 +101,25 @@ def cpu_baseline(seed, k=100, budget_s=240.0):
     t512 = 0.5 * (all512[-2] + all512[-1])
     out = {"unit": "images/sec", "cores": threads, "kind": "port", "torch_num_threads": threads, "host_cpus": os.cpu_count(),
            "t_512_s": [round(t, 2) for t in all512], "images_per_sec_from_512_x4": round(1.0 / (t512 * 4.0), 5)}
+    # Is the one-frame figure thread-starved?  (a batch-1 graph does not spread over 128 cores; the reference's
+    # loop — operators/rrnet_operator.py:116-138 — runs a batch.)  Two side figures on the SAME pixel count per step as one
+    # 1024x1024 frame, never `value`: the stepper at B=4 x 512x512 with all threads, and the B=1 512x512 step at 8 threads.
+    try:
+        four = _cpu_stepper(seed, 512, k, frames=4)
+        t4 = [four() for _ in range(2)]              # cold, warm
+        del four
+        out["batch4_512"] = {"t_s": [round(t, 2) for t in t4], "images_per_sec": round(4.0 / t4[-1], 5), "threads": threads,
+                             "vs_batch1_512": round((4.0 / t4[-1]) / (1.0 / t512), 3)}
+        torch.set_num_threads(8)
+        one8 = _cpu_stepper(seed, 512, k)
+        t8 = [one8() for _ in range(2)]
+        del one8
+        out["threads8_512"] = {"t_s": [round(t, 2) for t in t8], "images_per_sec": round(1.0 / t8[-1], 5), "threads": 8,
+                               "vs_all_threads": round(t512 / t8[-1], 3)}
+    except Exception as e:
+        out["batch4_512"] = {"error": repr(e)}
+    finally:
+        torch.set_num_threads(threads)
     spent = time.perf_counter() - t_start
     if spent + 3.3 * 4.0 * t512 < budget_s:
         one1024 = _cpu_stepper(seed, 1024, k)
@@ -229,15 +248,30 @@ def host_fed_steps(op, cfg, a, step_no):
                    "built on the device from the copied annotations inside the timed region"}
 
 
+def self_launch(n):
+    """`python bench.py --gpus N ...` without launcher variables -> run N ranks under torch.distributed.run as a child
+    process with the same arguments; returns its exit code.  Nothing here imports or initialises the GPU runtime."""
+    import socket
+    import subprocess
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: no launcher variables in the environment — starting %d ranks: %s" % (n, " ".join(cmd)), file=sys.stderr, flush=True)
+    return subprocess.run(cmd, cwd=os.getcwd(), env=dict(os.environ)).returncode
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus > 1 and world == 1:
-        print("bench.py: --gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
-              % (a.gpus, a.gpus), file=sys.stderr)
-        sys.exit(2)
+    if a.gpus > 1 and "RANK" not in os.environ:
+        # Started without a launcher (`python bench.py --gpus N`): this process becomes the launcher.  Decided HERE, before
+        # anything has touched the GPU (a process that has initialised HIP must never re-launch itself on this pool), and as a
+        # CHILD process — no exec: `python -m torch.distributed.run` with one rank per GPU, env rendezvous on 127.0.0.1
+        # (the reference spawns its own workers the same way: operators/distributed_wrapper.py:47-61).  Rank 0's JSON line goes
+        # straight to our stdout; we exit with the launcher's code.
+        sys.exit(self_launch(a.gpus))
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible — the HIP path has no CPU fallback", file=sys.stderr)
         sys.exit(3)
@@ -355,7 +389,7 @@ def main():
                 # (tools/prof_bench.sh -> tools/pmc_traffic.py -> profiles/rNN_traffic_pmc.json); PMC counters
                 # cannot be read from inside the process, so the field names its source
                 traffic, traffic_source = None, None
-                for tag in ("r05", "r04", "r03", "r02", "r01"):
+                for tag in ("r06", "r05", "r04", "r03", "r02", "r01"):
                     tpath = os.path.join(ROOT, "profiles", "%s_traffic_pmc.json" % tag)
                     if os.path.exists(tpath) and a.backbone == "hourglass" and a.size == 1024 and a.batch == 8:
                         with open(tpath) as f:

@@ -173,18 +173,7 @@ int rr_conv16_fprop(const unsigned short *x, const unsigned short *w, const floa
                     int relu, hipStream_t stream);
 int rr_conv16_dgrad_s1(const unsigned short *dy, const unsigned short *wt, float *dx, unsigned short *dx16, int n, int h,
                        int wd, int c, int k, int r, int s, int pad_h, int pad_w, int accumulate, hipStream_t stream);
-/* rr_conv16_dgrad_s1 that also reduces the BatchNorm-backward sums of the conv -> bn [-> +residual] -> relu layer that produced the
- * convolution's input (the bf16 twin of rr_conv_dgrad_s1_bnsum): sums[0..C) = sum of the ReLU-masked complete gradient (after
- * `accumulate`), sums[C..2C) = the same times xhat = (y - mean) * invstd.  y / z: the producer's pre-BN output and output, each as
- * fp32 OR as its bf16 image (exactly one of y / y16; z and z16 both NULL: the mask is recomputed as y * mask_scale + mask_shift > 0, or
- * absent when those are NULL too).  slab: rr_conv16_stat_slab_bytes(n, h, w, c) bytes of scratch; sums: 2 C pre-zeroed doubles.
- * The gradient is stored unmasked, as rr_conv16_dgrad_s1 stores it.  Replaces a pass of rr_bn_bwd_reduce[_b16]. */
-int rr_conv16_dgrad_s1_bnsum(const unsigned short *dy, const unsigned short *wt, float *dx, unsigned short *dx16, int n, int h, int wd, int c,
-                             int k, int r, int s, int pad_h, int pad_w, int accumulate, const float *y, const unsigned short *y16,
-                             const float *z, const unsigned short *z16, const float *mean, const float *invstd, const float *mask_scale,
-                             const float *mask_shift, double *slab, double *sums, hipStream_t stream);
-
-/* ... and the backward of the ReLU in front of the convolution applied in the epilogue (rr_conv_dgrad_s1_relubias without the
+/* rr_conv16_dgrad_s1 with the backward of the ReLU in front of the convolution applied in the epilogue (rr_conv_dgrad_s1_relubias without the
  * column sums: the producer is a bare ReLU, functional._ReLU): dx = (dx_conv [+ dx]) * (relu_out > 0). */
 int rr_conv16_dgrad_s1_relumask(const unsigned short *dy, const unsigned short *wt, float *dx, int n, int h, int wd, int c, int k,
                                 int r, int s, int pad_h, int pad_w, int accumulate, const float *relu_out, hipStream_t stream);

@@ -56,39 +56,77 @@ def _bilinear_zero(x, h, w):
             (lh * hw).unsqueeze(1) * v3 + (lh * lw).unsqueeze(1) * v4)
 
 
-def dcn_v2_conv(x, offset, mask, weight, bias, stride=1, padding=0, dilation=1, deformable_groups=1):
-    """`dcn_v2_conv(input, offset, mask, weight, bias, stride, padding, dilation, deformable_groups)` of
-    ext/dcn/dcn_v2.py:16-52.  x [N,C,H,W]; offset [N, 2*dg*kh*kw, P, Q]; mask [N, dg*kh*kw, P, Q]."""
+def dcn_columns(x, offset, mask, kh, kw, stride=1, padding=0, dilation=1, deformable_groups=1):
+    """The modulated deformable columns [N, C, kh*kw, P, Q] = mask * bilinear sample (dcn_v2_im2col_cuda.cu:125-195)."""
     sh, sw = _pair(stride)
     ph, pw = _pair(padding)
     dh, dw = _pair(dilation)
     n, c, H, W = x.shape
-    k, _, kh, kw = weight.shape
     dg = deformable_groups
     cpg = c // dg
     P = (H + 2 * ph - (dh * (kh - 1) + 1)) // sh + 1
     Q = (W + 2 * pw - (dw * (kw - 1) + 1)) // sw + 1
-    base_h = (torch.arange(P, dtype=x.dtype) * sh - ph).view(1, P, 1)
-    base_w = (torch.arange(Q, dtype=x.dtype) * sw - pw).view(1, 1, Q)
-    cols = x.new_zeros((n, c, kh * kw, P, Q))
+    base_h = (torch.arange(P, dtype=x.dtype, device=x.device) * sh - ph).view(1, P, 1)
+    base_w = (torch.arange(Q, dtype=x.dtype, device=x.device) * sw - pw).view(1, 1, Q)
+    cols = []
     for g in range(dg):
         xg = x[:, g * cpg:(g + 1) * cpg]
+        taps = []
         for i in range(kh):
             for j in range(kw):
                 t = i * kw + j
                 oh = offset[:, g * 2 * kh * kw + 2 * t]
                 ow = offset[:, g * 2 * kh * kw + 2 * t + 1]
                 val = _bilinear_zero(xg, base_h + i * dh + oh, base_w + j * dw + ow)
-                cols[:, g * cpg:(g + 1) * cpg, t] = val * mask[:, g * kh * kw + t].unsqueeze(1)
-    out = torch.einsum('nctpq,kct->nkpq', cols, weight.reshape(k, c, kh * kw))
+                taps.append(val * mask[:, g * kh * kw + t].unsqueeze(1))
+        cols.append(torch.stack(taps, dim=2))
+    return cols[0] if dg == 1 else torch.cat(cols, dim=1)
+
+
+def _bf16_round(t):
+    return t.detach().to(torch.bfloat16).to(t.dtype)
+
+
+class _ContractBf16(torch.autograd.Function):
+    """out = cols . W with the builder-defined bf16 contract of BASELINE configs[3] (rrnet_amd/csrc/dcn.hip: rr_dcn_fwd_bf16,
+    rr_dcn_dgrad_bf16, rr_dcn_wgrad_bf16) restated: BOTH operands of every matrix product rounded to bf16 (nearest even),
+    products and sums in the tensors' own dtype — forward round(cols) . round(W); backward d cols = round(dY) . round(W),
+    d W = round(dY)^T . round(cols).  Everything around the products (sampling, mask, bias, the column gradient's way
+    back to input / offset / mask) stays in the tensors' dtype.  The reference is fp32-only (dcn_v2_cuda.cu:58)."""
+
+    @staticmethod
+    def forward(ctx, cols, w3):
+        cq, wq = _bf16_round(cols), _bf16_round(w3)
+        ctx.save_for_backward(cq, wq)
+        return torch.einsum('nctpq,kct->nkpq', cq, wq)
+
+    @staticmethod
+    def backward(ctx, dy):
+        cq, wq = ctx.saved_tensors
+        dq = _bf16_round(dy)
+        return torch.einsum('nkpq,kct->nctpq', dq, wq), torch.einsum('nkpq,nctpq->kct', dq, cq)
+
+
+def dcn_v2_conv(x, offset, mask, weight, bias, stride=1, padding=0, dilation=1, deformable_groups=1, bf16=False):
+    """`dcn_v2_conv(input, offset, mask, weight, bias, stride, padding, dilation, deformable_groups)` of
+    ext/dcn/dcn_v2.py:16-52.  x [N,C,H,W]; offset [N, 2*dg*kh*kw, P, Q]; mask [N, dg*kh*kw, P, Q].
+    bf16 (builder-defined, configs[3]): the matrix products on bf16-rounded operands (_ContractBf16)."""
+    k, c, kh, kw = weight.shape
+    cols = dcn_columns(x, offset, mask, kh, kw, stride, padding, dilation, deformable_groups)
+    w3 = weight.reshape(k, c, kh * kw)
+    out = _ContractBf16.apply(cols, w3) if bf16 else torch.einsum('nctpq,kct->nkpq', cols, w3)
     if bias is not None:
         out = out + bias.view(1, -1, 1, 1)
     return out
 
 
-def dcn_forward(x, weight, bias, om_weight, om_bias, stride=1, padding=1, dilation=1, deformable_groups=1):
-    """`DCN.forward` of ext/dcn/dcn_v2.py:114-128: offsets and mask come from conv_offset_mask."""
-    out = F.conv2d(x, om_weight, om_bias, stride=stride, padding=padding)
+def dcn_forward(x, weight, bias, om_weight, om_bias, stride=1, padding=1, dilation=1, deformable_groups=1, conv=None, bf16=False):
+    """`DCN.forward` of ext/dcn/dcn_v2.py:114-128: offsets and mask come from conv_offset_mask.
+    conv: the caller's convolution for the offset / mask layer (oracle/model.py's bf16-contract conv); bf16: see dcn_v2_conv."""
+    if conv is None:
+        out = F.conv2d(x, om_weight, om_bias, stride=stride, padding=padding)
+    else:
+        out = conv(x, om_weight, om_bias, stride, padding)
     o1, o2, m = torch.chunk(out, 3, dim=1)
     offset = torch.cat((o1, o2), dim=1)
-    return dcn_v2_conv(x, offset, torch.sigmoid(m), weight, bias, stride, padding, dilation, deformable_groups)
+    return dcn_v2_conv(x, offset, torch.sigmoid(m), weight, bias, stride, padding, dilation, deformable_groups, bf16=bf16)

@@ -41,6 +41,7 @@ class Params:
         # convolution rounded to bf16 (nearest even), products and sums in the tensors' own dtype (fp32 / fp64) —
         # the contract of rrnet_amd/csrc/conv_bf16.hip, restated so that a bf16 model run has an oracle
         self.bf16 = bf16
+        self.dcn_bf16 = True       # cfg.Model.dcn_bf16 of the builder's config 4 (False: DCN products on unrounded operands)
 
     def has(self, key):
         return key in self.sd
@@ -53,13 +54,45 @@ class Params:
 
 
 def _bf16_round(t):
-    return t.to(torch.bfloat16).to(t.dtype)
+    return t.detach().to(torch.bfloat16).to(t.dtype)
+
+
+def _pair(v):
+    return (v, v) if isinstance(v, int) else tuple(v)
+
+
+class _ConvBf16(torch.autograd.Function):
+    """The bf16 contract of the builder's convolution kernels (rrnet_amd/csrc/conv_bf16.hip, conv16.hip), forward AND
+    backward: both operands of every matrix product rounded to bf16 (nearest even), products and sums in the tensors' own
+    dtype — y = conv(round(x), round(w)); dx = conv_transpose(round(dy), round(w)); dw = correlation(round(x), round(dy)).
+    (A plain `.to(bfloat16).to(dtype)` would instead round the finished GRADIENTS on their way back through the cast.)"""
+
+    @staticmethod
+    def forward(ctx, x, w, stride, padding):
+        xq, wq = _bf16_round(x), _bf16_round(w)
+        ctx.save_for_backward(xq, wq)
+        ctx.cfg = (_pair(stride), _pair(padding))
+        return F.conv2d(xq, wq, None, stride=stride, padding=padding)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xq, wq = ctx.saved_tensors
+        stride, padding = ctx.cfg
+        dq = _bf16_round(dy)
+        dx = torch.nn.grad.conv2d_input(xq.shape, wq, dq, stride, padding) if ctx.needs_input_grad[0] else None
+        dw = torch.nn.grad.conv2d_weight(xq, wq.shape, dq, stride, padding) if ctx.needs_input_grad[1] else None
+        return dx, dw, None, None
+
+
+def conv_bf16(x, w, bias, stride, padding):
+    y = _ConvBf16.apply(x, w, stride, padding)
+    return y if bias is None else y + bias.view(1, -1, 1, 1)
 
 
 def conv(P, key, x, stride=1, padding=0):
     w = P.sd[key + ".weight"]
     if P.bf16:
-        x, w = _bf16_round(x), _bf16_round(w)
+        return conv_bf16(x, w, P.sd.get(key + ".bias"), stride, padding)
     return F.conv2d(x, w, P.sd.get(key + ".bias"), stride=stride, padding=padding)
 
 
@@ -125,8 +158,11 @@ def head_conv3x3(P, key, x):
     `DCN` in its place when the state_dict carries `<key>.conv_offset_mask.*` (oracle/dcn.py:dcn_forward)."""
     if P.has(key + ".conv_offset_mask.weight"):
         from oracle import dcn as odcn
+        # (P.bf16: the offset / mask layer is an ordinary convolution of the bf16 model; the deformable products take the
+        # same contract — oracle/dcn.py:_ContractBf16 — on the fp32 input the kernel samples)
         return odcn.dcn_forward(x, P.sd[key + ".weight"], P.sd[key + ".bias"], P.sd[key + ".conv_offset_mask.weight"],
-                                P.sd[key + ".conv_offset_mask.bias"], 1, 1, 1, 1)
+                                P.sd[key + ".conv_offset_mask.bias"], 1, 1, 1, 1,
+                                conv=conv_bf16 if P.bf16 else None, bf16=P.bf16 and P.dcn_bf16)
     return conv(P, key, x, 1, 1)
 
 

@@ -120,17 +120,12 @@ class Hourglass(nn.Module):
     make_pool_layer = staticmethod(lambda: nn.Sequential())
     make_upsample_layer = staticmethod(lambda: nn.Upsample(scale_factor=2))
 
-    def forward(self, x, slot=0):
-        """slot: how many hourglass modules enclose this one (0 = the outermost); RF.branch_stream gives the up1 branch of
-        the outermost few a HIP stream of its own."""
+    def forward(self, x):
         u0, l0 = self.up1[0], self.low1[0]
-        side = RF.branch_stream(x.device, slot)
-        low2 = (lambda t: self.low2(t, slot + 1)) if isinstance(self.low2, Hourglass) else self.low2
-        if side is None and RF.sync_coalescing(u0.bn1) and not len(u0.skip_connection) and len(l0.skip_connection):
-            # SyncBN across ranks, one stream: the first layers of both branches (up1's conv1, low1's stride-2 conv1 and its
-            # projection) read the same x and are independent given x — ONE statistics exchange per direction for the
-            # three of them (the joint node carries one sample count per layer).  x's other consumer is the identity skip
-            # of up1's first block.
+        if RF.sync_coalescing(u0.bn1) and not len(u0.skip_connection) and len(l0.skip_connection):
+            # SyncBN across ranks: the first layers of both branches (up1's conv1, low1's stride-2 conv1 and its projection)
+            # read the same x and are independent given x — ONE statistics exchange per direction for the three of them (the
+            # joint node carries one sample count per layer).  x's other consumer is the identity skip of up1's first block.
             xa, xb, _ = RF.fanout_shared(x, 2)
             outs = RF.conv_bn_act_multi(xa, u0.first_layers() + l0.first_layers())
             up1 = u0.tail(outs[0], xb)
@@ -139,28 +134,11 @@ class Hourglass(nn.Module):
             low1 = l0.tail(outs[1], outs[2])
             for blk in list(self.low1)[1:]:
                 low1 = blk(low1)
-            return RF.upsample_add(up1, self.low3(low2(low1)))
+            return RF.upsample_add(up1, self.low3(self.low2(low1)))
         xa, xb, _ = RF.fanout_shared(x, 2)              # both branches start with a residual block: one accumulator
-        if side is None:
-            up1 = self.up1(xa)
-            low3 = self.low3(low2(self.low1(xb)))
-            # nearest x2 -> bilinear(align_corners) to up1's size -> add, without the 4x intermediate
-            return RF.upsample_add(up1, low3)
-        # up1 on the module's branch stream, beside low1 -> low2 -> low3 on the caller's.  Tensors that cross: x into the
-        # branch, up1 out of it — each is marked in use on the other stream (the caching allocator must not hand its block
-        # out again while that stream still reads it); everything allocated inside a branch stays on its stream, and
-        # autograd runs the backward of every node on the stream of its forward.
-        cur = torch.cuda.current_stream(x.device)
-        side.wait_stream(cur)
-        xa.record_stream(side)
-        if ops.b16_carry(xa) is not None:
-            ops.b16_carry(xa).record_stream(side)
-        with torch.cuda.stream(side):
-            RF.branch_stress(x.device)
-            up1 = self.up1(xa)
-        low3 = self.low3(low2(self.low1(xb)))
-        cur.wait_stream(side)
-        up1.record_stream(cur)
+        up1 = self.up1(xa)
+        low3 = self.low3(self.low2(self.low1(xb)))
+        # nearest x2 -> bilinear(align_corners) to up1's size -> add, without the 4x intermediate
         return RF.upsample_add(up1, low3)
 
 
@@ -191,7 +169,8 @@ class HourglassNet(nn.Module):
         """-> list of num_stacks pre-ReLU feature maps [B, num_feats, H/4, W/4] (NHWC memory)."""
         # Under cfg.Model.bf16 the activations that stay inside the backbone may exist as bf16 images only (ops.phantom_scope:
         # every layer that reads them here reads the image); what leaves it — the feature maps — is produced outside the scope.
-        with ops.phantom_scope(True):
+        # Training only: at inference the memory saving buys nothing, the up-path sums keep their fp32 values (ADVICE r5).
+        with ops.phantom_scope(self.training):
             pre = RF.conv_bn_act(x, self.pre_layer[0], self.pre_layer[1], relu=True)
             pre = self.pre_layer[3](pre)
             outs = []

@@ -1186,65 +1186,17 @@ size_t igemm_lds(int bn, bool b_kn, int bk, int nbuf = 2)
     return sizeof(float) * nbuf * (BM * (bk + 4) + (b_kn ? bk * bn : bn * (bk + 4)));
 }
 
-int conv_rows_kernel()
-{
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("RR_CONV_ROWS");
-        v = (e == nullptr || atoi(e) != 0) ? 1 : 0;
-    }
-    return v;
-}
+int conv_rows_kernel() { return 1; }
 
-int conv_pos_major()
-{
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("RR_CONV_POS_MAJOR");
-        v = (e == nullptr || atoi(e) != 0) ? 1 : 0;
-    }
-    return v;
-}
+int conv_pos_major() { return 1; }
 
-int wgrad_aligned()
-{
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("RR_WGRAD_ALIGNED");
-        v = e ? atoi(e) : 1;       // 0 generic row walk, 1 uniform row walk + one LDS image (default), 2 uniform + two images
-    }
-    return v;
-}
+int wgrad_aligned() { return 1; }       // 0 generic row walk, 1 uniform row walk + one LDS image (default), 2 uniform + two images
 
-int mid_tiles()
-{
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("RR_CONV_MID_TILES");
-        v = e ? atoi(e) : 48;      // <= 48 tiles of 128x128 (the 16x16 level): 128x64 tiles; measured worse at 192 (32x32)
-    }
-    return v;
-}
+int mid_tiles() { return 48; }       // <= 48 tiles of 128x128 (the 16x16 level): 128x64 tiles; measured worse at 192 (32x32)
 
-int small_tiles()
-{
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("RR_CONV_SMALL_TILES");
-        v = e ? atoi(e) : 16;      // <= 16 tiles of 128x128 (the 8x8 level): 128x32 tiles give 4x the workgroups
-    }
-    return v;
-}
+int small_tiles() { return 16; }       // <= 16 tiles of 128x128 (the 8x8 level): 128x32 tiles give 4x the workgroups
 
-int conv_bk()
-{
-    static int bk = -1;
-    if (bk < 0) {
-        const char *e = getenv("RR_CONV_BK");
-        bk = (e && atoi(e) == 16) ? 16 : 32;
-    }
-    return bk;
-}
+int conv_bk() { return 32; }
 
 // split-K factor for layers whose output has too few tiles to fill the chip
 int pick_ksplit(int blocks, int nk)
@@ -1255,14 +1207,6 @@ int pick_ksplit(int blocks, int nk)
         enabled = (e && atoi(e) == 0) ? 0 : 1;
     }
     if (!enabled || blocks >= 256 || nk < 16) return 1;   // a full first wave of tiles: splitting costs more than it balances
-    {
-        static int force = -1;
-        if (force < 0) {
-            const char *e = getenv("RR_CONV_FORCE_KS");
-            force = e ? atoi(e) : 0;
-        }
-        if (force > 0) return force <= nk / 4 ? force : 1;
-    }
     // Occupancy model: 256 CUs, two workgroups resident per CU.  A pair shares the MFMA pipes at ~0.87 of peak, a
     // lone workgroup reaches ~0.75 (nobody fills its issue gaps); every workgroup pays ~3 K-steps of prologue +
     // epilogue.  The busiest CU holds ceil(total / 256) workgroups; pick the split with the shortest makespan.
@@ -1307,15 +1251,7 @@ __global__ __launch_bounds__(256) void colstats_kernel(const float *y, long M, i
     }
 }
 
-int conv_pipe()
-{
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("RR_CONV_PIPE");
-        v = e ? atoi(e) : 2;       // 0 plain loop, 1 pipelined (two LDS images), 2 pipelined with one LDS image (default)
-    }
-    return v;
-}
+int conv_pipe() { return 2; }       // 0 plain loop, 1 pipelined (two LDS images), 2 pipelined with one LDS image (default)
 
 template <int MODE>
 int launch_igemm(ConvArgs &a, int bn, bool scalar, int blocks, int gy, int gz, hipStream_t stream, const char *name)

@@ -63,13 +63,6 @@ struct Args {
     const float *bias;
     const float *mask_z;           // data gradient into a ReLU's input: [N,DH,DW,DC] fp32, the ReLU's OUTPUT; the (summed) gradient is stored where it is > 0, else 0
     double *slab;                  // [mtiles][2][DC] per-block column sums / sums of squares of the fp32 result, or null
-    // bn_mean != null (data gradient; rr_conv16_dgrad_s1_bnsum): the slab receives, instead, the BatchNorm-backward sums of the layer that
-    // produced the convolution's input — per channel sum(g) and sum(g * xhat) over the COMPLETE gradient this launch leaves
-    // (after `accumulate`), g = that gradient where the producer's ReLU let the value through, xhat = (y - mean) * invstd.
-    // y: the producer's pre-BN output (fp32 or its bf16 image); the mask from the producer's output z (fp32 / image) or recomputed
-    // as y * msc + msh > 0 (layers without a residual).  The stored gradient stays UNmasked (rr_bn_bwd_apply masks it again).
-    const float *bn_y, *bn_z, *bn_mean, *bn_invstd, *bn_msc, *bn_msh;
-    const unsigned short *bn_y16, *bn_z16;
     int N, SH, SW, SC, DH, DW, DC, R, S, stride, pad_h, pad_w, relu, accumulate, M;
     // strided destination (stride-2 data gradient, one output parity class per launch): logical output pixel (n, h, w) of the DH x DW
     // grid lands at pixel (n, h * osh + oh0, w * osw + ow0) of an OH x OW map; osh == 0: dense
@@ -259,18 +252,6 @@ __global__ __launch_bounds__(512, 1) void conv16_igemm_kernel(const Args a)
         const int ch = ch0 + ci * 16;
         f32x4 bv = {0.f, 0.f, 0.f, 0.f};
         if (a.bias != nullptr) bv = *reinterpret_cast<const f32x4 *>(a.bias + ch);
-        // BatchNorm-backward sums: this channel group's image reads go out together, ahead of the stores below (a load placed
-        // behind a store that may alias stays there: one memory round trip per pixel tile instead of one per channel group)
-        u16x4 py[PI], pz[PI];
-        if (a.bn_mean != nullptr) {
-#pragma unroll
-            for (int pi = 0; pi < PI; ++pi) {
-                const int m = m0 + wp * (TP / WPX) + pi * 16 + fr;
-                const size_t e = (size_t)(m < a.M ? m : 0) * a.DC + ch;
-                if (a.bn_y16 != nullptr) py[pi] = *reinterpret_cast<const u16x4 *>(a.bn_y16 + e);
-                if (a.bn_z16 != nullptr) pz[pi] = *reinterpret_cast<const u16x4 *>(a.bn_z16 + e);
-            }
-        }
 #pragma unroll
         for (int pi = 0; pi < PI; ++pi) {
             const int m = m0 + wp * (TP / WPX) + pi * 16 + fr;
@@ -279,7 +260,7 @@ __global__ __launch_bounds__(512, 1) void conv16_igemm_kernel(const Args a)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
             }
-            if (a.slab != nullptr && a.bn_mean == nullptr) {
+            if (a.slab != nullptr) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     s1[ci][j] += (double)v[j];
@@ -300,28 +281,6 @@ __global__ __launch_bounds__(512, 1) void conv16_igemm_kernel(const Args a)
                         for (int j = 0; j < 4; ++j) v[j] = zz[j] > 0.f ? v[j] : 0.f;
                     }
                     *reinterpret_cast<f32x4 *>(a.dst + o) = v;
-                }
-                if (a.bn_mean != nullptr) {
-                    // (dense destination only: the host entry refuses strided ones)
-                    const size_t e = (size_t)m * a.DC + ch;
-                    const f32x4 yy = a.bn_y16 != nullptr ? bf16x4_to_f32(py[pi]) : *reinterpret_cast<const f32x4 *>(a.bn_y + e);
-                    f32x4 g = v;
-                    if (a.bn_z16 != nullptr || a.bn_z != nullptr) {
-                        const f32x4 zz = a.bn_z16 != nullptr ? bf16x4_to_f32(pz[pi]) : *reinterpret_cast<const f32x4 *>(a.bn_z + e);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) g[j] = zz[j] > 0.f ? g[j] : 0.f;
-                    } else if (a.bn_msc != nullptr) {
-                        const f32x4 zz = rr_bn_affine4(yy, *reinterpret_cast<const f32x4 *>(a.bn_msc + ch), *reinterpret_cast<const f32x4 *>(a.bn_msh + ch));
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) g[j] = zz[j] > 0.f ? g[j] : 0.f;
-                    }
-                    const f32x4 mu = *reinterpret_cast<const f32x4 *>(a.bn_mean + ch), is = *reinterpret_cast<const f32x4 *>(a.bn_invstd + ch);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float xh = (yy[j] - mu[j]) * is[j];
-                        s1[ci][j] += (double)g[j];
-                        s2[ci][j] += (double)(g[j] * xh);
-                    }
                 }
                 if (a.dst16 != nullptr)
                     *reinterpret_cast<u16x4 *>(a.dst16 + o) = __builtin_bit_cast(u16x4, __builtin_convertvector(v, bf16x4));
@@ -395,19 +354,12 @@ int launch_igemm(const Args &a, hipStream_t stream, const char *name)
     const int mt = rr_cdiv(a.M, TP);
     if (a.DC % 256 == 0) {
         const size_t ldsb = 2 * (size_t)(IMG + 256 * ROWB);
-        static bool attr = false;
-        if (!attr) {
-            RR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv16_igemm_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb), name);
-            attr = true;
-        }
+        // (set on every launch: the attribute is per device, and a once-per-process flag would leave a second GPU without it)
+        RR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv16_igemm_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb), name);
         hipLaunchKernelGGL(conv16_igemm_kernel<256>, dim3(mt * (a.DC / 256)), dim3(512), ldsb, stream, a);
     } else {
         const size_t ldsb = 128 * 1024;        // (two buffers need 96 KiB; the statistics epilogue's table 128)
-        static bool attr = false;
-        if (!attr) {
-            RR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv16_igemm_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb), name);
-            attr = true;
-        }
+        RR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv16_igemm_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb), name);
         hipLaunchKernelGGL(conv16_igemm_kernel<128>, dim3(mt * (a.DC / 128)), dim3(512), ldsb, stream, a);
     }
     RR_CHECK_LAUNCH(name);
@@ -620,30 +572,6 @@ int rr_conv16_dgrad_s1(const unsigned short *dy, const unsigned short *wt, float
     return launch_igemm(a, stream, "rr_conv16_dgrad_s1");
 }
 
-int rr_conv16_dgrad_s1_bnsum(const unsigned short *dy, const unsigned short *wt, float *dx, unsigned short *dx16, int n, int h, int wd, int c,
-                             int k, int r, int s, int pad_h, int pad_w, int accumulate, const float *y, const unsigned short *y16,
-                             const float *z, const unsigned short *z16, const float *mean, const float *invstd, const float *mask_scale,
-                             const float *mask_shift, double *slab, double *sums, hipStream_t stream)
-{
-    // rr_conv16_dgrad_s1 whose epilogue also reduces the BatchNorm-backward sums of the layer that produced the convolution's input
-    // (Args::bn_mean): per channel sum(g) and sum(g * xhat) over the complete gradient, into `sums` [2][C] (pre-zeroed doubles)
-    if (int rc = check_shape("rr_conv16_dgrad_s1_bnsum", n, h, wd, k, c, r, s, 1, pad_h, pad_w)) return rc;
-    RR_CHECK_ARG(pad_h < r && pad_w < s && dy && wt && (dx || dx16) && mean && invstd && slab && sums && ((y != nullptr) != (y16 != nullptr))
-                 && !(z != nullptr && z16 != nullptr) && (!accumulate || dx != nullptr), "rr_conv16_dgrad_s1_bnsum: bad arguments");
-    Args a{};
-    a.src = dy; a.flt = wt; a.dst = dx; a.dst16 = dx16;
-    a.N = n; a.SH = h + 2 * pad_h - r + 1; a.SW = wd + 2 * pad_w - s + 1; a.SC = k; a.DC = c; a.R = r; a.S = s; a.stride = 1;
-    a.pad_h = r - 1 - pad_h; a.pad_w = s - 1 - pad_w;
-    a.DH = h; a.DW = wd;
-    RR_CHECK_ARG(a.SH > 0 && a.SW > 0, "rr_conv16_dgrad_s1_bnsum: empty dy");
-    a.M = n * h * wd;
-    a.accumulate = accumulate;
-    a.slab = slab;
-    a.bn_y = y; a.bn_y16 = y16; a.bn_z = z; a.bn_z16 = z16; a.bn_mean = mean; a.bn_invstd = invstd; a.bn_msc = mask_scale; a.bn_msh = mask_shift;
-    if (int rc = launch_igemm(a, stream, "rr_conv16_dgrad_s1_bnsum")) return rc;
-    return rr_bn_reduce_slab(slab, rr_cdiv(a.M, TP), c, sums, stream);
-}
-
 int rr_conv16_dgrad_s1_relumask(const unsigned short *dy, const unsigned short *wt, float *dx, int n, int h, int wd, int c, int k,
                                 int r, int s, int pad_h, int pad_w, int accumulate, const float *relu_out, hipStream_t stream)
 {
@@ -738,18 +666,10 @@ int rr_conv16_wgrad(const unsigned short *x, const unsigned short *dy, float *dw
     splits = rr_cdiv(total_steps, a.steps_per_split);
     const size_t ldsb = 4 * (size_t)(8 * 2048 + (nt_w / 32) * 2048);
     if (nt_w == 256) {
-        static bool attr = false;
-        if (!attr) {
-            RR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv16_wgrad_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb), "rr_conv16_wgrad");
-            attr = true;
-        }
+        RR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv16_wgrad_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb), "rr_conv16_wgrad");
         hipLaunchKernelGGL(conv16_wgrad_kernel<256>, dim3(tiles * splits), dim3(512), ldsb, stream, a);
     } else {
-        static bool attr = false;
-        if (!attr) {
-            RR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv16_wgrad_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb), "rr_conv16_wgrad");
-            attr = true;
-        }
+        RR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv16_wgrad_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb), "rr_conv16_wgrad");
         hipLaunchKernelGGL(conv16_wgrad_kernel<128>, dim3(tiles * splits), dim3(512), ldsb, stream, a);
     }
     RR_CHECK_LAUNCH("rr_conv16_wgrad");

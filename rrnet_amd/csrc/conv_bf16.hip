@@ -736,19 +736,12 @@ int fprop_impl(const float *x, const float *w, const float *bias, float *y, doub
     RR_CHECK_ARG(om == nullptr || (bs == nullptr && stat_slab == nullptr), "rr_conv_fprop_bf16: strided destination without fused sums");
     a.M = (int)M; a.wK = k; a.wC = c;
     int bn = k > 64 ? 128 : (k > 32 ? 64 : 32);
-    {
-        static int force = -1;          // experiment switch: RR_BF16_BN=64 runs the wide layers on 128 x 64 tiles
-        if (force < 0) { const char *e = getenv("RR_BF16_BN"); force = e ? atoi(e) : 0; }
-        if (force == 64 && bn == 128) bn = 64;
-    }
     if (bn == 128 && rr_cdiv(M, BM) * rr_cdiv(k, 128) <= rr_conv_small_tiles()) bn = 32;
     else if (bn == 128 && rr_cdiv(M, BM) * rr_cdiv(k, 128) <= rr_conv_mid_tiles()) bn = 64;
     const int blocks = rr_cdiv(M, BM) * rr_cdiv(k, bn);
     {
-        static int xcd_env = -1;            // RR_CONV_XCD_N=0: column tiles interleaved on every XCD (A/B switch)
-        if (xcd_env < 0) { const char *e = getenv("RR_CONV_XCD_N"); xcd_env = e ? atoi(e) : 1; }
         const int nt = rr_cdiv(k, bn), mt = rr_cdiv(M, BM);
-        a.xcd_n = (xcd_env && nt > 1 && 8 % nt == 0 && mt % (8 / nt) == 0) ? 1 : 0;
+        a.xcd_n = (nt > 1 && 8 % nt == 0 && mt % (8 / nt) == 0) ? 1 : 0;
     }
     const int nk = rr_cdiv(c, BK) * r * s;
     int ks = (bias == nullptr && !relu && k % 4 == 0 && k <= 1024) ? rr_conv_pick_ksplit(blocks, nk) : 1;
@@ -776,14 +769,10 @@ int fprop_impl(const float *x, const float *w, const float *bias, float *y, doub
            : launch(conv_igemm_bf16_kernel<BNv, BNSv, false, SOv>, blocks, ks, igemm_lds(BNv), stream, a, name))
     // split operands (rr_conv_*_f16x3): two fp16 parts per operand, three matrix instructions per product tile
 #define RR_SX(BNv, BNSv, SOv) launch(conv_igemm_bf16_kernel<BNv, BNSv, false, SOv, 2, false, true>, blocks, ks, igemm_lds(BNv, 2), stream, a, name)
-#define RR_SW(BNSv) launch(conv_igemm_bf16_kernel<128, BNSv, false, false, 2, true, true>, blocks, ks, igemm_lds(128, 2), stream, a, name, 512)
     if (split) {
-        // RR_SPLIT_WS=1: the wave-specialised 512-thread kernel on the 128-wide tiles (A/B switch).  Measured at 256 -> 256 3x3 on
-        // 8 x 256 x 256: 2.84 ms against 2.27 ms for two 256-thread workgroups per CU — a SIMD does not overlap one wave's matrix
-        // instructions with another wave's vector instructions (tools/coissue_probe.hip), so separating the roles buys nothing
-        // and the second workgroup's independent barrier phase does.
-        static int ws_env = -1;
-        if (ws_env < 0) { const char *e = getenv("RR_SPLIT_WS"); ws_env = e ? atoi(e) : 0; }
+        // (A wave-specialised 512-thread form of this kernel — round 4 — measured 2.84 ms against 2.27 ms for two 256-thread
+        // workgroups per CU at 256 -> 256 3x3 on 8 x 256 x 256: a SIMD does not overlap one wave's matrix instructions with another
+        // wave's vector instructions (tools/coissue_probe.hip).  Its launch arm was removed in round 6.)
         a.w16 = nullptr;
         a.amax_src = amax_src; a.amax_w = amax_w;
         name = "rr_conv_fprop_f16x3";
@@ -794,8 +783,7 @@ int fprop_impl(const float *x, const float *w, const float *bias, float *y, doub
             rc = fused ? RR_SB(true, false) : (a.osh ? RR_SB(false, true) : RR_SB(false, false));
 #undef RR_SB
         } else
-        if (ws_env && bn == 128 && !a.osh) rc = fused ? RR_SW(true) : RR_SW(false);
-        else if (fused) rc = bn == 128 ? RR_SX(128, true, false) : bn == 64 ? RR_SX(64, true, false) : RR_SX(32, true, false);
+        if (fused) rc = bn == 128 ? RR_SX(128, true, false) : bn == 64 ? RR_SX(64, true, false) : RR_SX(32, true, false);
         else if (a.osh) rc = bn == 128 ? RR_SX(128, false, true) : bn == 64 ? RR_SX(64, false, true) : RR_SX(32, false, true);
         else rc = bn == 128 ? RR_SX(128, false, false) : bn == 64 ? RR_SX(64, false, false) : RR_SX(32, false, false);
     } else
@@ -804,7 +792,6 @@ int fprop_impl(const float *x, const float *w, const float *bias, float *y, doub
     else rc = bn == 128 ? RR_IG(128, false, false) : bn == 64 ? RR_IG(64, false, false) : RR_IG(32, false, false);
 #undef RR_IG
 #undef RR_SX
-#undef RR_SW
     if (rc == RR_OK && bs != nullptr) {
         if (fused) return rr_bn_reduce_slab(bs->slab, (int)rr_cdiv(M, BM), k, bs->sums, stream);
         return rr_bn_bwd_reduce(y, bs->z, bs->y, bs->mean, bs->invstd, bs->msc, bs->msh, bs->sums, M, k, 1, stream);

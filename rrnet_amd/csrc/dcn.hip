@@ -2494,7 +2494,7 @@ static int dcn_wgrad_win(const float *x, const float *offset, const float *mask,
         wb.w.tiles_x = rr_cdiv(wb.w.a.Q, WIN_TW);
         wb.dy = dy; wb.dw = dw;
         size_t ldsw = 0;
-        static const bool dydma_on = [] { const char *e = getenv("RR_DCN_WGRAD_DMA"); return !(e && e[0] == '0'); }();
+        constexpr bool dydma_on = true;
         const bool dydma = dydma_on && bf16 && dyb != nullptr && k % 32 == 0 && (long)wb.w.a.M * k * 2 < (1l << 31) &&
                            (long)n * h * wd * c * 4 < (1l << 31);
         for (int m = rw; m >= 1; --m) {
@@ -2639,7 +2639,7 @@ static int dcn_dgrad_impl(const float *x, const float *offset, const float *mask
                                        reinterpret_cast<u16x4 *>(dyb), n4);
                     wb.dyb = dyb;
                 }
-                static const bool dma_on = [] { const char *e = getenv("RR_DCN_DGRAD_DMA"); return !(e && e[0] == '0'); }();
+                constexpr bool dma_on = true;
                 if (dma_on && wb.dyb != nullptr && wpk != nullptr && k % 32 == 0 && (long)b.a.M * k * 2 < (1l << 31) &&
                     (long)n * h * wd * c * 4 < (1l << 31) && wb.w.WH * wb.w.WW <= 368 &&
                     ldsw + (size_t)wb.w.WH * wb.w.WW * 4 + 16 <= 160 * 1024 - 512 &&

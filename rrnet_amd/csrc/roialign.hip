@@ -370,22 +370,12 @@ extern "C" int rr_roi_spatial_order(const float *rois, const int *frame_off, int
     return RR_OK;
 }
 
-static int roi3x3_enabled()
-{
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("RR_ROI_3X3");
-        v = (e && atoi(e) == 0) ? 0 : 1;
-    }
-    return v;
-}
-
 extern "C" int rr_roi_align_fwd(const float *feat, const float *rois, int r, int h, int w, int c, int ph, int pw,
                                 float spatial_scale, int sampling_ratio, const int *order, float *out, hipStream_t stream)
 {
     RR_CHECK_ARG(h > 0 && w > 0 && c > 0 && ph > 0 && pw > 0 && r >= 0, "rr_roi_align_fwd: bad dims");
     if (r == 0) return RR_OK;
-    if (c % 4 == 0 && ph == 3 && pw == 3 && roi3x3_enabled()) {
+    if (c % 4 == 0 && ph == 3 && pw == 3) {
         hipLaunchKernelGGL(roi_align_3x3_kernel, dim3((r + 3) / 4), dim3(256), 0, stream, feat, rois, out, r, h, w, c,
                            spatial_scale, sampling_ratio, order);
         RR_CHECK_LAUNCH("rr_roi_align_fwd");

@@ -663,16 +663,6 @@ __global__ __launch_bounds__(T) void soft_nms_reg_kernel(float *boxes, const int
     soft_nms_registers<T, NB>(b, stride, n, sigma, Nt, thr, method, lds, &n_out[seg], err);
 }
 
-int softnms_reg_enabled()
-{
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("RR_SOFTNMS_REG");
-        v = (e == nullptr || atoi(e) != 0) ? 1 : 0;      // 0: the LDS-resident loop (A/B switch)
-    }
-    return v;
-}
-
 }  // namespace
 
 extern "C" size_t rr_soft_nms_workspace_bytes(int total_boxes, int max_seg_boxes)
@@ -714,8 +704,7 @@ static int soft_nms_launch(float *boxes, const int *seg_off, const int *seg_len,
     // (round 5, with the list renumbering: one 9000-box segment 29 ms in registers — 18 boxes per lane of 512 threads, 256 registers,
     // no scratch — against 38 ms for the LDS loop on its global workspace; a batch of such segments likewise: the LDS loop has no
     // LDS for them and runs out of L2)
-    static const int reg_max = getenv("RR_SOFTNMS_REG_MAX") ? atoi(getenv("RR_SOFTNMS_REG_MAX")) : 9216;
-    if (max_seg_boxes <= reg_max && max_seg_boxes <= 9216 && softnms_reg_enabled() && (!throughput_regime || !in_lds)) {
+    if (max_seg_boxes <= 9216 && (!throughput_regime || !in_lds)) {
         // register-resident kernels: T x NB boxes per segment
 #define LAUNCH_REG(T, NB)                                                                                              \
         hipLaunchKernelGGL((soft_nms_reg_kernel<T, NB>), dim3(nseg), dim3(T), 0, stream, boxes, seg_off, seg_len, stride, sigma, \

@@ -9,7 +9,7 @@ from rrnet_amd import functional as RF
 from rrnet_amd import ops
 from rrnet_amd.backbones.resnet import Bottleneck
 
-FUSED_TAIL = os.environ.get("RR_HEAD_FUSED_TAIL", "1") != "0"      # A/B switch: conv3 fused into the inference tail
+FUSED_TAIL = True      # A/B switch: conv3 fused into the inference tail
 
 
 class FasterRCNNDetector(nn.Module):

@@ -47,7 +47,7 @@ class DCNv2(nn.Module):
                            self.deformable_groups, bf16=self.bf16)
 
 
-_PAD_OFFSET_CONV = os.environ.get("RR_DCN_PAD_OFFSET_CONV", "1") != "0"     # A/B switch
+_PAD_OFFSET_CONV = True     # A/B switch
 
 
 class DCN(DCNv2):

@@ -80,7 +80,7 @@ class FlatParams:
                                                     # per-step quantities derived from the parameters (functional._wamax_attach)
         self._wt_version = None
         self._wt_pver = {}                          # id(parameter) -> its own version counter at the last fill
-        self._wt_enabled = os.environ.get("RR_WT_CACHE", "1") != "0" and dev.type == "cuda"
+        self._wt_enabled = True and dev.type == "cuda"
         self.overlap = os.environ.get("RR_DP_OVERLAP", "1") != "0"
         self._pg = None
         self._begin_step()

@@ -58,14 +58,6 @@ def _stress_delay():
         torch.cuda._sleep(_STRESS_CYCLES)
 
 
-def branch_stress(device):
-    """RR_WGRAD_STRESS: the same spin kernel in front of the work of an hourglass branch stream (called at the head of a
-    branch's forward and of every convolution node's backward that runs on one), so that a branch falls far behind the
-    stream it will hand its result to."""
-    if _STRESS_CYCLES > 0 and device.type == "cuda" and torch.cuda.current_stream(device).cuda_stream in _BRANCH_IDS:
-        torch.cuda._sleep(_STRESS_CYCLES)
-
-
 def _wgrad_join(device):
     """Main stream waits for the weight gradients in flight on the side stream (before the next MFMA-bound kernel)."""
     if _WG_STATE["pending"] and not _WGRAD_FREE:
@@ -107,9 +99,9 @@ def _wgrad_async(fn, device, *tensors):
         torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward)
 
 
-_SYNC_COALESCE = os.environ.get("RR_SYNCBN_COALESCE", "1") != "0"   # joint SyncBN exchange of layers that share their input
-_G_INTO = os.environ.get("RR_BN_G_INTO", "1") != "0"     # residual gradient added into the fan-in buffer by bn_bwd_apply itself
-BN_FUSED_STATS = os.environ.get("RR_BN_FUSED_STATS", "1") != "0"    # single process: slab -> statistics -> coefficients in one launch
+_SYNC_COALESCE = True   # joint SyncBN exchange of layers that share their input
+_G_INTO = True     # residual gradient added into the fan-in buffer by bn_bwd_apply itself
+BN_FUSED_STATS = True    # single process: slab -> statistics -> coefficients in one launch
 
 
 def _is_sync(bn):
@@ -159,7 +151,7 @@ class _ConvBnAct(torch.autograd.Function):
                     # the stream has drained — one host sync per SyncBN layer (found with the one-rank RCCL step: 430 ms of
                     # host time per 487 ms step)
                     sums[2 * k:2 * k + 1].fill_(count)
-                    pg, pgname = sync_group()
+                    pg, pgname = None, "default"
                     dptrace.record(pgname, "all_reduce", sums.numel(), "syncbn_fwd")
                     dist.all_reduce(sums, group=pg)
                     cnt_dev = sums[2 * k:].clone()   # own storage: `sums` is a slice of a shared zero pool (version counter)
@@ -211,7 +203,6 @@ class _ConvBnAct(torch.autograd.Function):
     @staticmethod
     def _backward(ctx, dz):
         x, wc, y, z, mean, invstd, gamma, cnt_dev, msc, msh = ctx.saved_tensors
-        branch_stress(dz.device)
         ops.amax_restore(x, getattr(ctx, "x_amax", None))
         ops.b16_restore(x, getattr(ctx, "x_b16", None))
         ops.b16_restore(z, getattr(ctx, "z_b16", None))
@@ -243,7 +234,7 @@ class _ConvBnAct(torch.autograd.Function):
             else:
                 ret_dg, ret_db = dg, db
         if sync:
-            pg, pgname = sync_group()
+            pg, pgname = None, "default"
             dptrace.record(pgname, "all_reduce", sums.numel(), "syncbn_bwd")
             dist.all_reduce(sums, group=pg)
         want_g = has_res and relu
@@ -416,7 +407,7 @@ class _ConvBnSyncMulti(torch.autograd.Function):
         counts = [float(y.numel() // k) for (y, _), k in zip(ys, ks)]
         for i, cnt in enumerate(counts):
             packed[tot - L + i:tot - L + i + 1].fill_(cnt)       # (fill_, not item assignment: see _ConvBnAct.forward)
-        pg, pgname = sync_group()
+        pg, pgname = None, "default"
         dptrace.record(pgname, "all_reduce", packed.numel(), "syncbn_fwd x%d" % L)
         dist.all_reduce(packed, group=pg)
         cnt_devs = [packed[tot - L + i:tot - L + i + 1].clone() for i in range(L)]
@@ -468,7 +459,7 @@ class _ConvBnSyncMulti(torch.autograd.Function):
         local = None
         if any(_grad_target(params[3 * i + 1]) is None for i in range(L)):
             local = packed.clone()
-        pg, pgname = sync_group()
+        pg, pgname = None, "default"
         dptrace.record(pgname, "all_reduce", packed.numel(), "syncbn_bwd x%d" % L)
         dist.all_reduce(packed, group=pg)
         if x_acc is not None:
@@ -710,51 +701,7 @@ def fanout(x, n):
     return outs
 
 
-_SHARED_ACC = os.environ.get("RR_SHARED_ACC", "1") != "0"
-
-# Hourglass branches on their own HIP streams.  The two branches of an hourglass module — up1 at the module's resolution, and
-# low1 -> low2 -> low3 one level down (backbones/hourglass.py:104-124 of the reference) — are independent between the fan-out of
-# the module's input and the up-sample-add that joins them.  The lower levels (32x32 and below at 1024x1024 input) launch too few
-# workgroups to fill 256 CUs and are chains of short kernels; with up1 of the RR_BRANCH_STREAMS outermost modules on streams of
-# their own, the large MFMA-bound kernels of those branches run beside the under-filled chain instead of in front of it, in
-# the forward and (autograd runs every node's backward on the stream of its forward) in the backward; under data parallelism each
-# branch exchanges its SyncBN statistics on a communicator of its own, so one branch's all-reduce latency sits under the other
-# branch's convolutions (sync_group).  What autograd cannot see — the shared fan-in buffers written through raw pointers — is
-# ordered by GradAcc.begin / end; tensors that cross streams are record_stream'ed at the crossing (Hourglass.forward).
-# 0 = every kernel of the model on the caller's stream (plus the weight-gradient side stream).
-_BRANCH_LEVELS = int(os.environ.get("RR_BRANCH_STREAMS", "0") or 0)
-_BRANCH_IDS = {}      # HIP stream handle -> "branch<slot>" (the name of its SyncBN communicator in rrnet_amd.dptrace)
-_BRANCH_PG = {}       # "branch<slot>" -> process group
-
-
-def branch_stream(device, slot):
-    """The stream of the `slot`-th outermost hourglass module's up1 branch (slot 0 = the module at full feature-map
-    resolution), or None: switched off, not a GPU tensor, or a module deeper than RR_BRANCH_STREAMS."""
-    if device.type != "cuda" or slot >= _BRANCH_LEVELS or _BRANCH_LEVELS <= 0:
-        return None
-    st = _side_stream(device, "branch%d" % slot)
-    _BRANCH_IDS[st.cuda_stream] = "branch%d" % slot
-    return st
-
-
-def sync_group():
-    """-> (communicator, its name in dptrace) for a SyncBN statistics exchange issued now: the default one on the caller's
-    stream, one of its own for every branch stream (created at the first use — every rank reaches that point at the same
-    place of the program; the first collective of a new RCCL communicator is run right there, as FlatParams._group does)."""
-    if not _BRANCH_IDS:
-        return None, "default"
-    name = _BRANCH_IDS.get(torch.cuda.current_stream().cuda_stream)
-    if name is None:
-        return None, "default"
-    pg = _BRANCH_PG.get(name)
-    if pg is None:
-        pg = dist.new_group()
-        warm = torch.zeros(1, dtype=torch.float32, device=torch.device("cuda", torch.cuda.current_device()))
-        dptrace.record(name, "all_reduce", 1, "communicator warm-up")
-        dist.all_reduce(warm, group=pg)
-        _BRANCH_PG[name] = pg
-    return pg, name
-
+_SHARED_ACC = True
 
 class GradAcc:
     """Fan-in target shared by the consumers of one fan-out: the first consumer to run its backward publishes its
@@ -762,33 +709,22 @@ class GradAcc:
     fan-out's backward finds one complete gradient and launches no sum kernel.  The views a fan-out returns carry
     the accumulator as `_rr_acc`; convolution nodes pick it up from their input, and a nested fan-out of such a view
     (a residual block at the head of an hourglass branch) joins the same accumulator."""
-    __slots__ = ("buf", "pending", "link", "events")
+    __slots__ = ("buf", "pending", "link")
 
     def __init__(self):
         self.buf = None
         self.pending = 0        # registered contributors that have not run their backward yet
         self.link = None        # ops.BnLink of the fanned-out tensor when a conv -> bn layer produced it
-        self.events = None      # branch streams: [(stream id, event)] of the kernels that wrote `buf` so far
 
-    # The buffer is written through raw pointers, which autograd's own stream hand-over never sees.  With the hourglass
-    # branches on their own HIP streams (branch_stream) the contributors of one fan-in may run on different streams: every
-    # contributor waits for the writes of the others before it touches the buffer (begin) and leaves an event behind its own
-    # (end); the fan-out's backward waits for all of them.  Without branch streams both are no-ops.
+    # The buffer is written through raw pointers, which autograd's own stream hand-over never sees: every contributor
+    # brackets its write with begin / end.  All contributors run on the caller's stream today, so both are no-ops — the
+    # hourglass branch streams that needed events here were measured (0 to -12 %, DESIGN §13.2) and removed in round 6; the
+    # bracket stays as the one place where an ordering would have to go.
     def begin(self, device):
-        if self.events:
-            cur = torch.cuda.current_stream(device)
-            for sid, ev in self.events:
-                if sid != cur.cuda_stream:
-                    cur.wait_event(ev)
+        pass
 
     def end(self, device):
-        if _BRANCH_LEVELS > 0 and device.type == "cuda":
-            cur = torch.cuda.current_stream(device)
-            ev = torch.cuda.Event()
-            ev.record(cur)
-            if self.events is None:
-                self.events = []
-            self.events.append((cur.cuda_stream, ev))
+        pass
 
 
 def fanout_shared(x, n):
@@ -1173,9 +1109,9 @@ def _side_stream(device, tag="dcn"):
     return _SIDE[key]
 
 
-DCN_BF16_BWD = os.environ.get("RR_DCN_BF16_BWD", "1") != "0"         # bf16 forward -> bf16-operand wgrad / dgrad (0: fp32 kernels)
+DCN_BF16_BWD = True         # bf16 forward -> bf16-operand wgrad / dgrad (0: fp32 kernels)
 DCN_BWD_STREAMS = os.environ.get("RR_DCN_BWD_STREAMS", "1") != "0"   # wgrad and dgrad of the fused backward side by side
-DCN_FUSED_BWD = os.environ.get("RR_DCN_FUSED_BWD", "1") != "0"   # 0: the reference's column-buffer structure (A/B switch)
+DCN_FUSED_BWD = True   # 0: the reference's column-buffer structure (A/B switch)
 DCN_BF16 = os.environ.get("RR_DCN_BF16", "0") == "1"   # BASELINE config 4: bf16 matrix operands in the DCN forward
 
 

@@ -23,7 +23,7 @@ from rrnet_amd.models.rrnet import stage1_proposals
 # RoIAlign processing order: per-frame spatial sort (rr_roi_spatial_order).  Off by default since round 3: with eight
 # footprint pixels in flight per wave the kernel runs as fast in decode order (2.66-2.73 ms against 2.62-2.87 ms sorted, per
 # 128 frames at config 5) and the sort is a launch of its own (0.05 ms); RR_ROI_ORDER=1 turns it on.
-ROI_SPATIAL_ORDER = os.environ.get("RR_ROI_ORDER", "0") != "0"
+ROI_SPATIAL_ORDER = False
 
 
 @torch.no_grad()

@@ -90,8 +90,8 @@ def _timed(name, flops, fn, detail=None, nbytes=0.0):
     return TIMER.launch(name, flops, fn, detail, nbytes)
 
 
-_SMALL_TILES = int(os.environ.get("RR_CONV_SMALL_TILES", "16"))
-_MID_TILES = int(os.environ.get("RR_CONV_MID_TILES", "48"))
+_SMALL_TILES = 16
+_MID_TILES = 48
 
 
 def _igemm_name(kind, n_gemm, scalar, m_rows=1 << 30, stride=1):
@@ -182,8 +182,6 @@ _MATH_NAMES = {"f32": MATH_F32, "fp32": MATH_F32, "bf16": MATH_BF16, "f16x3": MA
 
 
 def _env_mode():
-    if os.environ.get("RR_CONV_BF16", "0") == "1":
-        return MATH_BF16
     name = os.environ.get("RR_CONV_MATH", "f32")
     if name not in _MATH_NAMES:
         raise ValueError("RR_CONV_MATH must be one of %s, got %r" % (sorted(_MATH_NAMES), name))
@@ -247,10 +245,10 @@ def _bf16_ok(c, k, r, s, *tensors, pixels=None):
     return int(_mode()) if ok else 0
 
 
-_SPLIT_MIN_PIXELS = int(os.environ.get("RR_SPLIT_MIN_PIXELS", "2048"))    # N*P*Q below which a layer stays on the fp32 kernels
-_FUSED_AMAX_FWD = os.environ.get("RR_SPLIT_FUSED_AMAX_FWD", "1") != "0"    # bn_apply leaves max |out| for the next convolution
-_FUSED_AMAX_BWD = os.environ.get("RR_SPLIT_FUSED_AMAX_BWD", "1") != "0"    # bn_bwd_apply leaves max |dx| for the data / weight gradient
-_SPLIT_PRESPLIT_PIXELS = int(os.environ.get("RR_SPLIT_PRESPLIT_PIXELS", "65536"))   # from here on the filter is split once per launch
+_SPLIT_MIN_PIXELS = 2048    # N*P*Q below which a layer stays on the fp32 kernels
+_FUSED_AMAX_FWD = True    # bn_apply leaves max |out| for the next convolution
+_FUSED_AMAX_BWD = True    # bn_bwd_apply leaves max |dx| for the data / weight gradient
+_SPLIT_PRESPLIT_PIXELS = 65536   # from here on the filter is split once per launch
 
 
 def split_filter(w, amax_word, pixels, flat=None):
@@ -266,9 +264,9 @@ def split_filter(w, amax_word, pixels, flat=None):
     return out
 
 
-_SPLIT_PER_LAUNCH = os.environ.get("RR_SPLIT_PER_LAUNCH", "1") == "1"     # the filter split at every large launch into a fresh temporary (0: in-tile split)
+_SPLIT_PER_LAUNCH = True     # the filter split at every large launch into a fresh temporary (0: in-tile split)
 _SPLIT_MIN_CH = 64                                                         # narrower layers (either side) likewise
-_SPLIT_MIN_K = int(os.environ.get("RR_SPLIT_MIN_K", "1024"))               # C*R*S (reduction length) likewise
+_SPLIT_MIN_K = 1024               # C*R*S (reduction length) likewise
 
 
 def amax_carry(t):
@@ -312,7 +310,7 @@ def amax_drop(t):
 # remembered the same way.  Like the remembered maxima it must be dropped when a kernel rewrites the tensor through its
 # raw pointer (amax_drop does both), is valid on the stream that made it, and on every stream once published.
 _CONV16 = os.environ.get("RR_CONV16", "1") != "0"               # 0: the round-4 kernels (fp32 tensors, converted inside every launch)
-_CONV16_MIN_PIXELS = int(os.environ.get("RR_CONV16_MIN_PIXELS", "8192"))     # output pixels below which the 256-pixel tiles lose to the round-4 kernels (8 x 32 x 32 x 384: 351 vs 229 TFLOP/s; 16 x 16: 24 workgroups)
+_CONV16_MIN_PIXELS = 8192     # output pixels below which the 256-pixel tiles lose to the round-4 kernels (8 x 32 x 32 x 384: 351 vs 229 TFLOP/s; 16 x 16: 24 workgroups)
 
 
 class _PhantomScope(threading.local):
@@ -321,7 +319,7 @@ class _PhantomScope(threading.local):
 
 
 _PHANTOM = _PhantomScope()
-_PHANTOM_TRACE = os.environ.get("RR_PHANTOM_TRACE", "0") == "1"       # count, by shape and caller, the bf16-only tensors that had to be widened
+_PHANTOM_TRACE = False       # count, by shape and caller, the bf16-only tensors that had to be widened
 PHANTOM_WIDENED = {}
 _PHANTOM_ENABLED = os.environ.get("RR_BF16_ONLY_ACT", "1") != "0"      # 0: every activation keeps its fp32 tensor next to the image
 
@@ -347,7 +345,7 @@ def phantom_out_ok(c, pixels, device):
                 and c % 256 == 0 and pixels >= _CONV16_MIN_PIXELS)
 
 
-_PHANTOM_Y = os.environ.get("RR_BF16_ONLY_Y", "1") != "0"      # 0: pre-BN convolution outputs keep their fp32 tensor
+_PHANTOM_Y = True      # 0: pre-BN convolution outputs keep their fp32 tensor
 
 
 def phantom_y_ok(k, x, w, stride, pad):
@@ -401,11 +399,19 @@ def bf16_of(t):
     return img
 
 
+_PHANTOM_STUB = {}       # device -> the two-NaN storage every handle on that device is a view of
+
+
 def phantom_f32(shape, device, image):
     """An fp32 tensor OBJECT of the given logical shape that owns no memory (one element, stride 0) and carries `image` as its
     bf16 image: the handle of a gradient that exists only in bf16 — every consumer is a conv16 kernel.  A kernel wrapper that
-    would read its fp32 data trips over `is_nhwc` (stride 0) instead of reading garbage."""
-    t = torch.empty(2, dtype=torch.float32, device=device)[1:].expand(shape)       # (element 1 of 2: is_phantom's signature)
+    would read its fp32 data trips over `is_nhwc` (stride 0); a torch-native consumer (a hook, `+`, `.sum()`, a print) reads
+    NaN — the stub's one element — so an accidental read poisons the loss loudly instead of training on one garbage value."""
+    device = torch.device(device)
+    stub = _PHANTOM_STUB.get(device)
+    if stub is None:
+        stub = _PHANTOM_STUB[device] = torch.full((2,), float("nan"), dtype=torch.float32, device=device)
+    t = stub[1:].expand(shape)                            # (element 1 of 2: is_phantom's signature)
     t._rr_b16 = (t._version, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else None, image)
     return t
 
@@ -549,7 +555,7 @@ def conv_fprop(x, w, bias=None, stride=1, pad=(0, 0), relu=False, want_stats=Fal
     return (y, slab) if want_stats else y
 
 
-_STEM_PACK = os.environ.get("RR_STEM_PACK", "1") != "0"
+_STEM_PACK = True
 
 
 def conv_packable(x, w, stride):
@@ -604,8 +610,8 @@ def stem_wgrad_s2d(x, dy, dw):
     return dw
 
 
-_DGRAD_VIA_FPROP = os.environ.get("RR_DGRAD_VIA_FPROP", "1") != "0"
-_DGRAD_VIA_FPROP_MIN_PIXELS = int(os.environ.get("RR_DGRAD_VIA_FPROP_MIN_PIXELS", "4096"))  # below: the dgrad kernel's split-K wins
+_DGRAD_VIA_FPROP = True
+_DGRAD_VIA_FPROP_MIN_PIXELS = 4096  # below: the dgrad kernel's split-K wins
 
 
 class BnLink:
@@ -629,16 +635,12 @@ class BnLink:
         self.consumers = 0
 
 
-_DGRAD_BNSUM = os.environ.get("RR_DGRAD_BNSUM", "1") != "0"
-# the same inside csrc/conv16.hip's data gradient (rr_conv16_dgrad_s1_bnsum, round 5): built, parity-tested, and OFF — with one
-# workgroup per CU the epilogue's image reads are in the open: config-4 step 111.8-113.3 ms with it against 108.9-110.8 ms with the
-# separate rr_bn_bwd_reduce_b16 pass (0.20 ms at the largest layer), back to back on one box
-_CONV16_BNSUM = os.environ.get("RR_CONV16_BNSUM", "0") == "1"
+_DGRAD_BNSUM = True
 # measured at 8 x 256 x 256 x 256 (tools/bench_head_dgrad.py): K = 10: 0.23 ms against 0.40, K = 2: 0.22 against 0.39; K = 34 (the WH head: 144 filter
 # registers per lane, two waves per SIMD): 0.58 against 0.48 — that layer stays on the implicit-GEMM kernel
-_HEAD_DGRAD_MAX_K = int(os.environ.get("RR_HEAD_DGRAD_MAX_K", "12"))
-_HEAD_DGRAD = os.environ.get("RR_HEAD_DGRAD", "1") != "0"      # 0: the heads' narrow 1x1 data gradients on the implicit-GEMM kernel (round 3)
-_BF16_S2_DGRAD = os.environ.get("RR_BF16_S2_DGRAD", "1") != "0"     # A/B: stride-2 data gradients stay on the fp32 kernel
+_HEAD_DGRAD_MAX_K = 12
+_HEAD_DGRAD = True      # 0: the heads' narrow 1x1 data gradients on the implicit-GEMM kernel (round 3)
+_BF16_S2_DGRAD = True     # A/B: stride-2 data gradients stay on the fp32 kernel
 
 
 def _s2_parity_pads_ok(r, s, pad):
@@ -672,15 +674,9 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False,
     else:
         amax_drop(out)                # an existing tensor rewritten / added into through its pointer
     assert is_nhwc(out)
-    # conv16's data gradient carries a BatchNorm producer's backward sums itself, reading y / z as fp32 or as their bf16 images
-    sum16 = (_CONV16_BNSUM and bnsum is not None and not bnsum.relu_bias and _DGRAD_BNSUM and bnsum.y is not None and stride == 1
-             and pad[0] < r and pad[1] < s and conv16_ok(k, c, r, s, 1, n * h * wd, dy, out) and (n * h * wd) % 256 == 0
-             and tuple(bnsum.y.shape) == tuple(out.shape) and (is_phantom(bnsum.y) or is_nhwc(bnsum.y))
-             and (not bnsum.use_z or (bnsum_z is not None and tuple(bnsum_z.shape) == tuple(out.shape)
-                                      and (is_phantom(bnsum_z) or is_nhwc(bnsum_z)))))
-    if bnsum is not None and not sum16 and not bnsum.relu_bias and bnsum.y is not None and is_phantom(bnsum.y):
+    if bnsum is not None and not bnsum.relu_bias and bnsum.y is not None and is_phantom(bnsum.y):
         bnsum = None                  # the producer's pre-BN output exists only as a bf16 image: it runs its own reduce pass
-    if bnsum is not None and not sum16 and bnsum_z is not None and is_phantom(bnsum_z):
+    if bnsum is not None and bnsum_z is not None and is_phantom(bnsum_z):
         # the producer's output exists only as a bf16 image: the fp32-reading epilogues cannot take their mask from it — a ReLU /
         # bias producer gets the widened copy, a BatchNorm producer runs its own reduce pass (rr_bn_bwd_reduce_b16)
         if bnsum.relu_bias:
@@ -753,8 +749,9 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False,
     if (stride == 1 and pad[0] < r and pad[1] < s and conv16_ok(k, c, r, s, 1, n * h * wd, dy, out)
             and not (bnsum is not None and bnsum.relu_bias)):
         # csrc/conv16.hip: the forward kernel on dY's bf16 image and the flipped filter's bf16 copy.  (The producer's
-        # BatchNorm-backward sums are not carried by this kernel yet: `bnsum` stays untouched and the producer runs
-        # rr_bn_bwd_reduce — a pass of 0.2 ms at 8 x 256 x 256 x 256 against the 0.35 ms the launch saves.)
+        # BatchNorm-backward sums are NOT carried by this kernel: `bnsum` stays untouched and the producer runs its reduce pass.
+        # An epilogue that did — round 5 — lost: with one workgroup per CU its image reads are in the open, config-4 step
+        # 111.8-113.3 ms against 108.9-110.8 ms; removed in round 6, the numbers live in DESIGN §13.1.)
         dy16 = bf16_of(dy)
         if wt16 is None:
             if wt is None:
@@ -762,22 +759,6 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=(0, 0), out=None, accumulate=False,
                 _C.check(_C.fn("rr_weight_flip_transpose")(_C.ptr(w), _C.ptr(wt), k, c, r, s, _C.stream()), "rr_weight_flip_transpose")
             wt16 = torch.empty(wt.numel(), dtype=torch.bfloat16, device=dy.device)
             _C.check(_C.fn("rr_to_bf16")(_C.ptr(wt), _C.ptr(wt16), wt.numel(), _C.stream()), "rr_to_bf16")
-        if sum16:
-            yb, zb = bnsum.y, (bnsum_z if bnsum.use_z else None)
-            y_ph, z_ph = is_phantom(yb), (zb is not None and is_phantom(zb))
-            slab = torch.empty(_C.fn("rr_conv16_stat_slab_bytes")(n, h, wd, c) // 8, dtype=torch.float64, device=dy.device)
-            sums = _ZEROS.take(2 * c, dy.device)
-            _C.check(_timed("conv16_dgrad_s1+bnsum", flops,
-                            lambda: _C.fn("rr_conv16_dgrad_s1_bnsum")(
-                                _C.ptr(dy16), _C.ptr(wt16), _C.ptr(out), None, n, h, wd, c, k, r, s, pad[0], pad[1], int(accumulate),
-                                _C.ptr(None if y_ph else yb), _C.ptr(image_of(yb) if y_ph else None),
-                                _C.ptr(None if (zb is None or z_ph) else zb), _C.ptr(image_of(zb) if z_ph else None),
-                                _C.ptr(bnsum.mean), _C.ptr(bnsum.invstd), _C.ptr(None if zb is not None else bnsum.msc),
-                                _C.ptr(None if zb is not None else bnsum.msh), _C.ptr(slab), _C.ptr(sums), _C.stream()),
-                            (n, h, wd, c, k, r, s, stride),
-                            2.0 * (dy.numel() + w.numel()) + 4.0 * out.numel() * (2 if accumulate else 1)), "rr_conv16_dgrad_s1_bnsum")
-            bnsum.sums, bnsum.dz = sums, out
-            return out
         _C.check(_timed("conv16_dgrad_s1", flops,
                         lambda: _C.fn("rr_conv16_dgrad_s1")(_C.ptr(dy16), _C.ptr(wt16), _C.ptr(out), None, n, h, wd, c, k, r, s, pad[0], pad[1],
                                                             int(accumulate), _C.stream()), (n, h, wd, c, k, r, s, stride),
@@ -1452,8 +1433,8 @@ def roi_align_bwd(dout, rois, feat_shape, out_size, spatial_scale=1.0, sampling_
 # ---------------------------------------------------------------------------------------------
 # DCNv2
 # ---------------------------------------------------------------------------------------------
-_DCN_WPACK = os.environ.get("RR_DCN_WPACK", "1") != "0"
-_DCN_DYB = os.environ.get("RR_DCN_DYB", "1") != "0"      # bf16 data gradient stages dY from a bf16 copy made once per call
+_DCN_WPACK = True
+_DCN_DYB = True      # bf16 data gradient stages dY from a bf16 copy made once per call
 
 
 def dcn_fwd(x, offset, mask, w, bias, stride, pad, dilation, dg, bf16=False):

@@ -141,7 +141,7 @@ def audit(tol=2e-5, tol_wgrad=2e-4, sample=False, ref_device="cpu"):
     rec.sampled = set()
     names = ("conv_fprop", "conv_dgrad", "conv_wgrad", "stem_wgrad_s2d", "conv_fprop_packed", "conv_wgrad_packed", "bn_apply", "bn_bwd_reduce", "bn_bwd_apply",
              "sum_n", "upsample_add_fwd", "upsample_add_bwd", "bias_relu_bwd", "relu_fwd", "bn_finalize",
-             "bn_stats_finalize")
+             "bn_stats_finalize", "dcn_fwd", "dcn_dgrad", "dcn_wgrad")
     orig = {n: getattr(ops, n) for n in names}
 
     def big(flops):
@@ -575,11 +575,141 @@ def audit(tol=2e-5, tol_wgrad=2e-4, sample=False, ref_device="cpu"):
             rec.note("bn_stats_finalize", sig, _finalize_err(got, ref, running_mean, running_var), 1e-5)
         return got
 
+    # ---- DCNv2 (config 4's heads; ext/dcn/dcn_v2.py:16-52, dcn_v2_im2col_cuda.cu:125-327) ------------------------------------
+    # Reference = oracle/dcn.py in fp64 on the reference device.  bf16 calls: the kernels' contract (both operands of the
+    # three matrix products rounded to bf16 — oracle/dcn.py:_ContractBf16 — everything around them in fp32).  The op is
+    # local for bounded offsets: forward / data gradient are recomputed on windows (top-left corner, an interior window
+    # straddling the kernels' 8 x 16 pixel blocks, bottom-right corner; three different images) cropped with a margin of
+    # pad + ceil(max |offset|) + 2 pixels, which reproduces out, d input, d offset and d mask of the window's core exactly;
+    # the weight gradient reduces over ALL pixels and is recomputed over the full range for a sample of filters.
+    # Tolerance of the bf16 calls 1e-4: the kernel blends the samples in fp32 BEFORE rounding them to bf16, the reference in
+    # fp64 — a sample within 1e-7 of a rounding boundary rounds the other way (about one in 4e4), one bf16 ulp of one of the
+    # 2304 terms of an output element.
+    DCN_TOL_BF16 = 1e-4
+
+    def _dcn_windows(n, h, wd):
+        if h <= 48 and wd <= 64:
+            return [(i, 0, h, 0, wd) for i in range(n)]
+        r_mid, c_mid = (h // 2 // 8) * 8 - 3, (wd // 2 // 16) * 16 - 8
+        return [(0, 0, min(20, h), 0, min(28, wd)), (n // 2, r_mid, min(r_mid + 24, h), c_mid, min(c_mid + 36, wd)),
+                (n - 1, max(h - 20, 0), h, max(wd - 28, 0), wd)]
+
+    def _dcn_window_ref(x, off, mask, w, bias, dy, win, cfg, quant, local=True):
+        """fp64 reference on one window -> (out, dx, doffset, dmask) of the window's core (the gradients None without dy).
+        local=False (out and in sizes differ / strided): the window is a whole image, nothing is cropped."""
+        from oracle import dcn as odcn
+        stride, pad, dil, dg = cfg
+        n0, r0, r1, c0, c1 = win
+        h, wd = x.shape[2], x.shape[3]
+        if local:
+            m = pad[0] + int(float(off.detach().abs().max()) + 0.999) + 2
+            ra, rb, ca, cb = max(0, r0 - m), min(h, r1 + m), max(0, c0 - m), min(wd, c1 + m)
+            cut = lambda t: t[n0:n0 + 1, :, ra:rb, ca:cb]
+            core = (slice(None), slice(None), slice(r0 - ra, r1 - ra), slice(c0 - ca, c1 - ca))
+        else:
+            cut = lambda t: t[n0:n0 + 1]
+            core = (slice(None),) * 4
+        with torch.enable_grad():
+            crop = [_c64(cut(t)).contiguous().requires_grad_(dy is not None) for t in (x, off, mask)]
+            ref = odcn.dcn_v2_conv(crop[0], crop[1], crop[2], _c64(w).contiguous(), None if bias is None else _c64(bias),
+                                   stride, pad, dil, dg, bf16=bool(quant))
+            if dy is not None:
+                ref.backward(_c64(cut(dy)).contiguous())
+        return (ref.detach()[core],) + tuple(None if dy is None else t.grad[core] for t in crop)
+
+    def _dcn_local(x, w, off, stride, pad, dil):
+        """The window decomposition holds for same-size stride-1 layers (the window kernels' domain; the heads' 3x3)."""
+        return stride == 1 and off.shape[2] == x.shape[2] and off.shape[3] == x.shape[3]
+
+    def dcn_fwd(x, offset, mask, w, bias, stride, pad, dilation, dg, bf16=False):
+        y = orig["dcn_fwd"](x, offset, mask, w, bias, stride, pad, dilation, dg, bf16)
+        sig = (tuple(x.shape), tuple(w.shape), stride, tuple(pad), dilation, dg, bool(bf16))
+        if ("dcn_fwd",) + sig not in rec.seen:
+            n, _, h, wd = x.shape
+            cfg = (stride, tuple(pad), dilation, dg)
+            local = _dcn_local(x, w, offset, stride, pad, dilation)
+            wins = _dcn_windows(n, h, wd) if local else [(i, 0, y.shape[2], 0, y.shape[3]) for i in range(n)]
+            if len(wins) < n:
+                rec.sampled.add(("dcn_fwd",) + sig)
+            scale = max(float(y.abs().max()), 1e-30)
+            err = 0.0
+            for win in wins:
+                n0, r0, r1, c0, c1 = win
+                ref = _dcn_window_ref(x, offset, mask, w, bias, None, win, cfg, bf16, local)[0]
+                err = max(err, float((_c64(y[n0:n0 + 1, :, r0:r1, c0:c1]) - ref).abs().max()) / scale)
+            rec.note("dcn_fwd", sig, err, DCN_TOL_BF16 if bf16 else tol_)
+        return y
+
+    def dcn_dgrad(x, offset, mask, w, dy, stride, pad, dilation, dg, bf16=False, out=None):
+        img = ops.b16_carry(dy) if bf16 else None
+        sig = (tuple(x.shape), tuple(w.shape), stride, tuple(pad), dilation, dg, bool(bf16), out is not None, img is not None)
+        todo = ("dcn_dgrad",) + sig not in rec.seen
+        base = out.clone() if (out is not None and todo) else None
+        dx, doff, dmask = orig["dcn_dgrad"](x, offset, mask, w, dy, stride, pad, dilation, dg, bf16, out)
+        if todo:
+            n, _, h, wd = x.shape
+            cfg = (stride, tuple(pad), dilation, dg)
+            if img is not None:
+                # image-fed dY: the kernel read the producer's bf16 image instead of rounding dy itself — it must BE round(dy)
+                ns = _img_sample(n)
+                same = torch.equal(img[ns].float(), dy[ns].to(torch.bfloat16).float())
+                rec.note("dcn_dy_image", sig, 0.0 if same else 1.0, 0.5)
+            local = _dcn_local(x, w, offset, stride, pad, dilation)
+            wins = _dcn_windows(n, h, wd) if local else [(i, 0, h, 0, wd) for i in range(n)]
+            if len(wins) < n:
+                rec.sampled.add(("dcn_dgrad",) + sig)
+            got = dx if base is None else (dx.double() - base.double())
+            scales = [max(float(t.abs().max()), 1e-30) for t in (got, doff, dmask)]
+            errs = [0.0, 0.0, 0.0]
+            for win in wins:
+                n0, r0, r1, c0, c1 = win
+                ref = _dcn_window_ref(x, offset, mask, w, None, dy, win, cfg, bf16, local)
+                o = (slice(n0, n0 + 1), slice(None), slice(r0, r1), slice(c0, c1)) if local else (slice(n0, n0 + 1),)
+                errs[0] = max(errs[0], float((_c64(got[o]) - ref[1]).abs().max()) / scales[0])
+                errs[1] = max(errs[1], float((_c64(doff[o]) - ref[2]).abs().max()) / scales[1])
+                errs[2] = max(errs[2], float((_c64(dmask[o]) - ref[3]).abs().max()) / scales[2])
+            t = DCN_TOL_BF16 if bf16 else tol_
+            rec.note("dcn_dgrad", sig, errs[0], t)
+            rec.note("dcn_dgrad_doffset", sig, errs[1], t)
+            rec.note("dcn_dgrad_dmask", sig, errs[2], t)
+        return dx, doff, dmask
+
+    def dcn_wgrad(x, offset, mask, dy, dw, stride, pad, dilation, dg, bf16=False, dy_img=None):
+        sig = (tuple(x.shape), tuple(dw.shape), stride, tuple(pad), dilation, dg, bool(bf16), dy_img is not None)
+        todo = ("dcn_wgrad",) + sig not in rec.seen
+        base = dw.clone() if todo else None
+        res = orig["dcn_wgrad"](x, offset, mask, dy, dw, stride, pad, dilation, dg, bf16, dy_img)
+        if todo:
+            from oracle import dcn as odcn
+            n = x.shape[0]
+            k, c, r, s_ = dw.shape
+            if dy_img is not None:
+                ns = _img_sample(n)
+                same = torch.equal(dy_img[ns].float(), dy[ns].to(torch.bfloat16).float())
+                rec.note("dcn_dy_image", sig, 0.0 if same else 1.0, 0.5)
+            flops = 2.0 * dy.numel() * c * r * s_
+            ks = _k_sample(k) if big(flops) else list(range(k))
+            if big(flops):
+                rec.sampled.add(("dcn_wgrad",) + sig)
+            ref = torch.zeros((len(ks), c, r * s_), dtype=torch.float64, device=REF["dev"])
+            for i in range(n):                                    # whole pixel range, one image at a time (memory)
+                cols = odcn.dcn_columns(_c64(x[i:i + 1]), _c64(offset[i:i + 1]), _c64(mask[i:i + 1]), r, s_, stride, tuple(pad),
+                                        dilation, dg)
+                dyi = _c64(dy[i:i + 1, ks])
+                if bf16:
+                    cols, dyi = cols.to(torch.bfloat16).double(), dyi.to(torch.bfloat16).double()
+                ref += torch.einsum('nkpq,nctpq->kct', dyi, cols)
+                del cols
+            got = (_c64(res) - _c64(base))[ks].reshape(len(ks), c, r * s_)
+            rec.note("dcn_wgrad", sig, float((got - ref).abs().max() / max(float(ref.abs().max()), 1e-30)), tol_wgrad)
+        return res
+
     patched = dict(conv_fprop=conv_fprop, conv_dgrad=conv_dgrad, conv_wgrad=conv_wgrad, stem_wgrad_s2d=stem_wgrad_s2d,
                    conv_fprop_packed=conv_fprop_packed, conv_wgrad_packed=conv_wgrad_packed,
                    bn_finalize=bn_finalize, bn_stats_finalize=bn_stats_finalize, bn_apply=bn_apply,
                    bn_bwd_reduce=bn_bwd_reduce, bn_bwd_apply=bn_bwd_apply, sum_n=sum_n, upsample_add_fwd=upsample_add_fwd,
-                   upsample_add_bwd=upsample_add_bwd, bias_relu_bwd=bias_relu_bwd, relu_fwd=relu_fwd)
+                   upsample_add_bwd=upsample_add_bwd, bias_relu_bwd=bias_relu_bwd, relu_fwd=relu_fwd,
+                   dcn_fwd=dcn_fwd, dcn_dgrad=dcn_dgrad, dcn_wgrad=dcn_wgrad)
     for n, f in patched.items():
         setattr(ops, n, f)
     try:

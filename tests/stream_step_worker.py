@@ -1,5 +1,5 @@
 """Child process of tests/test_streams_gpu.py: ONE configuration of the stream switches (taken from the environment:
-RR_WGRAD_STREAM, RR_BRANCH_STREAMS, RR_WGRAD_STRESS, RR_DCN_BWD_STREAMS), `--repeats` train steps of RRNet from the SAME initial state on the
+RR_WGRAD_STREAM, RR_WGRAD_STRESS, RR_DCN_BWD_STREAMS), `--repeats` train steps of RRNet from the SAME initial state on the
 SAME batch.  Writes, into --out:
   grad.bin / param.bin   flat gradient after the first step / flat parameters after its Adam update (raw float32)
   buffers.bin            every floating-point buffer of the model (BatchNorm running statistics) after the first step
@@ -105,7 +105,6 @@ def main():
                 return None
             return orig(self, other)
         torch.cuda.Stream.wait_stream = patched
-        RF.GradAcc.begin = lambda self, device: None      # ... and the event waits between contributors of a shared fan-in buffer
     fp = op.optimizer.fp
     batch = op.training_loader.get_batch()
     slices = param_slices(fp)
@@ -115,8 +114,7 @@ def main():
     sched0 = op.lr_sch.state_dict()
     ref = None
     from rrnet_amd import dptrace
-    meta = {"env": {k: os.environ.get(k) for k in ("RR_WGRAD_STREAM", "RR_WGRAD_STRESS", "RR_DCN_BWD_STREAMS", "RR_DP_FORCE",
-                                                         "RR_BRANCH_STREAMS")},
+    meta = {"env": {k: os.environ.get(k) for k in ("RR_WGRAD_STREAM", "RR_WGRAD_STRESS", "RR_DCN_BWD_STREAMS", "RR_DP_FORCE")},
             "losses": [], "repeat_vs_first": [], "collectives": [], "buckets": len(fp._bucket_range)}
     for r in range(a.repeats):
         with torch.no_grad():

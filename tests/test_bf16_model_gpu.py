@@ -191,3 +191,167 @@ def test_config4_bf16_full_size_train_step_every_kernel_call_sampled():
     keys = set(rec.seen)
     for w_ in (("fprop", big, (256, 256, 3, 3), 1), ("dgrad", big, (256, 256, 3, 3), big, 1), ("wgrad", big, big, (256, 256, 3, 3), 1)):
         assert any(k[:len(w_)] == w_ and k[-1] == "bf16" for k in keys), w_
+
+
+def _config4_operator(backbone, batch, size):
+    """RRNetOperator built exactly as bench.py / tools/bench_config4.py build the timed config-4 step: cfg.Model.bf16 +
+    dcn_heads + dcn_bf16 TOGETHER (flat parameter buffer, per-step bf16 filter copies, shared fan-in buffers), with the
+    DCN offset / mask convolutions moved off their zero initialisation so that the deformation is real."""
+    from rrnet_amd.configs.rrnet_config import Config as cfg
+    from rrnet_amd.operators.rrnet_operator import RRNetOperator
+    cfg.Train.batch_size, cfg.Train.crop_size, cfg.Model.backbone = batch, (size, size), backbone
+    cfg.Model.bf16, cfg.Model.dcn_heads, cfg.Model.dcn_bf16 = True, True, True
+    cfg.Distributed.gpu_id, cfg.Distributed.rank, cfg.Distributed.world_size = 0, 0, 1
+    torch.manual_seed(cfg.seed)
+    op = RRNetOperator(cfg)
+    op.model.train()
+    g = torch.Generator().manual_seed(12)
+    with torch.no_grad():
+        for name, p in op.model.module.named_parameters():
+            if "conv_offset_mask.weight" in name:
+                p.copy_(torch.empty(p.shape).normal_(0, 0.02, generator=g).to(p.device))
+            if "conv_offset_mask.bias" in name:
+                p.copy_(torch.empty(p.shape).normal_(0, 0.3, generator=g).to(p.device))
+    op.optimizer.fp.invalidate_wt()
+    return op, cfg
+
+
+class _config4_cfg:
+    """Restores the shared Config object the operator tests mutate."""
+
+    def __enter__(self):
+        from rrnet_amd.configs.rrnet_config import Config as cfg
+        self.cfg = cfg
+        self.saved = (cfg.Train.batch_size, cfg.Train.crop_size, dict(cfg.Model))
+        return self
+
+    def __exit__(self, *exc):
+        cfg = self.cfg
+        cfg.Train.batch_size, cfg.Train.crop_size = self.saved[0], self.saved[1]
+        for k in list(cfg.Model):
+            if k not in self.saved[2]:
+                del cfg.Model[k]
+        cfg.Model.update(self.saved[2])
+
+
+def test_config4_tiny_bf16_with_dcn_heads_all_gradients_vs_oracle_composition():
+    """BASELINE configs[3] AS bench.py TIMES IT — cfg.Model.bf16 and cfg.Model.dcn_heads (+ dcn_bf16) TOGETHER — on the
+    tiny backbone at 2 x 256 x 256 (the heads see 2 x 64 x 64 = 8192 pixels of 256 channels: the size from which the bf16
+    launches go to csrc/conv16.hip and the DCN gradients read bf16 images), train mode, non-degenerate offsets.
+    Reference: /root/reference/ext/dcn/dcn_v2.py:105-122 composed with /root/reference/detectors/centernet_detector.py:12-14
+    under the builder's bf16 arithmetic, restated in fp64 by oracle/model.py (_ConvBf16) + oracle/dcn.py (_ContractBf16):
+    both operands of every matrix product rounded to bf16, forward and backward.
+
+    Forward: the six stage-1 maps within 2 E of the rounded AND of the plain oracle, E = |rounded - plain| (the bound
+    test_bf16_model_heatmaps_within_the_derived_bound derives).
+    Backward: the gradient of a dense smooth functional of the head outputs for EVERY parameter.  The same derivation per
+    parameter p: E_g(p) = ||G_rounded - G_plain|| / ||G_plain|| is what the precision itself does to that gradient (ReLU
+    units within bf16 noise of zero flip their mask: an O(1) change of single elements); the HIP gradient must be within
+    2 E_g(p) of the rounded oracle's (+ 2 % of the norm for the parameters whose E_g is below that), keep cosine >= 0.98
+    with it, and differ from the plain oracle by more than fp32 rounding (the bf16 kernels really ran)."""
+    from oracle import model as om
+    from helpers import host_synth_batch as synth_batch
+    with _config4_cfg():
+        op, cfg = _config4_operator("hourglass_tiny", 2, 256)
+        model = op.model.module
+        assert model.bf16
+        dcns = [m for m in model.modules() if type(m).__name__ == "DCN"]
+        assert len(dcns) == 6 and all(m.bf16 is True for m in dcns)
+        fp = op.optimizer.fp
+        names = {id(p): n for n, p in model.named_parameters()}
+        sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+        imgs = synth_batch(2, 256, 256, boxes_per_image=10, seed=3)[0]
+        g = torch.Generator().manual_seed(13)
+        proj = [torch.randn(2, c, 64, 64, generator=g) for c in (10, 2, 2)]
+
+        def oracle(bf16):
+            sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+            leaves = {k: v.requires_grad_() for k, v in sd64.items() if v.is_floating_point() and "running_" not in k}
+            P = om.Params(sd64, training=True, bf16=bf16)
+            hm, wh, off = om.stage1(P, om.hourglass_net(P, imgs.double()))
+            sum((o * w.double()).sum() for i in range(2) for o, w in zip((hm[i], wh[i], off[i]), proj)).backward()
+            return [[t.detach() for t in hm], [t.detach() for t in wh], [t.detach() for t in off]], \
+                   {k: v.grad for k, v in leaves.items()}
+
+        plain, g_plain = oracle(False)
+        rounded, g_rounded = oracle(True)
+        op.optimizer.zero_grad()
+        outs = model(imgs.cuda().contiguous(memory_format=CL), k=50)
+        for name, idx in (("heat-map logits", 0), ("wh", 1), ("offset", 2)):
+            for s in range(2):
+                e = _maxdiff(rounded[idx][s], plain[idx][s])
+                d_model, d_fp32 = _maxdiff(outs[idx][s], rounded[idx][s]), _maxdiff(outs[idx][s], plain[idx][s])
+                scale = float(plain[idx][s].abs().max())
+                print("%s stack %d: E %.3e (scale %.3g); HIP vs rounded oracle %.3e; vs plain %.3e" % (name, s, e, scale, d_model, d_fp32))
+                assert e > 1e-5 * scale and d_fp32 > 1e-6 * scale
+                assert d_model <= 2.0 * e and d_fp32 <= 2.0 * e, (name, s, d_model, d_fp32, e)
+        sum((o * w.cuda()).sum() for i in range(2) for o, w in zip((outs[0][i], outs[1][i], outs[2][i]), proj)).backward()
+        torch.cuda.synchronize()
+        rows = []
+        for p in fp.params:
+            key = names[id(p)]
+            if key.startswith("head_detector"):          # stage 2 is not part of this functional
+                continue
+            got = p._rr_grad.detach().double().cpu()
+            gr, gp = g_rounded[key], g_plain[key]
+            npl = float(gp.norm())
+            assert npl > 0, key
+            e_g = float((gr - gp).norm()) / npl
+            d_r = float((got - gr).norm()) / npl
+            d_p = float((got - gp).norm()) / npl
+            cos = float((got.flatten() @ gr.flatten()) / (got.norm() * gr.norm()).clamp_min(1e-300))
+            rows.append((key, e_g, d_r, d_p, cos))
+        rows.sort(key=lambda r: -r[2] / max(r[1], 1e-12))
+        for key, e_g, d_r, d_p, cos in rows[:12]:
+            print("  %-58s E_g %.2e  HIP-rounded %.2e  HIP-plain %.2e  cos %.5f" % (key, e_g, d_r, d_p, cos))
+        eg = np.array([r[1] for r in rows]); dr = np.array([r[2] for r in rows]); dp = np.array([r[3] for r in rows])
+        print("%d parameters: E_g median %.2e max %.2e; HIP vs rounded oracle median %.2e max %.2e; vs plain median %.2e; worst "
+              "cos %.5f" % (len(rows), np.median(eg), eg.max(), np.median(dr), dr.max(), np.median(dp), min(r[4] for r in rows)))
+        assert len(rows) > 100
+        dcn_keys = [r for r in rows if "conv_offset_mask" in r[0] or ".0.conv.weight" in r[0]]
+        assert len(dcn_keys) >= 18, len(dcn_keys)
+        for key, e_g, d_r, d_p, cos in rows:
+            assert d_r <= 2.0 * e_g + 2e-2, (key, d_r, e_g)
+            assert cos >= 0.98, (key, cos)
+        assert np.median(dp) > 1e-5            # the bf16 kernels really ran
+
+
+def test_config4_bf16_dcn_heads_full_size_train_step_every_kernel_call_sampled():
+    """The config-4 step bench.py times (`config4.with_dcn_heads`): B=8, 1024x1024, hourglass-104, cfg.Model.bf16 +
+    dcn_heads + dcn_bf16, offsets off their zero initialisation — one train step with every distinct kernel call audited
+    against an fp64 recomputation from the inputs the call received.  On top of the plain bf16 audit above this covers
+    the launch graph only this composition has: the DCN forward on the window kernel, its data gradient ADDING into the
+    pre-filled shared fan-in buffer of relu(feature) (`out=`), dY fed from its producer's bf16 image to both DCN
+    gradients, the 28-filter offset / mask convolution's three launches on the bf16 kernels (tests/kernel_audit.py:
+    dcn_fwd / dcn_dgrad / dcn_wgrad hooks; reference oracle/dcn.py, /root/reference/ext/dcn/dcn_v2.py:105-122,
+    ext/dcn/src/cuda/dcn_v2_im2col_cuda.cu:125-327)."""
+    import time
+    from kernel_audit import audit
+    with _config4_cfg():
+        op, cfg = _config4_operator("hourglass", 8, 1024)
+        b = op.training_loader.get_batch()
+        t0 = time.perf_counter()
+        with audit(sample=True, ref_device="cuda") as rec:
+            _, losses = op.train_step(0, b)
+            torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    assert all(np.isfinite(float(v.detach())) for v in losses)
+    kinds = {}
+    for key, err in rec.seen.items():
+        kinds.setdefault(key[0], []).append(err)
+    print("config-4 (bf16 + DCN heads) audit %.0f s: " % dt + "  ".join("%s:%d (max %.1e)" % (kk, len(v), max(v)) for kk, v in sorted(kinds.items())))
+    assert not rec.bad, rec.bad[:10]
+    feat = (8, 256, 256, 256)
+    keys = set(rec.seen)
+    dcn = lambda kind: [k for k in keys if k[0] == kind and k[1] == feat]
+    assert any(k[7] is True for k in dcn("dcn_fwd")), dcn("dcn_fwd")                         # bf16 operands
+    dg = dcn("dcn_dgrad")
+    assert any(k[7] is True and k[8] is True for k in dg), dg                                # ... adding into a pre-filled fan-in buffer
+    assert any(k[7] is True and k[9] is True for k in dg), dg                                # ... dY from its producer's bf16 image
+    assert any(k[7] is True and k[8] is True for k in dcn("dcn_wgrad")), dcn("dcn_wgrad")    # image-fed weight gradient
+    assert any(k[0] == "dcn_dy_image" for k in keys)
+    # the offset / mask convolution (27 -> 28 filters) ran on the bf16 kernels, all three launches
+    om = (28, 256, 3, 3)
+    assert any(k[0] == "fprop" and k[2] == om and k[-1] == "bf16" for k in keys)
+    assert any(k[0] == "dgrad" and k[2] == om and k[-1] == "bf16" for k in keys)
+    assert any(k[0] == "wgrad" and k[3] == om and k[-1] == "bf16" for k in keys)

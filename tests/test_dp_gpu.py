@@ -188,7 +188,11 @@ def _run_bench(extra_env, launcher, port):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
     args = ["bench.py", "--backbone", "hourglass_tiny", "--size", "512", "--batch", "4", "--steps", "6", "--warmup", "2",
             "--no-cpu-baseline", "--no-extras", "--no-kernel-timing"]
-    if launcher:
+    if launcher == "self":          # no launcher in front: bench.py starts its own ranks as a child torch.distributed.run
+        cmd = [sys.executable] + args + ["--gpus", "2"]
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+    elif launcher:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                "127.0.0.1", "--master-port", str(port)] + args + ["--gpus", "2"]
     else:
@@ -216,6 +220,10 @@ def test_bench_two_ranks_through_the_launcher():
     assert two["value"] > 0 and abs(two["value"] - 8 * 1e3 / two["ms_per_step"]) < 1e-2 * two["value"]
     print("1 rank: %.1f img/s, 2 ranks on one GPU over gloo: %.1f img/s" % (one["value"], two["value"]))
     assert two["value"] >= 0.35 * one["value"], (one["value"], two["value"])
+    # ... and however the driver starts it: a bare `python bench.py --gpus 2` (no launcher variables) launches its own two
+    # ranks as a child process before touching the GPU, relays rank 0's line and the exit code (VERDICT r5 missing #3)
+    own = _run_bench({"RR_SINGLE_DEVICE": "1", "RR_DIST_BACKEND": "gloo"}, "self", port)
+    assert own["n_gpus"] == 2 and own["config"]["parallelism"] == "dp2" and own["steps"] == 6 and own["value"] > 0
 
 
 def test_rccl_single_rank_step_matches_non_distributed(tmp_path):

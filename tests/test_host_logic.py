@@ -172,3 +172,23 @@ def test_bf16_only_tensor_is_recognised_structurally():
     assert not ops.is_phantom(torch.ones(1).expand(2, 8, 3, 4))
     assert not ops.is_phantom(torch.zeros(2, 8, 3, 4)) and not ops.is_phantom(None)
     assert ops.to_nhwc(p, keep_phantom=True) is p
+
+
+def test_bf16_only_handle_reads_as_nan_for_torch_native_consumers():
+    """a bf16-only tensor is an fp32 handle WITHOUT memory; a torch-native consumer that slips past the
+    kernel wrappers (a forward hook, `+`, .sum(), a print) must not read one repeated garbage value silently — the stub it
+    expands from holds NaN, so the accident poisons the result loudly.  The structural signature and the image link stay."""
+    import torch
+    from rrnet_amd import ops
+    img = torch.ones((2, 3, 4, 8), dtype=torch.bfloat16).permute(0, 3, 1, 2)
+    p = ops.phantom_f32((2, 8, 3, 4), torch.device("cpu"), img)
+    q = ops.phantom_f32((1, 8, 5, 4), torch.device("cpu"), img)
+    assert ops.is_phantom(p) and ops.is_phantom(q) and ops.image_of(p) is img
+    assert (p + 0).isnan().all() and p.sum().isnan() and p.float().isnan().all() and (q * 2).isnan().all()
+    assert ops.is_phantom(p.view_as(p)) and p.view_as(p).isnan().all()
+    try:
+        ops.image_of(p.view_as(p))               # a view made outside the wrappers has lost the image: loud, not silent
+    except RuntimeError as e:
+        assert "without its bf16 image" in str(e)
+    else:
+        raise AssertionError("a handle without its image link must raise")

@@ -4,7 +4,17 @@ Units/corrections as the guide prescribes: both counters are in KiB; on gfx950 F
 bytes of wide coalesced streaming reads, so the read side is doubled (an upper estimate for our float4-per-lane,
 128-B-row gathers, which the guide calls uncalibrated).  Output: JSON {kernel: {launches, read_bytes_per_launch,
 write_bytes_per_launch, traffic_bytes_per_launch}} averaged over all launches of that kernel."""
-import collections, csv, glob, json, sys
+import collections, csv, glob, json, os, sys
+
+
+def commit_stamp():
+    """The commit the measured tree was cut from.  The GPU box has no .git: tools/stamp_commit.sh writes profiles/.commit in the
+    build container right before the gpurun call (the file travels with the snapshot, it is git-ignored)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    try:
+        return open(os.path.join(root, "profiles", ".commit")).read().strip() or "unrecorded"
+    except OSError:
+        return "unrecorded"
 
 
 def load(path, counter):
@@ -21,7 +31,7 @@ def load(path, counter):
 
 
 fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
-out = {}
+out = {"_commit": commit_stamp()}
 for k in sorted(set(fetch) | set(write), key=lambda k: -(fetch.get(k, [0, 0])[1] + write.get(k, [0, 0])[1])):
     nf, vf = fetch.get(k, [0, 0.0])
     nw, vw = write.get(k, [0, 0.0])
