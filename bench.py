@@ -211,7 +211,8 @@ def config4_train_step(a, steps=5):
     out = bench_config4.run(a.batch, a.size, steps, True, a.backbone)
     try:
         pl = bench_config4.run(a.batch, a.size, steps, False, a.backbone, True)
-        out["plain"] = {kk: pl[kk] for kk in ("value", "unit", "ms_per_step", "steps", "workload", "allocator", "step_mfma_frac", "finite_after_timed_steps")
+        out["plain"] = {kk: pl[kk] for kk in ("value", "unit", "ms_per_step", "steps", "workload", "allocator", "step_mfma_frac", "finite_after_timed_steps",
+                                              "host_enqueue_ms_per_step")
                         if kk in pl}
     except Exception as e:
         out["plain"] = {"value": None, "error": repr(e)}

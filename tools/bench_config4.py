@@ -18,9 +18,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def run(batch=8, size=1024, steps=5, dcn=True, backbone="hourglass", bf16=None, conv_math=None):
+def run(batch=8, size=1024, steps=5, dcn=True, backbone="hourglass", bf16=None, conv_math=None, curve=None):
     """bf16 (default: with the DCN heads): cfg.Model.bf16 — bf16 matrix operands in EVERY convolution of the backbone and
-    the heads (csrc/conv_bf16.hip), not only in the six deformable layers."""
+    the heads (csrc/conv_bf16.hip), not only in the six deformable layers.
+    curve: a list that receives the five losses of EVERY step (warm-up included; one host read per step: not for timings)."""
     bf16 = dcn if bf16 is None else bf16
     from rrnet_amd.configs.rrnet_config import Config as cfg
     from rrnet_amd.operators.rrnet_operator import RRNetOperator
@@ -65,15 +66,22 @@ def run(batch=8, size=1024, steps=5, dcn=True, backbone="hourglass", bf16=None, 
         step_no = 2000                                   # past the stage-2 warm-up: all four losses on
 
         last = [None]
+        host = [0.0]
+        from rrnet_amd import ops
 
         def one():
             nonlocal step_no
             b = batches[step_no % len(batches)]
+            h0 = time.perf_counter()
             last[0] = op.train_step(step_no, (b[0], b[1].clone()) + tuple(b[2:]))[1]
+            host[0] += time.perf_counter() - h0
             step_no += 1
+            if curve is not None:
+                curve.append([round(float(v.detach()), 5) for v in last[0]])
         for _ in range(3):      # three: the allocator's pool of an in-process run (after other workloads' empty_cache) settles by then
             one()
         torch.cuda.synchronize()
+        host[0], ops.SYNC_WAIT_S = 0.0, 0.0
         t0 = time.perf_counter()
         for _ in range(steps):
             one()
@@ -85,6 +93,8 @@ def run(batch=8, size=1024, steps=5, dcn=True, backbone="hourglass", bf16=None, 
         if not finite:
             raise RuntimeError("bench_config4: non-finite losses / gradients / parameters after the timed steps")
         out = {"finite_after_timed_steps": finite, "value": round(batch / t, 4), "unit": "images/sec", "ms_per_step": round(t * 1e3, 2), "steps": steps,
+               # host side of a step: time inside train_step() minus the time blocked in its one device -> host read (RoI count)
+               "host_enqueue_ms_per_step": round((host[0] - ops.SYNC_WAIT_S) / steps * 1e3, 2),
                "dcn_layers": n_dcn, "dtype": ("f32 (large layers: operands split into two fp16 parts, three MFMA products, fp32 accumulation)"
                                               if conv_math == "f16x3" else "bf16 matrix operands, fp32 accumulation / storage" if bf16 else "f32"),
                "workload": (("RRNet hourglass-104 + %d DCN head layers (offsets ~ N(0,1)) train step, B=%d, %dx%d"
@@ -97,6 +107,8 @@ def run(batch=8, size=1024, steps=5, dcn=True, backbone="hourglass", bf16=None, 
                             "held_by_earlier_workloads_GiB": round(base_gib, 2),
                             "segments": ms_["segment.all.current"], "hipMallocs": ms_["num_device_alloc"],
                             "hipFrees": ms_["num_device_free"], "alloc_retries": ms_["num_alloc_retries"]}
+        if curve is not None:
+            out["timing_valid"] = False      # (a loss read per step synchronises the host with the device)
         if backbone == "hourglass" and size == 1024:
             # 7.02 TFLOP of convolution per image; the six DCN layers replace plain 3x3 layers of the same FLOPs
             peak = 2500.0 if (bf16 or conv_math == "f16x3") else 157.3
@@ -119,7 +131,14 @@ if __name__ == "__main__":
     ap.add_argument("--fp32", action="store_true", help="fp32 convolutions (round 3's config-4 definition: only the DCN layers in bf16)")
     ap.add_argument("--bf16", action="store_true", help="bf16 convolutions even with --plain")
     ap.add_argument("--math", default=None, help="cfg.Model.conv_math: f32 | bf16 | f16x3")
+    ap.add_argument("--curve", action="store_true", help="record the five losses of every step (key `loss_curve`): the numerics A/B of a "
+                    "switch over a few hundred steps, e.g. RR_BF16_ONLY_ACT=0 / 1 (ADVICE r5)")
     a = ap.parse_args()
     torch.cuda.set_device(0)
     bf16 = True if a.bf16 else (False if a.fp32 else None)
-    print(json.dumps(run(a.batch, a.size, a.steps, not a.plain, a.backbone, bf16, a.math)))
+    curve = [] if a.curve else None
+    res = run(a.batch, a.size, a.steps, not a.plain, a.backbone, bf16, a.math, curve)
+    if curve is not None:
+        res["loss_curve"] = curve
+        res["env"] = {k: v for k, v in os.environ.items() if k.startswith("RR_")}
+    print(json.dumps(res))
