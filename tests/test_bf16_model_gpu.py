@@ -243,12 +243,20 @@ def test_config4_tiny_bf16_with_dcn_heads_all_gradients_vs_oracle_composition():
     both operands of every matrix product rounded to bf16, forward and backward.
 
     Forward: the six stage-1 maps within 2 E of the rounded AND of the plain oracle, E = |rounded - plain| (the bound
-    test_bf16_model_heatmaps_within_the_derived_bound derives).
-    Backward: the gradient of a dense smooth functional of the head outputs for EVERY parameter.  The same derivation per
-    parameter p: E_g(p) = ||G_rounded - G_plain|| / ||G_plain|| is what the precision itself does to that gradient (ReLU
-    units within bf16 noise of zero flip their mask: an O(1) change of single elements); the HIP gradient must be within
-    2 E_g(p) of the rounded oracle's (+ 2 % of the norm for the parameters whose E_g is below that), keep cosine >= 0.98
-    with it, and differ from the plain oracle by more than fp32 rounding (the bf16 kernels really ran)."""
+    test_bf16_model_heatmaps_within_the_derived_bound derives; measured |HIP - rounded| = 0.8-1.2 E).
+    Backward, two statements about the gradient of a dense smooth functional of the head outputs for EVERY parameter:
+      (i)  per kernel call, tight: the whole forward + backward runs under tests/kernel_audit.py — every distinct launch (the
+           DCN forward / data gradient incl. `out=` accumulation and image-fed dY / weight gradient, the 28-filter offset
+           convolution, every bf16 convolution, BatchNorm, fan-in) equals its fp64 recomputation on bf16-rounded operands
+           from the inputs the call received (2e-5; DCN bf16 calls 1e-4; weight gradients 2e-4);
+      (ii) end to end, derived like E: E_g(p) = ||G_rounded - G_plain|| / ||G_plain|| is what the precision itself does to the
+           gradient of parameter p.  It is LARGE in this network (measured: median 0.47): ~0.3 % of the ReLU inputs of each of
+           the ~45 layers lie within bf16 noise of zero and flip their mask, each flip an O(1) change of one gradient path.
+           The HIP model is a third sample of the same noise (its own flips are independent of the rounded oracle's: measured
+           ||HIP - rounded||^2 = ||HIP - plain||^2 + ||rounded - plain||^2 to 1 %), so the bounds are: ||HIP - plain|| <=
+           1.5 E_g + 0.02 and ||HIP - rounded|| <= 2 E_g + 0.02 (norms relative to ||G_plain||) for every parameter — a
+           missing / doubled / sign-flipped contribution to a parameter's gradient is an error of >= 1 — and the HIP
+           gradient differs from the plain oracle's by more than fp32 rounding (the bf16 kernels really ran)."""
     from oracle import model as om
     from helpers import host_synth_batch as synth_batch
     with _config4_cfg():
@@ -275,18 +283,28 @@ def test_config4_tiny_bf16_with_dcn_heads_all_gradients_vs_oracle_composition():
 
         plain, g_plain = oracle(False)
         rounded, g_rounded = oracle(True)
+        from kernel_audit import audit
         op.optimizer.zero_grad()
-        outs = model(imgs.cuda().contiguous(memory_format=CL), k=50)
-        for name, idx in (("heat-map logits", 0), ("wh", 1), ("offset", 2)):
-            for s in range(2):
-                e = _maxdiff(rounded[idx][s], plain[idx][s])
-                d_model, d_fp32 = _maxdiff(outs[idx][s], rounded[idx][s]), _maxdiff(outs[idx][s], plain[idx][s])
-                scale = float(plain[idx][s].abs().max())
-                print("%s stack %d: E %.3e (scale %.3g); HIP vs rounded oracle %.3e; vs plain %.3e" % (name, s, e, scale, d_model, d_fp32))
-                assert e > 1e-5 * scale and d_fp32 > 1e-6 * scale
-                assert d_model <= 2.0 * e and d_fp32 <= 2.0 * e, (name, s, d_model, d_fp32, e)
-        sum((o * w.cuda()).sum() for i in range(2) for o, w in zip((outs[0][i], outs[1][i], outs[2][i]), proj)).backward()
-        torch.cuda.synchronize()
+        with audit(ref_device="cuda") as rec:
+            outs = model(imgs.cuda().contiguous(memory_format=CL), k=50)
+            for name, idx in (("heat-map logits", 0), ("wh", 1), ("offset", 2)):
+                for s in range(2):
+                    e = _maxdiff(rounded[idx][s], plain[idx][s])
+                    d_model, d_fp32 = _maxdiff(outs[idx][s], rounded[idx][s]), _maxdiff(outs[idx][s], plain[idx][s])
+                    scale = float(plain[idx][s].abs().max())
+                    print("%s stack %d: E %.3e (scale %.3g); HIP vs rounded oracle %.3e; vs plain %.3e" % (name, s, e, scale, d_model, d_fp32))
+                    assert e > 1e-5 * scale and d_fp32 > 1e-6 * scale
+                    assert d_model <= 2.0 * e and d_fp32 <= 2.0 * e, (name, s, d_model, d_fp32, e)
+            sum((o * w.cuda()).sum() for i in range(2) for o, w in zip((outs[0][i], outs[1][i], outs[2][i]), proj)).backward()
+            torch.cuda.synchronize()
+        kinds = {}
+        for key, err in rec.seen.items():
+            kinds.setdefault(key[0], []).append(err)
+        print("per-call audit: " + "  ".join("%s:%d (max %.1e)" % (kk, len(v), max(v)) for kk, v in sorted(kinds.items())))
+        assert not rec.bad, rec.bad[:10]
+        for kind in ("dcn_fwd", "dcn_dgrad", "dcn_dgrad_doffset", "dcn_dgrad_dmask", "dcn_wgrad", "fprop", "dgrad", "wgrad", "bn_bwd_apply"):
+            assert kind in kinds, (kind, sorted(kinds))
+        assert any(k[0] == "dcn_dgrad" and k[7] is True and k[8] is True for k in rec.seen), "no DCN data gradient added into a fan-in buffer"
         rows = []
         for p in fp.params:
             key = names[id(p)]
@@ -312,7 +330,13 @@ def test_config4_tiny_bf16_with_dcn_heads_all_gradients_vs_oracle_composition():
         assert len(dcn_keys) >= 18, len(dcn_keys)
         for key, e_g, d_r, d_p, cos in rows:
             assert d_r <= 2.0 * e_g + 2e-2, (key, d_r, e_g)
-            assert cos >= 0.98, (key, cos)
+            assert d_p <= 1.5 * e_g + 2e-2, (key, d_p, e_g)
+        # the three gradients behave as the truth + two independent samples of the precision's noise
+        tri = np.sqrt(dp ** 2 + eg ** 2)
+        big = eg > 0.05
+        print("||HIP - rounded|| / sqrt(||HIP - plain||^2 + E_g^2): median %.3f over the %d parameters with E_g > 0.05" %
+              (np.median(dr[big] / tri[big]), int(big.sum())))
+        assert 0.7 <= np.median(dr[big] / tri[big]) <= 1.3
         assert np.median(dp) > 1e-5            # the bf16 kernels really ran
 
 

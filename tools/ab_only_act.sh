@@ -29,5 +29,8 @@ for n, r in arms.items():
               "total_by_window": [round(sum(x[0] for x in c[i:i + w]) / len(c[i:i + w]), 4) for i in range(0, len(c), w)],
               "hm_by_window": [round(sum(x[1] for x in c[i:i + w]) / len(c[i:i + w]), 4) for i in range(0, len(c), w)]}
 json.dump(out, open("profiles/%s_only_act_ab.json" % tag, "w"), indent=1)
+import os
+os.makedirs("gpurun_out/profiles_%s" % tag, exist_ok=True)
+json.dump(out, open("gpurun_out/profiles_%s/%s_only_act_ab.json" % (tag, tag), "w"), indent=1)
 print(json.dumps(out)[:3000])
 PY
