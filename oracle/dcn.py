@@ -56,7 +56,19 @@ def _bilinear_zero(x, h, w):
             (lh * hw).unsqueeze(1) * v3 + (lh * lw).unsqueeze(1) * v4)
 
 
-def dcn_columns(x, offset, mask, kh, kw, stride=1, padding=0, dilation=1, deformable_groups=1):
+def _position(base, off, origin, pos_fp32):
+    """Sample coordinate = integer grid position + learned offset.  pos_fp32: evaluated as the reference's kernel does — ONE
+    float32 addition of the (exact) integer position and the offset (dcn_v2_im2col_cuda.cu:159-160, `const float h_im = h_in +
+    i * dilation_h + offset_h`): at row 200 that rounds the position to 1.5e-5 of a pixel, which an fp64 restatement would
+    not reproduce.  origin: the crop's first row / column in the full map, so that a cropped window rounds exactly like the
+    full tensor.  The gradient passes straight through (the rounding is a constant shift)."""
+    if not pos_fp32:
+        return base + off
+    rounded = ((base + origin).to(torch.float32) + off.detach().to(torch.float32)).to(off.dtype)
+    return off + (rounded - origin - off.detach())
+
+
+def dcn_columns(x, offset, mask, kh, kw, stride=1, padding=0, dilation=1, deformable_groups=1, pos_fp32=False, origin=(0, 0)):
     """The modulated deformable columns [N, C, kh*kw, P, Q] = mask * bilinear sample (dcn_v2_im2col_cuda.cu:125-195)."""
     sh, sw = _pair(stride)
     ph, pw = _pair(padding)
@@ -77,7 +89,7 @@ def dcn_columns(x, offset, mask, kh, kw, stride=1, padding=0, dilation=1, deform
                 t = i * kw + j
                 oh = offset[:, g * 2 * kh * kw + 2 * t]
                 ow = offset[:, g * 2 * kh * kw + 2 * t + 1]
-                val = _bilinear_zero(xg, base_h + i * dh + oh, base_w + j * dw + ow)
+                val = _bilinear_zero(xg, _position(base_h + i * dh, oh, origin[0], pos_fp32), _position(base_w + j * dw, ow, origin[1], pos_fp32))
                 taps.append(val * mask[:, g * kh * kw + t].unsqueeze(1))
         cols.append(torch.stack(taps, dim=2))
     return cols[0] if dg == 1 else torch.cat(cols, dim=1)
@@ -107,12 +119,13 @@ class _ContractBf16(torch.autograd.Function):
         return torch.einsum('nkpq,kct->nctpq', dq, wq), torch.einsum('nkpq,nctpq->kct', dq, cq)
 
 
-def dcn_v2_conv(x, offset, mask, weight, bias, stride=1, padding=0, dilation=1, deformable_groups=1, bf16=False):
+def dcn_v2_conv(x, offset, mask, weight, bias, stride=1, padding=0, dilation=1, deformable_groups=1, bf16=False, pos_fp32=False,
+                origin=(0, 0)):
     """`dcn_v2_conv(input, offset, mask, weight, bias, stride, padding, dilation, deformable_groups)` of
     ext/dcn/dcn_v2.py:16-52.  x [N,C,H,W]; offset [N, 2*dg*kh*kw, P, Q]; mask [N, dg*kh*kw, P, Q].
     bf16 (builder-defined, configs[3]): the matrix products on bf16-rounded operands (_ContractBf16)."""
     k, c, kh, kw = weight.shape
-    cols = dcn_columns(x, offset, mask, kh, kw, stride, padding, dilation, deformable_groups)
+    cols = dcn_columns(x, offset, mask, kh, kw, stride, padding, dilation, deformable_groups, pos_fp32, origin)
     w3 = weight.reshape(k, c, kh * kw)
     out = _ContractBf16.apply(cols, w3) if bf16 else torch.einsum('nctpq,kct->nkpq', cols, w3)
     if bias is not None:
