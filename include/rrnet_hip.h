@@ -167,8 +167,6 @@ int rr_conv_wgrad_bf16(const float *x, const float *dy, float *dw, int n, int h,
  * that is again a convolution): either may be NULL, not both.  stat_slab: [ceil(M / 256)][2][K] doubles
  * (rr_conv16_stat_slab_bytes), reduced by rr_bn_reduce_slab / rr_bn_stats_finalize like the fp32 kernel's. */
 int rr_conv16_supported(int c, int k, int r, int s, int stride);
-/* development aid (tools/conv16_stamps.py): 8 x 72 x 6 s_memtime stamps of one workgroup of the next rr_conv16_* forward-kernel launches */
-int rr_conv16_debug_stamps(unsigned long long *buf);
 size_t rr_conv16_stat_slab_bytes(int n, int p, int q, int k);
 int rr_conv16_fprop(const unsigned short *x, const unsigned short *w, const float *bias, float *y, unsigned short *y16,
                     double *stat_slab, int n, int h, int wd, int c, int k, int r, int s, int stride, int pad_h, int pad_w,

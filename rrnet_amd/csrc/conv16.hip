@@ -67,7 +67,6 @@ struct Args {
     // strided destination (stride-2 data gradient, one output parity class per launch): logical output pixel (n, h, w) of the DH x DW
     // grid lands at pixel (n, h * osh + oh0, w * osw + ow0) of an OH x OW map; osh == 0: dense
     int OH, OW, osh, osw, oh0, ow0;
-    int abl;                       // development (RR_CONV16_ABL): 1 = every DMA piece fetches zeros (no memory traffic), 2 = no fragment reads
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nb)
@@ -326,200 +325,16 @@ __global__ __launch_bounds__(512, 1) void conv16_igemm_kernel(const Args a)
     conv16_epilogue<TCH>(a, acc, lds, m0, k0, m_tile, hw, wp, wc, lane, t);
 }
 
-// ---- ping-pong main loop (round 6; 256-channel tiles) ------------------------------------------------------------------------------
-// Same tile, same wave tiles, same accumulators and epilogue as conv16_igemm_kernel<256>; what changes is WHEN a wave touches
-// memory.  There, every wave ran the same program in step: fragment reads, LDS-DMA pieces and MFMAs interleaved in all eight
-// waves at once, one vmcnt(0) + barrier per 64-deep K-tile — the matrix pipe measured busy 0.46 of the launch
-// (profiles/r05_conv16_pmc.txt): a wave's own DMA issue (60-185 cycles a piece, MI355X_MICROARCH.md) and read waits sit IN its
-// MFMA stream, and its SIMD partner is stalled on the same thing at the same moment.  Here the two waves of a SIMD alternate
-// roles (the guide's 256^2 template; HIP source): the K loop runs in sub-phases of 32 reduction indices (half a 128-byte line
-// of one tap), each a LOAD segment — the wave's twelve fragment reads for the sub-phase into registers, its four LDS-DMA
-// pieces for the sub-phase two ahead, a counted s_waitcnt vmcnt(4) — a raw s_barrier, a COMPUTE segment of 32 bare MFMAs, a
-// raw s_barrier; waves 4-7 (the other pixel half; they share SIMDs with waves 0-3) run ONE barrier behind, so on every SIMD
-// one wave computes while its partner loads.  LDS: a ring of four 32-KiB slots (pixel image | filter image, rows of 64 B,
-// 16-byte chunks XOR-swizzled with (-(row >> 2)) & 3: conflict-free ds_read_b128 in the hardware's lane groups).  Hazards, in
-// barrier intervals (group 0: load s in interval 2s, compute in 2s+1; group 1 one later):  slot (s+2)&3 is written by pieces
-// issued in intervals 2s / 2s+1 and was last read (sub-phase s-2) in intervals 2s-4 / 2s-3, reads retired by lgkmcnt(0) before
-// their barrier;  it is read in intervals 2s+4 / 2s+5, and every wave's vmcnt(4) at the end of its load segment of s+1
-// (intervals 2s+2 / 2s+3) has retired its pieces for s+2 before the barrier that opens interval 2s+4.  The DMA is never
-// drained inside the loop.
-constexpr int PP_ROWB = 64;
-constexpr int PP_IMG = 256 * PP_ROWB;
-constexpr int PP_SLOT = 2 * PP_IMG;
-
-template <bool DBG, int PM>       // PM: how many of a sub-phase's four DMA pieces are issued among the MFMAs (the rest in the load segment)
-__global__ __launch_bounds__(512, 1) void conv16_pp_kernel(const Args a, unsigned long long *dbg)
-{
-    constexpr int TCH = 256, PI = 8;
-    extern __shared__ __align__(16) unsigned char lds[];          // [4][pixel image 16 KiB | filter image 16 KiB]
-    const int t = threadIdx.x, lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wp = wave >> 2, wc = wave & 3;                       // pixel half (= ping-pong group), channel quarter
-    const int nct = a.DC / TCH;
-    const int logical = xcd_remap(blockIdx.x, gridDim.x);
-    const int c_tile = logical % nct, m_tile = logical / nct;
-    const int m0 = m_tile * TP, k0 = c_tile * TCH;
-    const int RS = a.R * a.S;
-    const int nsub = (a.SC / 32) * RS;                             // sub-phases: (64-channel chunk, tap, half line)
-    const int hw = a.DH * a.DW;
-
-    // ---- the two rows of each operand image this lane fills (piece j*8 + wave: rows (j*8 + wave)*16 + lane/4, slot lane%4)
-    const int prow = lane >> 2;
-    const int src_chunk = (lane & 3) ^ ((0 - (prow >> 2)) & 3);    // the logical 16-byte chunk that belongs in slot lane%4 of its row
-    int x_off[2], w_off[2];
-    unsigned x_mask = 0u;                                          // 16 tap bits per row
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int row = (j * 8 + wave) * 16 + prow;
-        const int m = m0 + row;
-        int n = 0, h = 0, w = 0;
-        const bool live = m < a.M;
-        if (live) {
-            n = m / hw;
-            const int rem = m - n * hw;
-            h = rem / a.DW;
-            w = rem - h * a.DW;
-        }
-        const int ih0 = h * a.stride - a.pad_h, iw0 = w * a.stride - a.pad_w;
-        unsigned mk = 0u;
-        if (live)
-            for (int ri = 0; ri < a.R; ++ri) {
-                const int ih = ih0 + ri;
-                if (ih < 0 || ih >= a.SH) continue;
-                for (int si = 0; si < a.S; ++si) {
-                    const int iw = iw0 + si;
-                    if (iw >= 0 && iw < a.SW) mk |= 1u << (ri * a.S + si);
-                }
-            }
-        x_mask |= mk << (16 * j);
-        x_off[j] = (int)(((((long)n * a.SH + ih0) * a.SW + iw0) * a.SC) * 2 + src_chunk * 16);
-        w_off[j] = (int)(((long)(k0 + row) * RS * a.SC) * 2 + src_chunk * 16);
-    }
-    const i32x4w rs_src = make_srd_words(a.src, (long)a.N * a.SH * a.SW * a.SC * 2);
-    const i32x4w rs_flt = make_srd_words(a.flt, (long)a.DC * RS * a.SC * 2);
-
-    // wave-uniform walk over the sub-phases: half line inner, tap, 64-channel chunk outer (the two halves of a line and the taps
-    // of a chunk re-read the same lines from L2)
-    int p_cch = 0, p_tap = 0, p_ri = 0, p_si = 0, p_half = 0;
-    int xdelta = 0, wdelta = 0, tapbit = 0;
-    auto prep = [&]() {
-        xdelta = ((p_ri * a.SW + p_si) * a.SC + p_cch * 64 + p_half * 32) * 2;
-        wdelta = (p_tap * a.SC + p_cch * 64 + p_half * 32) * 2;
-        tapbit = p_tap;
-        p_half ^= 1;
-        if (p_half == 0) {
-            ++p_tap;
-            if (++p_si == a.S) { p_si = 0; ++p_ri; }
-            if (p_tap == RS) { p_tap = 0; p_ri = 0; p_si = 0; ++p_cch; }
-        }
-    };
-    unsigned p_live = 1u;                        // 0 behind the last sub-phase: the pieces still issue (uniform vmcnt counts) and fetch zeros
-    auto piece = [&](int j, int slot) {          // j = 0, 1: pixel rows; 2, 3: filter rows
-        unsigned char *X = lds + slot * PP_SLOT;
-        if (j < 2) {
-            const unsigned ok = (x_mask >> (16 * j + tapbit)) & p_live;
-            const unsigned off = ok ? (unsigned)(x_off[j] + xdelta) : OOB;
-            dma16_free(rs_src, __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void *)(X + (j * 8 + wave) * 1024)), off);
-        } else {
-            const unsigned off = p_live ? (unsigned)(w_off[j - 2] + wdelta) : OOB;
-            dma16_free(rs_flt, __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void *)(X + PP_IMG + ((j - 2) * 8 + wave) * 1024)), off);
-        }
-    };
-
-    f32x4 acc[4][PI];
-#pragma unroll
-    for (int ci = 0; ci < 4; ++ci)
-#pragma unroll
-        for (int pi = 0; pi < PI; ++pi) acc[ci][pi] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    // fragment addresses: row (lane % 16) of a 16-row block, chunk (lane / 16) ^ swizzle(row)
-    const int fr = lane & 15, fq = lane >> 4;
-    const int f_off = fr * PP_ROWB + ((fq ^ ((0 - (fr >> 2)) & 3)) * 16);
-    const int x_base = wp * 128 * PP_ROWB + f_off, w_base = PP_IMG + wc * 64 * PP_ROWB + f_off;
-
-    // prologue: sub-phases 0, 1 and 2 in flight, landed, visible
-#pragma unroll
-    for (int s0 = 0; s0 < 3; ++s0) {
-        p_live = s0 < nsub ? 1u : 0u;
-        prep();
-#pragma unroll
-        for (int j = 0; j < 4; ++j) piece(j, s0);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (wp == 1) __builtin_amdgcn_s_barrier();                      // the stagger: group 1 runs one barrier interval behind group 0
-
-    // DBG (tools/conv16_stamps.py; never the product instantiation): six s_memtime stamps per sub-phase and wave, kept in the 32 KiB of
-    // LDS behind the ring (a global store in the loop would count into vmcnt) and written out at the end by one workgroup
-    unsigned long long *stamps = reinterpret_cast<unsigned long long *>(lds + 4 * PP_SLOT);
-    auto stamp = [&](int s, int i) {
-        if constexpr (DBG) {
-            const unsigned long long tt = __builtin_amdgcn_s_memtime();
-            if (lane == 0 && s < 72) stamps[(wave * 72 + s) * 6 + i] = tt;
-        }
-    };
-    for (int s = 0; s < nsub; ++s) {
-        // ---- load segment: this sub-phase's fragments, the pieces of sub-phase s + 2
-        stamp(s, 0);
-        const unsigned char *B = lds + (s & 3) * PP_SLOT;
-        bf16x8 wf[4], xf[PI];
-        if (!(a.abl & 2)) {
-#pragma unroll
-        for (int ci = 0; ci < 4; ++ci) wf[ci] = *reinterpret_cast<const bf16x8 *>(B + w_base + ci * 16 * PP_ROWB);
-#pragma unroll
-        for (int pi = 0; pi < PI; ++pi) xf[pi] = *reinterpret_cast<const bf16x8 *>(B + x_base + pi * 16 * PP_ROWB);
-        } else {
-#pragma unroll
-        for (int ci = 0; ci < 4; ++ci) { wf[ci] = bf16x8{}; asm volatile("" : "+v"(wf[ci])); }
-#pragma unroll
-        for (int pi = 0; pi < PI; ++pi) { xf[pi] = bf16x8{}; asm volatile("" : "+v"(xf[pi])); }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // the four pieces of sub-phase s + 3 (slot (s + 3) & 3: last read in sub-phase s - 1, retired before the barrier that opened
-        // this interval): 4 - PM here, PM among the MFMAs below
-        p_live = (s + 3 < nsub && !(a.abl & 1)) ? 1u : 0u;
-        prep();
-#pragma unroll
-        for (int j = 0; j < 4 - PM; ++j) piece(j, (s + 3) & 3);
-        stamp(s, 1);
-        // everything but the youngest 8 - PM pieces (sub-phase s + 3's from this segment, s + 2's... no: s + 3's 4 - PM and sub-phase
-        // s + 2's four) has landed — i.e. sub-phase s + 1's; this segment's reads are retired
-        if constexpr (PM == 0) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-        else if constexpr (PM == 1) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");
-        else if constexpr (PM == 2) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-        stamp(s, 2);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        stamp(s, 3);
-        // ---- compute segment: 32 MFMAs from registers (+ PM pieces, spread evenly)
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int pi = 0; pi < PI; ++pi) {
-#pragma unroll
-            for (int ci = 0; ci < 4; ++ci) acc[ci][pi] = mfma(wf[ci], xf[pi], acc[ci][pi]);
-            if constexpr (PM == 1) { if (pi == 3) piece(3, (s + 3) & 3); }
-            else if constexpr (PM == 2) { if (pi == 1) piece(2, (s + 3) & 3); if (pi == 5) piece(3, (s + 3) & 3); }
-            else if constexpr (PM == 4) { if ((pi & 1) == 0) piece(pi >> 1, (s + 3) & 3); }
-        }
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        stamp(s, 4);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        stamp(s, 5);
-    }
-    if (wp == 0) __builtin_amdgcn_s_barrier();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // (the trailing zero pieces too: the epilogue reuses the ring)
-    __syncthreads();
-    if constexpr (DBG) {
-        if (dbg != nullptr && blockIdx.x == gridDim.x / 2)
-            for (int i = t; i < 8 * 72 * 6; i += 512) dbg[i] = stamps[i];
-        __syncthreads();
-    }
-    conv16_epilogue<TCH>(a, acc, lds, m0, k0, m_tile, hw, wp, wc, lane, t);
-}
+// (Round 6: a ping-pong form of this loop — the guide's 256^2 template: the two waves of every SIMD alternating a load segment
+// (twelve fragment reads into registers, the sub-phase's LDS-DMA pieces, a counted vmcnt) with a segment of 32 bare MFMAs, waves
+// 4-7 one barrier behind waves 0-3, a ring of four 32-deep slots, the DMA never drained — was built on this tile and epilogue
+// (commit 30cab69), gave bit-identical results and measured 1.06-1.08 PFLOP/s at the dominant layer against 1.07-1.10 for the loop
+// above, with 0, 1, 2 or all 4 of a sub-phase's pieces moved among the MFMAs.  In-kernel stamps: a load segment takes 780 + 128
+// cycles (a DMA piece costs its wave 75-100 issue cycles beside the partner's MFMA stream, a ds_read_b128 ~39), the MFMA segment
+// 590, each barrier >= 112: the critical path is load -> barrier -> load, ~2 x 1100 cycles per 32-deep sub-phase for 2 x 512 of
+// matrix work.  Ablations: with every piece fetching zeros (no memory traffic) 1.19-1.25 PFLOP/s, without fragment reads 1.15-1.18
+// — on zero operands, which clock ~15 % higher: neither the memory path nor LDS bandwidth binds; the instruction stream around the
+// MFMAs does.  profiles/r06_conv16_pingpong_ab.txt.  Removed from the product.)
 
 // Stride-2 data gradient as four stride-1 correlations, one per output parity class (ph, pw) = (h % 2, w % 2), each with the
 // sub-filter of the taps that reach the class (a 3x3 visits 1 / 2 / 2 / 4 taps instead of masking three quarters of a dilated
@@ -548,8 +363,6 @@ __global__ __launch_bounds__(256) void parity_pack_bf16_kernel(const float *w, u
     }
 }
 
-unsigned long long *g_dbg_stamps = nullptr;      // development: rr_conv16_debug_stamps
-
 int check_shape(const char *name, int n, int h, int wd, int c, int k, int r, int s, int stride, int pad_h, int pad_w)
 {
     RR_CHECK_ARG(n > 0 && h > 0 && wd > 0 && c > 0 && k > 0 && r > 0 && s > 0 && pad_h >= 0 && pad_w >= 0, "%s: bad dims", name);
@@ -558,25 +371,10 @@ int check_shape(const char *name, int n, int h, int wd, int c, int k, int r, int
     return RR_OK;
 }
 
-int launch_igemm(const Args &a_in, hipStream_t stream, const char *name)
+int launch_igemm(const Args &a, hipStream_t stream, const char *name)
 {
-    Args a = a_in;
-    static const int abl = [] { const char *e = getenv("RR_CONV16_ABL"); return e ? atoi(e) : 0; }();
-    a.abl = abl;
     const int mt = rr_cdiv(a.M, TP);
-    static const int pp = [] { const char *e = getenv("RR_CONV16_PP"); return e ? atoi(e) : 1; }();      // (development A/B switch)
-    if (a.DC % 256 == 0 && pp) {
-        static const int pm = [] { const char *e = getenv("RR_CONV16_PM"); return e ? atoi(e) : 2; }();      // (development A/B switch)
-        const size_t ldsb = (g_dbg_stamps != nullptr ? 5 : 4) * (size_t)PP_SLOT;
-#define RR_PP(DBGv, PMv)                                                                                                               \
-        do {                                                                                                                          \
-            RR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv16_pp_kernel<DBGv, PMv>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb), name); \
-            hipLaunchKernelGGL((conv16_pp_kernel<DBGv, PMv>), dim3(mt * (a.DC / 256)), dim3(512), ldsb, stream, a, g_dbg_stamps);     \
-        } while (0)
-        if (g_dbg_stamps != nullptr) { if (pm == 0) RR_PP(true, 0); else if (pm == 1) RR_PP(true, 1); else if (pm == 4) RR_PP(true, 4); else RR_PP(true, 2); }
-        else { if (pm == 0) RR_PP(false, 0); else if (pm == 1) RR_PP(false, 1); else if (pm == 4) RR_PP(false, 4); else RR_PP(false, 2); }
-#undef RR_PP
-    } else if (a.DC % 256 == 0) {
+    if (a.DC % 256 == 0) {
         const size_t ldsb = 2 * (size_t)(IMG + 256 * ROWB);
         // (set on every launch: the attribute is per device, and a once-per-process flag would leave a second GPU without it)
         RR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv16_igemm_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb), name);
@@ -759,8 +557,6 @@ int rr_conv16_supported(int c, int k, int r, int s, int stride)
 {
     return c % BK == 0 && k % 128 == 0 && r * s <= 16 && (stride == 1 || stride == 2);
 }
-
-int rr_conv16_debug_stamps(unsigned long long *buf) { g_dbg_stamps = buf; return RR_OK; }
 
 size_t rr_conv16_stat_slab_bytes(int n, int p, int q, int k) { return sizeof(double) * 2 * (size_t)rr_cdiv((long)n * p * q, TP) * k; }
 
