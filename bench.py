@@ -433,6 +433,8 @@ def main():
         cc = dptrace.counts()
         out["collectives_per_step"] = {"total": round(sum(cc.values()) / a.steps, 1),
                                        **{k: round(v / a.steps, 1) for k, v in sorted(cc.items())}}
+        if dptrace.HOST_S:
+            out["dp_host_ms_per_step"] = {k: round(v / a.steps * 1e3, 2) for k, v in sorted(dptrace.HOST_S.items())}
         if dp_force and world == 1:
             out["dp_force"] = "one-rank %s process group: SyncBN exchanges + bucketed gradient all-reduce issued for real" % \
                               dist.get_backend()

@@ -295,6 +295,18 @@ int rr_bn_reduce_slab(const double *slab, int mtiles, int c, double *sums, hipSt
 int rr_bn_finalize(const double *sums, double count, const double *count_dev, const float *gamma, const float *beta,
                    float *running_mean, float *running_var, float momentum, float eps, float *mean,
                    float *invstd, float *scale, float *shift, int c, long *num_batches_tracked, hipStream_t stream);
+/* SyncBN (data parallel; /root/reference/operators/distributed_wrapper.py:40-61 converts every BatchNorm): the three small steps
+ * around a statistics exchange without extra launches.  rr_bn_reduce_slab_count = rr_bn_reduce_slab that also stores the local
+ * sample count into *count_slot (a slot of the buffer that goes through the all-reduce);  rr_bn_finalize_count = rr_bn_finalize
+ * with the (exchanged) count read from the device and copied to *count_out for the backward;  rr_bn_affine_grad adds the LOCAL
+ * BatchNorm-backward sums into dbeta / dgamma before they are exchanged. */
+int rr_bn_reduce_slab_count(const double *slab, int mtiles, int c, double *sums, double count, double *count_slot,
+                            hipStream_t stream);
+int rr_bn_finalize_count(const double *sums, const double *count_dev, const float *gamma, const float *beta,
+                         float *running_mean, float *running_var, float momentum, float eps, float *mean,
+                         float *invstd, float *scale, float *shift, int c, long *num_batches_tracked,
+                         double *count_out, hipStream_t stream);
+int rr_bn_affine_grad(const double *sums, float *dgamma, float *dbeta, int c, hipStream_t stream);
 /* rr_bn_reduce_slab + rr_bn_finalize in one launch, for the single-process case (no SyncBN exchange of the sums in
  * between); fixed summation order (no atomics). */
 int rr_bn_stats_finalize(const double *slab, int mtiles, double count, const float *gamma, const float *beta,

@@ -36,8 +36,10 @@ inline int ew_blocks(long n4) { long b = (n4 + EW_THREADS - 1) / EW_THREADS; ret
 // block = 32 columns x 8 row lanes; grid.y slices the mtiles; one double atomic per column per block
 // (sums is zeroed by the caller).
 __global__ __launch_bounds__(256) void bn_reduce_slab_kernel(const double *slab, int mtiles, int C2, int rows_per_block,
-                                                             double *sums)
+                                                             double *sums, double count = 0.0, double *count_slot = nullptr)
 {
+    // (SyncBN: the local sample count travels with the sums through the all-reduce — written here instead of by a fill launch)
+    if (count_slot != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *count_slot = count;
     __shared__ double red[8][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int col = blockIdx.x * 32 + tx;
@@ -61,12 +63,14 @@ __global__ __launch_bounds__(256) void bn_reduce_slab_kernel(const double *slab,
 // with the unbiased variance, as nn.BatchNorm2d does in training mode).
 __global__ void bn_finalize_kernel(const double *sums, double count_h, const double *count_d, const float *gamma, const float *beta,
                                    float *running_mean, float *running_var, float momentum, float eps,
-                                   float *mean, float *invstd, float *scale, float *shift, int C, long *num_batches_tracked)
+                                   float *mean, float *invstd, float *scale, float *shift, int C, long *num_batches_tracked,
+                                   double *count_out = nullptr)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;   // nn.BatchNorm2d's counter, without its own launch
-    if (c >= C) return;
     const double count = count_d ? *count_d : count_h;   // device count: SyncBN with ragged per-rank sample counts
+    if (c == 0 && count_out) *count_out = count;         // (kept for the backward in storage of its own: no clone launch)
+    if (c >= C) return;
     const double m = sums[c] / count;
     double var = sums[C + c] / count - m * m;
     if (var < 0.0) var = 0.0;
@@ -749,6 +753,49 @@ extern "C" int rr_bn_reduce_slab(const double *slab, int mtiles, int c, double *
     hipLaunchKernelGGL(bn_reduce_slab_kernel, dim3(rr_cdiv(2 * c, 32), rr_cdiv(mtiles, rows)), dim3(256), 0, stream, slab,
                        mtiles, 2 * c, rows, sums);
     RR_CHECK_LAUNCH("rr_bn_reduce_slab");
+    return RR_OK;
+}
+
+// dbeta += sums[0..C), dgamma += sums[C..2C): the affine gradients from the LOCAL BatchNorm-backward sums (SyncBN takes them before
+// the sums are exchanged; one launch instead of two casts and two adds)
+__global__ void bn_affine_grad_kernel(const double *sums, float *dgamma, float *dbeta, int C)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    dbeta[c] += (float)sums[c];
+    dgamma[c] += (float)sums[C + c];
+}
+
+extern "C" int rr_bn_affine_grad(const double *sums, float *dgamma, float *dbeta, int c, hipStream_t stream)
+{
+    RR_CHECK_ARG(c > 0 && sums && dgamma && dbeta, "rr_bn_affine_grad: bad arguments");
+    hipLaunchKernelGGL(bn_affine_grad_kernel, dim3(rr_cdiv(c, 128)), dim3(128), 0, stream, sums, dgamma, dbeta, c);
+    RR_CHECK_LAUNCH("rr_bn_affine_grad");
+    return RR_OK;
+}
+
+extern "C" int rr_bn_reduce_slab_count(const double *slab, int mtiles, int c, double *sums, double count, double *count_slot,
+                                       hipStream_t stream)
+{
+    RR_CHECK_ARG(mtiles > 0 && c > 0 && count_slot, "rr_bn_reduce_slab_count: bad arguments");
+    int parts = rr_cdiv(mtiles, 64);
+    if (parts > 64) parts = 64;
+    const int rows = rr_cdiv(mtiles, parts);
+    hipLaunchKernelGGL(bn_reduce_slab_kernel, dim3(rr_cdiv(2 * c, 32), rr_cdiv(mtiles, rows)), dim3(256), 0, stream, slab,
+                       mtiles, 2 * c, rows, sums, count, count_slot);
+    RR_CHECK_LAUNCH("rr_bn_reduce_slab_count");
+    return RR_OK;
+}
+
+extern "C" int rr_bn_finalize_count(const double *sums, const double *count_dev, const float *gamma, const float *beta,
+                                    float *running_mean, float *running_var, float momentum, float eps, float *mean,
+                                    float *invstd, float *scale, float *shift, int c, long *num_batches_tracked,
+                                    double *count_out, hipStream_t stream)
+{
+    RR_CHECK_ARG(c > 0 && count_dev && count_out, "rr_bn_finalize_count: bad arguments");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(rr_cdiv(c, 128)), dim3(128), 0, stream, sums, 0.0, count_dev, gamma, beta,
+                       running_mean, running_var, momentum, eps, mean, invstd, scale, shift, c, num_batches_tracked, count_out);
+    RR_CHECK_LAUNCH("rr_bn_finalize_count");
     return RR_OK;
 }
 

@@ -35,6 +35,21 @@ def record(comm, op, numel, note=""):
         EVENTS.append((comm, op, int(numel), note))
 
 
+HOST_S = {}                 # communicator -> host seconds spent inside its collective calls since the last reset()
+
+
+def all_reduce(t, group, comm, note=""):
+    """A blocking-semantics all-reduce (ordered behind, and ahead of, the current stream) of the data-parallel path: counted,
+    traced, and its HOST time accumulated per communicator — bench.py reports it as `dp_host_ms_per_step`, the part of the
+    forced one-rank step's overhead that is enqueue cost rather than device idle around the exchange."""
+    import time
+    import torch.distributed as dist
+    record(comm, "all_reduce", t.numel(), note)
+    h0 = time.perf_counter()
+    dist.all_reduce(t, group=group)
+    HOST_S[comm] = HOST_S.get(comm, 0.0) + time.perf_counter() - h0
+
+
 def mark(note):
     """A non-collective event whose position in the sequence matters (a parameter's gradient reported complete)."""
     if ENABLED:
@@ -44,6 +59,7 @@ def mark(note):
 def reset():
     EVENTS.clear()
     COUNTS.clear()
+    HOST_S.clear()
 
 
 def counts():

@@ -144,19 +144,20 @@ class _ConvBnAct(torch.autograd.Function):
             mom = bn.momentum if bn.momentum is not None else 0.1
             # (layers of more than 512 pixel tiles keep the two-kernel form: the fused kernel runs C/32 workgroups only)
             if sync or not BN_FUSED_STATS or slab.numel() > 512 * 2 * k:   # SyncBN exchange: one small all-reduce of [sum, sumsq, count] (C5 in SURVEY §2.2);
-                sums = ops.bn_reduce_slab(slab, k, extra=1)
                 if sync:
-                    # the global count stays on the device.  fill_ (scalar as a kernel argument), NOT `sums[2 * k] = count`:
-                    # that indexing form copies a pageable host scalar, and a pageable H2D copy blocks the host until
-                    # the stream has drained — one host sync per SyncBN layer (found with the one-rank RCCL step: 430 ms of
-                    # host time per 487 ms step)
-                    sums[2 * k:2 * k + 1].fill_(count)
-                    pg, pgname = None, "default"
-                    dptrace.record(pgname, "all_reduce", sums.numel(), "syncbn_fwd")
-                    dist.all_reduce(sums, group=pg)
-                    cnt_dev = sums[2 * k:].clone()   # own storage: `sums` is a slice of a shared zero pool (version counter)
-                mean, invstd, scale, shift = ops.bn_finalize(sums, count, gamma, beta, bn.running_mean, bn.running_var,
-                                                             mom, bn.eps, cnt_dev, bn.num_batches_tracked)
+                    # SyncBN exchange: one small all-reduce of [sum, sumsq, count] (C5 in SURVEY §2.2).  The local count is stored into
+                    # the buffer by the slab reduction itself and read back on the device by the finalize kernel, which also leaves it
+                    # in storage of its own for the backward: two launches around the collective (round 5: reduce, fill_, clone,
+                    # finalize — and a `sums[2 * k] = count` item assignment before that, a pageable H2D copy that blocked the host
+                    # until the stream had drained: 430 ms of host time per 487 ms step)
+                    sums = ops.bn_reduce_slab(slab, k, extra=1, count=count)
+                    dptrace.all_reduce(sums, None, "default", "syncbn_fwd")
+                    mean, invstd, scale, shift, cnt_dev = ops.bn_finalize_sync(sums, sums[2 * k:], gamma, beta, bn.running_mean,
+                                                                               bn.running_var, mom, bn.eps, bn.num_batches_tracked)
+                else:
+                    sums = ops.bn_reduce_slab(slab, k, extra=1)
+                    mean, invstd, scale, shift = ops.bn_finalize(sums, count, gamma, beta, bn.running_mean, bn.running_var,
+                                                                 mom, bn.eps, None, bn.num_batches_tracked)
             else:      # nothing to exchange: slab -> statistics -> coefficients in one launch
                 mean, invstd, scale, shift = ops.bn_stats_finalize(slab, count, gamma, beta, bn.running_mean,
                                                                    bn.running_var, mom, bn.eps, bn.num_batches_tracked)
@@ -226,17 +227,18 @@ class _ConvBnAct(torch.autograd.Function):
         fused_affine = dg_t is not None and db_t is not None and not sync
         if not fused_affine:
             # gradients of gamma/beta come from the LOCAL sums (SyncBN averages them later like any grad)
-            db = sums[:k].float()
-            dg = sums[k:2 * k].float()
-            if dg_t is not None:
-                dg_t.add_(dg)
-                db_t.add_(db)
+            if dg_t is not None and db_t is not None and dg_t.is_cuda:
+                ops.bn_affine_grad(sums, dg_t, db_t)            # one launch, before the sums are exchanged
             else:
-                ret_dg, ret_db = dg, db
+                db = sums[:k].float()
+                dg = sums[k:2 * k].float()
+                if dg_t is not None:
+                    dg_t.add_(dg)
+                    db_t.add_(db)
+                else:
+                    ret_dg, ret_db = dg, db
         if sync:
-            pg, pgname = None, "default"
-            dptrace.record(pgname, "all_reduce", sums.numel(), "syncbn_bwd")
-            dist.all_reduce(sums, group=pg)
+            dptrace.all_reduce(sums, None, "default", "syncbn_bwd")
         want_g = has_res and relu
         x_acc, res_acc = ctx.accs
         # the residual's fan-in buffer already holds another consumer's gradient: add the masked gradient into it
@@ -397,26 +399,24 @@ class _ConvBnSyncMulti(torch.autograd.Function):
             ks.append(ws[i].shape[0])
         tot = 2 * sum(ks) + L
         packed = ops._ZEROS.take(tot, x.device)                      # [sums_0 | sums_1 | .. | count_0 | count_1 | ..]
-        off = 0
-        for (y, slab), k in zip(ys, ks):
-            mt = slab.numel() // (2 * k)
-            ops._C.check(ops._C.fn("rr_bn_reduce_slab")(ops._C.ptr(slab), mt, k, ops._C.ptr(packed[off:off + 2 * k]),
-                                                        ops._C.stream()), "rr_bn_reduce_slab")
-            off += 2 * k
-        # one sample count per layer (layers of different stride see different numbers of pixels)
+        # one sample count per layer (layers of different stride see different numbers of pixels), stored into the packed buffer by
+        # the layer's slab reduction (no fill launch); after the exchange the finalize kernel leaves it in storage of its own
         counts = [float(y.numel() // k) for (y, _), k in zip(ys, ks)]
-        for i, cnt in enumerate(counts):
-            packed[tot - L + i:tot - L + i + 1].fill_(cnt)       # (fill_, not item assignment: see _ConvBnAct.forward)
-        pg, pgname = None, "default"
-        dptrace.record(pgname, "all_reduce", packed.numel(), "syncbn_fwd x%d" % L)
-        dist.all_reduce(packed, group=pg)
-        cnt_devs = [packed[tot - L + i:tot - L + i + 1].clone() for i in range(L)]
+        off = 0
+        for i, ((y, slab), k) in enumerate(zip(ys, ks)):
+            mt = slab.numel() // (2 * k)
+            ops._C.check(ops._C.fn("rr_bn_reduce_slab_count")(ops._C.ptr(slab), mt, k, ops._C.ptr(packed[off:off + 2 * k]), counts[i],
+                                                              ops._C.ptr(packed[tot - L + i:]), ops._C.stream()), "rr_bn_reduce_slab_count")
+            off += 2 * k
+        dptrace.all_reduce(packed, None, "default", "syncbn_fwd x%d" % L)
+        cnt_devs = []
         outs, saved, off = [], [], 0
         for i, ((bn, stride, pad, relu), (y, _), k) in enumerate(zip(specs, ys, ks)):
             gamma, beta = params[3 * i + 1], params[3 * i + 2]
             mom = bn.momentum if bn.momentum is not None else 0.1
-            mean, invstd, scale, shift = ops.bn_finalize(packed[off:off + 2 * k], counts[i], gamma, beta, bn.running_mean,
-                                                         bn.running_var, mom, bn.eps, cnt_devs[i], bn.num_batches_tracked)
+            mean, invstd, scale, shift, cnt = ops.bn_finalize_sync(packed[off:off + 2 * k], packed[tot - L + i:], gamma, beta,
+                                                                   bn.running_mean, bn.running_var, mom, bn.eps, bn.num_batches_tracked)
+            cnt_devs.append(cnt)
             off += 2 * k
             outs.append(ops.bn_apply(y, scale, shift, None, relu))
             saved += [y, mean, invstd, gamma, scale if relu else None, shift if relu else None]
@@ -452,16 +452,17 @@ class _ConvBnSyncMulti(torch.autograd.Function):
             gp, bp = params[3 * i + 1], params[3 * i + 2]
             dg_t, db_t = _grad_target(gp), _grad_target(bp)
             if dg_t is not None:
-                db_t.add_(packed[off:off + k].float())
-                dg_t.add_(packed[off + k:off + 2 * k].float())
+                if dg_t.is_cuda:
+                    ops.bn_affine_grad(packed[off:off + 2 * k], dg_t, db_t)
+                else:
+                    db_t.add_(packed[off:off + k].float())
+                    dg_t.add_(packed[off + k:off + 2 * k].float())
                 _mark(gp, bp)
             off += 2 * k
         local = None
         if any(_grad_target(params[3 * i + 1]) is None for i in range(L)):
             local = packed.clone()
-        pg, pgname = None, "default"
-        dptrace.record(pgname, "all_reduce", packed.numel(), "syncbn_bwd x%d" % L)
-        dist.all_reduce(packed, group=pg)
+        dptrace.all_reduce(packed, None, "default", "syncbn_bwd x%d" % L)
         if x_acc is not None:
             x_acc.pending += L - 1                 # this node contributes L data gradients to the fan-in buffer
         grads, dx, off = [], None, 0

@@ -897,13 +897,41 @@ class _ZeroPool:
 _ZEROS = _ZeroPool()
 
 
-def bn_reduce_slab(slab, c, extra=0):
+def bn_reduce_slab(slab, c, extra=0, count=None):
     """slab [mtiles,2,c] doubles -> sums [2c (+extra)] doubles (extra slots zeroed: room for the
-    sample count in the SyncBN exchange)."""
+    sample count in the SyncBN exchange).  count: the local sample count, stored into sums[2c] by the same launch."""
     sums = _ZEROS.take(2 * c + extra, slab.device)
     mtiles = slab.numel() // (2 * c)
+    if count is not None:
+        assert extra >= 1
+        _C.check(_C.fn("rr_bn_reduce_slab_count")(_C.ptr(slab), mtiles, c, _C.ptr(sums), float(count), _C.ptr(sums[2 * c:]), _C.stream()),
+                 "rr_bn_reduce_slab_count")
+        return sums
     _C.check(_C.fn("rr_bn_reduce_slab")(_C.ptr(slab), mtiles, c, _C.ptr(sums), _C.stream()), "rr_bn_reduce_slab")
     return sums
+
+
+def bn_finalize_sync(sums, count_slot, gamma, beta, running_mean, running_var, momentum, eps, num_batches_tracked=None):
+    """bn_finalize for an exchanged statistics buffer: the (global) sample count is read from the device (`count_slot`, a slot of
+    the buffer that went through the all-reduce) and handed back in storage of its own for the backward.
+    -> mean, invstd, scale, shift, count (float64 [1])"""
+    c = gamma.numel()
+    buf = _f32(4 * c, gamma.device)
+    mean, invstd, scale, shift = buf[0:c], buf[c:2 * c], buf[2 * c:3 * c], buf[3 * c:4 * c]
+    cnt = torch.empty(1, dtype=torch.float64, device=gamma.device)
+    assert num_batches_tracked is None or num_batches_tracked.dtype == torch.int64
+    _C.check(_C.fn("rr_bn_finalize_count")(_C.ptr(sums), _C.ptr(count_slot), _C.ptr(gamma), _C.ptr(beta), _C.ptr(running_mean),
+                                           _C.ptr(running_var), float(momentum), float(eps), _C.ptr(mean), _C.ptr(invstd),
+                                           _C.ptr(scale), _C.ptr(shift), c, _C.ptr(num_batches_tracked), _C.ptr(cnt), _C.stream()),
+             "rr_bn_finalize_count")
+    return mean, invstd, scale, shift, cnt
+
+
+def bn_affine_grad(sums, dgamma, dbeta):
+    """dbeta += sums[:c], dgamma += sums[c:2c] (the LOCAL BatchNorm-backward sums, before their SyncBN exchange): one launch."""
+    c = dgamma.numel()
+    assert dgamma.is_contiguous() and dbeta.is_contiguous() and dgamma.dtype == torch.float32
+    _C.check(_C.fn("rr_bn_affine_grad")(_C.ptr(sums), _C.ptr(dgamma), _C.ptr(dbeta), c, _C.stream()), "rr_bn_affine_grad")
 
 
 def bn_finalize(sums, count, gamma, beta, running_mean, running_var, momentum, eps, count_dev=None,
