@@ -81,7 +81,7 @@ def floor_table(dev):
     out = torch.empty(4096, device=dev)
     res = {}
     steps = 20000
-    for threads in (64, 256, 1024):
+    for threads in (64, 256, 512, 1024):
         for blocks in (1, 1280):
             st = torch.cuda.current_stream().cuda_stream
 

@@ -55,6 +55,7 @@ extern "C" int softnms_floor_run(int threads, int blocks, int steps, const float
 {
     if (threads == 64) hipLaunchKernelGGL(floor_kernel<64>, dim3(blocks), dim3(64), 0, stream, seed, steps, out);
     else if (threads == 256) hipLaunchKernelGGL(floor_kernel<256>, dim3(blocks), dim3(256), 0, stream, seed, steps, out);
+    else if (threads == 512) hipLaunchKernelGGL(floor_kernel<512>, dim3(blocks), dim3(512), 0, stream, seed, steps, out);
     else if (threads == 1024) hipLaunchKernelGGL(floor_kernel<1024>, dim3(blocks), dim3(1024), 0, stream, seed, steps, out);
     else return -1;
     return hipGetLastError() == hipSuccess ? 0 : -2;
