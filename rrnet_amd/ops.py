@@ -112,13 +112,15 @@ def is_nhwc(t):
 
 
 def is_phantom(t):
-    """A bf16-only activation / gradient (phantom_f32): an fp32 tensor OBJECT without memory — every stride 0 — whose values live in
-    its bf16 image.  Recognised by its strides, so views and tensors unpacked from an autograd node stay recognisable; such a new
-    object has lost the image link, and using it fails loudly (image_of) instead of reading one repeated value."""
-    # (strides all zero alone would also match an expanded scalar — autograd's gradient of `.sum()`; a phantom is the SECOND element
-    # of a two-element storage, which views and saved tensors preserve)
-    return (t is not None and t.dim() == 4 and t.stride() == (0, 0, 0, 0) and t.numel() > 1 and t.storage_offset() == 1
-            and t.untyped_storage().nbytes() == 8)
+    """A bf16-only activation / gradient (phantom_f32): an fp32 tensor OBJECT without memory whose values live in its bf16 image.
+    Recognised by IDENTITY: every such handle is a zero-stride view of the one per-device NaN stub (_PHANTOM_STUB), so the test is
+    "does t view that storage" — views and tensors unpacked from an autograd node keep it, nothing else can have it (round 5 went
+    by a signature: strides 0, offset 1, an 8-byte storage).  A view that lost the image link (the Python attribute) fails loudly
+    in image_of(); a torch-native read of the handle returns NaN."""
+    if t is None or t.dim() != 4 or t.stride() != (0, 0, 0, 0):
+        return False
+    stub = _PHANTOM_STUB.get(t.device)
+    return stub is not None and t.untyped_storage().data_ptr() == stub.untyped_storage().data_ptr()
 
 
 def image_of(t):

@@ -157,3 +157,41 @@ def test_conv16_dgrad_with_relu_mask_epilogue():
     ref = (ops.conv_dgrad(ops.to_nhwc(r(dy)), ops.to_nhwc(r(wt)), (n, c, h, w), 1, (1, 1)) + others) * (z > 0)
     _close(buf, ref, "masked fan-in sum", 2e-5)
     assert float((buf * (z <= 0)).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("cfg", SHAPES[:8], ids=lambda c: "n%dc%dh%dw%dk%dr%d_s%d" % c)
+def test_conv16_kernels_against_torch_fp64_directly(cfg):
+    """the test above pins csrc/conv16.hip to csrc/conv.hip — HIP against HIP, transitively fine only because
+    conv.hip is pinned to torch fp64 elsewhere; a defect SHARED by the two families at a shape only conv16's dispatch reaches
+    would pass.  Here the three conv16 launches (forward, stride-1 / stride-2 data gradient, weight gradient) are compared with an
+    implementation that shares nothing with csrc/: torch's fp64 convolution and its gradients on the device (ATen slow_conv2d +
+    dgemm), on the bf16-rounded operands — the kernels' contract (reference layers: /root/reference/backbones/hourglass.py:12-61)."""
+    import torch.nn.functional as F
+    from rrnet_amd import _C, ops
+    n, c, h, w, k, r, stride = cfg
+    pad = (r // 2, r // 2)
+    x = ops.to_nhwc(_mk((n, c, h, w), 11).relu_())
+    wt = ops.to_nhwc(_mk((k, c, r, r), 12) / float(np.sqrt(c * r * r)))
+    x16, w16 = x.to(torch.bfloat16), wt.to(torch.bfloat16)
+    x64, w64 = x16.double().contiguous(), w16.double().contiguous()
+    p, q = ops.out_hw(h, w, r, r, stride, pad[0], pad[1])
+    # forward
+    y = ops.empty_nhwc(n, k, p, q, x.device)
+    _C.check(_C.fn("rr_conv16_fprop")(_C.ptr(x16), _C.ptr(w16), None, _C.ptr(y), None, None, n, h, w, c, k, r, r, stride, pad[0], pad[1], 0,
+                                      _C.stream()), "fprop")
+    _close(y.double(), F.conv2d(x64, w64, None, stride, pad), "fprop vs torch fp64", 2e-5)
+    # data gradient (through the dispatch: stride 1 -> the forward kernel on the flipped filter, stride 2 -> four parity classes)
+    dy = ops.to_nhwc(_mk((n, k, p, q), 13))
+    dy16 = dy.to(torch.bfloat16)
+    with ops.bf16_scope(ops.MATH_BF16):
+        takes = ops.dgrad16_takes(tuple(dy.shape), tuple(wt.shape), (n, c, h, w), stride, pad)
+        dx = ops.conv_dgrad(dy16.float(), wt, (n, c, h, w), stride, pad)
+    ref = torch.nn.grad.conv2d_input((n, c, h, w), w64, dy16.double().contiguous(), stride, pad)
+    _close(dx.double(), ref, "dgrad vs torch fp64 (conv16 launch: %s)" % takes, 2e-5)
+    # weight gradient
+    if _C.fn("rr_conv16_wgrad_supported")(c, k, r, r, stride):
+        dw = ops.zeros_nhwc(k, c, r, r, x.device)
+        _C.check(_C.fn("rr_conv16_wgrad")(_C.ptr(x16), _C.ptr(dy16), _C.ptr(dw), n, h, w, c, k, r, r, stride, pad[0], pad[1], _C.stream()),
+                 "wgrad")
+        refw = torch.nn.grad.conv2d_weight(x64, (k, c, r, r), dy16.double().contiguous(), stride, pad)
+        _close(dw.double(), refw, "wgrad vs torch fp64", 5e-5)

@@ -160,16 +160,16 @@ def test_profiles_index_names_only_files_that_exist():
     assert not missing, "profiles/README.md indexes files that are not in profiles/: %s" % missing
 
 
-def test_bf16_only_tensor_is_recognised_structurally():
-    """ops.is_phantom (host logic, CPU tensors suffice): a bf16-only activation is element 1 of a two-element fp32 storage expanded
-    with zero strides; views keep the signature, an expanded scalar (autograd's gradient of .sum()) does not have it."""
+def test_bf16_only_tensor_is_recognised_by_identity():
+    """ops.is_phantom (host logic, CPU tensors suffice): a bf16-only activation is a zero-stride view of the per-device NaN stub;
+    views keep the identity, an expanded scalar (autograd's gradient of .sum()) or a look-alike built by hand does not have it."""
     import torch
     from rrnet_amd import ops
     img = torch.zeros((2, 3, 4, 8), dtype=torch.bfloat16).permute(0, 3, 1, 2)
-    p = torch.empty(2)[1:].expand(2, 8, 3, 4)
-    p._rr_b16 = (p._version, None, img)
+    p = ops.phantom_f32((2, 8, 3, 4), torch.device("cpu"), img)
     assert ops.is_phantom(p) and ops.is_phantom(p.view_as(p)) and ops.image_of(p) is img
     assert not ops.is_phantom(torch.ones(1).expand(2, 8, 3, 4))
+    assert not ops.is_phantom(torch.empty(2)[1:].expand(2, 8, 3, 4))          # round 5's signature alone is not enough any more
     assert not ops.is_phantom(torch.zeros(2, 8, 3, 4)) and not ops.is_phantom(None)
     assert ops.to_nhwc(p, keep_phantom=True) is p
 
