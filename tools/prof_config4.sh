@@ -8,7 +8,7 @@ for mode in dcn plain; do
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_c4${mode}_$TAG -- python3 tools/bench_config4.py --steps 3 $extra > gpurun_out/config4_bf16_${mode}_$TAG.json 2> gpurun_out/config4_bf16_${mode}_$TAG.err
   f=$(find gpurun_out/prof_c4${mode}_$TAG -name "*_kernel_stats.csv" | head -1)
   cp "$f" gpurun_out/${TAG}_config4_bf16_${mode}_kernel_stats_full.csv
-  head -45 "$f" > profiles/${TAG}_config4_bf16_${mode}_kernel_stats.csv
+  cp "$f" profiles/${TAG}_config4_bf16_${mode}_kernel_stats.csv          # untruncated
   tail -1 gpurun_out/config4_bf16_${mode}_$TAG.json > profiles/${TAG}_config4_bf16_${mode}_bench.json
   find gpurun_out/prof_c4${mode}_$TAG -name "*_kernel_trace.csv" -delete
 done

@@ -3,7 +3,7 @@
 #   bash tools/prof_round.sh r05      (GPU box)      then here:  cp gpurun_out/profiles_r05/* profiles/
 # Counters (--pmc) run in their own passes beside --kernel-trace only (MI355X_MICROARCH.md; gpurun refuses other mixes).
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
-TAG=${1:-r05}
+TAG=${1:-r06}
 OUT=gpurun_out/profiles_$TAG
 mkdir -p gpurun_out $OUT
 stats() { find "$1" -name "*_kernel_stats.csv" | head -1; }
@@ -31,6 +31,10 @@ cp profiles/${TAG}_config4_bf16_* $OUT/
 # 4. counter passes over the conv16 kernels at the dominant layer
 bash tools/pmc_conv16.sh $TAG > gpurun_out/pmc_conv16_$TAG.out 2>&1
 cp profiles/${TAG}_conv16_pmc.txt $OUT/
+
+# 4b. counter passes over the DCN window kernels at the bench layer
+bash tools/pmc_dcn.sh $TAG > gpurun_out/pmc_dcn_$TAG.out 2>&1
+cp profiles/${TAG}_dcn_pmc.txt $OUT/
 
 # 5. one-stream kernel trace of the headline step, broken down by kernel family
 RR_WGRAD_STREAM=0 timeout 900 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_${TAG}_one -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-kernel-timing --no-host-fed > gpurun_out/prof_${TAG}_one.log 2>&1
