@@ -88,55 +88,57 @@ def _cpu_stepper(seed, size, k, frames=1):
 def cpu_baseline(seed, k=100, budget_s=300.0):
     """The oracle ("port": torch-CPU restatement of the reference graph, oracle/model.py + ops.py) running the
     hourglass-104 RRNet train step INCLUDING the Adam update on this box's host cores, on the bench's own frame size.
-    `value` = 1 / mean of two WARM real 1024x1024 steps (one frame each; a first, cold step of the same stepper is run and
-    reported beside them, never averaged in).  The 512x512 steps of earlier rounds are kept as a cross-check list
-    (`t_512_s`; conv FLOPs scale with the pixel count, so t_1024 ~ 4 t_512 — round 4's value was that extrapolation and read
-    27 % slower than the real 1024^2 step of the same run).  If the budget does not allow three 1024^2 steps the value falls
-    back to the extrapolation and says so in `sample`."""
+    The thread count is CHOSEN, not assumed: one warm 512x512 step at 8 / 16 / 32 / 64 / all threads (round 6: on the 256-CPU GPU
+    box torch's default of 128 threads ran the step 6.7x SLOWER than 8 threads — a batch-1 graph of ~170 small convolutions does
+    not spread over 128 cores, it drowns in fork / join; the 128-thread figure of earlier rounds under-stated the host).
+    `value` = 1 / mean of two WARM real 1024x1024 steps (one frame each) at the fastest thread count (a first, cold step of the
+    same stepper is run and reported beside them, never averaged in); `cores` = that thread count.  Side figures, never `value`:
+    the sweep itself (`threads_sweep_512`), the all-threads 1024x1024 step of earlier rounds when the budget allows
+    (`all_threads_1024`), and the stepper at B=4 x 512x512 — the same pixels per step as one 1024x1024 frame — at the chosen
+    thread count (`batch4_512`: does a batch help?).  Reference loop: operators/rrnet_operator.py:116-138."""
     t_start = time.perf_counter()
-    threads = torch.get_num_threads()
+    default_threads = torch.get_num_threads()
     one512 = _cpu_stepper(seed, 512, k)
-    all512 = [one512() for _ in range(3)]            # first = cold; the last two are the warm pair
+    one512()                                          # cold: allocator, thread pool
+    sweep = {}
+    for th in sorted({8, 16, 32, 64, default_threads}):
+        if th > (os.cpu_count() or th):
+            continue
+        torch.set_num_threads(th)
+        one512()                                      # the pool's first step at this size is not representative either
+        sweep[th] = round(one512(), 3)
+    best = min(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    t512 = sweep[best]
     del one512
-    t512 = 0.5 * (all512[-2] + all512[-1])
-    out = {"unit": "images/sec", "cores": threads, "kind": "port", "torch_num_threads": threads, "host_cpus": os.cpu_count(),
-           "t_512_s": [round(t, 2) for t in all512], "images_per_sec_from_512_x4": round(1.0 / (t512 * 4.0), 5)}
-    # Is the one-frame figure thread-starved?  (VERDICT r5: a batch-1 graph does not spread over 128 cores; the reference's
-    # loop — operators/rrnet_operator.py:116-138 — runs a batch.)  Two side figures on the SAME pixel count per step as one
-    # 1024x1024 frame, never `value`: the stepper at B=4 x 512x512 with all threads, and the B=1 512x512 step at 8 threads.
+    out = {"unit": "images/sec", "cores": best, "kind": "port", "torch_default_threads": default_threads, "host_cpus": os.cpu_count(),
+           "threads_sweep_512": {"seconds_per_warm_512x512_step_by_threads": sweep, "chosen": best},
+           "images_per_sec_from_512_x4": round(1.0 / (t512 * 4.0), 5)}
     try:
-        four = _cpu_stepper(seed, 512, k, frames=4)
-        t4 = [four() for _ in range(2)]              # cold, warm
-        del four
-        out["batch4_512"] = {"t_s": [round(t, 2) for t in t4], "images_per_sec": round(4.0 / t4[-1], 5), "threads": threads,
-                             "vs_batch1_512": round((4.0 / t4[-1]) / (1.0 / t512), 3)}
-        torch.set_num_threads(8)
-        one8 = _cpu_stepper(seed, 512, k)
-        t8 = [one8() for _ in range(2)]
-        del one8
-        out["threads8_512"] = {"t_s": [round(t, 2) for t in t8], "images_per_sec": round(1.0 / t8[-1], 5), "threads": 8,
-                               "vs_all_threads": round(t512 / t8[-1], 3)}
-    except Exception as e:
-        out["batch4_512"] = {"error": repr(e)}
-    finally:
-        torch.set_num_threads(threads)
-    spent = time.perf_counter() - t_start
-    if spent + 3.3 * 4.0 * t512 < budget_s:
         one1024 = _cpu_stepper(seed, 1024, k)
         all1024 = [one1024() for _ in range(3)]
         t1024 = 0.5 * (all1024[1] + all1024[2])
         out["value"] = round(1.0 / t1024, 5)
         out["t_1024_s"] = [round(t, 2) for t in all1024]
         out["sample"] = ("oracle torch-CPU RRNet hourglass-104 train step (fwd+losses+bwd+Adam), 1 frame 1024x1024 (the bench's frame "
-                         "size), k=%d, %d threads: steps %s s (first = cold); value = 1 / mean of the two warm ones = 1 / %.2f s.  "
-                         "Cross-check: 512x512 steps %s s -> x4 = %.2f s"
-                         % (k, threads, " / ".join("%.2f" % t for t in all1024), t1024,
-                            " / ".join("%.2f" % t for t in all512), 4.0 * t512))
-    else:
-        out["value"] = out["images_per_sec_from_512_x4"]
-        out["sample"] = ("oracle torch-CPU RRNet hourglass-104 train step, 1 frame 512x512, k=%d, %d threads: steps %s s; the budget "
-                         "(%.0f s) did not allow three 1024x1024 steps: value = 1 / (4 x mean of the last two) — an EXTRAPOLATION"
-                         % (k, threads, " / ".join("%.2f" % t for t in all512), budget_s))
+                         "size), k=%d, %d threads (the fastest of the sweep %s s per 512x512 step): steps %s s (first = cold); value = 1 / mean of "
+                         "the two warm ones = 1 / %.2f s" % (k, best, sweep, " / ".join("%.2f" % t for t in all1024), t1024))
+        if default_threads != best and time.perf_counter() - t_start + 2.2 * 4.0 * sweep[default_threads] < budget_s:
+            torch.set_num_threads(default_threads)
+            one1024()
+            out["all_threads_1024"] = {"threads": default_threads, "t_s": round(one1024(), 2)}
+            torch.set_num_threads(best)
+        del one1024
+        four = _cpu_stepper(seed, 512, k, frames=4)
+        t4 = [four() for _ in range(2)]              # cold, warm
+        del four
+        out["batch4_512"] = {"t_s": [round(t, 2) for t in t4], "images_per_sec": round(4.0 / t4[-1], 5), "threads": best,
+                             "vs_batch1_512": round((4.0 / t4[-1]) * t512, 3)}
+    except Exception as e:
+        out.setdefault("value", out["images_per_sec_from_512_x4"])
+        out.setdefault("sample", "1024x1024 steps failed (%r): value = 1 / (4 x the warm 512x512 step at %d threads) — an EXTRAPOLATION" % (e, best))
+    finally:
+        torch.set_num_threads(default_threads)
     return out
 
 
