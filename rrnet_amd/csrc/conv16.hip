@@ -336,6 +336,14 @@ __global__ __launch_bounds__(512, 1) void conv16_igemm_kernel(const Args a)
 // — on zero operands, which clock ~15 % higher: neither the memory path nor LDS bandwidth binds; the instruction stream around the
 // MFMAs does.  profiles/r06_conv16_pingpong_ab.txt.  Removed from the product.)
 
+// (Round 6, second experiment, also removed from the product: FOUR waves, one per SIMD, 128 x 128 wave tiles of
+// v_mfma_f32_32x32x16_bf16 — 256 accumulator AGPRs + 142 VGPRs, half the fragment reads per MFMA, 32-cycle gaps for the rest, ring of four
+// slots, counted vmcnt.  Same results (1.2e-6), same speed: 1.01 PFLOP/s.  Its ablations are the useful part
+// (profiles/r06_conv16_w4_ablation.txt): with NO pieces, reads or barriers — 32 bare MFMAs per sub-step — the launch still takes
+// 0.481 ms = 1.29 PFLOP/s; without fragment reads alone nothing changes; with pieces that fetch nothing 1.36 (zero operands clock
+// higher).  On random operands the chip does not hold 2.4 GHz under sustained matrix load: the practical ceiling of this tile is
+// ~1.3 PFLOP/s, the kept kernel sits at ~0.8 of it, and what separates the two is the DMA traffic, not the loop structure.)
+
 // Stride-2 data gradient as four stride-1 correlations, one per output parity class (ph, pw) = (h % 2, w % 2), each with the
 // sub-filter of the taps that reach the class (a 3x3 visits 1 / 2 / 2 / 4 taps instead of masking three quarters of a dilated
 // filter) — csrc/conv_bf16.hip's decomposition; here the sub-filters are packed, flipped and transposed straight to bf16
