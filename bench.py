@@ -223,7 +223,11 @@ def config4_train_step(a, steps=5):
         r = bench_conv16.run_shape(8, 256, 256, 256, 256, 3, 1, reps=10, check=True)
         out["conv16_dominant_layer"] = {"shape": "N8 C256 256x256 K256 3x3", "gflop": 618.5, "mfma_peak_tflops": 2500.0,
                                         **{kk: r[kk] for kk in r if kk.endswith("_tflops") or kk.endswith("_ms") or kk.endswith("_err")},
-                                        "fprop_frac_of_peak": round(r["fprop_nostats_tflops"] / 2500.0, 4)}
+                                        "fprop_frac_of_peak": round(r["fprop_nostats_tflops"] / 2500.0, 4),
+                                        # not a live measurement: the bare MFMA loop of this tile on random operands (no DMA, reads or
+                                        # barriers) measured 1 285 TFLOP/s — the chip does not hold 2.4 GHz under sustained matrix load
+                                        "mfma_loop_alone_tflops": 1285.0, "mfma_loop_alone_source": "profiles/r06_conv16_w4_ablation.txt",
+                                        "fprop_frac_of_mfma_loop_alone": round(r["fprop_nostats_tflops"] / 1285.0, 4)}
     except Exception as e:
         out["conv16_dominant_layer"] = {"error": repr(e)}
     return out
