@@ -282,6 +282,17 @@ __device__ __forceinline__ RegCand wave_best(RegCand c)
     return r;
 }
 
+#ifdef RR_SNMS_STAMP
+// development build only (tools/softnms_stamps.sh): cycles of wave 0 per phase of the register kernel's outer step, summed over the launch
+__device__ unsigned long long g_snms_stamp[8];
+#define SN_DECL unsigned long long st_acc[7] = {0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime()
+#define SN_T(i) do { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); st_acc[i] += t__ - st_last; st_last = t__; } while (0)
+#define SN_FLUSH do { if (tid == 0) { for (int q_ = 0; q_ < 7; ++q_) atomicAdd(&g_snms_stamp[q_], st_acc[q_]); atomicAdd(&g_snms_stamp[7], 1ull); } } while (0)
+#else
+#define SN_DECL
+#define SN_T(i)
+#define SN_FLUSH
+#endif
 constexpr int SMALL_SEG_REG = 256;          // one box per lane of four waves
 constexpr int REG_DEAD = 0x7fffffff;         // position of a box that is out of the game (dead, or a padding slot)
 constexpr int REG_MASK_WORDS = 288;          // 32-bit words of one dead-position mask: positions < 9216
@@ -388,7 +399,9 @@ __device__ __forceinline__ void soft_nms_registers(float *b, const int stride, c
     int dummy;
     RegCand sel = block_best(lane_best(-1), 0, dummy);
     int my_err = 0;
+    SN_DECL;
     for (int i = 0; i < N; ++i) {
+        SN_T(6);
         const int maxpos = (int)~sel.kp;
         const float tx1 = sel.x1, ty1 = sel.y1, tx2 = sel.x2, ty2 = sel.y2;
         const double tarea = ((double)(tx2 - tx1) + 1.0) * ((double)(ty2 - ty1) + 1.0);
@@ -409,6 +422,7 @@ __device__ __forceinline__ void soft_nms_registers(float *b, const int stride, c
         // ---- the expensive half (double-precision union, IEEE division, double exp) runs once per OVERLAPPING box of the
         // busiest lane, not once per register slot that holds an overlapping box somewhere in the wave: every lane picks
         // its lowest pending slot, gathers that box with selects (no dynamically indexed registers), updates its score
+        SN_T(0);
         unsigned deadbits = 0u;
         while (__any(ovl != 0u)) {
             if (ovl != 0u) {
@@ -445,6 +459,7 @@ __device__ __forceinline__ void soft_nms_registers(float *b, const int stride, c
             }
         }
         // ---- the lane's best surviving candidate for the next step
+        SN_T(1);
         RegCand c;
         c.ks = 0u; c.kp = 0u; c.x1 = c.y1 = c.x2 = c.y2 = 0.f;
 #pragma unroll
@@ -459,7 +474,9 @@ __device__ __forceinline__ void soft_nms_registers(float *b, const int stride, c
         }
         const int ndead = __popc(deadbits);
         int D;
+        SN_T(2);
         sel = block_best(c, ndead, D);
+        SN_T(3);
         if (D == 0) continue;
         // ---- renumbering = the reference's swap-with-last compaction: the k-th dead position from the left below the new
         // N receives the k-th surviving box from the right end.
@@ -566,6 +583,7 @@ __device__ __forceinline__ void soft_nms_registers(float *b, const int stride, c
         for (int w = tid; w < REG_MASK_WORDS; w += T) masks[mbuf * REG_MASK_WORDS + w] = 0u;
         mask_dirty = true;                                          // (the mask just used, cleared by the next death step whichever path it takes)
     }
+    SN_FLUSH;
     if (my_err) *err = 1;
     // rows [0, N) in selection order = position order
 #pragma unroll
@@ -664,6 +682,18 @@ __global__ __launch_bounds__(T) void soft_nms_reg_kernel(float *boxes, const int
 }
 
 }  // namespace
+
+#ifdef RR_SNMS_STAMP
+extern "C" int rr_snms_stamps(unsigned long long *host_out, int reset)
+{
+    if (host_out && hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_snms_stamp), sizeof(unsigned long long) * 8) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_snms_stamp), z, sizeof(z)) != hipSuccess) return 2;
+    }
+    return 0;
+}
+#endif
 
 extern "C" size_t rr_soft_nms_workspace_bytes(int total_boxes, int max_seg_boxes)
 {
