@@ -387,13 +387,13 @@ class _ConvBnSyncMulti(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, x_acc, specs, *params):
-        # specs: [(bn module, stride, pad, relu)], params: w0, gamma0, beta0, w1, gamma1, beta1, ...
+        # specs: [(bn module, stride, pad, relu, BnLink)], params: w0, gamma0, beta0, w1, gamma1, beta1, ...
         ctx.bf16 = ops.BF16
         x = ops.to_nhwc(x)
         L = len(specs)
         ws = [ops.to_nhwc(params[3 * i]) for i in range(L)]
         ys, ks = [], []
-        for i, (bn, stride, pad, relu) in enumerate(specs):
+        for i, (bn, stride, pad, relu, _link) in enumerate(specs):
             y, slab = ops.conv_fprop(x, ws[i], None, stride, pad, False, want_stats=True)
             ys.append((y, slab))
             ks.append(ws[i].shape[0])
@@ -411,7 +411,7 @@ class _ConvBnSyncMulti(torch.autograd.Function):
         dptrace.all_reduce(packed, None, "default", "syncbn_fwd x%d" % L)
         cnt_devs = []
         outs, saved, off = [], [], 0
-        for i, ((bn, stride, pad, relu), (y, _), k) in enumerate(zip(specs, ys, ks)):
+        for i, ((bn, stride, pad, relu, link), (y, _), k) in enumerate(zip(specs, ys, ks)):
             gamma, beta = params[3 * i + 1], params[3 * i + 2]
             mom = bn.momentum if bn.momentum is not None else 0.1
             mean, invstd, scale, shift, cnt = ops.bn_finalize_sync(packed[off:off + 2 * k], packed[tot - L + i:], gamma, beta,
@@ -419,9 +419,15 @@ class _ConvBnSyncMulti(torch.autograd.Function):
             cnt_devs.append(cnt)
             off += 2 * k
             outs.append(ops.bn_apply(y, scale, shift, None, relu))
+            if link is not None:
+                # what a consumer's data gradient needs to produce this layer's BatchNorm-backward sums in its epilogue (as
+                # _ConvBnAct does: no residual here, so the ReLU mask is recomputed from y)
+                link.y, link.mean, link.invstd, link.use_z = y, mean, invstd, False
+                link.msc, link.msh = (scale, shift) if relu else (None, None)
             saved += [y, mean, invstd, gamma, scale if relu else None, shift if relu else None]
         ctx.save_for_backward(x, *cnt_devs, *ws, *saved)
-        ctx.meta = (L, [(st, tuple(pd), rl) for (_, st, pd, rl) in specs], ks, counts, x_acc, tuple(x.shape))
+        ctx.meta = (L, [(st, tuple(pd), rl) for (_, st, pd, rl, _l) in specs], ks, counts, x_acc, tuple(x.shape))
+        ctx.links = [lk for (_, _, _, _, lk) in specs]
         ctx.params = params
         return tuple(outs)
 
@@ -444,10 +450,21 @@ class _ConvBnSyncMulti(torch.autograd.Function):
             dzl.append(dz)
             k = ks[i]
             n, c, h, w = y.shape
-            ops._C.check(ops._C.fn("rr_bn_bwd_reduce")(ops._C.ptr(dz), ops._C.ptr(None), ops._C.ptr(y), ops._C.ptr(mean),
-                                                       ops._C.ptr(invstd), ops._C.ptr(msc), ops._C.ptr(msh),
-                                                       ops._C.ptr(packed[off:off + 2 * k]), n * h * w, c, 1, ops._C.stream()),
-                         "rr_bn_bwd_reduce")
+            link = ctx.links[i]
+            fused = None
+            if link is not None and link.sums is not None:
+                # the data gradient that produced dz already reduced it (rr_conv_dgrad_s1_bnsum) — valid only if what arrives
+                # here is that very tensor
+                if link.dz is not None and link.dz.data_ptr() == dz.data_ptr() and link.dz.shape == dz.shape:
+                    fused = link.sums
+                link.sums = link.dz = None
+            if fused is not None:
+                packed[off:off + 2 * k].copy_(fused[:2 * k])
+            else:
+                ops._C.check(ops._C.fn("rr_bn_bwd_reduce")(ops._C.ptr(dz), ops._C.ptr(None), ops._C.ptr(y), ops._C.ptr(mean),
+                                                           ops._C.ptr(invstd), ops._C.ptr(msc), ops._C.ptr(msh),
+                                                           ops._C.ptr(packed[off:off + 2 * k]), n * h * w, c, 1, ops._C.stream()),
+                             "rr_bn_bwd_reduce")
             # gradients of gamma / beta come from the LOCAL sums (averaged later like any gradient)
             gp, bp = params[3 * i + 1], params[3 * i + 2]
             dg_t, db_t = _grad_target(gp), _grad_target(bp)
@@ -511,11 +528,16 @@ def conv_bn_act_multi(x, layers):
         x_acc = getattr(x, "_rr_acc", None)
         if x.requires_grad and x_acc is not None:
             x_acc.pending += 1
-        specs = [(bn, conv.stride[0], tuple(conv.padding), relu) for conv, bn, relu in layers]
+        links = [ops.BnLink() for _ in layers]
+        specs = [(bn, conv.stride[0], tuple(conv.padding), relu, lk) for (conv, bn, relu), lk in zip(layers, links)]
         params = []
         for conv, bn, _ in layers:
             params += [conv.weight, bn.weight, bn.bias]
-        return list(_ConvBnSyncMulti.apply(x, x_acc, specs, *params))
+        outs = list(_ConvBnSyncMulti.apply(x, x_acc, specs, *params))
+        for o, lk in zip(outs, links):
+            if lk.y is not None:
+                o._rr_bnlink = lk          # a single convolution consumer's data gradient may carry this layer's backward sums
+        return outs
     return [conv_bn_act(x, conv, bn, relu=relu) for conv, bn, relu in layers]
 
 
